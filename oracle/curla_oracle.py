@@ -1,0 +1,368 @@
+"""CPU oracle for the CURL/SAC learner hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This module is a from-scratch CPU restatement (NumPy for the integer/byte work,
+PyTorch-CPU fp32 for the floating-point work) of the path that
+``CurlSacAgent.update()`` walks in the reference (paulvantieghem/curla).  It
+exists to *check* the HIP path; nothing under ``curla_amd/`` imports it and the
+product never falls back to it.  Allowed importers: ``tests/``,
+``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``.
+
+Parity status: PINNED.  ``tests/golden/*.npz`` were produced by importing the
+unmodified reference in the build container (``tests/golden/make_goldens.py``);
+``tests/test_oracle_golden.py`` checks every function below against them
+(crop/sample indices and cropped bytes bit-exact, losses / activations /
+gradients to 1e-5 per-tensor norm-relative).
+
+Every function cites the reference lines it restates (paths relative to the
+reference checkout).  The restatement is functional: parameters are a flat
+``dict[str, Tensor]`` keyed like the reference ``state_dict`` and all randomness
+(crop offsets, sample indices, Gaussian noise) is an explicit input.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Params = Dict[str, torch.Tensor]
+
+
+# --------------------------------------------------------------------------
+# shapes
+# --------------------------------------------------------------------------
+def conv_out_hw(h: int, w: int, num_layers: int) -> Tuple[int, int]:
+    """Spatial size after the conv stack: first layer 3x3 stride 2, the rest
+    3x3 stride 1, no padding (encoder.py:54-63).  The reference looks the
+    result up in a table (encoder.py:21-29,38-47); this is the arithmetic the
+    table rows encode ((76,135)->(31,61), (90,160)->(38,73))."""
+    h = (h - 3) // 2 + 1
+    w = (w - 3) // 2 + 1
+    for _ in range(num_layers - 1):
+        h, w = h - 2, w - 2
+    return h, w
+
+
+def random_crop_output_shape(input_hw: Tuple[int, int], factor: float = 0.84) -> Tuple[int, int]:
+    """augmentations.py:21-24: ceil(x * 0.84) per side."""
+    return tuple(int(np.ceil(x * factor)) for x in input_hw)
+
+
+# --------------------------------------------------------------------------
+# integer / byte path (NumPy)
+# --------------------------------------------------------------------------
+def draw_sample_cpc_indices(n_valid: int, batch: int, crop_max_h: int, crop_max_w: int,
+                            random_crop: bool = True, rng=np.random):
+    """The draws ``ReplayBuffer.sample_cpc`` makes from NumPy's global legacy
+    stream, in the reference's order (utils.py:147, then augmentations.py:66-67
+    once each for obs, next_obs, pos via utils.py:156-158): idxs, (h1,w1) x3.
+    ``randint`` upper bounds are exclusive.  Returns (idxs, [(h1,w1)]*3)."""
+    idxs = rng.randint(0, n_valid, size=batch)
+    offs = []
+    if random_crop:
+        for _ in range(3):
+            h1 = rng.randint(0, crop_max_h, batch)
+            w1 = rng.randint(0, crop_max_w, batch)
+            offs.append((h1, w1))
+    return idxs, offs
+
+
+def random_crop(imgs: np.ndarray, h1: np.ndarray, w1: np.ndarray, out_hw: Tuple[int, int]) -> np.ndarray:
+    """out[b,c,i,j] = in[b,c,h1[b]+i,w1[b]+j]  (augmentations.py:47-75; the
+    reference builds all sliding windows and picks one per sample)."""
+    n, c = imgs.shape[:2]
+    oh, ow = out_hw
+    out = np.empty((n, c, oh, ow), dtype=imgs.dtype)
+    for b in range(n):
+        out[b] = imgs[b, :, h1[b]:h1[b] + oh, w1[b]:w1[b] + ow]
+    return out
+
+
+def center_crop(img: np.ndarray, out_hw: Tuple[int, int]) -> np.ndarray:
+    """augmentations.py:26-45 (evaluation augmentation of RandomCrop)."""
+    h, w = img.shape[-2:]
+    oh, ow = out_hw
+    top, left = (h - oh) // 2, (w - ow) // 2
+    return img[..., top:top + oh, left:left + ow]
+
+
+# --------------------------------------------------------------------------
+# networks (PyTorch CPU fp32)
+# --------------------------------------------------------------------------
+def encoder_forward(p: Params, prefix: str, obs: torch.Tensor, num_layers: int,
+                    detach: bool = False, output_logits: bool = True,
+                    conv_prefix: Optional[str] = None, outputs: Optional[dict] = None) -> torch.Tensor:
+    """CNNEncoder.forward (encoder.py:77-110).  obs: float NCHW in [0,255].
+    ``conv_prefix`` lets the actor use the critic's conv tensors (weight tying,
+    encoder.py:112-116 / curl_sac.py:290)."""
+    cp = conv_prefix if conv_prefix is not None else prefix
+    x = obs / 255.0
+    for i in range(num_layers):
+        x = torch.relu(F.conv2d(x, p[f"{cp}convs.{i}.weight"], p[f"{cp}convs.{i}.bias"],
+                                stride=2 if i == 0 else 1))
+        if outputs is not None:
+            outputs[f"conv{i + 1}"] = x
+    h = x.reshape(x.size(0), -1)
+    if detach:
+        h = h.detach()
+    h_fc = F.linear(h, p[f"{prefix}fc.weight"], p[f"{prefix}fc.bias"])
+    h_norm = F.layer_norm(h_fc, (h_fc.size(-1),), p[f"{prefix}ln.weight"], p[f"{prefix}ln.bias"], 1e-5)
+    if outputs is not None:
+        outputs["fc"] = h_fc
+        outputs["ln"] = h_norm
+    return h_norm if output_logits else torch.tanh(h_norm)
+
+
+def mlp3(p: Params, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """Linear-ReLU-Linear-ReLU-Linear trunk (curl_sac.py:70-74,129-133)."""
+    x = torch.relu(F.linear(x, p[f"{prefix}0.weight"], p[f"{prefix}0.bias"]))
+    x = torch.relu(F.linear(x, p[f"{prefix}2.weight"], p[f"{prefix}2.bias"]))
+    return F.linear(x, p[f"{prefix}4.weight"], p[f"{prefix}4.bias"])
+
+
+def actor_forward(actor: Params, critic: Params, obs: torch.Tensor, noise: Optional[torch.Tensor],
+                  num_layers: int, log_std_min: float, log_std_max: float,
+                  detach_encoder: bool = False, compute_pi: bool = True, compute_log_pi: bool = True):
+    """Actor.forward + gaussian_logprob + squash (curl_sac.py:20-35,79-110).
+    The conv tensors come from ``critic`` (tied); fc/ln/trunk from ``actor``.
+    ``noise`` replaces ``torch.randn_like(mu)`` (curl_sac.py:97)."""
+    merged = dict(actor)
+    for k, v in critic.items():
+        if k.startswith("encoder.convs."):
+            merged[k] = v
+    z = encoder_forward(merged, "encoder.", obs, num_layers, detach=detach_encoder)
+    mu, log_std = mlp3(merged, "trunk.", z).chunk(2, dim=-1)
+    log_std = torch.tanh(log_std)
+    log_std = log_std_min + 0.5 * (log_std_max - log_std_min) * (log_std + 1)
+    pi = log_pi = None
+    if compute_pi:
+        pi = mu + noise * log_std.exp()
+    if compute_log_pi:
+        residual = (-0.5 * noise.pow(2) - log_std).sum(-1, keepdim=True)
+        log_pi = residual - 0.5 * np.log(2 * np.pi) * noise.size(-1)
+    mu = torch.tanh(mu)
+    if pi is not None:
+        pi = torch.tanh(pi)
+    if log_pi is not None:
+        log_pi = log_pi - torch.log(F.relu(1 - pi.pow(2)) + 1e-6).sum(-1, keepdim=True)
+    return mu, pi, log_pi, log_std
+
+
+def critic_forward(critic: Params, obs: torch.Tensor, action: torch.Tensor, num_layers: int,
+                   detach_encoder: bool = False, outputs: Optional[dict] = None):
+    """Critic.forward / QFunction.forward (curl_sac.py:135-169)."""
+    z = encoder_forward(critic, "encoder.", obs, num_layers, detach=detach_encoder, outputs=outputs)
+    za = torch.cat([z, action], dim=1)
+    return mlp3(critic, "Q1.trunk.", za), mlp3(critic, "Q2.trunk.", za)
+
+
+def curl_logits(W: torch.Tensor, z_a: torch.Tensor, z_pos: torch.Tensor) -> torch.Tensor:
+    """CURL.compute_logits (curl_sac.py:211-222)."""
+    Wz = torch.matmul(W, z_pos.T)
+    logits = torch.matmul(z_a, Wz)
+    return logits - torch.max(logits, 1)[0][:, None]
+
+
+# --------------------------------------------------------------------------
+# phases: loss + gradients from explicit weights / batch / noise
+# --------------------------------------------------------------------------
+def _leafify(p: Params) -> Params:
+    return {k: v.detach().clone().requires_grad_(True) for k, v in p.items()}
+
+
+def _grads(p: Params) -> Dict[str, Optional[torch.Tensor]]:
+    return {k: (None if v.grad is None else v.grad.detach().clone()) for k, v in p.items()}
+
+
+def critic_phase(actor: Params, critic: Params, critic_target: Params, log_alpha: torch.Tensor,
+                 obs, action, reward, next_obs, not_done, noise, *, num_layers: int, discount: float,
+                 log_std_min: float, log_std_max: float, detach_encoder: bool = False):
+    """CurlSacAgent.update_critic up to and including backward
+    (curl_sac.py:349-367).  Returns dict(loss, target_Q, q1, q2, grads, enc)."""
+    with torch.no_grad():
+        _, policy_action, log_pi, _ = actor_forward(actor, critic, next_obs, noise, num_layers,
+                                                    log_std_min, log_std_max)
+        tq1, tq2 = critic_forward(critic_target, next_obs, policy_action, num_layers)
+        alpha = log_alpha.detach().exp()
+        target_V = torch.min(tq1, tq2) - alpha * log_pi
+        target_Q = reward + (not_done * discount * target_V)
+        target_Q = target_Q.to(torch.float32)
+    c = _leafify(critic)
+    enc = {}
+    q1, q2 = critic_forward(c, obs, action, num_layers, detach_encoder=detach_encoder, outputs=enc)
+    loss = F.mse_loss(q1, target_Q) + F.mse_loss(q2, target_Q)
+    loss.backward()
+    return dict(loss=loss.detach(), target_Q=target_Q, q1=q1.detach(), q2=q2.detach(),
+                policy_action=policy_action, next_log_pi=log_pi,
+                grads=_grads(c), enc={k: v.detach() for k, v in enc.items()})
+
+
+def actor_phase(actor: Params, critic: Params, log_alpha: torch.Tensor, obs, noise, *,
+                num_layers: int, log_std_min: float, log_std_max: float, target_entropy: float):
+    """CurlSacAgent.update_actor_and_alpha up to the two backward calls
+    (curl_sac.py:373-403).  Live gradients: the actor's own fc/ln/trunk and
+    log_alpha; gradients deposited on critic tensors are dead in the reference
+    (cleared before any step reads them) and are not returned."""
+    a = _leafify(actor)
+    la = log_alpha.detach().clone().requires_grad_(True)
+    _, pi, log_pi, log_std = actor_forward(a, critic, obs, noise, num_layers, log_std_min, log_std_max,
+                                           detach_encoder=True)
+    q1, q2 = critic_forward(critic, obs, pi, num_layers, detach_encoder=True)
+    actor_Q = torch.min(q1, q2)
+    actor_loss = (la.exp().detach() * log_pi - actor_Q).mean()
+    entropy = 0.5 * log_std.shape[1] * (1.0 + np.log(2 * np.pi)) + log_std.sum(dim=-1)
+    actor_loss.backward()
+    alpha_loss = (la.exp() * (-log_pi - target_entropy).detach()).mean()
+    alpha_loss.backward()
+    grads = {k: g for k, g in _grads(a).items() if g is not None}
+    return dict(actor_loss=actor_loss.detach(), alpha_loss=alpha_loss.detach(), entropy=entropy.mean().detach(),
+                alpha=la.exp().detach(), pi=pi.detach(), log_pi=log_pi.detach(), log_std=log_std.detach(),
+                q1=q1.detach(), q2=q2.detach(), grads=grads, log_alpha_grad=la.grad.detach().clone())
+
+
+def cpc_phase(critic: Params, critic_target: Params, W: torch.Tensor, obs_anchor, obs_pos, *, num_layers: int):
+    """CurlSacAgent.update_cpc up to backward (curl_sac.py:406-417): anchors
+    through the online encoder, positives through the target encoder under
+    no_grad, bilinear logits, cross-entropy against arange(B)."""
+    enc = _leafify({k: v for k, v in critic.items() if k.startswith("encoder.")})
+    Wl = W.detach().clone().requires_grad_(True)
+    z_a = encoder_forward(enc, "encoder.", obs_anchor, num_layers)
+    with torch.no_grad():
+        z_pos = encoder_forward(critic_target, "encoder.", obs_pos, num_layers)
+    logits = curl_logits(Wl, z_a, z_pos)
+    labels = torch.arange(logits.shape[0]).long()
+    loss = F.cross_entropy(logits, labels)
+    loss.backward()
+    return dict(loss=loss.detach(), z_a=z_a.detach(), z_pos=z_pos, logits=logits.detach(),
+                grads=_grads(enc), W_grad=Wl.grad.detach().clone())
+
+
+def soft_update(net: Params, target: Params, tau: float, prefix: str) -> None:
+    """utils.soft_update_params (utils.py:37-41), in place on ``target`` for
+    every tensor under ``prefix``."""
+    for k, v in net.items():
+        if k.startswith(prefix):
+            target[k].copy_(tau * v + (1 - tau) * target[k])
+
+
+# --------------------------------------------------------------------------
+# initialisation (for the CPU baseline / smoke; parity tests load fixtures)
+# --------------------------------------------------------------------------
+def _orthogonal(shape, gain=1.0, gen=None):
+    t = torch.empty(shape)
+    torch.nn.init.orthogonal_(t, gain, generator=gen)
+    return t
+
+
+def init_encoder(prefix: str, in_ch: int, hw: Tuple[int, int], feature_dim: int, num_layers: int,
+                 num_filters: int, gen=None) -> Params:
+    """Shapes of CNNEncoder.__init__ (encoder.py:54-67) with weight_init
+    (curl_sac.py:38-54): delta-orthogonal convs, orthogonal fc, zero biases,
+    LayerNorm ones/zeros."""
+    p: Params = {}
+    gain = math.sqrt(2.0)
+    for i in range(num_layers):
+        cin = in_ch if i == 0 else num_filters
+        w = torch.zeros(num_filters, cin, 3, 3)
+        w[:, :, 1, 1] = _orthogonal((num_filters, cin), gain, gen)
+        p[f"{prefix}convs.{i}.weight"] = w
+        p[f"{prefix}convs.{i}.bias"] = torch.zeros(num_filters)
+    oh, ow = conv_out_hw(hw[0], hw[1], num_layers)
+    p[f"{prefix}fc.weight"] = _orthogonal((feature_dim, num_filters * oh * ow), 1.0, gen)
+    p[f"{prefix}fc.bias"] = torch.zeros(feature_dim)
+    p[f"{prefix}ln.weight"] = torch.ones(feature_dim)
+    p[f"{prefix}ln.bias"] = torch.zeros(feature_dim)
+    return p
+
+
+def init_mlp3(prefix: str, din: int, hidden: int, dout: int, gen=None) -> Params:
+    p: Params = {}
+    for j, (a, b) in zip((0, 2, 4), ((din, hidden), (hidden, hidden), (hidden, dout))):
+        p[f"{prefix}{j}.weight"] = _orthogonal((b, a), 1.0, gen)
+        p[f"{prefix}{j}.bias"] = torch.zeros(b)
+    return p
+
+
+class OracleAgent:
+    """Stateful wrapper chaining the phases with ``torch.optim.Adam`` exactly as
+    ``CurlSacAgent.__init__/update`` does (curl_sac.py:226-318,426-451): five
+    optimizers, tied convs, the encoder stepped by both ``encoder_optimizer``
+    and ``cpc_optimizer`` from the same gradients.  Used for the CPU baseline
+    timing and for the smoke check; parity is asserted per phase."""
+
+    def __init__(self, obs_shape, action_shape, hidden_dim=1024, discount=0.99, init_temperature=0.1,
+                 alpha_lr=1e-4, alpha_beta=0.5, actor_lr=1e-3, actor_beta=0.9, actor_log_std_min=-10,
+                 actor_log_std_max=2, actor_update_freq=2, critic_lr=1e-3, critic_beta=0.9, critic_tau=0.01,
+                 critic_target_update_freq=2, encoder_feature_dim=50, encoder_lr=1e-3, encoder_tau=0.05,
+                 num_layers=4, num_filters=32, cpc_update_freq=1, detach_encoder=False, pixel_sac=False,
+                 seed=1):
+        gen = torch.Generator().manual_seed(seed)
+        c, h, w = obs_shape
+        A = action_shape[0]
+        self.num_layers, self.discount = num_layers, discount
+        self.lo, self.hi = actor_log_std_min, actor_log_std_max
+        self.actor_update_freq, self.critic_target_update_freq = actor_update_freq, critic_target_update_freq
+        self.cpc_update_freq, self.critic_tau, self.encoder_tau = cpc_update_freq, critic_tau, encoder_tau
+        self.detach_encoder, self.pixel_sac = detach_encoder, pixel_sac
+        self.target_entropy = -float(np.prod(action_shape))
+        self.critic = init_encoder("encoder.", c, (h, w), encoder_feature_dim, num_layers, num_filters, gen)
+        self.critic.update(init_mlp3("Q1.trunk.", encoder_feature_dim + A, hidden_dim, 1, gen))
+        self.critic.update(init_mlp3("Q2.trunk.", encoder_feature_dim + A, hidden_dim, 1, gen))
+        self.critic_target = {k: v.clone() for k, v in self.critic.items()}
+        enc_a = init_encoder("encoder.", c, (h, w), encoder_feature_dim, num_layers, num_filters, gen)
+        self.actor = {k: v for k, v in enc_a.items() if ".convs." not in k}
+        self.actor.update(init_mlp3("trunk.", encoder_feature_dim, hidden_dim, 2 * A, gen))
+        self.W = torch.rand(encoder_feature_dim, encoder_feature_dim, generator=gen)
+        self.log_alpha = torch.tensor(np.log(init_temperature))
+        for d in (self.critic, self.actor):
+            for v in d.values():
+                v.requires_grad_(True)
+        self.W.requires_grad_(True)
+        self.log_alpha.requires_grad_(True)
+        enc_params = [v for k, v in self.critic.items() if k.startswith("encoder.")]
+        self.actor_opt = torch.optim.Adam(list(self.actor.values()), lr=actor_lr, betas=(actor_beta, 0.999))
+        self.critic_opt = torch.optim.Adam(list(self.critic.values()), lr=critic_lr, betas=(critic_beta, 0.999))
+        self.alpha_opt = torch.optim.Adam([self.log_alpha], lr=alpha_lr, betas=(alpha_beta, 0.999))
+        self.encoder_opt = torch.optim.Adam(enc_params, lr=encoder_lr)
+        self.cpc_opt = torch.optim.Adam([self.W] + enc_params, lr=encoder_lr)
+
+    @staticmethod
+    def _apply(opt, params, grads):
+        for v, g in zip(params, grads):
+            v.grad = g
+        opt.step()
+        for v in params:
+            v.grad = None
+
+    def update(self, obs, action, reward, next_obs, not_done, pos, noise_c, noise_a, step, only_cpc=False):
+        out = {}
+        if not only_cpc:
+            r = critic_phase(self.actor, self.critic, self.critic_target, self.log_alpha, obs, action, reward,
+                             next_obs, not_done, noise_c, num_layers=self.num_layers, discount=self.discount,
+                             log_std_min=self.lo, log_std_max=self.hi, detach_encoder=self.detach_encoder)
+            out["critic_loss"] = r["loss"]
+            keys = list(self.critic.keys())
+            self._apply(self.critic_opt, [self.critic[k] for k in keys], [r["grads"][k] for k in keys])
+            if step % self.actor_update_freq == 0:
+                r = actor_phase(self.actor, self.critic, self.log_alpha, obs, noise_a, num_layers=self.num_layers,
+                                log_std_min=self.lo, log_std_max=self.hi, target_entropy=self.target_entropy)
+                out["actor_loss"], out["alpha_loss"] = r["actor_loss"], r["alpha_loss"]
+                keys = list(self.actor.keys())
+                self._apply(self.actor_opt, [self.actor[k] for k in keys], [r["grads"][k] for k in keys])
+                self._apply(self.alpha_opt, [self.log_alpha], [r["log_alpha_grad"]])
+            if step % self.critic_target_update_freq == 0:
+                with torch.no_grad():
+                    soft_update(self.critic, self.critic_target, self.critic_tau, "Q1.")
+                    soft_update(self.critic, self.critic_target, self.critic_tau, "Q2.")
+                    soft_update(self.critic, self.critic_target, self.encoder_tau, "encoder.")
+        if not self.pixel_sac and step % self.cpc_update_freq == 0:
+            r = cpc_phase(self.critic, self.critic_target, self.W, obs, pos, num_layers=self.num_layers)
+            out["curl_loss"] = r["loss"]
+            keys = [k for k in self.critic if k.startswith("encoder.")]
+            params = [self.critic[k] for k in keys]
+            grads = [r["grads"][k] for k in keys]
+            self._apply(self.encoder_opt, params, grads)
+            self._apply(self.cpc_opt, [self.W] + params, [r["W_grad"]] + grads)
+        return out

@@ -1,0 +1,162 @@
+"""Pins oracle/curla_oracle.py to the golden vectors generated from the
+reference (tests/golden/make_goldens.py).  CPU only."""
+import hashlib
+
+import numpy as np
+import torch
+
+from oracle import curla_oracle as O
+from tests._util import assert_close, load, sub, summarize
+
+torch.set_num_threads(1)
+HP = dict(num_layers=4, log_std_min=-10, log_std_max=2)
+
+
+def _f(x):
+    return torch.from_numpy(np.asarray(x, dtype=np.float32))
+
+
+def test_shape_arithmetic_matches_reference_tables():
+    # encoder.py:21-29 rows that are well-formed in the reference
+    assert O.conv_out_hw(76, 135, 4) == (31, 61)
+    assert O.conv_out_hw(90, 160, 4) == (38, 73)
+    # the square tables (ints in the reference, encoder.py:21-23)
+    assert [O.conv_out_hw(84, 84, n)[0] for n in (2, 4, 6)] == [39, 35, 31]
+    assert [O.conv_out_hw(64, 64, n)[0] for n in (2, 4, 6)] == [29, 25, 21]
+    g = load("crop84.npz")
+    assert tuple(g["default_shape_84"]) == O.random_crop_output_shape((84, 84))
+    assert tuple(g["default_shape_90_160"]) == O.random_crop_output_shape((90, 160))
+
+
+def test_random_crop_bit_exact_84_to_76():
+    g = load("crop84.npz")
+    imgs = np.random.RandomState(int(g["imgs_seed"])).randint(0, 256, (16, 9, 84, 84), dtype=np.uint8)
+    rs = np.random.RandomState(int(g["numpy_seed"]))
+    h1 = rs.randint(0, 8, 16)
+    w1 = rs.randint(0, 8, 16)
+    assert np.array_equal(h1, g["h1"]) and np.array_equal(w1, g["w1"])
+    assert h1.max() <= 7  # exclusive upper bound (augmentations.py:66-67)
+    out = O.random_crop(imgs, h1, w1, (76, 76))
+    assert hashlib.sha256(out.tobytes()).hexdigest() == str(g["out_sha256"])
+    assert np.array_equal(out[:2], g["out_first2"])
+    assert np.array_equal(O.center_crop(imgs[0], (76, 76)), g["center_crop0"])
+
+
+def test_sample_cpc_draw_order_bit_exact():
+    g = load("tiny.npz")
+    rs = np.random.RandomState()
+    st = list(rs.get_state())
+    st[1], st[2] = g["meta/numpy_state_keys"], int(g["meta/numpy_state_pos"])
+    rs.set_state(tuple(st))
+    ih, iw = g["meta/in_hw"]
+    oh, ow = g["meta/out_hw"]
+    idxs, offs = O.draw_sample_cpc_indices(int(g["meta/n_valid"]), 8, ih - oh, iw - ow, rng=rs)
+    assert np.array_equal(idxs, g["rng/idxs"])
+    for (h1, w1), nm in zip(offs, ("obs", "next_obs", "pos")):
+        assert np.array_equal(h1, g[f"rng/h1_{nm}"]) and np.array_equal(w1, g[f"rng/w1_{nm}"])
+    # and the cropped bytes the reference fed its networks
+    for nm, full in (("obs", "obs_full"), ("next_obs", "next_obs_full"), ("pos", "obs_full")):
+        out = O.random_crop(g[f"batch/{full}"], g[f"rng/h1_{nm}"], g[f"rng/w1_{nm}"], (oh, ow))
+        assert np.array_equal(out, g[f"batch/{nm}"])
+
+
+def _state(g):
+    return (sub(g, "state0/actor/"), sub(g, "state0/critic/"), sub(g, "state0/critic_target/"),
+            torch.from_numpy(g["state0/W"]), torch.from_numpy(g["state0/log_alpha"]))
+
+
+def test_critic_phase_matches_reference():
+    g = load("tiny.npz")
+    actor, critic, target, W, la = _state(g)
+    r = O.critic_phase(actor, critic, target, la, _f(g["batch/obs"]), _f(g["batch/action"]), _f(g["batch/reward"]),
+                       _f(g["batch/next_obs"]), _f(g["batch/not_done"]), _f(g["noise/critic"]), discount=0.99, **HP)
+    assert_close(r["policy_action"], g["critic/policy_action"], 1e-5, "policy_action")
+    assert_close(r["next_log_pi"], g["critic/next_log_pi"], 1e-5, "next_log_pi")
+    assert_close(r["q1"], g["critic/q1"], 1e-5, "q1")
+    assert_close(r["q2"], g["critic/q2"], 1e-5, "q2")
+    assert_close(r["loss"], g["scalar/train_critic/loss"], 1e-5, "critic loss")
+    for k in ("conv1", "conv2", "conv3", "conv4", "fc", "ln"):
+        assert_close(r["enc"][k], g[f"critic/enc/{k}"], 1e-5, k)
+    n = 0
+    for k, v in sub(g, "critic/grad/").items():
+        assert_close(r["grads"][k], v, 1e-5, "critic grad " + k)
+        n += 1
+    assert n == 24  # curl_sac.py:301: all critic tensors get a gradient
+
+
+def test_actor_phase_matches_reference():
+    g = load("tiny.npz")
+    actor, _, _, _, la = _state(g)
+    critic = sub(g, "critic_after/")  # weights after the critic Adam step (curl_sac.py:368)
+    r = O.actor_phase(actor, critic, la, _f(g["batch/obs"]), _f(g["noise/actor"]), target_entropy=-2.0, **HP)
+    for k in ("pi", "log_pi", "log_std", "q1", "q2"):
+        assert_close(r[k], g[f"actor/{k}"], 1e-5, k)
+    assert_close(r["actor_loss"], g["scalar/train_actor/loss"], 1e-5, "actor loss")
+    assert_close(r["alpha_loss"], g["scalar/train_alpha/loss"], 1e-5, "alpha loss")
+    assert_close(r["entropy"], g["scalar/train_actor/entropy"], 1e-5, "entropy")
+    assert_close(r["alpha"], g["scalar/train_alpha/value"], 1e-6, "alpha")
+    assert_close(r["log_alpha_grad"], g["alpha/grad/log_alpha"], 1e-5, "log_alpha grad")
+    ref = sub(g, "actor/grad/")
+    assert len(ref) == 10 and set(ref) == set(r["grads"])  # convs get no actor gradient
+    for k, v in ref.items():
+        assert_close(r["grads"][k], v, 1e-5, "actor grad " + k)
+
+
+def test_soft_update_matches_reference():
+    g = load("tiny.npz")
+    critic, target = sub(g, "critic_after/"), sub(g, "state0/critic_target/")
+    O.soft_update(critic, target, 0.01, "Q1.")
+    O.soft_update(critic, target, 0.01, "Q2.")
+    O.soft_update(critic, target, 0.05, "encoder.")
+    for k, v in sub(g, "target_after/").items():
+        assert_close(target[k], v, 1e-6, "target " + k)
+
+
+def test_cpc_phase_matches_reference():
+    g = load("tiny.npz")
+    critic, target = sub(g, "critic_after/"), sub(g, "target_after/")
+    W = torch.from_numpy(g["state0/W"])
+    r = O.cpc_phase(critic, target, W, _f(g["batch/obs"]), _f(g["batch/pos"]), num_layers=4)
+    for k in ("z_a", "z_pos", "logits"):
+        assert_close(r[k], g[f"cpc/{k}"], 1e-5, k)
+    assert_close(r["loss"], g["scalar/train/curl_loss"], 1e-5, "curl loss")
+    ref = sub(g, "cpc/grad/")
+    assert len(ref) == 13
+    for k, v in ref.items():
+        got = r["W_grad"] if k == "W" else r["grads"][k]
+        assert_close(got, v, 2e-5, "cpc grad " + k)
+
+
+def test_acting_path_matches_reference():
+    g = load("tiny.npz")
+    actor, critic, _, _, _ = _state(g)
+    obs = O.center_crop(g["act/obs"], tuple(g["meta/out_hw"]))
+    x = _f(obs)[None]
+    mu, _, _, _ = O.actor_forward(actor, critic, x, None, compute_pi=False, compute_log_pi=False, **HP)
+    assert_close(mu.flatten(), g["act/select"], 1e-5, "select_action")
+    _, pi, _, _ = O.actor_forward(actor, critic, x, _f(g["act/noise"]), compute_log_pi=False, **HP)
+    assert_close(pi.flatten(), g["act/sample"], 1e-5, "sample_action")
+
+
+def test_full_shape_update_summaries():
+    """84x84 -> 76x76 (BASELINE config-1 geometry): weights regenerated from
+    the NumPy recipe, whole update() compared through per-tensor summaries."""
+    from tests.golden_recipes import c1shape_inputs
+    g = load("c1shape.npz")
+    inp = c1shape_inputs(g)
+    assert hashlib.sha256(inp["obs"].tobytes()).hexdigest() == str(g["batch/obs_sha256"])
+    actor, critic, target, W, la = inp["actor"], inp["critic"], inp["target"], inp["W"], inp["log_alpha"]
+    obs, nxt, pos = _f(inp["obs"]), _f(inp["next_obs"]), _f(inp["pos"])
+    act, rew, nd = _f(g["batch/action"]), _f(g["batch/reward"]), _f(g["batch/not_done"])
+    r = O.critic_phase(actor, critic, target, la, obs, act, rew, nxt, nd, _f(g["noise/critic"]), discount=0.99, **HP)
+    assert_close(r["loss"], g["scalar/train_critic/loss"], 1e-5, "critic loss")
+    for k in ("q1", "q2"):
+        assert_close(summarize(r[k]), g[f"sum/critic/{k}"], 1e-5, k)
+    for k, v in sub(g, "sum/critic/grad/", as_torch=False).items():
+        assert_close(summarize(r["grads"][k]), v, 2e-5, "critic grad " + k)
+    # chain the optimizer steps exactly as update() does to reach the later phases
+    ag = inp["agent"]
+    out = ag.update(obs, act, rew, nxt, nd, pos, _f(g["noise/critic"]), _f(g["noise/actor"]), step=0)
+    assert_close(out["actor_loss"], g["scalar/train_actor/loss"], 1e-5, "actor loss")
+    assert_close(out["alpha_loss"], g["scalar/train_alpha/loss"], 1e-5, "alpha loss")
+    assert_close(out["curl_loss"], g["scalar/train/curl_loss"], 1e-5, "curl loss")
