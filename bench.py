@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""Benchmark of the CURL+SAC learner hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one ``CurlSacAgent.update()`` (critic + [actor/alpha + target soft
+update on even steps] + CURL, curl_sac.py:426-451) on one per-GPU minibatch of
+512 transitions sampled from the HBM-resident replay ring (84x84x9 uint8 frames,
+random-crop to 76x76, encoder 4 layers x 32 filters, feature 50, hidden 1024) --
+BASELINE.json configs[1]; with N>1 every rank does the same on its own ring
+shard and the three gradient buckets are all-reduced over RCCL (weak scaling).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_TFLOPS = 157.3  # MI355X dense fp32 (vector == f32 MFMA), MI355X_MICROARCH.md chip table
+IN_HW, CROP_HW, FRAMES_C, BATCH, HIDDEN = (84, 84), (76, 76), 9, 512, 1024
+CAPACITY = 100_000
+
+
+def conv_layer_flops(hw_in, num_layers=4, nf=32, cin=FRAMES_C):
+    """Algorithmic FLOPs per sample of each conv layer (2*Ho*Wo*Cout*Cin*9), SURVEY.md 8d."""
+    h, w = (hw_in[0] - 3) // 2 + 1, (hw_in[1] - 3) // 2 + 1
+    out = [2.0 * h * w * nf * cin * 9]
+    for _ in range(num_layers - 1):
+        h, w = h - 2, w - 2
+        out.append(2.0 * h * w * nf * nf * 9)
+    return out
+
+
+class NullLogger:
+    def log(self, *a, **k):
+        pass
+
+    log_histogram = log_param = log_image = log
+
+
+def cpu_baseline(calls=4):
+    """The oracle (CPU restatement pinned to the reference) on the host cores:
+    a bounded sample of the same workload (same shapes, B=512)."""
+    from oracle import curla_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    rs = np.random.RandomState(0)
+    ag = O.OracleAgent((FRAMES_C,) + CROP_HW, (2,), hidden_dim=HIDDEN)
+    B = BATCH
+
+    def batch():
+        f = lambda: torch.from_numpy(rs.randint(0, 256, (B, FRAMES_C) + CROP_HW, dtype=np.uint8)).float()  # noqa: E731
+        return (f(), torch.from_numpy(rs.uniform(-1, 1, (B, 2)).astype(np.float32)),
+                torch.from_numpy(rs.randn(B, 1).astype(np.float32)), f(), torch.ones(B, 1), f(),
+                torch.randn(B, 2), torch.randn(B, 2))
+    ag.update(*batch(), step=0)  # warm-up
+    t0 = time.perf_counter()
+    for s in range(1, calls + 1):
+        ag.update(*batch(), step=s)
+    dt = time.perf_counter() - t0
+    return {"value": calls / dt, "unit": "batch-512 gradient updates/s", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{calls} OracleAgent.update() calls at B=512, 76x76x9, hidden 1024 "
+            f"(steps 1..{calls}, after 1 warm-up), torch {torch.__version__} CPU"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--capacity", type=int, default=CAPACITY)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import curla_amd
+    from curla_amd import ops
+
+    # identical parameters on every rank (same seed), rank-specific sampling streams
+    curla_amd.set_seed_everywhere(1)
+    aug = curla_amd.RandomCrop(IN_HW, CROP_HW)
+    agent = curla_amd.CurlSacAgent(
+        (FRAMES_C,) + CROP_HW, (2,), dev, aug, hidden_dim=HIDDEN, discount=0.99, init_temperature=0.1, alpha_lr=1e-4,
+        alpha_beta=0.5, actor_lr=1e-3, actor_beta=0.9, critic_lr=1e-3, critic_beta=0.9, critic_tau=0.01,
+        encoder_feature_dim=50, encoder_lr=1e-3, encoder_tau=0.05, num_layers=4, num_filters=32, log_interval=10 ** 9)
+    if distributed:
+        agent.enable_data_parallel()
+    curla_amd.set_seed_everywhere(1 + rank)
+
+    # replay ring shard, pre-filled on the device with i.i.d. uniform bytes (worst case for any compression)
+    cap = args.capacity // world
+    rb = curla_amd.ReplayBuffer((FRAMES_C,) + IN_HW, (2,), cap, BATCH, dev, aug)
+    g = torch.Generator(device=dev).manual_seed(rank)
+    for ring in (rb._obs_store, rb._next_store):
+        for s in range(0, ring.numel(), 1 << 28):
+            e = min(ring.numel(), s + (1 << 28))
+            ring[s:e] = torch.randint(0, 256, (e - s,), dtype=torch.uint8, device=dev, generator=g)
+    rb.actions.uniform_(-1, 1, generator=g)
+    rb.rewards.normal_(generator=g)
+    rb.not_dones.fill_(1.0)
+    rb.not_dones[49::50] = 0.0
+    rb.idx, rb.full = 0, True
+
+    L = NullLogger()
+    # HIP-event timing of the dominant kernel (stride-1 32->32 conv forward) on its own stream
+    flops = conv_layer_flops(CROP_HW)
+    ev_pairs = []
+    real_s1 = ops.conv_s1_fwd
+    recording = [False]
+
+    def timed_s1(x, w, b, out):
+        if not recording[0]:
+            return real_s1(x, w, b, out)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        real_s1(x, w, b, out)
+        e1.record()
+        ev_pairs.append((e0, e1, 2.0 * x.shape[0] * out.shape[1] * out.shape[2] * 32 * 32 * 9))
+    ops.conv_s1_fwd = timed_s1
+
+    def barrier():
+        if distributed:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    step = 0
+    for _ in range(args.warmup):
+        agent.update(rb, L, step)
+        step += 1
+    barrier()
+    recording[0] = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        agent.update(rb, L, step)
+        step += 1
+    barrier()
+    dt = time.perf_counter() - t0
+    recording[0] = False
+
+    if distributed:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        kflops = sum(p[2] for p in ev_pairs)
+        kms = sum(p[0].elapsed_time(p[1]) for p in ev_pairs)
+        achieved = kflops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
+        updates_per_s = world * args.steps / dt
+        per_update = BATCH * (5 * sum(flops) + 2 * (2 * sum(flops) - flops[0]))  # n_f=5, n_b=2
+        out = {
+            "metric": "SAC+CURL gradient updates/sec, batch=512 84x84x9",
+            "value": updates_per_s,
+            "unit": "batch-512 gradient updates/s (sum over ranks)",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: CurlSacAgent.update(), per-GPU batch 512, 84x84x9 uint8 "
+                                   "replay ring -> random_crop 76x76, encoder 4x32 filters feat 50, hidden 1024, "
+                                   "CURL+critic+actor (actor/target every 2nd step)",
+                       "replay_capacity": cap * world, "parallelism": f"dp{world}"},
+            "transitions_per_s": updates_per_s * BATCH,
+            "conv_algorithmic_gflop_per_update": per_update / 1e9,
+            "conv_roofline_frac_whole_update": per_update * (args.steps / dt) / (PEAK_F32_TFLOPS * 1e12),
+            "roofline": {"bound": "mfma", "kernel": "conv_s1_kernel<FWD> (3x3 s1 32->32 + bias + ReLU, f32 MFMA 16x16x4)",
+                         "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": None,
+                         "launches": len(ev_pairs), "avg_launch_ms": kms / max(1, len(ev_pairs))},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if distributed:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,103 @@
+"""ctypes binding of libcurla_hip.so (include/curla_hip.h).
+
+There is no fallback: if the library is missing or a kernel reports an error
+the call raises.  ``torch`` is used only to obtain device pointers and the
+current HIP stream handle.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcurla_hip.so")
+
+c_int, c_ll, c_float, c_size_t, vp = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/curla_hip.h
+SIGNATURES = {
+    "curla_conv1_fwd": [vp, c_int, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, vp],
+    "curla_conv3x3_s1_fwd": [vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp],
+    "curla_conv3x3_s1_dgrad": [vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp],
+    "curla_conv3x3_s1_wgrad": [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp],
+    "curla_conv1_wgrad": [vp, c_int, vp, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                          c_float, vp],
+    "curla_conv_wgrad_workspace_floats": [c_int],
+    "curla_gemm": [vp, c_int, c_int, c_ll, vp, c_int, c_int, c_ll, vp, c_int, c_ll, c_int, c_int, c_int, c_int, c_int,
+                   c_ll, c_float, vp, c_ll, c_int, vp, c_int, c_ll, vp],
+    "curla_splitk_reduce": [vp, c_int, c_ll, c_int, c_int, c_int, vp, c_int, vp, c_int, vp],
+    "curla_fc_ln_fwd": [vp, c_int, c_ll, c_int, vp, vp, vp, c_int, c_int, c_float, vp, vp, vp, vp, c_int, vp],
+    "curla_ln_bwd": [vp, vp, vp, vp, c_int, c_int, vp, vp, vp, vp],
+    "curla_colsum": [vp, c_int, c_int, c_int, c_ll, vp, c_ll, c_int, vp],
+    "curla_actor_head_fwd": [vp, vp, c_int, c_int, c_float, c_float, vp, vp, vp, vp, vp, vp],
+    "curla_actor_head_bwd": [vp, vp, vp, c_float, vp, vp, vp, vp, c_int, c_int, c_float, c_float, vp, vp],
+    "curla_concat": [vp, vp, c_int, c_int, c_int, vp, vp],
+    "curla_split_sum": [vp, c_ll, c_int, c_int, c_int, vp, vp, vp],
+    "curla_td_target": [vp, c_ll, vp, vp, vp, vp, c_float, c_int, vp, vp],
+    "curla_critic_loss": [vp, c_ll, vp, c_int, vp, vp, vp],
+    "curla_actor_loss": [vp, c_ll, vp, vp, c_int, vp, c_float, c_int, vp, vp, vp, vp],
+    "curla_curl_ce": [vp, c_int, c_int, vp, vp, vp, vp],
+    "curla_mean": [vp, c_int, vp, vp],
+    "curla_soft_update": [vp, vp, c_size_t, c_float, c_float, vp],
+    "curla_crop_nchw": [vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, vp],
+    "curla_store_frame": [vp, vp, c_ll, c_int, c_int, c_int, vp],
+    "curla_nhwc_to_nchw": [vp, vp, c_int, c_int, c_int, c_int, vp],
+    "curla_version": [],
+}
+_RESTYPES = {"curla_conv_wgrad_workspace_floats": c_size_t, "curla_version": ctypes.c_char_p}
+_ERRORS = {-1: "CURLA_ERR_ARG (bad pointer/size/alignment)", -2: "CURLA_ERR_LAUNCH (HIP launch failed)",
+           -3: "CURLA_ERR_UNSUPPORTED (shape not supported by the gfx950 kernels)"}
+
+
+class CurlaHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library; raises if it has not been built (python -m curla_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CurlaHipError(f"{LIB_PATH} is missing: build it with `python -m curla_amd.build` "
+                            "(there is no CPU/PyTorch fallback for the learner path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library drift apart
+        fn.argtypes = args
+        fn.restype = _RESTYPES.get(name, c_int)
+    _lib = lib
+    return lib
+
+
+_trace_hook = None
+
+
+def set_trace_hook(fn):
+    """Host-logic tests only: route every kernel call to ``fn(name, args)`` instead
+    of the library, to inspect the launch schedule on a machine without a GPU.
+    Nothing is computed while a hook is installed.  Pass None to remove it."""
+    global _trace_hook
+    _trace_hook = fn
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; raise on a non-zero status."""
+    if _trace_hook is not None:
+        _trace_hook(name, args)
+        return
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise CurlaHipError(f"{name} failed: {_ERRORS.get(rc, rc)}")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    if _trace_hook is not None:
+        return 0
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,41 @@
+"""Builds curla_amd/libcurla_hip.so (the C-ABI HIP library) in-tree with hipcc."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libcurla_hip.so")
+SOURCES = ["conv.hip", "gemm.hip", "heads.hip"]
+ARCH = "gfx950"  # MI355X only
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "curla_hip.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=False):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build_library(force="--force" in sys.argv, verbose=True))

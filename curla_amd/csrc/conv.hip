@@ -1,0 +1,772 @@
+// 3x3 convolution kernels of the CNNEncoder hot path, gfx950.
+//
+// Reference semantics: encoder.py:54-63 (Conv2d k=3, first layer stride 2, the
+// rest stride 1, no padding) + encoder.py:77-90 (obs/255, relu(conv)).  The
+// backward kernels are the autograd of those lines.
+//
+// Layout: activations are NHWC fp32 in HBM ([B][H][W][32]); conv weights stay
+// in the reference OIHW layout (they are nn.Parameters shared with Adam) and
+// are re-gathered into MFMA operand registers at kernel start.  Every inner
+// product runs on the exact-f32 matrix pipe (v_mfma_f32_16x16x4_f32), which has
+// the same 157 TFLOP/s roof as the fp32 vector pipe but needs one operand VGPR
+// per lane instead of 2 per FMA.  GEMM view of the forward:
+//   D[cout (16 per m-tile, 2 tiles)][pixel (16 per n-tile)] += W[cout][k] * X[k][pixel],
+//   k = (tap, cin).  A 512-thread workgroup stages a band of input rows in LDS
+// (pixel stride padded 32 -> 36 floats) and its 8 waves walk the band's
+// 16-pixel tiles; the next band is prefetched into registers while the MFMAs
+// of the current one run.
+#include "common.h"
+
+namespace {
+
+constexpr int kLdsPix = 36;   // floats per pixel in LDS (32 channels + 4 pad: conflict-free b128 reads)
+constexpr int kWStride = 289; // LDS row stride while re-gathering the OIHW weights
+constexpr int kMaxPf = 12;    // float4 prefetch registers per thread (band <= 512*12/8 = 768 pixels)
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+struct ConvS1Args {
+  const float* in;   // [B][Hs][Ws][32]
+  const float* w;    // OIHW [32][32][3][3]
+  const float* aux;  // FWD: bias[32]; DGRAD: activation below, [B][Ho][Wo][32] (ReLU mask)
+  float* out;        // [B][Ho][Wo][32]
+  int B, Hs, Ws, Ho, Wo, pad, th, nbands;
+};
+
+// ---------------------------------------------------------------------------
+// stride-1 32->32 conv: forward (bias+ReLU) and data-gradient (full correlation
+// with the flipped/transposed filter, ReLU mask of the layer below fused in).
+// ---------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void conv_s1_kernel(ConvS1Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int WT = a.Wo + 2;
+
+  // ---- weights -> registers (A operand).  A wave owns ONE 16-channel output
+  // tile (mt) for all its pixel tiles, so it keeps 72 weight registers, not 144;
+  // wave pairs (2p, 2p+1) share pixel tiles.  k-step (q,e) of tap t covers
+  // cin = 16q + 4kq' + e over the four lane groups kq'.
+  const int mt = wave & 1, tslot = wave >> 1;
+  for (int i = tid; i < 32 * 288; i += 512) {
+    int r = i / 288;
+    lds[r * kWStride + (i - r * 288)] = a.w[i];
+  }
+  __syncthreads();
+  float wr[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int co = mt * 16 + li;
+      const int ci = 16 * (s >> 2) + 4 * kq + (s & 3);
+      wr[t][s] = (MODE == MODE_FWD) ? lds[co * kWStride + ci * 9 + t] : lds[ci * kWStride + co * 9 + (8 - t)];
+    }
+  f32x4 bias4 = {0, 0, 0, 0};
+  if (MODE == MODE_FWD) bias4 = *reinterpret_cast<const f32x4*>(a.aux + mt * 16 + 4 * kq);
+  __syncthreads();
+
+  const int nitems = a.B * a.nbands;
+  f32x4 pf[kMaxPf];
+
+  auto issue = [&](int item) {
+    const int b = item / a.nbands, band = item - b * a.nbands;
+    const int y0 = band * a.th;
+    const int rows = min(a.th, a.Ho - y0) + 2;
+    const int n4 = rows * WT * 8;
+#pragma unroll
+    for (int u = 0; u < kMaxPf; ++u) {
+      const int f = tid + u * 512;
+      f32x4 v = {0, 0, 0, 0};
+      if (f < n4) {
+        const int pix = f >> 3, ch = f & 7;
+        const int r = pix / WT, c = pix - r * WT;
+        const int sy = y0 + r - a.pad, sx = c - a.pad;
+        if (sy >= 0 && sy < a.Hs && sx >= 0 && sx < a.Ws)
+          v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(b * a.Hs + sy) * a.Ws + sx) * 32 + ch * 4);
+      }
+      pf[u] = v;
+    }
+  };
+  auto commit = [&](int item) {
+    const int b = item / a.nbands, band = item - b * a.nbands;
+    const int rows = min(a.th, a.Ho - band * a.th) + 2;
+    const int n4 = rows * WT * 8;
+#pragma unroll
+    for (int u = 0; u < kMaxPf; ++u) {
+      const int f = tid + u * 512;
+      if (f < n4) *reinterpret_cast<f32x4*>(lds + (f >> 3) * kLdsPix + (f & 7) * 4) = pf[u];
+    }
+  };
+
+  int item = blockIdx.x;
+  if (item < nitems) issue(item);
+  while (item < nitems) {
+    commit(item);
+    __syncthreads();
+    const int next = item + gridDim.x;
+    if (next < nitems) issue(next);
+
+    const int b = item / a.nbands, band = item - b * a.nbands;
+    const int y0 = band * a.th;
+    const int npix = min(a.th, a.Ho - y0) * a.Wo;
+    const int ntiles = (npix + 15) >> 4;
+    for (int t = tslot; t < ntiles; t += 4) {
+      const int p = t * 16 + li;
+      const bool pv = p < npix;
+      const int pc = pv ? p : 0;
+      const int ty = pc / a.Wo, x = pc - ty * a.Wo;
+      const float* base = lds + (ty * WT + x) * kLdsPix + 4 * kq;
+      // two accumulation chains so dependent MFMAs never wait on each other
+      f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float* ptr = base + (dy * WT + dx) * kLdsPix;
+          const f32x4 b0 = *reinterpret_cast<const f32x4*>(ptr);
+          const f32x4 b1 = *reinterpret_cast<const f32x4*>(ptr + 16);
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            acc0 = mfma16(wr[dy * 3 + dx][e], b0[e], acc0);
+            acc1 = mfma16(wr[dy * 3 + dx][e + 1], b0[e + 1], acc1);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; e += 2) {
+            acc0 = mfma16(wr[dy * 3 + dx][4 + e], b1[e], acc0);
+            acc1 = mfma16(wr[dy * 3 + dx][5 + e], b1[e + 1], acc1);
+          }
+        }
+      if (pv) {
+        const size_t g = ((size_t)(b * a.Ho + y0 + ty) * a.Wo + x) * 32 + mt * 16 + 4 * kq;
+        f32x4 v = acc0 + acc1;
+        if (MODE == MODE_FWD) {
+          v += bias4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        } else {
+          const f32x4 m = *reinterpret_cast<const f32x4*>(a.aux + g);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = m[r] > 0.f ? v[r] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(a.out + g) = v;
+      }
+    }
+    __syncthreads();
+    item = next;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// first layer: Cin = C (9 or 12 ...), stride 2, input either the uint8 replay
+// frames (gather by index + random-crop offsets + /255 fused into the load) or
+// a float NCHW tensor in [0,255] (the reference's tensor contract).
+// K index of the GEMM is k = dy*KR + (dx*C + c), KR = 3C rounded up to 4; the
+// (dx,c) run is contiguous in an HWC row, so one LDS row holds it directly.
+// ---------------------------------------------------------------------------
+struct Conv1Args {
+  const void* src;     // SRC_U8: frames [N][Hs][Ws][C] u8;  SRC_F32: [B][C][Hc][Wc] f32
+  const int64_t* idx;  // [B] frame index (u8 source) or nullptr -> b
+  const int32_t* h1;   // [B] crop row offset or nullptr -> 0
+  const int32_t* w1;   // [B] crop col offset or nullptr -> 0
+  const float* w;      // OIHW [32][C][3][3]
+  const float* bias;   // [32]
+  float* out;          // [B][Ho][Wo][32]
+  int B, C, Hs, Ws, Hc, Wc, Ho, Wo, th, nbands;
+  float scale;
+};
+
+enum { SRC_U8 = 0, SRC_F32 = 1 };
+
+__device__ __forceinline__ int conv1_row_stride(int Wc, int C) { return ((Wc * C + 3) & ~3) + 4; }
+
+// Stage input rows [r0, r0+rows) of sample b's (cropped) image into LDS as
+// f32 HWC rows of stride RS, scaled by `scale`.
+template <int SRC>
+__device__ __forceinline__ void conv1_stage(float* lds, const void* src, const int64_t* idx, const int32_t* h1,
+                                            const int32_t* w1, int b, int C, int Hs, int Ws, int Hc, int Wc, int r0,
+                                            int rows, int RS, float scale, int tid, int nthreads) {
+  const int rowf = Wc * C;
+  if (SRC == SRC_U8) {
+    const int64_t fi = idx ? idx[b] : b;
+    const int oh = h1 ? h1[b] : 0, ow = w1 ? w1[b] : 0;
+    const uint8_t* frame = static_cast<const uint8_t*>(src) + (size_t)fi * Hs * Ws * C;
+    const int G = (rowf + 3) >> 2;
+    for (int i = tid; i < rows * G; i += nthreads) {
+      const int r = i / G, g = i - r * G;
+      const uint8_t* p = frame + ((size_t)(oh + r0 + r) * Ws + ow) * C + 4 * g;
+      const uintptr_t ad = reinterpret_cast<uintptr_t>(p);
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(ad & ~(uintptr_t)3);
+      const uint32_t sh = (uint32_t)(ad & 3);
+      const uint32_t d0 = q[0];
+      const uint32_t d1 = sh ? q[1] : 0u;   // only touch the next dword when the run straddles it
+      const uint32_t v = __builtin_amdgcn_alignbyte(d1, d0, sh);
+      f32x4 o;
+      o[0] = (float)(v & 0xff) * scale;
+      o[1] = (float)((v >> 8) & 0xff) * scale;
+      o[2] = (float)((v >> 16) & 0xff) * scale;
+      o[3] = (float)(v >> 24) * scale;
+      *reinterpret_cast<f32x4*>(lds + r * RS + 4 * g) = o;
+    }
+  } else {
+    const float* img = static_cast<const float*>(src) + (size_t)b * C * Hc * Wc;
+    const int n = rows * rowf;
+    for (int i = tid; i < n; i += nthreads) {
+      const int x = i % Wc;
+      const int t = i / Wc;
+      const int r = t % rows, c = t / rows;
+      lds[r * RS + x * C + c] = img[((size_t)c * Hc + r0 + r) * Wc + x] * scale;
+    }
+  }
+}
+
+template <int SRC, int C>
+__global__ __launch_bounds__(512) void conv1_fwd_kernel(Conv1Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int KR = (3 * C + 3) & ~3;
+  constexpr int NS = 3 * KR / 4;  // k-steps
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int RS = conv1_row_stride(a.Wc, C);
+
+  for (int i = tid; i < 32 * C * 9; i += 512) lds[i] = a.w[i];
+  __syncthreads();
+  float wr[NS][2];
+  int koff[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int k = 4 * s + kq;
+    const int dy = k / KR, rr = k - dy * KR;
+    koff[s] = dy * RS + rr;
+    const bool ok = rr < 3 * C;
+    const int dx = ok ? rr / C : 0, c = ok ? rr - dx * C : 0;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) wr[s][mt] = ok ? lds[((mt * 16 + li) * C + c) * 9 + dy * 3 + dx] : 0.f;
+  }
+  f32x4 bias4[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) bias4[mt] = *reinterpret_cast<const f32x4*>(a.bias + mt * 16 + 4 * kq);
+  __syncthreads();
+
+  const int item = blockIdx.x;
+  const int b = item / a.nbands, band = item - b * a.nbands;
+  const int y0 = band * a.th;
+  const int tha = min(a.th, a.Ho - y0);
+  conv1_stage<SRC>(lds, a.src, a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Hc, a.Wc, 2 * y0, 2 * tha + 1, RS, a.scale, tid,
+                   512);
+  __syncthreads();
+
+  const int npix = tha * a.Wo;
+  const int ntiles = (npix + 15) >> 4;
+  for (int t = wave; t < ntiles; t += 8) {
+    const int p = t * 16 + li;
+    const bool pv = p < npix;
+    const int pc = pv ? p : 0;
+    const int ty = pc / a.Wo, x = pc - ty * a.Wo;
+    const float* base = lds + 2 * ty * RS + 2 * x * C;
+    f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float bv = base[koff[s]];
+      acc[0] = mfma16(wr[s][0], bv, acc[0]);
+      acc[1] = mfma16(wr[s][1], bv, acc[1]);
+    }
+    if (pv) {
+      const size_t g = ((size_t)(b * a.Ho + y0 + ty) * a.Wo + x) * 32 + 4 * kq;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        f32x4 v = acc[mt] + bias4[mt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        *reinterpret_cast<f32x4*>(a.out + g + mt * 16) = v;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient, stride-1 32->32:  dW[co][ci][tap] = sum_pixels g[p][co] * in[p+tap][ci]
+// GEMM view: D[co][ci] per tap, K = pixels (4 per MFMA).  36 accumulator tiles
+// (2 x 2 x 9) live in registers for the whole persistent workgroup; partial
+// sums leave through one slab per workgroup and a deterministic second pass.
+// ---------------------------------------------------------------------------
+struct WgradS1Args {
+  const float* in;  // [B][Hi][Wi][32]
+  const float* g;   // [B][Ho][Wo][32]
+  float* partial;   // [grid][kPartial]
+  int B, Hi, Wi, Ho, Wo, th, nbands;
+};
+constexpr int kPartialS1 = 32 * 288 + 32;
+
+__global__ __launch_bounds__(512, 2) void wgrad_s1_kernel(WgradS1Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  f32x4 acc[2][2][9];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[i][j][t] = f32x4{0, 0, 0, 0};
+  float bsum[2] = {0.f, 0.f};
+
+  const int nitems = a.B * a.nbands;
+  f32x4 pf[kMaxPf];
+  // band = (tha+2) input rows followed by tha gradient rows, both contiguous in HBM
+  auto issue = [&](int item) {
+    const int b = item / a.nbands, band = item - b * a.nbands;
+    const int y0 = band * a.th;
+    const int tha = min(a.th, a.Ho - y0);
+    const int nin = (tha + 2) * a.Wi * 8, ng = tha * a.Wo * 8;
+    const float* pin = a.in + ((size_t)(b * a.Hi + y0) * a.Wi) * 32;
+    const float* pg = a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
+#pragma unroll
+    for (int u = 0; u < kMaxPf; ++u) {
+      const int f = tid + u * 512;
+      f32x4 v = {0, 0, 0, 0};
+      if (f < nin)
+        v = *reinterpret_cast<const f32x4*>(pin + (size_t)f * 4);
+      else if (f < nin + ng)
+        v = *reinterpret_cast<const f32x4*>(pg + (size_t)(f - nin) * 4);
+      pf[u] = v;
+    }
+  };
+  auto commit = [&](int item) {
+    const int b = item / a.nbands, band = item - b * a.nbands;
+    const int tha = min(a.th, a.Ho - band * a.th);
+    const int nin = (tha + 2) * a.Wi * 8, ng = tha * a.Wo * 8;
+#pragma unroll
+    for (int u = 0; u < kMaxPf; ++u) {
+      const int f = tid + u * 512;
+      if (f < nin + ng) *reinterpret_cast<f32x4*>(lds + (f >> 3) * kLdsPix + (f & 7) * 4) = pf[u];
+    }
+  };
+
+  int item = blockIdx.x;
+  if (item < nitems) issue(item);
+  while (item < nitems) {
+    commit(item);
+    __syncthreads();
+    const int next = item + gridDim.x;
+    if (next < nitems) issue(next);
+
+    const int band = item % a.nbands;
+    const int tha = min(a.th, a.Ho - band * a.th);
+    const int npix = tha * a.Wo;
+    const float* ldsg = lds + (tha + 2) * a.Wi * kLdsPix;
+    const int nunits = (npix + 3) >> 2;  // 4 pixels per MFMA k-step
+    for (int u = wave; u < nunits; u += 8) {
+      // pixels of a k-step are 4 apart so the two lane groups of an LDS half hit disjoint banks
+      const int p = (u >> 2) * 16 + (u & 3) + 4 * kq;
+      const bool pv = p < npix;
+      const int pc = pv ? p : 0;
+      const int ty = pc / a.Wo, x = pc - ty * a.Wo;
+      const float* gp = ldsg + (ty * a.Wo + x) * kLdsPix + li;
+      const float a0 = pv ? gp[0] : 0.f, a1 = pv ? gp[16] : 0.f;
+      bsum[0] += a0;
+      bsum[1] += a1;
+      const float* ip = lds + (ty * a.Wi + x) * kLdsPix + li;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const float* q = ip + (dy * a.Wi + dx) * kLdsPix;
+          const float b0 = q[0], b1 = q[16];
+          const int t = dy * 3 + dx;
+          acc[0][0][t] = mfma16(a0, b0, acc[0][0][t]);
+          acc[0][1][t] = mfma16(a0, b1, acc[0][1][t]);
+          acc[1][0][t] = mfma16(a1, b0, acc[1][0][t]);
+          acc[1][1][t] = mfma16(a1, b1, acc[1][1][t]);
+        }
+    }
+    __syncthreads();
+    item = next;
+  }
+
+  // cross-wave sum in a fixed order (deterministic), then one slab per workgroup
+  bsum[0] += __shfl_xor(bsum[0], 16);
+  bsum[0] += __shfl_xor(bsum[0], 32);
+  bsum[1] += __shfl_xor(bsum[1], 16);
+  bsum[1] += __shfl_xor(bsum[1], 32);
+  for (int w = 0; w < 8; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+          for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int co = mt * 16 + 4 * kq + r, ci = ct * 16 + li;
+              float* d = lds + co * 288 + ci * 9 + t;
+              *d = (w == 0) ? acc[mt][ct][t][r] : *d + acc[mt][ct][t][r];
+            }
+      if (kq == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          float* d = lds + 32 * 288 + mt * 16 + li;
+          *d = (w == 0) ? bsum[mt] : *d + bsum[mt];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* slab = a.partial + (size_t)blockIdx.x * kPartialS1;
+  for (int i = tid; i < kPartialS1; i += 512) slab[i] = lds[i];
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient of the first layer (stride 2, Cin = C, input re-read from
+// the uint8 frames / float tensor exactly as the forward does).
+// D[co][k'] with k' = dy*KR + dx*C + c (the forward's K index), K = pixels.
+// ---------------------------------------------------------------------------
+struct Wgrad1Args {
+  const void* src;
+  const int64_t* idx;
+  const int32_t* h1;
+  const int32_t* w1;
+  const float* g;  // [B][Ho][Wo][32]
+  float* partial;  // [grid][32*C*9 + 32]
+  int B, C, Hs, Ws, Hc, Wc, Ho, Wo, th, nbands;
+  float scale;
+};
+
+template <int SRC, int C>
+__global__ __launch_bounds__(512) void wgrad1_kernel(Wgrad1Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int KR = (3 * C + 3) & ~3;
+  constexpr int NT = (3 * KR + 15) / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int RS = conv1_row_stride(a.Wc, C);
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
+  float bsum[2] = {0.f, 0.f};
+  int koff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int k = t * 16 + li;
+    const int dy = k / KR, rr = k - dy * KR;
+    koff[t] = (dy < 3) ? dy * RS + rr : 0;
+  }
+
+  const int nitems = a.B * a.nbands;
+  const int in_floats = (2 * a.th + 1) * RS;  // LDS offset of the gradient band
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int b = item / a.nbands, band = item - b * a.nbands;
+    const int y0 = band * a.th;
+    const int tha = min(a.th, a.Ho - y0);
+    conv1_stage<SRC>(lds, a.src, a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Hc, a.Wc, 2 * y0, 2 * tha + 1, RS, a.scale,
+                     tid, 512);
+    {
+      const float* pg = a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
+      const int ng = tha * a.Wo * 8;
+      for (int f = tid; f < ng; f += 512)
+        *reinterpret_cast<f32x4*>(lds + in_floats + (f >> 3) * kLdsPix + (f & 7) * 4) =
+            *reinterpret_cast<const f32x4*>(pg + (size_t)f * 4);
+    }
+    __syncthreads();
+    const int npix = tha * a.Wo;
+    const int nunits = (npix + 3) >> 2;
+    for (int u = wave; u < nunits; u += 8) {
+      const int p = (u >> 2) * 16 + (u & 3) + 4 * kq;
+      const bool pv = p < npix;
+      const int pc = pv ? p : 0;
+      const int ty = pc / a.Wo, x = pc - ty * a.Wo;
+      const float* gp = lds + in_floats + (ty * a.Wo + x) * kLdsPix + li;
+      const float a0 = pv ? gp[0] : 0.f, a1 = pv ? gp[16] : 0.f;
+      bsum[0] += a0;
+      bsum[1] += a1;
+      const float* ip = lds + 2 * ty * RS + 2 * x * C;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float bv = ip[koff[t]];
+        acc[0][t] = mfma16(a0, bv, acc[0][t]);
+        acc[1][t] = mfma16(a1, bv, acc[1][t]);
+      }
+    }
+    __syncthreads();
+  }
+
+  bsum[0] += __shfl_xor(bsum[0], 16);
+  bsum[0] += __shfl_xor(bsum[0], 32);
+  bsum[1] += __shfl_xor(bsum[1], 16);
+  bsum[1] += __shfl_xor(bsum[1], 32);
+  const int nw = 32 * C * 9;
+  for (int w = 0; w < 8; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int k = t * 16 + li;
+          const int dy = k / KR, rr = k - dy * KR;
+          if (dy < 3 && rr < 3 * C) {
+            const int dx = rr / C, c = rr - dx * C;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int co = mt * 16 + 4 * kq + r;
+              float* d = lds + (co * C + c) * 9 + dy * 3 + dx;
+              *d = (w == 0) ? acc[mt][t][r] : *d + acc[mt][t][r];
+            }
+          }
+        }
+      if (kq == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          float* d = lds + nw + mt * 16 + li;
+          *d = (w == 0) ? bsum[mt] : *d + bsum[mt];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* slab = a.partial + (size_t)blockIdx.x * (nw + 32);
+  for (int i = tid; i < nw + 32; i += 512) slab[i] = lds[i];
+}
+
+// second pass: dW = sum over workgroup slabs, in slab order
+__global__ void wgrad_reduce_kernel(const float* partial, int nslabs, int nw, float* dw, float* db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nw + 32) return;
+  float s = 0.f;
+  for (int k = 0; k < nslabs; ++k) s += partial[(size_t)k * (nw + 32) + i];
+  if (i < nw)
+    dw[i] = s;
+  else
+    db[i - nw] = s;
+}
+
+// ------------------------------ host-side planning ------------------------------
+constexpr int kMaxLds = 160 * 1024;
+
+// rows per band for the prefetching stride-1 kernels: the band must fit the
+// prefetch registers (768 pixels); among the fitting values pick the one
+// that wastes the fewest 16-pixel tile slots over the 8 waves.
+int plan_band_s1(int Ho, int Wo, int px_per_row_extra, int budget_px, int unit_px, int nslots) {
+  int best = 1;
+  double best_eff = -1.0;
+  for (int th = 1; th <= Ho; ++th) {
+    const int px = (th + 2) * (Wo + 2) + px_per_row_extra * th;
+    if (px > budget_px) break;
+    const int nb = (Ho + th - 1) / th;
+    double work = 0, slots = 0;
+    for (int bnd = 0; bnd < nb; ++bnd) {
+      const int tha = (bnd == nb - 1) ? Ho - bnd * th : th;
+      const int tiles = (tha * Wo + unit_px - 1) / unit_px;
+      work += tha * Wo / (double)unit_px;
+      slots += ((tiles + nslots - 1) / nslots) * nslots;
+    }
+    // halo rows are re-read per band: mild preference for taller bands
+    const double eff = work / slots * (double)th / (th + 2 + 4);
+    if (eff > best_eff) best_eff = eff, best = th;
+  }
+  return best;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+  if (bytes > (size_t)kMaxLds) return CURLA_ERR_UNSUPPORTED;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)bytes) != hipSuccess)
+    return CURLA_ERR_LAUNCH;
+  return CURLA_OK;
+}
+
+int launch_conv_s1(int mode, const float* in, const float* w, const float* aux, float* out, int B, int Hs, int Ws,
+                   hipStream_t st) {
+  ConvS1Args a;
+  a.in = in, a.w = w, a.aux = aux, a.out = out;
+  a.B = B, a.Hs = Hs, a.Ws = Ws;
+  a.pad = mode == MODE_FWD ? 0 : 2;
+  a.Ho = mode == MODE_FWD ? Hs - 2 : Hs + 2;
+  a.Wo = mode == MODE_FWD ? Ws - 2 : Ws + 2;
+  if (a.Ho <= 0 || a.Wo <= 0 || (a.Wo + 2) * 3 > 512 * kMaxPf / 8) return CURLA_ERR_UNSUPPORTED;
+  a.th = plan_band_s1(a.Ho, a.Wo, 0, 512 * kMaxPf / 8, 16, 4);
+  a.nbands = (a.Ho + a.th - 1) / a.th;
+  size_t lds = (size_t)(a.th + 2) * (a.Wo + 2) * kLdsPix * sizeof(float);
+  const size_t wl = (size_t)32 * kWStride * sizeof(float);
+  if (lds < wl) lds = wl;
+  const int nitems = B * a.nbands;
+  const int grid = nitems < curla_cu_count() ? nitems : curla_cu_count();
+  int rc;
+  if (mode == MODE_FWD) {
+    if ((rc = set_lds(conv_s1_kernel<MODE_FWD>, lds)) != CURLA_OK) return rc;
+    hipLaunchKernelGGL(conv_s1_kernel<MODE_FWD>, dim3(grid), dim3(512), lds, st, a);
+  } else {
+    if ((rc = set_lds(conv_s1_kernel<MODE_DGRAD>, lds)) != CURLA_OK) return rc;
+    hipLaunchKernelGGL(conv_s1_kernel<MODE_DGRAD>, dim3(grid), dim3(512), lds, st, a);
+  }
+  return curla_launch_status();
+}
+
+int plan_band_conv1(int Ho, int Wo, int Wc, int C, int g_px_per_row, size_t lds_budget) {
+  const int RS = ((Wc * C + 3) & ~3) + 4;
+  int best = 1;
+  double best_eff = -1.0;
+  for (int th = 1; th <= Ho; ++th) {
+    const size_t bytes = ((size_t)(2 * th + 1) * RS + (size_t)g_px_per_row * th * kLdsPix) * sizeof(float);
+    if (bytes > lds_budget) break;
+    const int nb = (Ho + th - 1) / th;
+    double work = 0, slots = 0;
+    for (int bnd = 0; bnd < nb; ++bnd) {
+      const int tha = (bnd == nb - 1) ? Ho - bnd * th : th;
+      const int tiles = (tha * Wo + 15) / 16;
+      work += tha * Wo / 16.0;
+      slots += ((tiles + 7) / 8) * 8;
+    }
+    const double eff = work / slots * (2.0 * th) / (2.0 * th + 1 + 2);
+    if (eff > best_eff) best_eff = eff, best = th;
+  }
+  return best;
+}
+
+}  // namespace
+
+// ------------------------------------ C ABI ------------------------------------
+extern "C" {
+
+int curla_conv3x3_s1_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Hi, int Wi,
+                         int channels, void* stream) {
+  CURLA_REQUIRE(in && w && bias && out && B > 0 && Hi >= 3 && Wi >= 3);
+  if (channels != 32) return CURLA_ERR_UNSUPPORTED;
+  CURLA_REQUIRE(aligned16(in) && aligned16(out) && aligned16(bias));
+  return launch_conv_s1(MODE_FWD, in, w, bias, out, B, Hi, Wi, static_cast<hipStream_t>(stream));
+}
+
+int curla_conv3x3_s1_dgrad(const float* g, const float* w, const float* act_below, float* gin, int B, int Ho, int Wo,
+                           int channels, void* stream) {
+  CURLA_REQUIRE(g && w && act_below && gin && B > 0 && Ho >= 1 && Wo >= 1);
+  if (channels != 32) return CURLA_ERR_UNSUPPORTED;
+  CURLA_REQUIRE(aligned16(g) && aligned16(gin) && aligned16(act_below));
+  return launch_conv_s1(MODE_DGRAD, g, w, act_below, gin, B, Ho, Wo, static_cast<hipStream_t>(stream));
+}
+
+static int conv1_common_check(const void* src, int src_is_u8, int B, int C, int Hs, int Ws, int Hc, int Wc,
+                              const int32_t* h1, const int32_t* w1) {
+  CURLA_REQUIRE(src && B > 0 && Hc >= 3 && Wc >= 3);
+  if (C != 9 && C != 12 && C != 3) return CURLA_ERR_UNSUPPORTED;
+  if (src_is_u8) {
+    CURLA_REQUIRE(Hs >= Hc && Ws >= Wc);
+    // dword-aligned frame starts are what the byte-aligning loader assumes
+    CURLA_REQUIRE(((size_t)Hs * Ws * C) % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0);
+    (void)h1, (void)w1;
+  }
+  return CURLA_OK;
+}
+
+#define CURLA_DISPATCH_C(C, SRCU8, KERNEL, ...)                                   \
+  do {                                                                            \
+    if ((C) == 9) {                                                               \
+      if (SRCU8) { KERNEL(SRC_U8, 9, __VA_ARGS__); } else { KERNEL(SRC_F32, 9, __VA_ARGS__); } \
+    } else if ((C) == 12) {                                                       \
+      if (SRCU8) { KERNEL(SRC_U8, 12, __VA_ARGS__); } else { KERNEL(SRC_F32, 12, __VA_ARGS__); } \
+    } else {                                                                      \
+      if (SRCU8) { KERNEL(SRC_U8, 3, __VA_ARGS__); } else { KERNEL(SRC_F32, 3, __VA_ARGS__); } \
+    }                                                                             \
+  } while (0)
+
+#define CONV1_FWD_LAUNCH(SRC, CC, grid, lds, st, a)                                       \
+  {                                                                                       \
+    rc = set_lds(conv1_fwd_kernel<SRC, CC>, lds);                                         \
+    if (rc == CURLA_OK) hipLaunchKernelGGL((conv1_fwd_kernel<SRC, CC>), dim3(grid), dim3(512), lds, st, a); \
+  }
+
+int curla_conv1_fwd(const void* src, int src_is_u8, const int64_t* idx, const int32_t* h1, const int32_t* w1,
+                    const float* w, const float* bias, float* out, int B, int C, int Hs, int Ws, int Hc, int Wc,
+                    int channels, float scale, void* stream) {
+  CURLA_REQUIRE(w && bias && out);
+  if (channels != 32) return CURLA_ERR_UNSUPPORTED;
+  int rc = conv1_common_check(src, src_is_u8, B, C, Hs, Ws, Hc, Wc, h1, w1);
+  if (rc != CURLA_OK) return rc;
+  Conv1Args a;
+  a.src = src, a.idx = idx, a.h1 = h1, a.w1 = w1, a.w = w, a.bias = bias, a.out = out;
+  a.B = B, a.C = C, a.Hs = Hs, a.Ws = Ws, a.Hc = Hc, a.Wc = Wc;
+  a.Ho = (Hc - 3) / 2 + 1, a.Wo = (Wc - 3) / 2 + 1;
+  a.scale = scale;
+  // two workgroups per CU so one stages while the other computes
+  a.th = plan_band_conv1(a.Ho, a.Wo, Wc, C, 0, 76 * 1024);
+  a.nbands = (a.Ho + a.th - 1) / a.th;
+  const int RS = ((Wc * C + 3) & ~3) + 4;
+  size_t lds = ((size_t)(2 * a.th + 1) * RS + 8) * sizeof(float);
+  const size_t wl = (size_t)32 * C * 9 * sizeof(float);
+  if (lds < wl) lds = wl;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int grid = B * a.nbands;
+  CURLA_DISPATCH_C(C, src_is_u8, CONV1_FWD_LAUNCH, grid, lds, st, a);
+  if (rc != CURLA_OK) return rc;
+  return curla_launch_status();
+}
+
+// workspace (floats) the weight-gradient kernels need for their per-workgroup slabs
+size_t curla_conv_wgrad_workspace_floats(int cin) {
+  return (size_t)curla_cu_count() * ((size_t)32 * cin * 9 + 32);
+}
+
+int curla_conv3x3_s1_wgrad(const float* in, const float* g, float* dw, float* db, float* workspace, int B, int Hi,
+                           int Wi, int channels, void* stream) {
+  CURLA_REQUIRE(in && g && dw && db && workspace && B > 0 && Hi >= 3 && Wi >= 3);
+  if (channels != 32) return CURLA_ERR_UNSUPPORTED;
+  CURLA_REQUIRE(aligned16(in) && aligned16(g));
+  WgradS1Args a;
+  a.in = in, a.g = g, a.partial = workspace;
+  a.B = B, a.Hi = Hi, a.Wi = Wi, a.Ho = Hi - 2, a.Wo = Wi - 2;
+  if ((a.Wo + 2) * 3 + a.Wo > 512 * kMaxPf / 8) return CURLA_ERR_UNSUPPORTED;
+  a.th = plan_band_s1(a.Ho, a.Wo, a.Wo, 512 * kMaxPf / 8, 4, 8);
+  a.nbands = (a.Ho + a.th - 1) / a.th;
+  size_t lds = (size_t)((a.th + 2) * Wi + a.th * a.Wo) * kLdsPix * sizeof(float);
+  if (lds < kPartialS1 * sizeof(float)) lds = kPartialS1 * sizeof(float);
+  const int nitems = B * a.nbands;
+  const int grid = nitems < curla_cu_count() ? nitems : curla_cu_count();
+  int rc = set_lds(wgrad_s1_kernel, lds);
+  if (rc != CURLA_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(wgrad_s1_kernel, dim3(grid), dim3(512), lds, st, a);
+  if ((rc = curla_launch_status()) != CURLA_OK) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kPartialS1 + 255) / 256), dim3(256), 0, st, workspace, grid, 32 * 288,
+                     dw, db);
+  return curla_launch_status();
+}
+
+#define WGRAD1_LAUNCH(SRC, CC, grid, lds, st, a)                                        \
+  {                                                                                     \
+    rc = set_lds(wgrad1_kernel<SRC, CC>, lds);                                          \
+    if (rc == CURLA_OK) hipLaunchKernelGGL((wgrad1_kernel<SRC, CC>), dim3(grid), dim3(512), lds, st, a); \
+  }
+
+int curla_conv1_wgrad(const void* src, int src_is_u8, const int64_t* idx, const int32_t* h1, const int32_t* w1,
+                      const float* g, float* dw, float* db, float* workspace, int B, int C, int Hs, int Ws, int Hc,
+                      int Wc, int channels, float scale, void* stream) {
+  CURLA_REQUIRE(g && dw && db && workspace);
+  if (channels != 32) return CURLA_ERR_UNSUPPORTED;
+  int rc = conv1_common_check(src, src_is_u8, B, C, Hs, Ws, Hc, Wc, h1, w1);
+  if (rc != CURLA_OK) return rc;
+  CURLA_REQUIRE(aligned16(g));
+  Wgrad1Args a;
+  a.src = src, a.idx = idx, a.h1 = h1, a.w1 = w1, a.g = g, a.partial = workspace;
+  a.B = B, a.C = C, a.Hs = Hs, a.Ws = Ws, a.Hc = Hc, a.Wc = Wc;
+  a.Ho = (Hc - 3) / 2 + 1, a.Wo = (Wc - 3) / 2 + 1;
+  a.scale = scale;
+  a.th = plan_band_conv1(a.Ho, a.Wo, Wc, C, a.Wo, 150 * 1024);
+  a.nbands = (a.Ho + a.th - 1) / a.th;
+  const int RS = ((Wc * C + 3) & ~3) + 4;
+  const int nw = 32 * C * 9;
+  size_t lds = ((size_t)(2 * a.th + 1) * RS + (size_t)a.th * a.Wo * kLdsPix + 8) * sizeof(float);
+  if (lds < (size_t)(nw + 32) * sizeof(float)) lds = (size_t)(nw + 32) * sizeof(float);
+  const int nitems = B * a.nbands;
+  const int grid = nitems < curla_cu_count() ? nitems : curla_cu_count();
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  CURLA_DISPATCH_C(C, src_is_u8, WGRAD1_LAUNCH, grid, lds, st, a);
+  if (rc != CURLA_OK) return rc;
+  if ((rc = curla_launch_status()) != CURLA_OK) return rc;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nw + 32 + 255) / 256), dim3(256), 0, st, workspace, grid, nw, dw, db);
+  return curla_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,219 @@
+// Batched fp32 GEMM on the exact-f32 matrix pipe (v_mfma_f32_16x16x4_f32) with
+// fused epilogues.  Serves every dense layer of the path: encoder fc
+// (encoder.py:66,98) forward/backward, the actor trunk and twin-Q MLPs
+// (curl_sac.py:70-74,129-133) and the CURL bilinear logits
+// z_a (W z_pos^T) (curl_sac.py:219-220) with their backward products.
+//
+//   C[z][m][n] = epilogue( alpha * sum_k opA(A)[m][k] * opB(B)[n][k] )
+//   opA: row-major A[m*lda + k]   or k-major A[k*lda + m]   (transposed operand)
+//   opB: row-major B[n*ldb + k]   or k-major B[k*ldb + n]
+//   epilogue: + bias[n], ReLU, zero where mask[m][n] <= 0 (ReLU backward).
+// grid.z enumerates batch x split-K; a split writes its partial product to
+// C + split * split_stride and the caller reduces (deterministic order).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 32;
+constexpr int RSTR = BK + 1;   // LDS stride, row-major tile [64][BK]
+constexpr int KSTR = BM + 16;  // LDS stride, k-major tile [BK][64]  (80 = 16 mod 32: the two lane groups of a half are disjoint)
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* mask;
+  int M, N, K, lda, ldb, ldc, ldmask;
+  long long sA, sB, sC, sBias, sMask, sSplit;
+  int nbatch, ksplit, kchunk;
+  float alpha;
+  int relu, vecA, vecB;
+};
+
+// load one BK x 64 operand tile into registers (2 float4 per thread)
+template <bool KMAJOR>
+__device__ __forceinline__ void tile_load(const float* __restrict__ P, int ld, int rows_total, int r0, int k0, int kend,
+                                          int vec, int tid, f32x4 (&reg)[2]) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    f32x4 v = {0, 0, 0, 0};
+    if (!KMAJOR) {
+      const int row = (tid >> 3) + 32 * u, k4 = (tid & 7) * 4;
+      const int gr = r0 + row, gk = k0 + k4;
+      if (gr < rows_total) {
+        const float* p = P + (size_t)gr * ld + gk;
+        if (vec && gk + 3 < kend) {
+          v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (gk + i < kend) v[i] = p[i];
+        }
+      }
+    } else {
+      const int k = (tid >> 4) + 16 * u, r4 = (tid & 15) * 4;
+      const int gk = k0 + k, gr = r0 + r4;
+      if (gk < kend) {
+        const float* p = P + (size_t)gk * ld + gr;
+        if (vec && gr + 3 < rows_total) {
+          v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (gr + i < rows_total) v[i] = p[i];
+        }
+      }
+    }
+    reg[u] = v;
+  }
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ void tile_store(float* __restrict__ S, int tid, const f32x4 (&reg)[2]) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (!KMAJOR) {
+      const int row = (tid >> 3) + 32 * u, k4 = (tid & 7) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) S[row * RSTR + k4 + i] = reg[u][i];
+    } else {
+      const int k = (tid >> 4) + 16 * u, r4 = (tid & 15) * 4;
+      *reinterpret_cast<f32x4*>(S + k * KSTR + r4) = reg[u];
+    }
+  }
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ float frag(const float* __restrict__ S, int row, int k) {
+  return KMAJOR ? S[k * KSTR + row] : S[row * RSTR + k];
+}
+
+template <bool AK, bool BKM>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[BK * KSTR];
+  __shared__ __attribute__((aligned(16))) float Bs[BK * KSTR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int z = blockIdx.z;
+  const int batch = z / g.ksplit, ks = z - batch * g.ksplit;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const float* A = g.A + batch * g.sA;
+  const float* B = g.B + batch * g.sB;
+  float* C = g.C + batch * g.sC + ks * g.sSplit;
+  const int kbeg = ks * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+
+  f32x4 ra[2], rb[2];
+  if (kbeg < kend) {
+    tile_load<AK>(A, g.lda, g.M, m0, kbeg, kend, g.vecA, tid, ra);
+    tile_load<BKM>(B, g.ldb, g.N, n0, kbeg, kend, g.vecB, tid, rb);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    tile_store<AK>(As, tid, ra);
+    tile_store<BKM>(Bs, tid, rb);
+    __syncthreads();
+    if (k0 + BK < kend) {
+      tile_load<AK>(A, g.lda, g.M, m0, k0 + BK, kend, g.vecA, tid, ra);
+      tile_load<BKM>(B, g.ldb, g.N, n0, k0 + BK, kend, g.vecB, tid, rb);
+    }
+#pragma unroll
+    for (int s = 0; s < BK / 4; ++s) {
+      float fa[2], fb[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) fa[i] = frag<AK>(As, wm * 32 + i * 16 + li, 4 * s + kq);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) fb[j] = frag<BKM>(Bs, wn * 32 + j * 16 + li, 4 * s + kq);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fa[i], fb[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+
+  const bool epi = g.ksplit == 1;
+  const float* bias = (epi && g.bias) ? g.bias + batch * g.sBias : nullptr;
+  const float* mask = (epi && g.mask) ? g.mask + batch * g.sMask : nullptr;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wn * 32 + j * 16 + li;
+      if (n >= g.N) continue;
+      const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 32 + i * 16 + 4 * kq + r;
+        if (m >= g.M) continue;
+        float v = g.alpha * acc[i][j][r] + bv;
+        if (epi && g.relu) v = fmaxf(v, 0.f);
+        if (mask) v = mask[(size_t)m * g.ldmask + n] > 0.f ? v : 0.f;
+        C[(size_t)m * g.ldc + n] = v;
+      }
+    }
+}
+
+// sum split-K partials: C[m][n] = sum_s P[s][m][n] (+bias, ReLU)
+__global__ void splitk_reduce_kernel(const float* P, int nsplit, long long sSplit, int M, int N, int ldp, float* C,
+                                     int ldc, const float* bias, int relu) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * N) return;
+  const int m = i / N, n = i - m * N;
+  float s = 0.f;
+  for (int k = 0; k < nsplit; ++k) s += P[k * sSplit + (size_t)m * ldp + n];
+  if (bias) s += bias[n];
+  if (relu) s = fmaxf(s, 0.f);
+  C[(size_t)m * ldc + n] = s;
+}
+
+}  // namespace
+
+extern "C" {
+
+int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const float* B, int b_kmajor, int ldb,
+               long long strideB, float* C, int ldc, long long strideC, int M, int N, int K, int nbatch, int ksplit,
+               long long split_stride, float alpha, const float* bias, long long strideBias, int relu,
+               const float* mask, int ldmask, long long strideMask, void* stream) {
+  CURLA_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nbatch > 0 && ksplit > 0);
+  CURLA_REQUIRE(ksplit == 1 || (!bias && !mask && !relu));
+  GemmArgs g;
+  g.A = A, g.B = B, g.C = C, g.bias = bias, g.mask = mask;
+  g.M = M, g.N = N, g.K = K, g.lda = lda, g.ldb = ldb, g.ldc = ldc, g.ldmask = ldmask;
+  g.sA = strideA, g.sB = strideB, g.sC = strideC, g.sBias = strideBias, g.sMask = strideMask, g.sSplit = split_stride;
+  g.nbatch = nbatch, g.ksplit = ksplit;
+  int kc = (K + ksplit - 1) / ksplit;
+  kc = (kc + BK - 1) / BK * BK;  // chunk boundaries stay float4-aligned
+  g.kchunk = kc;
+  g.alpha = alpha, g.relu = relu;
+  g.vecA = (lda % 4 == 0) && (strideA % 4 == 0) && aligned16(A);
+  g.vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && aligned16(B);
+  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nbatch * ksplit);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a_kmajor && b_kmajor)
+    hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, st, g);
+  else if (a_kmajor)
+    hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, st, g);
+  else if (b_kmajor)
+    hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, st, g);
+  return curla_launch_status();
+}
+
+int curla_splitk_reduce(const float* partial, int nsplit, long long split_stride, int M, int N, int ldp, float* C,
+                        int ldc, const float* bias, int relu, void* stream) {
+  CURLA_REQUIRE(partial && C && nsplit > 0 && M > 0 && N > 0);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((M * N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     partial, nsplit, split_stride, M, N, ldp, C, ldc, bias, relu);
+  return curla_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,466 @@
+// Small fused kernels around the GEMMs: LayerNorm (encoder.py:67,101),
+// squashed-Gaussian policy head (curl_sac.py:20-35,87-108), SAC targets and
+// losses (curl_sac.py:353-359,378-399), CURL cross-entropy (curl_sac.py:411-413),
+// target soft update (utils.py:37-41), and the crop materialiser for callers
+// that want the reference's float NCHW minibatch tensors (utils.py:151-166).
+// All reductions are fixed-order (bitwise reproducible run to run).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// block-wide fixed-order sum of one value per thread (256 threads); result valid in every thread
+__device__ __forceinline__ float block_sum_256(float v, float* sm) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
+// ---- fc split-K reduce + bias + LayerNorm (one wave per row, F <= 64) ----
+__global__ void fc_ln_fwd_kernel(const float* P, int nsplit, long long sSplit, int ldp, const float* bias,
+                                 const float* gamma, const float* beta, int B, int F, float eps, float* fc_out,
+                                 float* y, float* xhat, float* rstd, int tanh_out) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int f = threadIdx.x & 63;
+  if (row >= B) return;
+  float v = 0.f;
+  if (f < F) {
+    for (int s = 0; s < nsplit; ++s) v += P[s * sSplit + (size_t)row * ldp + f];
+    v += bias[f];
+  }
+  const float mean = wave_sum(f < F ? v : 0.f) / F;
+  const float d = f < F ? v - mean : 0.f;
+  const float var = wave_sum(d * d) / F;
+  const float rs = 1.0f / sqrtf(var + eps);
+  if (f < F) {
+    const float xh = d * rs;
+    float o = xh * gamma[f] + beta[f];
+    if (tanh_out) o = tanhf(o);
+    if (fc_out) fc_out[(size_t)row * F + f] = v;
+    y[(size_t)row * F + f] = o;
+    if (xhat) xhat[(size_t)row * F + f] = xh;
+  }
+  if (f == 0 && rstd) rstd[row] = rs;
+}
+
+// dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat))
+__global__ void ln_bwd_kernel(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int F,
+                              float* dx) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int f = threadIdx.x & 63;
+  if (row >= B) return;
+  float g = 0.f, xh = 0.f;
+  if (f < F) {
+    g = dy[(size_t)row * F + f] * gamma[f];
+    xh = xhat[(size_t)row * F + f];
+  }
+  const float m1 = wave_sum(g) / F;
+  const float m2 = wave_sum(g * xh) / F;
+  if (f < F) dx[(size_t)row * F + f] = rstd[row] * (g - m1 - xh * m2);
+}
+
+// dgamma[f] = sum_b dy*xhat ; dbeta[f] = sum_b dy   (single block, F <= 64)
+__global__ void ln_param_grad_kernel(const float* dy, const float* xhat, int B, int F, float* dgamma, float* dbeta) {
+  __shared__ float sg[4][64], sb[4][64];
+  const int f = threadIdx.x & 63, part = threadIdx.x >> 6;
+  float ag = 0.f, ab = 0.f;
+  if (f < F)
+    for (int b = part; b < B; b += 4) {
+      const float d = dy[(size_t)b * F + f];
+      ag += d * xhat[(size_t)b * F + f];
+      ab += d;
+    }
+  sg[part][f] = ag, sb[part][f] = ab;
+  __syncthreads();
+  if (part == 0 && f < F) {
+    dgamma[f] = (sg[0][f] + sg[1][f]) + (sg[2][f] + sg[3][f]);
+    dbeta[f] = (sb[0][f] + sb[1][f]) + (sb[2][f] + sb[3][f]);
+  }
+}
+
+// out[z][n] = sum_m X[z][m][n]  (bias gradients); 64 columns x 4 row-parts per block
+__global__ void colsum_kernel(const float* X, int M, int N, int ldx, long long sX, float* out, long long sOut) {
+  __shared__ float sm[4][64];
+  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
+  const float* x = X + blockIdx.y * sX;
+  float a = 0.f;
+  if (n < N)
+    for (int m = part; m < M; m += 4) a += x[(size_t)m * ldx + n];
+  sm[part][c] = a;
+  __syncthreads();
+  if (part == 0 && n < N) out[blockIdx.y * sOut + n] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+}
+
+// ---- policy head ----
+constexpr int kMaxA = 8;
+constexpr float kHalfLog2Pi = 0.9189385332046727f;
+
+__global__ void actor_head_fwd_kernel(const float* out2a, const float* noise, int B, int A, float lo, float hi,
+                                      float* mu_t, float* pi_t, float* log_pi, float* log_std, float* tanh_ls) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float lp = 0.f, corr = 0.f;
+  for (int a = 0; a < A; ++a) {
+    const float mu = out2a[(size_t)b * 2 * A + a];
+    const float t = tanhf(out2a[(size_t)b * 2 * A + A + a]);
+    const float ls = lo + 0.5f * (hi - lo) * (t + 1.f);
+    if (mu_t) mu_t[(size_t)b * A + a] = tanhf(mu);
+    if (log_std) log_std[(size_t)b * A + a] = ls;
+    if (tanh_ls) tanh_ls[(size_t)b * A + a] = t;
+    if (noise) {
+      const float n = noise[(size_t)b * A + a];
+      const float p = tanhf(mu + n * expf(ls));
+      pi_t[(size_t)b * A + a] = p;
+      lp += -0.5f * n * n - ls;
+      corr += logf(fmaxf(1.f - p * p, 0.f) + 1e-6f);
+    }
+  }
+  if (noise && log_pi) log_pi[b] = lp - kHalfLog2Pi * A - corr;
+}
+
+// gradient of (sum_a gpi[a]*pi[a] + glp*log_pi) wrt the trunk output [mu | raw_log_std]
+__global__ void actor_head_bwd_kernel(const float* gpi, const float* glp_scalar, const double* log_alpha, float glp_scale,
+                                      const float* noise, const float* pi_t, const float* log_std,
+                                      const float* tanh_ls, int B, int A, float lo, float hi, float* dout2a) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  // d loss / d log_pi is the same for every row: alpha/B (actor loss) unless given explicitly
+  const float glp = glp_scalar ? glp_scalar[b] : glp_scale * (float)exp(*log_alpha);
+  for (int a = 0; a < A; ++a) {
+    const float p = pi_t[(size_t)b * A + a];
+    const float om = 1.f - p * p;
+    float gp = gpi[(size_t)b * A + a];
+    if (om > 0.f) gp += glp * (2.f * p / (om + 1e-6f));
+    const float gu = gp * om;
+    const float ls = log_std[(size_t)b * A + a];
+    const float t = tanh_ls[(size_t)b * A + a];
+    const float gls = gu * noise[(size_t)b * A + a] * expf(ls) - glp;
+    dout2a[(size_t)b * 2 * A + a] = gu;
+    dout2a[(size_t)b * 2 * A + A + a] = gls * 0.5f * (hi - lo) * (1.f - t * t);
+  }
+}
+
+// xa[z] = [ zfeat | act ] for the twin-Q input
+__global__ void concat_kernel(const float* zf, const float* act, int B, int F, int A, float* xa) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * (F + A)) return;
+  const int b = i / (F + A), c = i - b * (F + A);
+  xa[i] = c < F ? zf[(size_t)b * F + c] : act[(size_t)b * A + (c - F)];
+}
+
+// dxa[2][B][F+A] -> dz[B][F] (sum over the twin) and/or dact[B][A]
+__global__ void split_sum_kernel(const float* dxa, long long sTwin, int B, int F, int A, float* dz, float* dact) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * (F + A)) return;
+  const int b = i / (F + A), c = i - b * (F + A);
+  const float v = dxa[i] + dxa[sTwin + i];
+  if (c < F) {
+    if (dz) dz[(size_t)b * F + c] = v;
+  } else if (dact) {
+    dact[(size_t)b * A + (c - F)] = v;
+  }
+}
+
+// target_Q = r + not_done * gamma * (min(tq1,tq2) - alpha*log_pi)      (curl_sac.py:353-355)
+__global__ void td_target_kernel(const float* tq, long long sTwin, const float* log_pi, const float* reward,
+                                 const float* not_done, const double* log_alpha, float discount, int B,
+                                 float* target_q) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float alpha = (float)exp(*log_alpha);
+  const float v = fminf(tq[b], tq[sTwin + b]) - alpha * log_pi[b];
+  target_q[b] = reward[b] + not_done[b] * discount * v;
+}
+
+// loss = mse(q1,tQ) + mse(q2,tQ); dq = 2(q - tQ)/B                    (curl_sac.py:359)
+__global__ void critic_loss_kernel(const float* q, long long sTwin, const float* target_q, int B, float* loss,
+                                   float* dq) {
+  __shared__ float sm[4];
+  float a1 = 0.f, a2 = 0.f;
+  const float inv = 1.f / B;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float d1 = q[b] - target_q[b], d2 = q[sTwin + b] - target_q[b];
+    a1 += d1 * d1;
+    a2 += d2 * d2;
+    dq[b] = 2.f * d1 * inv;
+    dq[sTwin + b] = 2.f * d2 * inv;
+  }
+  const float s1 = block_sum_256(a1, sm);
+  const float s2 = block_sum_256(a2, sm);
+  if (threadIdx.x == 0) loss[0] = s1 * inv + s2 * inv;
+}
+
+// actor/alpha losses and their seeds                                  (curl_sac.py:378-399)
+// scalars: [0] actor_loss [1] alpha_loss [2] entropy mean [3] alpha
+__global__ void actor_loss_kernel(const float* q, long long sTwin, const float* log_pi, const float* log_std, int A,
+                                  const double* log_alpha, float target_entropy, int B, float* scalars, float* dq,
+                                  double* dlog_alpha) {
+  __shared__ float sm[4];
+  const float alpha = (float)exp(*log_alpha);
+  const float inv = 1.f / B;
+  float al = 0.f, hl = 0.f, en = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float q1 = q[b], q2 = q[sTwin + b];
+    al += alpha * log_pi[b] - fminf(q1, q2);
+    hl += -log_pi[b] - target_entropy;
+    float e = 0.f;
+    for (int a = 0; a < A; ++a) e += log_std[(size_t)b * A + a];
+    en += 0.5f * A * (1.0f + 1.8378770664093453f) + e;
+    // d(-min)/dq: the smaller one takes -1/B; an exact tie splits it (torch.min backward)
+    dq[b] = q1 < q2 ? -inv : (q1 == q2 ? -0.5f * inv : 0.f);
+    dq[sTwin + b] = q2 < q1 ? -inv : (q1 == q2 ? -0.5f * inv : 0.f);
+  }
+  const float s_al = block_sum_256(al, sm);
+  const float s_hl = block_sum_256(hl, sm);
+  const float s_en = block_sum_256(en, sm);
+  if (threadIdx.x == 0) {
+    scalars[0] = s_al * inv;
+    scalars[1] = alpha * (s_hl * inv);
+    scalars[2] = s_en * inv;
+    scalars[3] = alpha;
+    if (dlog_alpha) *dlog_alpha = (double)(alpha * (s_hl * inv));  // d/dlog_alpha exp(log_alpha)*c = alpha*c
+  }
+}
+
+// CURL InfoNCE: loss = mean_a( logsumexp_b(l[a][:]) - l[a][a] ); dl = (softmax - I)/B
+__global__ void curl_ce_kernel(const float* logits, int B, int ld, float* row_loss, float* dlogits) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= B) return;
+  const float* l = logits + (size_t)row * ld;
+  float mx = -INFINITY;
+  for (int j = lane; j < B; j += 64) mx = fmaxf(mx, l[j]);
+  mx = wave_max(mx);
+  float se = 0.f;
+  for (int j = lane; j < B; j += 64) se += expf(l[j] - mx);
+  se = wave_sum(se);
+  const float lse = logf(se) + mx;
+  if (lane == 0) row_loss[row] = lse - l[row];
+  if (dlogits) {
+    const float inv = 1.f / B;
+    for (int j = lane; j < B; j += 64) {
+      const float p = expf(l[j] - lse);
+      dlogits[(size_t)row * ld + j] = (p - (j == row ? 1.f : 0.f)) * inv;
+    }
+  }
+}
+
+__global__ void mean_kernel(const float* x, int n, float* out) {
+  __shared__ float sm[4];
+  float a = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) a += x[i];
+  const float s = block_sum_256(a, sm);
+  if (threadIdx.x == 0) out[0] = s / n;
+}
+
+// target <- tau*p + (1-tau)*target                                     (utils.py:37-41)
+__global__ void soft_update_kernel(const float* p, float* tgt, size_t n, float tau, float omt) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) tgt[i] = tau * p[i] + omt * tgt[i];
+}
+
+// out[b][c][i][j] = (float) frames[idx[b]][h1[b]+i][w1[b]+j][c]          (augmentations.py:47-75 + utils.py:161)
+__global__ void crop_nchw_kernel(const uint8_t* frames, const int64_t* idx, const int32_t* h1, const int32_t* w1,
+                                 int B, int C, int Hs, int Ws, int Hc, int Wc, float* out_f32, uint8_t* out_u8) {
+  const size_t n = (size_t)B * C * Hc * Wc;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int x = i % Wc;
+    size_t t = i / Wc;
+    const int y = t % Hc;
+    t /= Hc;
+    const int c = t % C;
+    const int b = t / C;
+    const int64_t fi = idx ? idx[b] : b;
+    const int oh = h1 ? h1[b] : 0, ow = w1 ? w1[b] : 0;
+    const uint8_t v = frames[(((size_t)fi * Hs + oh + y) * Ws + ow + x) * C + c];
+    if (out_f32) out_f32[i] = (float)v;
+    if (out_u8) out_u8[i] = v;
+  }
+}
+
+// frames[slot][y][x][c] = chw[c][y][x]   (replay add: the reference stores CHW, utils.py:120-128)
+__global__ void store_frame_kernel(const uint8_t* chw, uint8_t* frames, int64_t slot, int C, int H, int W) {
+  const int n = C * H * W;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int c = i % C, p = i / C;
+    frames[(size_t)slot * n + i] = chw[(size_t)c * H * W + p];
+  }
+}
+
+// NHWC float activation -> NCHW (for callers that read encoder.outputs)
+__global__ void nhwc_to_nchw_kernel(const float* in, float* out, int B, int H, int W, int C) {
+  const size_t n = (size_t)B * H * W * C;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int x = i % W;
+    size_t t = i / W;
+    const int y = t % H;
+    t /= H;
+    const int c = t % C;
+    const int b = t / C;
+    out[i] = in[(((size_t)b * H + y) * W + x) * C + c];
+  }
+}
+
+inline int nblocks(size_t n, int bs, int cap = 4096) {
+  size_t b = (n + bs - 1) / bs;
+  return (int)(b < (size_t)cap ? b : cap);
+}
+
+}  // namespace
+
+extern "C" {
+
+int curla_fc_ln_fwd(const float* partial, int nsplit, long long split_stride, int ldp, const float* bias,
+                    const float* gamma, const float* beta, int B, int F, float eps, float* fc_out, float* y,
+                    float* xhat, float* rstd, int tanh_out, void* stream) {
+  CURLA_REQUIRE(partial && bias && gamma && beta && y && B > 0 && F > 0 && nsplit > 0);
+  if (F > 64) return CURLA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(fc_ln_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), partial,
+                     nsplit, split_stride, ldp, bias, gamma, beta, B, F, eps, fc_out, y, xhat, rstd, tanh_out);
+  return curla_launch_status();
+}
+
+int curla_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int F, float* dx,
+                 float* dgamma, float* dbeta, void* stream) {
+  CURLA_REQUIRE(dy && xhat && rstd && gamma && dx && B > 0 && F > 0);
+  if (F > 64) return CURLA_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, dy, xhat, rstd, gamma, B, F, dx);
+  if (dgamma && dbeta) hipLaunchKernelGGL(ln_param_grad_kernel, dim3(1), dim3(256), 0, st, dy, xhat, B, F, dgamma, dbeta);
+  return curla_launch_status();
+}
+
+int curla_colsum(const float* X, int M, int N, int ldx, long long strideX, float* out, long long strideOut, int nbatch,
+                 void* stream) {
+  CURLA_REQUIRE(X && out && M > 0 && N > 0 && nbatch > 0);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, nbatch), dim3(256), 0, static_cast<hipStream_t>(stream), X, M,
+                     N, ldx, strideX, out, strideOut);
+  return curla_launch_status();
+}
+
+int curla_actor_head_fwd(const float* trunk_out, const float* noise, int B, int A, float log_std_min,
+                         float log_std_max, float* mu, float* pi, float* log_pi, float* log_std, float* tanh_ls,
+                         void* stream) {
+  CURLA_REQUIRE(trunk_out && B > 0 && A > 0 && A <= kMaxA);
+  CURLA_REQUIRE(!noise || pi);
+  hipLaunchKernelGGL(actor_head_fwd_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     trunk_out, noise, B, A, log_std_min, log_std_max, mu, pi, log_pi, log_std, tanh_ls);
+  return curla_launch_status();
+}
+
+int curla_actor_head_bwd(const float* gpi, const float* glp_rows, const double* log_alpha, float glp_scale,
+                         const float* noise, const float* pi, const float* log_std, const float* tanh_ls, int B,
+                         int A, float log_std_min, float log_std_max, float* dtrunk_out, void* stream) {
+  CURLA_REQUIRE(gpi && noise && pi && log_std && tanh_ls && dtrunk_out && B > 0 && A > 0 && A <= kMaxA);
+  CURLA_REQUIRE(glp_rows || log_alpha);
+  hipLaunchKernelGGL(actor_head_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), gpi,
+                     glp_rows, log_alpha, glp_scale, noise, pi, log_std, tanh_ls, B, A, log_std_min, log_std_max,
+                     dtrunk_out);
+  return curla_launch_status();
+}
+
+int curla_concat(const float* z, const float* act, int B, int F, int A, float* xa, void* stream) {
+  CURLA_REQUIRE(z && act && xa && B > 0 && F > 0 && A > 0);
+  hipLaunchKernelGGL(concat_kernel, dim3((B * (F + A) + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), z,
+                     act, B, F, A, xa);
+  return curla_launch_status();
+}
+
+int curla_split_sum(const float* dxa, long long twin_stride, int B, int F, int A, float* dz, float* dact,
+                    void* stream) {
+  CURLA_REQUIRE(dxa && B > 0 && F > 0 && A > 0 && (dz || dact));
+  hipLaunchKernelGGL(split_sum_kernel, dim3((B * (F + A) + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     dxa, twin_stride, B, F, A, dz, dact);
+  return curla_launch_status();
+}
+
+int curla_td_target(const float* tq, long long twin_stride, const float* log_pi, const float* reward,
+                    const float* not_done, const double* log_alpha, float discount, int B, float* target_q,
+                    void* stream) {
+  CURLA_REQUIRE(tq && log_pi && reward && not_done && log_alpha && target_q && B > 0);
+  hipLaunchKernelGGL(td_target_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), tq,
+                     twin_stride, log_pi, reward, not_done, log_alpha, discount, B, target_q);
+  return curla_launch_status();
+}
+
+int curla_critic_loss(const float* q, long long twin_stride, const float* target_q, int B, float* loss, float* dq,
+                      void* stream) {
+  CURLA_REQUIRE(q && target_q && loss && dq && B > 0);
+  hipLaunchKernelGGL(critic_loss_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), q, twin_stride,
+                     target_q, B, loss, dq);
+  return curla_launch_status();
+}
+
+int curla_actor_loss(const float* q, long long twin_stride, const float* log_pi, const float* log_std, int A,
+                     const double* log_alpha, float target_entropy, int B, float* scalars4, float* dq,
+                     double* dlog_alpha, void* stream) {
+  CURLA_REQUIRE(q && log_pi && log_std && log_alpha && scalars4 && dq && B > 0 && A > 0);
+  hipLaunchKernelGGL(actor_loss_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), q, twin_stride, log_pi,
+                     log_std, A, log_alpha, target_entropy, B, scalars4, dq, dlog_alpha);
+  return curla_launch_status();
+}
+
+int curla_curl_ce(const float* logits, int B, int ld, float* row_loss, float* loss, float* dlogits, void* stream) {
+  CURLA_REQUIRE(logits && row_loss && loss && B > 0 && ld >= B);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(curl_ce_kernel, dim3((B + 3) / 4), dim3(256), 0, st, logits, B, ld, row_loss, dlogits);
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, row_loss, B, loss);
+  return curla_launch_status();
+}
+
+int curla_mean(const float* x, int n, float* out, void* stream) {
+  CURLA_REQUIRE(x && out && n > 0);
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, out);
+  return curla_launch_status();
+}
+
+int curla_soft_update(const float* param, float* target, size_t n, float tau, float one_minus_tau, void* stream) {
+  CURLA_REQUIRE(param && target && n > 0);
+  hipLaunchKernelGGL(soft_update_kernel, dim3(nblocks(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), param,
+                     target, n, tau, one_minus_tau);
+  return curla_launch_status();
+}
+
+int curla_crop_nchw(const uint8_t* frames, const int64_t* idx, const int32_t* h1, const int32_t* w1, int B, int C,
+                    int Hs, int Ws, int Hc, int Wc, float* out_f32, uint8_t* out_u8, void* stream) {
+  CURLA_REQUIRE(frames && (out_f32 || out_u8) && B > 0 && C > 0 && Hc > 0 && Wc > 0 && Hs >= Hc && Ws >= Wc);
+  hipLaunchKernelGGL(crop_nchw_kernel, dim3(nblocks((size_t)B * C * Hc * Wc, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), frames, idx, h1, w1, B, C, Hs, Ws, Hc, Wc, out_f32, out_u8);
+  return curla_launch_status();
+}
+
+int curla_store_frame(const uint8_t* chw, uint8_t* frames, long long slot, int C, int H, int W, void* stream) {
+  CURLA_REQUIRE(chw && frames && slot >= 0 && C > 0 && H > 0 && W > 0);
+  hipLaunchKernelGGL(store_frame_kernel, dim3(nblocks((size_t)C * H * W, 256, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), chw, frames, (int64_t)slot, C, H, W);
+  return curla_launch_status();
+}
+
+int curla_nhwc_to_nchw(const float* in, float* out, int B, int H, int W, int C, void* stream) {
+  CURLA_REQUIRE(in && out && B > 0 && H > 0 && W > 0 && C > 0);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(nblocks((size_t)B * H * W * C, 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, out, B, H, W, C);
+  return curla_launch_status();
+}
+
+const char* curla_version(void) { return "curla_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,677 @@
+"""CURL + SAC learner on MI355X: Actor / QFunction / Critic / CURL /
+CurlSacAgent with the reference's API (curl_sac.py:57-465).
+
+Host code is Python on PyTorch-ROCm: parameters are ``nn.Parameter`` views into
+flat HBM buffers, the five optimizers are ``torch.optim.Adam`` -- exactly the
+reference's division of labour.  Everything between "minibatch indices" and
+".grad is filled in" runs as hand-written HIP kernels through the C ABI
+(include/curla_hip.h); there is no autograd graph and no PyTorch fallback.
+
+Schedule of one ``update()`` (reference curl_sac.py:426-451), with the sharing
+the reference's autograd cannot do:
+  critic phase : conv(next_obs; theta) -> actor head;  conv(next_obs; xi) -> target Q;
+                 conv(obs; theta) -> twin Q -> loss -> explicit backward -> Adam
+  actor phase  : conv(obs; theta') ONCE, reused by actor.fc, critic.fc and (below) CURL;
+                 only live gradients are computed (actor fc/ln/trunk, log_alpha)
+  soft update  : two flat lerps (Q block with critic_tau, encoder block with encoder_tau)
+  cpc phase    : anchor features reused from the actor phase on even steps;
+                 conv(pos; xi') -> bilinear logits (MFMA) -> CE -> backward -> 2x Adam
+=> 5 conv-stack forwards + 2 backwards per update instead of the reference's 7 + 2.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .encoder import CNNEncoder
+from .ops import ObsRef
+
+LOG_FREQ = 25_000
+
+
+def weight_init(m):
+    """Custom weight init for Conv2D and Linear layers (curl_sac.py:38-54)."""
+    if isinstance(m, nn.Linear):
+        nn.init.orthogonal_(m.weight.data)
+        if m.bias is not None:
+            m.bias.data.fill_(0.0)
+    elif isinstance(m, nn.Conv2d) or isinstance(m, nn.ConvTranspose2d):
+        # delta-orthogonal init from https://arxiv.org/pdf/1806.05393.pdf
+        assert m.weight.size(2) == m.weight.size(3)
+        m.weight.data.fill_(0.0)
+        if m.bias is not None:
+            m.bias.data.fill_(0.0)
+        mid = m.weight.size(2) // 2
+        gain = nn.init.calculate_gain('relu')
+        nn.init.orthogonal_(m.weight.data[:, :, mid, mid], gain)
+
+
+def _as_ref(obs):
+    if isinstance(obs, ObsRef):
+        return obs
+    return ObsRef.from_tensor(obs.contiguous().float())
+
+
+class _Mlp:
+    """Pointers of a 3-layer MLP (or of the first of two identically laid-out
+    twins, ``stride`` floats apart)."""
+
+    def __init__(self, seq, stride=0, grads=False):
+        lin = [seq[0], seq[2], seq[4]]
+        pick = (lambda p: p.grad) if grads else (lambda p: p)
+        self.W = [pick(layer.weight) for layer in lin]
+        self.b = [pick(layer.bias) for layer in lin]
+        self.stride = stride
+
+
+def _mlp_fwd(x, sx, P, nb, B, din, H, dout, h1, h2, out, relu_out=0):
+    s = P.stride
+    ops.linear_fwd(x, sx, P.W[0], s, P.b[0], s, h1, B * H, B, H, din, nb, relu=1)
+    ops.linear_fwd(h1, B * H, P.W[1], s, P.b[1], s, h2, B * H, B, H, H, nb, relu=1)
+    ops.linear_fwd(h2, B * H, P.W[2], s, P.b[2], s, out, B * dout, B, dout, H, nb, relu=relu_out)
+
+
+def _mlp_bwd(x, sx, P, G, nb, B, din, H, dout, h1, h2, dy, dh2, dh1, dx):
+    """Backward of _mlp_fwd.  G (parameter gradients) and dx are optional."""
+    s = P.stride
+    if G is not None:
+        ops.linear_dw(dy, B * dout, h2, B * H, G.W[2], s, B, dout, H, nb)
+        ops.colsum(dy, B, dout, dout, B * dout, G.b[2], s, nb)
+    ops.linear_dx(dy, B * dout, P.W[2], s, dh2, B * H, B, dout, H, nb, mask=h2, smask=B * H)
+    if G is not None:
+        ops.linear_dw(dh2, B * H, h1, B * H, G.W[1], s, B, H, H, nb)
+        ops.colsum(dh2, B, H, H, B * H, G.b[1], s, nb)
+    ops.linear_dx(dh2, B * H, P.W[1], s, dh1, B * H, B, H, H, nb, mask=h1, smask=B * H)
+    if G is not None:
+        ops.linear_dw(dh1, B * H, x, sx, G.W[0], s, B, H, din, nb)
+        ops.colsum(dh1, B, H, H, B * H, G.b[0], s, nb)
+    if dx is not None:
+        ops.linear_dx(dh1, B * H, P.W[0], s, dx, B * din, B, H, din, nb)
+
+
+class Actor(nn.Module):
+    """MLP actor network (curl_sac.py:57-121)."""
+
+    def __init__(self, obs_shape, action_shape, hidden_dim, encoder_feature_dim, log_std_min, log_std_max,
+                 num_layers, num_filters):
+        super().__init__()
+        self.encoder = CNNEncoder(obs_shape, encoder_feature_dim, num_layers, num_filters, output_logits=True)
+        self.log_std_min = log_std_min
+        self.log_std_max = log_std_max
+        self.action_dim = action_shape[0]
+        self.hidden_dim = hidden_dim
+        self.trunk = nn.Sequential(
+            nn.Linear(self.encoder.feature_dim, hidden_dim), nn.ReLU(),
+            nn.Linear(hidden_dim, hidden_dim), nn.ReLU(),
+            nn.Linear(hidden_dim, 2 * action_shape[0])
+        )
+        self.outputs = dict()
+        self.apply(weight_init)
+
+    def forward(self, obs, compute_pi=True, compute_log_pi=True, detach_encoder=False, noise=None):
+        """Inference forward on the HIP kernels; same return tuple as the
+        reference (mu, pi, log_pi, log_std) with pi/log_pi None when not asked
+        for.  ``noise`` replaces torch.randn_like (curl_sac.py:97)."""
+        z = self.encoder(obs, detach=detach_encoder)
+        B, A, H, F = z.shape[0], self.action_dim, self.hidden_dim, self.encoder.feature_dim
+        dev = z.device
+        h1 = torch.empty((B, H), device=dev)
+        h2 = torch.empty((B, H), device=dev)
+        out = torch.empty((B, 2 * A), device=dev)
+        _mlp_fwd(z, 0, _Mlp(self.trunk), 1, B, F, H, 2 * A, h1, h2, out)
+        mu = torch.empty((B, A), device=dev)
+        log_std = torch.empty((B, A), device=dev)
+        pi = log_pi = None
+        if compute_pi:
+            if noise is None:
+                noise = torch.randn((B, A), device=dev)
+            pi = torch.empty((B, A), device=dev)
+            log_pi = torch.empty((B, 1), device=dev) if compute_log_pi else None
+        ops.actor_head_fwd(out, noise if compute_pi else None, B, A, self.log_std_min, self.log_std_max, mu=mu, pi=pi,
+                           log_pi=log_pi, log_std=log_std)
+        self.outputs['mu'] = mu
+        self.outputs['std'] = log_std.exp()
+        return mu, pi, log_pi, log_std
+
+    def log(self, L, step, log_freq=LOG_FREQ):
+        if step % log_freq != 0:
+            return
+        for k, v in self.outputs.items():
+            L.log_histogram('train_actor/%s_hist' % k, v, step)
+        L.log_param('train_actor/fc1', self.trunk[0], step)
+        L.log_param('train_actor/fc2', self.trunk[2], step)
+        L.log_param('train_actor/fc3', self.trunk[4], step)
+
+
+class QFunction(nn.Module):
+    """MLP for q-function (curl_sac.py:124-139); parameter container."""
+
+    def __init__(self, obs_dim, action_dim, hidden_dim):
+        super().__init__()
+        self.trunk = nn.Sequential(
+            nn.Linear(obs_dim + action_dim, hidden_dim), nn.ReLU(),
+            nn.Linear(hidden_dim, hidden_dim), nn.ReLU(),
+            nn.Linear(hidden_dim, 1)
+        )
+
+
+class Critic(nn.Module):
+    """Critic network, employs two Q-functions (curl_sac.py:142-180)."""
+
+    def __init__(self, obs_shape, action_shape, hidden_dim, encoder_feature_dim, num_layers, num_filters):
+        super().__init__()
+        self.encoder = CNNEncoder(obs_shape, encoder_feature_dim, num_layers, num_filters, output_logits=True)
+        self.Q1 = QFunction(self.encoder.feature_dim, action_shape[0], hidden_dim)
+        self.Q2 = QFunction(self.encoder.feature_dim, action_shape[0], hidden_dim)
+        self.action_dim = action_shape[0]
+        self.hidden_dim = hidden_dim
+        self.outputs = dict()
+        self.twin_stride = None  # floats between Q1 and Q2 tensors once flattened by the agent
+        self.apply(weight_init)
+
+    def twin(self, grads=False):
+        if self.twin_stride is None:
+            raise RuntimeError("Critic parameters are not in the flat twin layout (constructed outside CurlSacAgent)")
+        return _Mlp(self.Q1.trunk, self.twin_stride, grads)
+
+    def forward(self, obs, action, detach_encoder=False):
+        assert obs.size(0) == action.size(0)  # curl_sac.py:136
+        z = self.encoder(obs, detach=detach_encoder)
+        B, A, H, F = z.shape[0], self.action_dim, self.hidden_dim, self.encoder.feature_dim
+        dev = z.device
+        xa = torch.empty((B, F + A), device=dev)
+        ops.concat(z, action.contiguous().float(), B, F, A, xa)
+        h1 = torch.empty((2, B, H), device=dev)
+        h2 = torch.empty((2, B, H), device=dev)
+        q = torch.empty((2, B, 1), device=dev)
+        _mlp_fwd(xa, 0, self.twin(), 2, B, F + A, H, 1, h1, h2, q)
+        self.outputs['q1'], self.outputs['q2'] = q[0], q[1]
+        return q[0], q[1]
+
+    def log(self, L, step, log_freq=LOG_FREQ):
+        if step % log_freq != 0:
+            return
+        for k, v in self.outputs.items():
+            L.log_histogram('train_critic/%s_hist' % k, v, step)
+        for i in range(3):
+            L.log_param('train_critic/q1_fc%d' % i, self.Q1.trunk[i * 2], step)
+            L.log_param('train_critic/q2_fc%d' % i, self.Q2.trunk[i * 2], step)
+
+
+class CURL(nn.Module):
+    """CURL head (curl_sac.py:183-222)."""
+
+    def __init__(self, obs_shape, z_dim, critic, critic_target, output_type="continuous"):
+        super().__init__()
+        self.encoder = critic.encoder
+        self.encoder_target = critic_target.encoder
+        self.W = nn.Parameter(torch.rand(z_dim, z_dim))
+        self.output_type = output_type
+
+    def encode(self, x, detach=False, ema=False):
+        return self.encoder_target(x) if ema else self.encoder(x)
+
+    def compute_logits(self, z_a, z_pos):
+        """(B,B) logits z_a (W z_pos^T) minus the row max (curl_sac.py:211-222),
+        both products on the MFMA GEMM."""
+        B, F = z_a.shape
+        WzT = torch.empty((B, F), device=z_a.device)
+        logits = torch.empty((B, B), device=z_a.device)
+        ops.linear_fwd(z_pos.contiguous(), 0, self.W, 0, None, 0, WzT, 0, B, F, F)
+        ops.linear_fwd(z_a.contiguous(), 0, WzT, 0, None, 0, logits, 0, B, B, F)
+        return logits - torch.max(logits, 1)[0][:, None]
+
+
+class _Workspace:
+    """Every per-update buffer for one batch size, allocated once (static
+    addresses: the kernel sequence is hipGraph-capturable)."""
+
+    def __init__(self, agent, B):
+        enc = agent.critic.encoder
+        dev = agent.device
+        F, A, H, L = enc.feature_dim, agent.action_dim, agent.hidden_dim, enc.num_layers
+        f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
+        shapes = [(B, h, w, enc.num_filters) for (h, w) in enc.layer_hw[1:]]
+        self.acts_main = [f(*s) for s in shapes]  # activations kept for a backward pass
+        self.acts_tmp = [f(*s) for s in shapes]   # no-grad passes
+        gmax = max(int(np.prod(s)) for s in shapes)
+        self.gbuf = [f(gmax), f(gmax)]
+        self.gviews = [[g[:int(np.prod(s))].view(s) for s in shapes] for g in self.gbuf]
+        self.wg_ws = f(max(ops.wgrad_workspace_floats(32), ops.wgrad_workspace_floats(enc.obs_shape[0])))
+        # features
+        self.z_a, self.z_t, self.z_c, self.z_pos = f(B, F), f(B, F), f(B, F), f(B, F)
+        self.xhat_c, self.rstd_c, self.xhat_a, self.rstd_a = f(B, F), f(B), f(B, F), f(B)
+        self.dz, self.dfc = f(B, F), f(B, F)
+        # actor trunk
+        self.a_h1, self.a_h2, self.a_out = f(B, H), f(B, H), f(B, 2 * A)
+        self.a_dh1, self.a_dh2, self.a_dout = f(B, H), f(B, H), f(B, 2 * A)
+        self.noise = f(B, A)
+        self.mu, self.pi, self.log_std, self.tanh_ls, self.gpi = f(B, A), f(B, A), f(B, A), f(B, A), f(B, A)
+        self.log_pi = f(B, 1)
+        # twin Q
+        self.xa, self.dxa = f(B, F + A), f(2, B, F + A)
+        self.q_h1, self.q_h2, self.q_dh1, self.q_dh2 = f(2, B, H), f(2, B, H), f(2, B, H), f(2, B, H)
+        self.q, self.dq, self.target_q = f(2, B, 1), f(2, B, 1), f(B, 1)
+        # scalars: [0] critic loss, [1..4] actor_loss/alpha_loss/entropy/alpha, [5] curl loss, [6] batch reward
+        self.scalars = torch.zeros(8, device=dev, dtype=torch.float32)
+        # CURL
+        self.WzT, self.dWzT = f(B, F), f(B, F)
+        self.logits, self.dlogits, self.row_loss = f(B, B), f(B, B), f(B)
+
+
+class CurlSacAgent(object):
+    """CURL representation learning with SAC (curl_sac.py:224-465)."""
+
+    def __init__(
+        self,
+        obs_shape,
+        action_shape,
+        device,
+        augmentor,
+        hidden_dim=256,
+        discount=0.99,
+        init_temperature=0.01,
+        alpha_lr=1e-3,
+        alpha_beta=0.9,
+        actor_lr=1e-3,
+        actor_beta=0.9,
+        actor_log_std_min=-10,
+        actor_log_std_max=2,
+        actor_update_freq=2,
+        critic_lr=1e-3,
+        critic_beta=0.9,
+        critic_tau=0.005,
+        critic_target_update_freq=2,
+        encoder_feature_dim=50,
+        encoder_lr=1e-3,
+        encoder_tau=0.005,
+        num_layers=4,
+        num_filters=32,
+        cpc_update_freq=1,
+        log_interval=100,
+        log_param_hist_imgs=False,
+        detach_encoder=False,
+        pixel_sac=False
+    ):
+        self.augmentor = augmentor
+        self.device = torch.device(device)
+        self.discount = discount
+        self.critic_tau = critic_tau
+        self.encoder_tau = encoder_tau
+        self.actor_update_freq = actor_update_freq
+        self.critic_target_update_freq = critic_target_update_freq
+        self.cpc_update_freq = cpc_update_freq
+        self.log_interval = log_interval
+        self.log_param_hist_imgs = log_param_hist_imgs
+        self.image_shape = tuple(obs_shape[-2:])
+        self.detach_encoder = detach_encoder
+        self.pixel_sac = pixel_sac
+        self.action_dim = action_shape[0]
+        self.hidden_dim = hidden_dim
+
+        # same construction order as the reference => same RNG stream => same init for a given seed
+        self.actor = Actor(obs_shape, action_shape, hidden_dim, encoder_feature_dim, actor_log_std_min,
+                           actor_log_std_max, num_layers, num_filters)
+        self.critic = Critic(obs_shape, action_shape, hidden_dim, encoder_feature_dim, num_layers, num_filters)
+        self.critic_target = Critic(obs_shape, action_shape, hidden_dim, encoder_feature_dim, num_layers, num_filters)
+        self.critic_target.load_state_dict(self.critic.state_dict())
+
+        # tie encoders between actor and critic, and CURL and critic
+        self.actor.encoder.copy_conv_weights_from(self.critic.encoder)
+
+        self.log_alpha = torch.tensor(np.log(init_temperature)).to(self.device)  # float64, like the reference
+        self.log_alpha.requires_grad = True
+        self.target_entropy = -np.prod(action_shape)
+
+        self.CURL = CURL(obs_shape, encoder_feature_dim, self.critic, self.critic_target, output_type='continuous')
+
+        self._to_flat_device_layout()
+
+        cuda = self.device.type == "cuda"
+        kw = dict(fused=True) if cuda else {}
+        actor_own = [p for n, p in self.actor.named_parameters() if ".convs." not in n]
+        enc_params = list(self.critic.encoder.parameters())
+        # Optimizers (curl_sac.py:299-313).  The reference hands Adam the tied convs (actor) and the target
+        # encoder (cpc) as well; their .grad is always None at step time there, so Adam never touches them.
+        self.actor_optimizer = torch.optim.Adam(actor_own, lr=actor_lr, betas=(actor_beta, 0.999), **kw)
+        self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), lr=critic_lr, betas=(critic_beta, 0.999), **kw)
+        self.log_alpha_optimizer = torch.optim.Adam([self.log_alpha], lr=alpha_lr, betas=(alpha_beta, 0.999), **kw)
+        self.encoder_optimizer = torch.optim.Adam(enc_params, lr=encoder_lr, **kw)
+        self.cpc_optimizer = torch.optim.Adam([self.CURL.W] + enc_params, lr=encoder_lr, **kw)
+
+        self._workspaces = {}
+        self._anchor_cache = None
+        self._dp_group = None
+        self._dp_world = 1
+        self.train()
+        self.critic_target.train()
+
+    # ------------------------------------------------------------------ layout
+    def _to_flat_device_layout(self):
+        """Move every parameter into flat fp32 device buffers (16-byte aligned
+        slots), Q1/Q2 as two identically laid-out blocks, and give each a
+        persistent .grad view into a mirror buffer.
+          critic flat : [ CURL.W | encoder (convs, fc, ln) | Q1 | Q2 ]
+          target flat : same layout (W slot unused)
+          actor flat  : [ encoder.fc, encoder.ln | trunk ]"""
+        dev = self.device
+        for m in (self.actor, self.critic, self.critic_target):
+            m.encoder.to_kernel_layout()
+
+        def place(named, flat_size_only=False, flat=None, gflat=None, off0=0):
+            off = off0
+            for _, p in named:
+                n = p.numel()
+                if not flat_size_only:
+                    dst = flat[off:off + n].view(p.shape)
+                    dst.copy_(p.data)
+                    p.data = dst
+                    if gflat is not None:
+                        p.grad = gflat[off:off + n].view(p.shape)
+                off += (n + 3) & ~3
+            return off
+
+        def critic_groups(critic, W):
+            enc = [("encoder." + n, p) for n, p in critic.encoder.named_parameters()]
+            q1 = [("Q1." + n, p) for n, p in critic.Q1.named_parameters()]
+            q2 = [("Q2." + n, p) for n, p in critic.Q2.named_parameters()]
+            return [("W", W)] if W is not None else [], enc, q1, q2
+
+        wl, enc, q1, q2 = critic_groups(self.critic, self.CURL.W)
+        w_sz = place(wl, True)
+        enc_sz = place(enc, True)
+        q_sz = place(q1, True)
+        total = w_sz + enc_sz + 2 * q_sz
+        self._lay = dict(w=(0, w_sz), enc=(w_sz, w_sz + enc_sz), q=(w_sz + enc_sz, total), total=total, qblock=q_sz)
+
+        def build(critic, W, with_grad):
+            flat = torch.zeros(total, device=dev, dtype=torch.float32)
+            gflat = torch.zeros(total, device=dev, dtype=torch.float32) if with_grad else None
+            wl_, enc_, q1_, q2_ = critic_groups(critic, W)
+            place(wl_, False, flat, gflat, 0)
+            place(enc_, False, flat, gflat, w_sz)
+            place(q1_, False, flat, gflat, w_sz + enc_sz)
+            place(q2_, False, flat, gflat, w_sz + enc_sz + q_sz)
+            critic.twin_stride = q_sz
+            return flat, gflat
+
+        self._critic_flat, self._critic_gflat = build(self.critic, self.CURL.W, True)
+        self._target_flat, _ = build(self.critic_target, None, False)
+        for p in self.critic_target.parameters():
+            p.requires_grad_(False)
+
+        actor_own = [(n, p) for n, p in self.actor.named_parameters() if ".convs." not in n]
+        a_sz = place(actor_own, True)
+        self._actor_flat = torch.zeros(a_sz, device=dev, dtype=torch.float32)
+        self._actor_gflat = torch.zeros(a_sz, device=dev, dtype=torch.float32)
+        place(actor_own, False, self._actor_flat, self._actor_gflat, 0)
+        self.log_alpha.grad = torch.zeros((), device=dev, dtype=torch.float64)
+
+    def _ws(self, B):
+        if B not in self._workspaces:
+            from . import _lib
+            if self.device.type != "cuda" and _lib._trace_hook is None:
+                raise RuntimeError("CurlSacAgent.update needs a CUDA/HIP device: the learner path has no CPU fallback")
+            self._workspaces[B] = _Workspace(self, B)
+        return self._workspaces[B]
+
+    # --------------------------------------------------------------- data parallel
+    def enable_data_parallel(self, process_group=None):
+        """Synchronous data parallelism (one process per GPU): before every
+        optimizer step the freshly written flat gradient bucket is summed over
+        ranks with one all-reduce (RCCL over xGMI) and divided by the world size
+        (SURVEY.md 8e).  Ranks must hold identical parameters (same seed)."""
+        import torch.distributed as dist
+        self._dp_group = process_group if process_group is not None else dist.group.WORLD
+        self._dp_world = dist.get_world_size(self._dp_group)
+
+    def _allreduce(self, *buckets):
+        if self._dp_world == 1:
+            return
+        import torch.distributed as dist
+        for t in buckets:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._dp_group)
+            t.div_(self._dp_world)
+
+    # ------------------------------------------------------------------ reference API
+    def train(self, training=True):
+        self.training = training
+        self.actor.train(training)
+        self.critic.train(training)
+        self.CURL.train(training)
+
+    @property
+    def alpha(self):
+        return self.log_alpha.exp()
+
+    def select_action(self, obs):
+        """curl_sac.py:330-337."""
+        with torch.no_grad():
+            obs = torch.FloatTensor(np.ascontiguousarray(obs)).to(self.device)
+            obs = obs.unsqueeze(0)
+            mu, _, _, _ = self.actor(obs, compute_pi=False, compute_log_pi=False)
+            return mu.cpu().data.numpy().flatten()
+
+    def sample_action(self, obs, noise=None):
+        """curl_sac.py:339-347."""
+        if obs.shape[-2:] != self.image_shape:
+            obs = self.augmentor.evaluation_augmentation(obs)
+        with torch.no_grad():
+            obs = torch.FloatTensor(np.ascontiguousarray(obs)).to(self.device)
+            obs = obs.unsqueeze(0)
+            mu, pi, _, _ = self.actor(obs, compute_log_pi=False, noise=noise)
+            return pi.cpu().data.numpy().flatten()
+
+    # ------------------------------------------------------------------ building blocks
+    def _encoder_backward(self, ws, obs_ref, dz, xhat, rstd, enc, conv_grads=True):
+        """Backward of fc+LN and (optionally) the conv stack from d(loss)/d(z);
+        writes .grad of enc.{ln,fc,convs}."""
+        B, F, K, L = obs_ref.B, enc.feature_dim, enc.flat_dim, enc.num_layers
+        acts = ws.acts_main
+        ops.ln_bwd(dz, xhat, rstd, enc.ln.weight, B, F, ws.dfc, dgamma=enc.ln.weight.grad, dbeta=enc.ln.bias.grad)
+        ops.colsum(ws.dfc, B, F, F, 0, enc.fc.bias.grad, 0)
+        h = acts[-1]
+        ops.linear_dw(ws.dfc, 0, h, 0, enc.fc.weight.grad, 0, B, F, K)
+        if not conv_grads:
+            return
+        cur = L % 2
+        g = ws.gviews[cur][L - 1]
+        ops.linear_dx(ws.dfc, 0, enc.fc.weight, 0, g, 0, B, F, K, mask=h)
+        for layer in range(L, 1, -1):  # layer l: input acts[l-2], output acts[l-1]
+            conv = enc.convs[layer - 1]
+            ops.conv_s1_wgrad(acts[layer - 2], g, conv.weight.grad, conv.bias.grad, ws.wg_ws)
+            cur ^= 1
+            gin = ws.gviews[cur][layer - 2]
+            ops.conv_s1_dgrad(g, conv.weight, acts[layer - 2], gin)
+            g = gin
+        ops.conv1_wgrad(obs_ref, g, enc.convs[0].weight.grad, enc.convs[0].bias.grad, ws.wg_ws)
+
+    def _noise(self, ws, noise):
+        if noise is None:
+            ws.noise.normal_()
+        else:
+            ws.noise.copy_(noise)
+        return ws.noise
+
+    # ------------------------------------------------------------------ phases
+    def update_critic(self, obs, action, reward, next_obs, not_done, L, step, noise=None):
+        """curl_sac.py:349-371."""
+        o, no = _as_ref(obs), _as_ref(next_obs)
+        B, A, H = o.B, self.action_dim, self.hidden_dim
+        enc, F = self.critic.encoder, self.critic.encoder.feature_dim
+        ws = self._ws(B)
+        self._anchor_cache = None
+        action, reward, not_done = action.contiguous(), reward.contiguous(), not_done.contiguous()
+
+        # -- target (no_grad block, curl_sac.py:350-355)
+        enc.conv_forward(no, ws.acts_tmp)                       # tied convs, online weights
+        self.actor.encoder.head_forward(ws.acts_tmp[-1], ws.z_a)
+        _mlp_fwd(ws.z_a, 0, _Mlp(self.actor.trunk), 1, B, F, H, 2 * A, ws.a_h1, ws.a_h2, ws.a_out)
+        nz = self._noise(ws, noise)
+        ops.actor_head_fwd(ws.a_out, nz, B, A, self.actor.log_std_min, self.actor.log_std_max, pi=ws.pi,
+                           log_pi=ws.log_pi)
+        tenc = self.critic_target.encoder
+        tenc.conv_forward(no, ws.acts_tmp)
+        tenc.head_forward(ws.acts_tmp[-1], ws.z_t)
+        ops.concat(ws.z_t, ws.pi, B, F, A, ws.xa)
+        _mlp_fwd(ws.xa, 0, self.critic_target.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.q)
+        ops.td_target(ws.q, B, ws.log_pi, reward, not_done, self.log_alpha, self.discount, B, ws.target_q)
+
+        # -- current Q estimates + loss + backward (curl_sac.py:357-367)
+        enc.conv_forward(o, ws.acts_main)
+        enc.head_forward(ws.acts_main[-1], ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c)
+        ops.concat(ws.z_c, action, B, F, A, ws.xa)
+        _mlp_fwd(ws.xa, 0, self.critic.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.q)
+        ops.critic_loss(ws.q, B, ws.target_q, B, ws.scalars[0:1], ws.dq)
+        if step % self.log_interval == 0:
+            L.log('train_critic/loss', ws.scalars[0], step)
+        _mlp_bwd(ws.xa, 0, self.critic.twin(), self.critic.twin(grads=True), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.dq,
+                 ws.q_dh2, ws.q_dh1, ws.dxa)
+        ops.split_sum(ws.dxa, B * (F + A), B, F, A, dz=ws.dz)
+        self._encoder_backward(ws, o, ws.dz, ws.xhat_c, ws.rstd_c, enc, conv_grads=not self.detach_encoder)
+
+        lay = self._lay
+        self._allreduce(self._critic_gflat[lay["enc"][0]:lay["total"]])
+        if self.detach_encoder:  # convs received no gradient: Adam must skip them (grad None in the reference)
+            saved = [(p, p.grad) for m in enc.convs for p in (m.weight, m.bias)]
+            for p, _ in saved:
+                p.grad = None
+            self.critic_optimizer.step()
+            for p, g in saved:
+                p.grad = g
+        else:
+            self.critic_optimizer.step()
+        if self.log_param_hist_imgs:
+            self.critic.log(L, step)
+
+    def update_actor_and_alpha(self, obs, L, step, noise=None):
+        """curl_sac.py:373-404.  Only the live gradients are produced: the
+        actor's own fc/ln/trunk and log_alpha (the reference also deposits
+        gradients on critic tensors that are zeroed before any step reads them)."""
+        o = _as_ref(obs)
+        B, A, H = o.B, self.action_dim, self.hidden_dim
+        enc, aenc, F = self.critic.encoder, self.actor.encoder, self.critic.encoder.feature_dim
+        ws = self._ws(B)
+
+        # one conv pass feeds actor.fc, critic.fc and (even steps) the CURL anchor branch
+        enc.conv_forward(o, ws.acts_main)
+        h = ws.acts_main[-1]
+        aenc.head_forward(h, ws.z_a, xhat=ws.xhat_a, rstd=ws.rstd_a)
+        enc.head_forward(h, ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c)
+        self._anchor_cache = obs
+
+        trunk = _Mlp(self.actor.trunk)
+        _mlp_fwd(ws.z_a, 0, trunk, 1, B, F, H, 2 * A, ws.a_h1, ws.a_h2, ws.a_out)
+        nz = self._noise(ws, noise)
+        lo, hi = self.actor.log_std_min, self.actor.log_std_max
+        ops.actor_head_fwd(ws.a_out, nz, B, A, lo, hi, mu=ws.mu, pi=ws.pi, log_pi=ws.log_pi, log_std=ws.log_std,
+                           tanh_ls=ws.tanh_ls)
+        ops.concat(ws.z_c, ws.pi, B, F, A, ws.xa)
+        _mlp_fwd(ws.xa, 0, self.critic.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.q)
+        ops.actor_loss(ws.q, B, ws.log_pi, ws.log_std, A, self.log_alpha, float(self.target_entropy), B,
+                       ws.scalars[1:5], ws.dq, self.log_alpha.grad)
+        if step % self.log_interval == 0:
+            L.log('train_actor/loss', ws.scalars[1], step)
+            L.log('train_actor/target_entropy', self.target_entropy, step)
+            L.log('train_actor/entropy', ws.scalars[3], step)
+
+        # backward: Q -> pi -> trunk -> LN -> fc (encoder detached, curl_sac.py:375-376)
+        _mlp_bwd(ws.xa, 0, self.critic.twin(), None, 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.dq, ws.q_dh2, ws.q_dh1,
+                 ws.dxa)
+        ops.split_sum(ws.dxa, B * (F + A), B, F, A, dact=ws.gpi)
+        ops.actor_head_bwd(ws.gpi, self.log_alpha, 1.0 / B, nz, ws.pi, ws.log_std, ws.tanh_ls, B, A, lo, hi, ws.a_dout)
+        _mlp_bwd(ws.z_a, 0, trunk, _Mlp(self.actor.trunk, grads=True), 1, B, F, H, 2 * A, ws.a_h1, ws.a_h2, ws.a_dout,
+                 ws.a_dh2, ws.a_dh1, ws.dz)
+        ops.ln_bwd(ws.dz, ws.xhat_a, ws.rstd_a, aenc.ln.weight, B, F, ws.dfc, dgamma=aenc.ln.weight.grad,
+                   dbeta=aenc.ln.bias.grad)
+        ops.colsum(ws.dfc, B, F, F, 0, aenc.fc.bias.grad, 0)
+        ops.linear_dw(ws.dfc, 0, h, 0, aenc.fc.weight.grad, 0, B, F, enc.flat_dim)
+
+        self._allreduce(self._actor_gflat, self.log_alpha.grad)
+        self.actor_optimizer.step()
+        if self.log_param_hist_imgs:
+            self.actor.log(L, step)
+        if step % self.log_interval == 0:
+            L.log('train_alpha/loss', ws.scalars[2], step)
+            L.log('train_alpha/value', ws.scalars[4], step)
+        self.log_alpha_optimizer.step()
+
+    def update_cpc(self, obs_anchor, obs_pos, cpc_kwargs, L, step):
+        """curl_sac.py:406-423."""
+        oa, op_ = _as_ref(obs_anchor), _as_ref(obs_pos)
+        B = oa.B
+        enc, tenc, F = self.critic.encoder, self.critic_target.encoder, self.critic.encoder.feature_dim
+        ws = self._ws(B)
+        if self._anchor_cache is None or self._anchor_cache is not obs_anchor:
+            enc.conv_forward(oa, ws.acts_main)
+            enc.head_forward(ws.acts_main[-1], ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c)
+        self._anchor_cache = None
+        tenc.conv_forward(op_, ws.acts_tmp)
+        tenc.head_forward(ws.acts_tmp[-1], ws.z_pos)
+
+        W = self.CURL.W
+        ops.linear_fwd(ws.z_pos, 0, W, 0, None, 0, ws.WzT, 0, B, F, F)         # (W z_pos^T)^T
+        ops.linear_fwd(ws.z_c, 0, ws.WzT, 0, None, 0, ws.logits, 0, B, B, F)   # z_a (W z_pos^T)
+        ops.curl_ce(ws.logits, B, B, ws.row_loss, ws.scalars[5:6], ws.dlogits)
+        ops.linear_dx(ws.dlogits, 0, ws.WzT, 0, ws.dz, 0, B, B, F)             # d z_a
+        ops.linear_dw(ws.dlogits, 0, ws.z_c, 0, ws.dWzT, 0, B, B, F)           # d (W z_pos^T)^T
+        ops.linear_dw(ws.dWzT, 0, ws.z_pos, 0, W.grad, 0, B, F, F)             # d W
+        self._encoder_backward(ws, oa, ws.dz, ws.xhat_c, ws.rstd_c, enc)
+
+        lay = self._lay
+        self._allreduce(self._critic_gflat[0:lay["enc"][1]])
+        self.encoder_optimizer.step()
+        self.cpc_optimizer.step()
+        if step % self.log_interval == 0:
+            L.log('train/curl_loss', ws.scalars[5], step)
+
+    def soft_update_targets(self):
+        """utils.soft_update_params x3 (curl_sac.py:442-445) as two flat lerps."""
+        lay = self._lay
+        (e0, e1), (q0, q1) = lay["enc"], lay["q"]
+        ops.soft_update(self._critic_flat[q0:q1], self._target_flat[q0:q1], self.critic_tau)
+        ops.soft_update(self._critic_flat[e0:e1], self._target_flat[e0:e1], self.encoder_tau)
+
+    def update(self, replay_buffer, L, step, only_cpc=False):
+        """curl_sac.py:426-451.  A curla_amd ReplayBuffer hands over references
+        into its HBM ring (gather + crop fused into the first conv); any other
+        buffer is used through the reference's ``sample_cpc()`` tensors."""
+        if hasattr(replay_buffer, "sample_cpc_refs"):
+            obs, action, reward, next_obs, not_done, cpc_kwargs = replay_buffer.sample_cpc_refs()
+        else:
+            obs, action, reward, next_obs, not_done, cpc_kwargs = replay_buffer.sample_cpc()
+
+        if step % self.log_interval == 0:
+            ws = self._ws(action.shape[0])
+            ops.mean(reward.contiguous(), reward.numel(), ws.scalars[6:7])
+            L.log('train/batch_reward', ws.scalars[6], step)
+
+        if not only_cpc:
+            self.update_critic(obs, action, reward, next_obs, not_done, L, step)
+            if step % self.actor_update_freq == 0:
+                self.update_actor_and_alpha(obs, L, step)
+            if step % self.critic_target_update_freq == 0:
+                self.soft_update_targets()
+
+        if not self.pixel_sac:
+            if step % self.cpc_update_freq == 0:
+                obs_anchor, obs_pos = cpc_kwargs["obs_anchor"], cpc_kwargs["obs_pos"]
+                self.update_cpc(obs_anchor, obs_pos, cpc_kwargs, L, step)
+
+    def save(self, model_dir, augmentation, step):
+        """curl_sac.py:453-456 (same three files, reference tensor layouts)."""
+        torch.save(self.CURL.state_dict(), '%s/%s_curl_%s.pt' % (model_dir, augmentation, step))
+        torch.save(self.actor.state_dict(), '%s/%s_actor_%s.pt' % (model_dir, augmentation, step))
+        torch.save(self.critic.state_dict(), '%s/%s_critic_%s.pt' % (model_dir, augmentation, step))
+
+    def load(self, model_dir, augmentation, step):
+        """curl_sac.py:458-465."""
+        self.CURL.load_state_dict(torch.load('%s/%s_curl_%s.pt' % (model_dir, augmentation, step)))
+        print('Loaded model %s/%s_curl_%s.pt' % (model_dir, augmentation, step))
+        self.actor.load_state_dict(torch.load('%s/%s_actor_%s.pt' % (model_dir, augmentation, step)))
+        print('Loaded model %s/%s_actor_%s.pt' % (model_dir, augmentation, step))
+        self.critic.load_state_dict(torch.load('%s/%s_critic_%s.pt' % (model_dir, augmentation, step)))
+        self.critic_target.load_state_dict(self.critic.state_dict())
+        print('Loaded model %s/%s_critic_%s.pt' % (model_dir, augmentation, step))

@@ -1,0 +1,206 @@
+"""CNNEncoder / PixelEncoder: the reference's pixel encoder (encoder.py:32-130)
+with the arithmetic on the MI355X kernels.
+
+The module tree mirrors the reference (``convs`` ModuleList of Conv2d, ``fc``
+Linear, ``ln`` LayerNorm) so ``state_dict()`` keys, ``parameters()`` order and
+the RNG stream consumed by construction are the same; the nn modules only hold
+Parameters -- ``forward`` runs HIP kernels, never ``nn.Conv2d.forward``.
+
+Differences from the reference, all deliberate:
+* ``out_dim`` is computed arithmetically; any H, W >= 7 works (the reference
+  table only admits 4 shapes and crashes on its square ones, encoder.py:38-47,66).
+* once an encoder is placed on the GPU by ``CurlSacAgent``, ``fc.weight`` stores
+  its input columns in (y, x, c) order (NHWC flatten) instead of (c, y, x);
+  ``state_dict()`` / ``load_state_dict()`` convert, so checkpoints are
+  reference-compatible in both directions.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def tie_weights(src, trg):
+    """encoder.py:12-15."""
+    assert type(src) == type(trg)
+    trg.weight = src.weight
+    trg.bias = src.bias
+
+
+def conv_out_hw(h, w, num_layers):
+    h, w = (h - 3) // 2 + 1, (w - 3) // 2 + 1
+    for _ in range(num_layers - 1):
+        h, w = h - 2, w - 2
+    return h, w
+
+
+class _FcLinear(nn.Linear):
+    """nn.Linear whose weight may be held with NHWC-ordered input columns."""
+
+    nhwc = None  # (C, H, W) once the columns are stored in (y, x, c) order
+
+    def to_reference_layout(self, w):
+        if self.nhwc is None:
+            return w
+        c, h, ww = self.nhwc
+        return w.reshape(-1, h, ww, c).permute(0, 3, 1, 2).reshape(w.shape[0], -1)
+
+    def from_reference_layout(self, w):
+        if self.nhwc is None:
+            return w
+        c, h, ww = self.nhwc
+        return w.reshape(-1, c, h, ww).permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+        if self.nhwc is not None:
+            destination[prefix + "weight"] = self.to_reference_layout(destination[prefix + "weight"].detach()).contiguous()
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        key = prefix + "weight"
+        if self.nhwc is not None and key in state_dict:
+            state_dict = dict(state_dict)
+            state_dict[key] = self.from_reference_layout(state_dict[key]).contiguous()
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
+
+class EncoderWorkspace:
+    """Activation buffers of one conv-stack pass for batch size B (NHWC fp32)."""
+
+    def __init__(self, enc, B, device):
+        self.B = B
+        self.acts = [torch.empty((B, h, w, enc.num_filters), device=device, dtype=torch.float32)
+                     for (h, w) in enc.layer_hw[1:]]
+
+
+class CNNEncoder(nn.Module):
+    """Convolutional encoder of pixel observations (encoder.py:32-110)."""
+
+    def __init__(self, obs_shape, feature_dim, num_layers=4, num_filters=32, output_logits=False):
+        super().__init__()
+        assert len(obs_shape) == 3
+        c, h, w = obs_shape
+        oh, ow = conv_out_hw(h, w, num_layers)
+        if h < 3 or w < 3 or oh < 1 or ow < 1:
+            raise NotImplementedError("Encoder does not support input shape")  # encoder.py:46-47
+        self.obs_shape = tuple(obs_shape)
+        self.feature_dim = feature_dim
+        self.num_layers = num_layers
+        self.num_filters = num_filters
+        self.convs = nn.ModuleList([nn.Conv2d(c, num_filters, 3, stride=2)])
+        for _ in range(num_layers - 1):
+            self.convs.append(nn.Conv2d(num_filters, num_filters, 3, stride=1))
+        # spatial size per layer: index 0 = input, l = output of conv l
+        hw = [(h, w), ((h - 3) // 2 + 1, (w - 3) // 2 + 1)]
+        for _ in range(num_layers - 1):
+            hw.append((hw[-1][0] - 2, hw[-1][1] - 2))
+        self.layer_hw = hw
+        self.out_dim = hw[-1]
+        self.flat_dim = num_filters * hw[-1][0] * hw[-1][1]
+        self.fc = _FcLinear(self.flat_dim, feature_dim)
+        self.ln = nn.LayerNorm(feature_dim)
+        self.outputs = dict()
+        self.output_logits = output_logits
+        self.record_outputs = False  # fill self.outputs (NCHW copies) for histogram/image logging
+        self._ws = {}
+        self._partial = {}
+
+    # -- kernel-side helpers ------------------------------------------------
+    def workspace(self, B, tag="infer"):
+        key = (B, tag)
+        if key not in self._ws:
+            self._ws[key] = EncoderWorkspace(self, B, self.fc.weight.device)
+        return self._ws[key]
+
+    def conv_params(self):
+        return [(m.weight, m.bias) for m in self.convs]
+
+    def ksplit(self, B):
+        """Split-K factor of the fc GEMM ([B, flat] x [flat, F]): enough
+        workgroups to fill 256 CUs about twice."""
+        mt = (B + 63) // 64
+        ks = max(1, min(64, 512 // mt))
+        return min(ks, max(1, self.flat_dim // 256))
+
+    def partial(self, B):
+        if B not in self._partial:
+            self._partial[B] = torch.empty((self.ksplit(B), B, self.feature_dim), device=self.fc.weight.device,
+                                           dtype=torch.float32)
+        return self._partial[B]
+
+    def conv_forward(self, obs_ref, acts, conv_params=None):
+        """relu(conv_l(...)) for l = 1..L (encoder.py:77-88); acts[l-1] receives layer l."""
+        cp = conv_params or self.conv_params()
+        ops.conv1_fwd(obs_ref, cp[0][0], cp[0][1], acts[0])
+        for i in range(1, self.num_layers):
+            ops.conv_s1_fwd(acts[i - 1], cp[i][0], cp[i][1], acts[i])
+        return acts[-1]
+
+    def head_forward(self, h, z, fc_out=None, xhat=None, rstd=None):
+        """fc + LayerNorm (+tanh) on the NHWC-flattened conv output (encoder.py:98-107)."""
+        B = h.shape[0]
+        if self.fc.nhwc is None:
+            raise RuntimeError("encoder weights are not in kernel layout; call CNNEncoder.to_kernel_layout() "
+                               "(CurlSacAgent does) before running the HIP path")
+        F, K = self.feature_dim, self.flat_dim
+        ks, part = self.ksplit(B), self.partial(B)
+        ops.gemm(h, 0, K, 0, self.fc.weight, 0, K, 0, part, F, 0, B, F, K, 1, ksplit=ks, split_stride=B * F)
+        ops.fc_ln_fwd(part, ks, B * F, F, self.fc.bias, self.ln.weight, self.ln.bias, B, F, z, fc_out=fc_out, xhat=xhat,
+                      rstd=rstd, eps=self.ln.eps, tanh_out=0 if self.output_logits else 1)
+        return z
+
+    def to_kernel_layout(self):
+        """Re-order fc.weight's input columns (c,y,x) -> (y,x,c) in place."""
+        if self.fc.nhwc is None:
+            nhwc = (self.num_filters,) + tuple(self.out_dim)
+            with torch.no_grad():
+                self.fc.nhwc = nhwc
+                self.fc.weight.data.copy_(self.fc.from_reference_layout(self.fc.weight.data.clone()))
+        return self
+
+    # -- reference API ---------------------------------------------------------
+    def forward_conv(self, obs):
+        """Reference returns the NCHW-flattened features (encoder.py:77-90); this
+        returns the NHWC-flattened ones ([B, H*W*C]) that ``fc`` is laid out for."""
+        ref = obs if isinstance(obs, ops.ObsRef) else ops.ObsRef.from_tensor(obs.contiguous().float())
+        ws = self.workspace(ref.B)
+        self.conv_forward(ref, ws.acts)
+        if self.record_outputs:
+            for i, a in enumerate(ws.acts):
+                out = torch.empty((a.shape[0], a.shape[3], a.shape[1], a.shape[2]), device=a.device, dtype=a.dtype)
+                ops.nhwc_to_nchw(a, out)
+                self.outputs["conv%s" % (i + 1)] = out
+        return ws.acts[-1].view(ref.B, -1)
+
+    def forward(self, obs, detach=False):
+        """Inference forward (no autograd graph: training gradients are produced
+        by CurlSacAgent's explicit backward kernels).  obs: float NCHW in [0,255]."""
+        h = self.forward_conv(obs)
+        z = torch.empty((h.shape[0], self.feature_dim), device=h.device, dtype=torch.float32)
+        fc_out = torch.empty_like(z) if self.record_outputs else None
+        self.head_forward(h, z, fc_out=fc_out)
+        if self.record_outputs:
+            self.outputs["fc"] = fc_out
+            self.outputs["ln" if self.output_logits else "tanh"] = z
+        return z
+
+    def copy_conv_weights_from(self, source):
+        """Tie convolutional layers (encoder.py:112-116)."""
+        for i in range(self.num_layers):
+            tie_weights(src=source.convs[i], trg=self.convs[i])
+
+    def log(self, L, step, log_freq):
+        """encoder.py:118-130."""
+        if step % log_freq != 0:
+            return
+        for k, v in self.outputs.items():
+            L.log_histogram('train_encoder/%s_hist' % k, v, step)
+            if len(v.shape) > 2:
+                L.log_image('train_encoder/%s_img' % k, v[0], step)
+        for i in range(self.num_layers):
+            L.log_param('train_encoder/conv%s' % (i + 1), self.convs[i], step)
+        L.log_param('train_encoder/fc', self.fc, step)
+        L.log_param('train_encoder/ln', self.ln, step)
+
+
+PixelEncoder = CNNEncoder  # upstream CURL's name for the same class

@@ -1,0 +1,173 @@
+"""Tensor-level wrappers over the C ABI (include/curla_hip.h).
+
+Every function enqueues HIP kernels on torch's current stream and returns
+immediately; tensors are only used for their device pointers.  Nothing here
+computes on the host and nothing falls back to PyTorch ops.
+"""
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream
+
+F32 = torch.float32
+
+
+def _dev(t, dtype=F32):
+    if not ((t.is_cuda or _lib._trace_hook is not None) and t.dtype == dtype and t.is_contiguous()):
+        raise _lib.CurlaHipError(f"expected a contiguous {dtype} CUDA tensor, got {t.dtype} {t.device} "
+                                 f"contiguous={t.is_contiguous()}")
+    return t
+
+
+class ObsRef:
+    """Where a minibatch's pixels live: either the uint8 NHWC replay ring plus
+    per-sample frame indices and crop offsets (fused gather+crop, the fast path)
+    or a float NCHW tensor in [0,255] (the reference's tensor contract)."""
+
+    __slots__ = ("src", "is_u8", "idx", "h1", "w1", "B", "C", "Hs", "Ws", "Hc", "Wc")
+
+    @staticmethod
+    def from_ring(frames, idx, h1, w1, B, crop_hw):
+        o = ObsRef()
+        _dev(frames, torch.uint8)
+        o.src, o.is_u8, o.idx, o.h1, o.w1, o.B = frames, 1, idx, h1, w1, B
+        _, o.Hs, o.Ws, o.C = frames.shape
+        o.Hc, o.Wc = crop_hw
+        return o
+
+    @staticmethod
+    def from_tensor(x):
+        o = ObsRef()
+        _dev(x)
+        o.src, o.is_u8, o.idx, o.h1, o.w1 = x, 0, None, None, None
+        o.B, o.C, o.Hc, o.Wc = x.shape
+        o.Hs, o.Ws = o.Hc, o.Wc
+        return o
+
+
+def conv1_fwd(obs: ObsRef, w, b, out, scale=1.0 / 255.0):
+    call("curla_conv1_fwd", ptr(obs.src), obs.is_u8, ptr(obs.idx), ptr(obs.h1), ptr(obs.w1), ptr(w), ptr(b), ptr(out),
+         obs.B, obs.C, obs.Hs, obs.Ws, obs.Hc, obs.Wc, w.shape[0], scale, stream())
+
+
+def conv1_wgrad(obs: ObsRef, g, dw, db, ws, scale=1.0 / 255.0):
+    call("curla_conv1_wgrad", ptr(obs.src), obs.is_u8, ptr(obs.idx), ptr(obs.h1), ptr(obs.w1), ptr(g), ptr(dw), ptr(db),
+         ptr(ws), obs.B, obs.C, obs.Hs, obs.Ws, obs.Hc, obs.Wc, dw.shape[0], scale, stream())
+
+
+def conv_s1_fwd(x, w, b, out):
+    B, H, W, C = x.shape
+    call("curla_conv3x3_s1_fwd", ptr(x), ptr(w), ptr(b), ptr(out), B, H, W, C, stream())
+
+
+def conv_s1_dgrad(g, w, act_below, gin):
+    B, H, W, C = g.shape
+    call("curla_conv3x3_s1_dgrad", ptr(g), ptr(w), ptr(act_below), ptr(gin), B, H, W, C, stream())
+
+
+def conv_s1_wgrad(x, g, dw, db, ws):
+    B, H, W, C = x.shape
+    call("curla_conv3x3_s1_wgrad", ptr(x), ptr(g), ptr(dw), ptr(db), ptr(ws), B, H, W, C, stream())
+
+
+def wgrad_workspace_floats(cin):
+    if _lib._trace_hook is not None:
+        return 256 * (32 * cin * 9 + 32)
+    return int(_lib.load().curla_conv_wgrad_workspace_floats(cin))
+
+
+def gemm(A, a_kmajor, lda, sA, Bm, b_kmajor, ldb, sB, C, ldc, sC, M, N, K, nbatch=1, ksplit=1, split_stride=0,
+         alpha=1.0, bias=None, sBias=0, relu=0, mask=None, ldmask=0, sMask=0):
+    call("curla_gemm", ptr(A), a_kmajor, lda, sA, ptr(Bm), b_kmajor, ldb, sB, ptr(C), ldc, sC, M, N, K, nbatch, ksplit,
+         split_stride, alpha, ptr(bias), sBias, relu, ptr(mask), ldmask, sMask, stream())
+
+
+def linear_fwd(x, sx, W, sW, bias, sb, out, so, M, N, K, nb=1, relu=0):
+    """out[z] = act(x[z] @ W[z]^T + bias[z]);  x [M,K], W [N,K] (nn.Linear layout)."""
+    gemm(x, 0, K, sx, W, 0, K, sW, out, N, so, M, N, K, nb, bias=bias, sBias=sb, relu=relu)
+
+
+def linear_dx(dy, sdy, W, sW, out, so, M, N, K, nb=1, mask=None, smask=0):
+    """out[z] = (dy[z] @ W[z]) masked;  dy [M,N], W [N,K] -> out [M,K]."""
+    gemm(dy, 0, N, sdy, W, 1, K, sW, out, K, so, M, K, N, nb, mask=mask, ldmask=K, sMask=smask)
+
+
+def linear_dw(dy, sdy, x, sx, out, so, M, N, K, nb=1):
+    """out[z] = dy[z]^T @ x[z];  dy [M,N], x [M,K] -> out [N,K]."""
+    gemm(dy, 1, N, sdy, x, 1, K, sx, out, K, so, N, K, M, nb)
+
+
+def fc_ln_fwd(partial, nsplit, split_stride, ldp, bias, gamma, beta, B, F, y, fc_out=None, xhat=None, rstd=None,
+              eps=1e-5, tanh_out=0):
+    call("curla_fc_ln_fwd", ptr(partial), nsplit, split_stride, ldp, ptr(bias), ptr(gamma), ptr(beta), B, F, eps,
+         ptr(fc_out), ptr(y), ptr(xhat), ptr(rstd), tanh_out, stream())
+
+
+def ln_bwd(dy, xhat, rstd, gamma, B, F, dx, dgamma=None, dbeta=None):
+    call("curla_ln_bwd", ptr(dy), ptr(xhat), ptr(rstd), ptr(gamma), B, F, ptr(dx), ptr(dgamma), ptr(dbeta), stream())
+
+
+def colsum(X, M, N, ldx, sX, out, sOut, nb=1):
+    call("curla_colsum", ptr(X), M, N, ldx, sX, ptr(out), sOut, nb, stream())
+
+
+def actor_head_fwd(trunk_out, noise, B, A, lo, hi, mu=None, pi=None, log_pi=None, log_std=None, tanh_ls=None):
+    call("curla_actor_head_fwd", ptr(trunk_out), ptr(noise), B, A, lo, hi, ptr(mu), ptr(pi), ptr(log_pi), ptr(log_std),
+         ptr(tanh_ls), stream())
+
+
+def actor_head_bwd(gpi, log_alpha, glp_scale, noise, pi, log_std, tanh_ls, B, A, lo, hi, dtrunk_out, glp_rows=None):
+    call("curla_actor_head_bwd", ptr(gpi), ptr(glp_rows), ptr(log_alpha), glp_scale, ptr(noise), ptr(pi), ptr(log_std),
+         ptr(tanh_ls), B, A, lo, hi, ptr(dtrunk_out), stream())
+
+
+def concat(z, act, B, F, A, xa):
+    call("curla_concat", ptr(z), ptr(act), B, F, A, ptr(xa), stream())
+
+
+def split_sum(dxa, twin_stride, B, F, A, dz=None, dact=None):
+    call("curla_split_sum", ptr(dxa), twin_stride, B, F, A, ptr(dz), ptr(dact), stream())
+
+
+def td_target(tq, twin_stride, log_pi, reward, not_done, log_alpha, discount, B, target_q):
+    call("curla_td_target", ptr(tq), twin_stride, ptr(log_pi), ptr(reward), ptr(not_done), ptr(log_alpha), discount, B,
+         ptr(target_q), stream())
+
+
+def critic_loss(q, twin_stride, target_q, B, loss, dq):
+    call("curla_critic_loss", ptr(q), twin_stride, ptr(target_q), B, ptr(loss), ptr(dq), stream())
+
+
+def actor_loss(q, twin_stride, log_pi, log_std, A, log_alpha, target_entropy, B, scalars4, dq, dlog_alpha):
+    call("curla_actor_loss", ptr(q), twin_stride, ptr(log_pi), ptr(log_std), A, ptr(log_alpha), target_entropy, B,
+         ptr(scalars4), ptr(dq), ptr(dlog_alpha), stream())
+
+
+def curl_ce(logits, B, ld, row_loss, loss, dlogits=None):
+    call("curla_curl_ce", ptr(logits), B, ld, ptr(row_loss), ptr(loss), ptr(dlogits), stream())
+
+
+def mean(x, n, out):
+    call("curla_mean", ptr(x), n, ptr(out), stream())
+
+
+def soft_update(param_flat, target_flat, tau):
+    # tau and (1 - tau) are rounded to fp32 separately, as `tau * p + (1 - tau) * t` does in torch (utils.py:39-41)
+    call("curla_soft_update", ptr(param_flat), ptr(target_flat), param_flat.numel(), float(tau), float(1 - tau),
+         stream())
+
+
+def crop_nchw(frames, idx, h1, w1, B, crop_hw, out_f32=None, out_u8=None):
+    _, Hs, Ws, C = frames.shape
+    call("curla_crop_nchw", ptr(frames), ptr(idx), ptr(h1), ptr(w1), B, C, Hs, Ws, crop_hw[0], crop_hw[1],
+         ptr(out_f32), ptr(out_u8), stream())
+
+
+def store_frame(chw_u8, frames, slot):
+    _, H, W, C = frames.shape
+    call("curla_store_frame", ptr(chw_u8), ptr(frames), int(slot), C, H, W, stream())
+
+
+def nhwc_to_nchw(x, out):
+    B, H, W, C = x.shape
+    call("curla_nhwc_to_nchw", ptr(x), ptr(out), B, H, W, C, stream())

@@ -1,0 +1,139 @@
+/* curla_hip.h -- C ABI of libcurla_hip.so: the MI355X (gfx950) kernels behind the
+ * CURL/SAC learner hot path of paulvantieghem/curla.
+ *
+ * The reference has no native layer (it is pure PyTorch); what each entry point
+ * replaces is therefore the ATen work dispatched by the cited reference lines
+ * (paths relative to the reference checkout).  The boundary is deliberately
+ * plain C: device pointers, sizes, a hipStream_t passed as void*.  No torch
+ * types, no exceptions across the boundary, no allocation, no host sync -- every
+ * call only enqueues kernels on `stream`, so callers may capture them into a
+ * hipGraph.  Return value: CURLA_OK or a negative CURLA_ERR_* code.
+ *
+ * Layouts:
+ *   activations        float32 NHWC  [B][H][W][32]
+ *   replay frames      uint8   NHWC  [capacity][H][W][C]   (C = 3 * frame_stack)
+ *   conv weights       float32 OIHW  (the reference's Parameter layout)
+ *   dense weights      float32 [out][in] row-major (nn.Linear layout); the encoder
+ *                      fc weight has its input columns in (y,x,c) order
+ *   twin-Q tensors     two equally shaped blocks separated by a `twin_stride`
+ */
+#ifndef CURLA_HIP_H
+#define CURLA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CURLA_OK 0
+#define CURLA_ERR_ARG (-1)         /* null / misaligned pointer, non-positive size */
+#define CURLA_ERR_LAUNCH (-2)      /* HIP reported a launch/attribute error */
+#define CURLA_ERR_UNSUPPORTED (-3) /* shape outside what the kernels are built for (cf. NotImplementedError, encoder.py:47) */
+
+const char* curla_version(void);
+
+/* ---- encoder convolutions (encoder.py:54-63 construction, :77-90 forward) ---- */
+
+/* First layer: 3x3 stride 2, C -> 32, + bias + ReLU, with the minibatch assembly
+ * fused into the load.  src_is_u8 = 1: `src` is the uint8 replay ring
+ * [N][Hs][Ws][C]; sample b reads frame idx[b] (NULL: b) cropped at
+ * (h1[b], w1[b]) (NULL: 0) to Hc x Wc -- replaces utils.py:151-166 (gather,
+ * RandomCrop.training_augmentation augmentations.py:47-75, .float()) and
+ * encoder.py:78 (`obs / 255.`, pass scale = 1/255).  src_is_u8 = 0: `src` is the
+ * reference's float NCHW tensor [B][C][Hc][Wc] in [0,255].  C in {3, 9, 12}. */
+int curla_conv1_fwd(const void* src, int src_is_u8, const int64_t* idx, const int32_t* h1, const int32_t* w1,
+                    const float* w, const float* bias, float* out, int B, int C, int Hs, int Ws, int Hc, int Wc,
+                    int channels, float scale, void* stream);
+
+/* Layers 2..L: 3x3 stride 1, 32 -> 32, + bias + ReLU (encoder.py:59-63,84-87). */
+int curla_conv3x3_s1_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Hi, int Wi,
+                         int channels, void* stream);
+
+/* Autograd of the above (what critic_loss.backward() / loss.backward() run,
+ * curl_sac.py:366,417).  `g` is the gradient w.r.t. the layer's pre-activation
+ * (already ReLU-masked).  dgrad writes the pre-activation gradient of the layer
+ * below: conv_transpose(g, w) zeroed where act_below <= 0. */
+int curla_conv3x3_s1_dgrad(const float* g, const float* w, const float* act_below, float* gin, int B, int Ho, int Wo,
+                           int channels, void* stream);
+int curla_conv3x3_s1_wgrad(const float* in, const float* g, float* dw, float* db, float* workspace, int B, int Hi,
+                           int Wi, int channels, void* stream);
+int curla_conv1_wgrad(const void* src, int src_is_u8, const int64_t* idx, const int32_t* h1, const int32_t* w1,
+                      const float* g, float* dw, float* db, float* workspace, int B, int C, int Hs, int Ws, int Hc,
+                      int Wc, int channels, float scale, void* stream);
+/* floats of `workspace` the two wgrad entry points need (per-workgroup partial slabs) */
+size_t curla_conv_wgrad_workspace_floats(int cin);
+
+/* ---- dense layers: encoder fc (encoder.py:66,98), actor trunk (curl_sac.py:70-74),
+ * twin Q (curl_sac.py:129-139), CURL bilinear logits (curl_sac.py:219-220) ----
+ * C[z] = epilogue(alpha * opA(A[z]) * opB(B[z])^T); a_kmajor/b_kmajor = operand is
+ * stored [K][rows]; epilogue = +bias[n], ReLU, zero where mask <= 0.  ksplit > 1
+ * writes partial products C + s*split_stride (no epilogue; reduce with
+ * curla_splitk_reduce or curla_fc_ln_fwd). */
+int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const float* B, int b_kmajor, int ldb,
+               long long strideB, float* C, int ldc, long long strideC, int M, int N, int K, int nbatch, int ksplit,
+               long long split_stride, float alpha, const float* bias, long long strideBias, int relu,
+               const float* mask, int ldmask, long long strideMask, void* stream);
+int curla_splitk_reduce(const float* partial, int nsplit, long long split_stride, int M, int N, int ldp, float* C,
+                        int ldc, const float* bias, int relu, void* stream);
+
+/* fc split-K reduce + bias + LayerNorm(eps) [+ tanh] (encoder.py:98-107).  Saves
+ * xhat / rstd for the backward when non-NULL.  F <= 64. */
+int curla_fc_ln_fwd(const float* partial, int nsplit, long long split_stride, int ldp, const float* bias,
+                    const float* gamma, const float* beta, int B, int F, float eps, float* fc_out, float* y,
+                    float* xhat, float* rstd, int tanh_out, void* stream);
+int curla_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int F, float* dx,
+                 float* dgamma, float* dbeta, void* stream);
+/* out[z][n] = sum_m X[z][m][n] (bias gradients) */
+int curla_colsum(const float* X, int M, int N, int ldx, long long strideX, float* out, long long strideOut, int nbatch,
+                 void* stream);
+
+/* ---- squashed-Gaussian policy head (curl_sac.py:20-35, 87-108) ----
+ * trunk_out [B][2A] = [mu | raw log_std]; `noise` replaces torch.randn_like
+ * (curl_sac.py:97); NULL noise = compute_pi False (select_action). */
+int curla_actor_head_fwd(const float* trunk_out, const float* noise, int B, int A, float log_std_min,
+                         float log_std_max, float* mu, float* pi, float* log_pi, float* log_std, float* tanh_ls,
+                         void* stream);
+/* gradient w.r.t. trunk_out of sum(gpi*pi) + glp*log_pi; glp = glp_rows[b] or glp_scale*exp(*log_alpha) */
+int curla_actor_head_bwd(const float* gpi, const float* glp_rows, const double* log_alpha, float glp_scale,
+                         const float* noise, const float* pi, const float* log_std, const float* tanh_ls, int B,
+                         int A, float log_std_min, float log_std_max, float* dtrunk_out, void* stream);
+
+/* torch.cat([z, action], 1) (curl_sac.py:138) and its backward summed over the twin */
+int curla_concat(const float* z, const float* act, int B, int F, int A, float* xa, void* stream);
+int curla_split_sum(const float* dxa, long long twin_stride, int B, int F, int A, float* dz, float* dact,
+                    void* stream);
+
+/* ---- SAC targets and losses ---- */
+/* target_Q = r + not_done*discount*(min(tq1,tq2) - exp(log_alpha)*log_pi) (curl_sac.py:353-355) */
+int curla_td_target(const float* tq, long long twin_stride, const float* log_pi, const float* reward,
+                    const float* not_done, const double* log_alpha, float discount, int B, float* target_q,
+                    void* stream);
+/* loss = mse(q1,tQ)+mse(q2,tQ) and dq = dloss/dq (curl_sac.py:359) */
+int curla_critic_loss(const float* q, long long twin_stride, const float* target_q, int B, float* loss, float* dq,
+                      void* stream);
+/* actor_loss, alpha_loss, entropy, alpha -> scalars4; dq = d actor_loss/dq; dlog_alpha (float64 like the
+ * reference's log_alpha, curl_sac.py:292) (curl_sac.py:378-399) */
+int curla_actor_loss(const float* q, long long twin_stride, const float* log_pi, const float* log_std, int A,
+                     const double* log_alpha, float target_entropy, int B, float* scalars4, float* dq,
+                     double* dlog_alpha, void* stream);
+/* CrossEntropyLoss(logits, arange(B)) and d/dlogits (curl_sac.py:221,411-413) */
+int curla_curl_ce(const float* logits, int B, int ld, float* row_loss, float* loss, float* dlogits, void* stream);
+int curla_mean(const float* x, int n, float* out, void* stream);
+
+/* target <- tau*param + (1-tau)*target over a flat parameter block (utils.py:37-41) */
+int curla_soft_update(const float* param, float* target, size_t n, float tau, float one_minus_tau, void* stream);
+
+/* ---- replay ring helpers ---- */
+/* float/uint8 NCHW crops exactly as sample_cpc returns them (utils.py:151-166) */
+int curla_crop_nchw(const uint8_t* frames, const int64_t* idx, const int32_t* h1, const int32_t* w1, int B, int C,
+                    int Hs, int Ws, int Hc, int Wc, float* out_f32, uint8_t* out_u8, void* stream);
+/* ReplayBuffer.add: one CHW uint8 observation into ring slot `slot` (utils.py:120-128) */
+int curla_store_frame(const uint8_t* chw, uint8_t* frames, long long slot, int C, int H, int W, void* stream);
+int curla_nhwc_to_nchw(const float* in, float* out, int B, int H, int W, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CURLA_HIP_H */

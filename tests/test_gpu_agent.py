@@ -1,0 +1,341 @@
+"""Phase-level parity of CurlSacAgent on the MI355X against (a) the golden
+vectors recorded from the reference and (b) the oracle on fresh inputs.
+Everything runs through the C ABI; integer outputs bit-exact, per-phase losses,
+activations and gradients within 1e-4 (per-tensor max-abs-normalised)."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from tests._util import RTOL, load, rel_err, sub, summarize
+
+pytestmark = pytest.mark.gpu
+
+REPORT = []
+
+
+def check(name, got, ref, tol=RTOL):
+    e = rel_err(got, ref)
+    REPORT.append((name, e))
+    assert np.isfinite(e) and e <= tol, f"{name}: rel err {e:.3e} > {tol:.1e}"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _report():
+    yield
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/agent_parity.txt", "a") as f:
+        for n, e in REPORT:
+            f.write(f"{n:70s} {e:.3e}\n")
+
+
+class NullLogger:
+    def __init__(self):
+        self.scalars = {}
+
+    def log(self, key, value, step, n=1):
+        self.scalars[key] = float(value.item() if isinstance(value, torch.Tensor) else value)
+
+    def log_histogram(self, *a, **k):
+        pass
+
+    def log_param(self, *a, **k):
+        pass
+
+    def log_image(self, *a, **k):
+        pass
+
+
+HP = dict(discount=0.99, init_temperature=0.1, alpha_lr=1e-4, alpha_beta=0.5, actor_lr=1e-3, actor_beta=0.9,
+          actor_log_std_min=-10, actor_log_std_max=2, actor_update_freq=2, critic_lr=1e-3, critic_beta=0.9,
+          critic_tau=0.01, critic_target_update_freq=2, encoder_feature_dim=50, encoder_lr=1e-3, encoder_tau=0.05,
+          num_layers=4, num_filters=32, log_interval=1)
+
+
+def make_agent(obs_shape, in_hw, hidden):
+    import curla_amd
+    aug = curla_amd.RandomCrop(in_hw, obs_shape[1:])
+    torch.manual_seed(0)
+    return curla_amd.CurlSacAgent(obs_shape, (2,), torch.device("cuda"), aug, hidden_dim=hidden, **HP), aug
+
+
+def load_state(agent, actor, critic, target, W, log_alpha):
+    """Through load_state_dict, i.e. through the reference checkpoint layout."""
+    agent.critic.load_state_dict(critic)
+    agent.actor.load_state_dict({**{k: v for k, v in critic.items() if ".convs." in k}, **actor})
+    agent.critic_target.load_state_dict(target)
+    with torch.no_grad():
+        agent.CURL.W.copy_(torch.as_tensor(W))
+        agent.log_alpha.copy_(torch.as_tensor(log_alpha))
+
+
+def grads_of(module, prefix=""):
+    out = {}
+    for n, p in module.named_parameters():
+        g = p.grad
+        if n.endswith("encoder.fc.weight") or n == "fc.weight":
+            enc = module.encoder if hasattr(module, "encoder") else module
+            g = enc.fc.to_reference_layout(g)
+        out[prefix + n] = g.detach().cpu()
+    return out
+
+
+def fill_ring(rb, obs_full, next_full):
+    """Put the fixture's B pre-crop frames in slots 0..B-1."""
+    n = len(obs_full)
+    rb.add_batch(obs_full, np.zeros((n, 2), np.float32), np.zeros(n, np.float32), next_full, np.zeros(n, bool))
+
+
+@pytest.fixture(scope="module")
+def tiny():
+    return load("tiny.npz")
+
+
+def _tiny_agent(g):
+    agent, aug = make_agent((9, 28, 34), (34, 40), 64)
+    load_state(agent, sub(g, "state0/actor/"), sub(g, "state0/critic/"), sub(g, "state0/critic_target/"),
+               g["state0/W"], g["state0/log_alpha"])
+    return agent, aug
+
+
+def _t(x):
+    return torch.as_tensor(np.asarray(x)).cuda()
+
+
+def test_state_dict_roundtrip_reference_layout(tiny):
+    agent, _ = _tiny_agent(tiny)
+    for name, mod in (("critic", agent.critic), ("critic_target", agent.critic_target)):
+        sd = mod.state_dict()
+        ref = sub(tiny, f"state0/{name}/")
+        assert list(sd.keys()) == list(ref.keys())
+        for k in ref:
+            assert torch.equal(sd[k].cpu(), ref[k]), k
+    sd = agent.actor.state_dict()
+    for k, v in sub(tiny, "state0/actor/").items():
+        assert torch.equal(sd[k].cpu(), v), k
+
+
+@pytest.mark.parametrize("path", ["tensors", "ring"])
+def test_critic_phase_vs_reference(tiny, path):
+    import curla_amd
+    g = tiny
+    agent, aug = _tiny_agent(g)
+    L = NullLogger()
+    B = 8
+    act, rew, nd = _t(g["batch/action"]), _t(g["batch/reward"]), _t(g["batch/not_done"])
+    if path == "tensors":
+        obs, nxt = _t(g["batch/obs"]).float(), _t(g["batch/next_obs"]).float()
+    else:
+        rb = curla_amd.ReplayBuffer((9, 34, 40), (2,), 16, B, torch.device("cuda"), aug)
+        fill_ring(rb, g["batch/obs_full"], g["batch/next_obs_full"])
+        offs = np.stack([g["rng/h1_obs"], g["rng/w1_obs"], g["rng/h1_next_obs"], g["rng/w1_next_obs"],
+                         g["rng/h1_pos"], g["rng/w1_pos"]]).astype(np.int32)
+        obs, _, _, nxt, _, kw = rb.sample_cpc_refs(indices=(np.arange(B), offs))
+        # the materialised crops must be the reference's bytes
+        o2, _, _, n2, _, kw2 = rb.sample_cpc(indices=(np.arange(B), offs))
+        assert np.array_equal(o2.cpu().numpy().astype(np.uint8), g["batch/obs"])
+        assert np.array_equal(n2.cpu().numpy().astype(np.uint8), g["batch/next_obs"])
+        assert np.array_equal(kw2["obs_pos"].cpu().numpy().astype(np.uint8), g["batch/pos"])
+    agent.critic_optimizer.step = lambda: None  # inspect gradients before Adam moves the weights
+    agent.update_critic(obs, act, rew, nxt, nd, L, 4, noise=_t(g["noise/critic"]))
+    ws = agent._ws(B)
+    check(f"[{path}] critic loss", L.scalars["train_critic/loss"], g["scalar/train_critic/loss"])
+    check(f"[{path}] q1", ws.q[0].cpu(), g["critic/q1"])
+    check(f"[{path}] q2", ws.q[1].cpu(), g["critic/q2"])
+    for i in range(4):
+        a = ws.acts_main[i].permute(0, 3, 1, 2).cpu()
+        check(f"[{path}] conv{i + 1}", a, g[f"critic/enc/conv{i + 1}"])
+    check(f"[{path}] ln", ws.z_c.cpu(), g["critic/enc/ln"])
+    got = grads_of(agent.critic)
+    ref = sub(g, "critic/grad/")
+    assert set(got) == set(ref)
+    for k in ref:
+        check(f"[{path}] critic grad {k}", got[k], ref[k])
+
+
+def test_actor_cpc_softupdate_vs_reference(tiny):
+    g = tiny
+    agent, aug = _tiny_agent(g)
+    L = NullLogger()
+    B = 8
+    agent.critic.load_state_dict(sub(g, "critic_after/"))  # theta' (after the critic Adam step)
+    obs, pos = _t(g["batch/obs"]).float(), _t(g["batch/pos"]).float()
+    for opt in (agent.actor_optimizer, agent.log_alpha_optimizer, agent.encoder_optimizer, agent.cpc_optimizer):
+        opt.step = lambda: None
+    agent.update_actor_and_alpha(obs, L, 4, noise=_t(g["noise/actor"]))
+    ws = agent._ws(B)
+    for k, buf in (("pi", ws.pi), ("log_pi", ws.log_pi), ("log_std", ws.log_std)):
+        check(f"actor {k}", buf.cpu(), g[f"actor/{k}"])
+    check("actor q1", ws.q[0].cpu(), g["actor/q1"])
+    check("actor q2", ws.q[1].cpu(), g["actor/q2"])
+    check("actor loss", L.scalars["train_actor/loss"], g["scalar/train_actor/loss"])
+    check("alpha loss", L.scalars["train_alpha/loss"], g["scalar/train_alpha/loss"])
+    check("entropy", L.scalars["train_actor/entropy"], g["scalar/train_actor/entropy"])
+    check("alpha", L.scalars["train_alpha/value"], g["scalar/train_alpha/value"])
+    check("log_alpha grad", agent.log_alpha.grad.cpu(), g["alpha/grad/log_alpha"])
+    got = grads_of(agent.actor)
+    ref = sub(g, "actor/grad/")
+    for k in ref:
+        check(f"actor grad {k}", got[k], ref[k])
+    # soft update from (theta', xi) -> xi'
+    agent.soft_update_targets()
+    sd = agent.critic_target.state_dict()
+    for k, v in sub(g, "target_after/").items():
+        check(f"target after soft update {k}", sd[k].cpu(), v, 1e-6)
+    # cpc phase, anchor features reused from the actor phase (same obs object)
+    agent.update_cpc(obs, pos, None, L, 4)
+    check("curl z_a", ws.z_c.cpu(), g["cpc/z_a"])
+    check("curl z_pos", ws.z_pos.cpu(), g["cpc/z_pos"])
+    lg = ws.logits.cpu()
+    check("curl logits", lg - lg.max(1)[0][:, None], g["cpc/logits"])
+    check("curl loss", L.scalars["train/curl_loss"], g["scalar/train/curl_loss"])
+    got = grads_of(agent.critic.encoder, "encoder.")
+    got["W"] = agent.CURL.W.grad.cpu()
+    ref = sub(g, "cpc/grad/")
+    for k in ref:
+        check(f"cpc grad {k}", got[k], ref[k])
+    # same phase without the cache (odd-step path)
+    agent._anchor_cache = None
+    agent.update_cpc(obs.clone(), pos, None, L, 5)
+    check("curl loss (no anchor cache)", L.scalars["train/curl_loss"], g["scalar/train/curl_loss"])
+    got2 = grads_of(agent.critic.encoder, "encoder.")
+    for k in ("encoder.convs.0.weight", "encoder.convs.2.weight", "encoder.fc.weight"):
+        check(f"cpc grad {k} (no anchor cache)", got2[k], ref[k])
+
+
+def test_acting_path_vs_reference(tiny):
+    g = tiny
+    agent, aug = _tiny_agent(g)
+    check("select_action", agent.select_action(aug.evaluation_augmentation(g["act/obs"])), g["act/select"])
+    check("sample_action", agent.sample_action(g["act/obs"], noise=_t(g["act/noise"])), g["act/sample"])
+    # module-level callables used by plot_tsne (latent_data.py:83,93)
+    x = _t(aug.evaluation_augmentation(g["act/obs"]).copy()).float()[None]
+    z = agent.actor.encoder(x)
+    assert z.shape == (1, 50)
+    q1, q2 = agent.critic(x, _t(np.zeros((1, 2), np.float32)))
+    assert q1.shape == (1, 1) and q2.shape == (1, 1)
+
+
+def test_full_shape_update_vs_reference_summaries():
+    """84x84 -> 76x76 (BASELINE geometry), weights from the seeded recipe,
+    the whole even-step update() chained with Adam, via the HBM ring."""
+    import curla_amd
+    from tests.golden_recipes import c1shape_inputs
+    g = load("c1shape.npz")
+    inp = c1shape_inputs(g)
+    agent, aug = make_agent((9, 76, 76), (84, 84), 128)
+    load_state(agent, inp["actor"], inp["critic"], inp["target"], inp["W"].numpy(), inp["log_alpha"].numpy())
+    B = 4
+    rb = curla_amd.ReplayBuffer((9, 84, 84), (2,), 8, B, torch.device("cuda"), aug)
+    fill_ring(rb, inp["obs_full"], inp["next_obs_full"])
+    rb.actions[:B] = _t(g["batch/action"])
+    rb.rewards[:B] = _t(g["batch/reward"])
+    rb.not_dones[:B] = _t(g["batch/not_done"])
+    offs = np.stack([g[f"rng/{a}_{b}"] for b in ("obs", "next_obs", "pos") for a in ("h1", "w1")]).astype(np.int32)
+    obs, act, rew, nxt, nd, kw = rb.sample_cpc_refs(indices=(np.arange(B), offs))
+    o2 = rb.sample_cpc(indices=(np.arange(B), offs))[0]
+    assert hashlib.sha256(o2.cpu().numpy().astype(np.uint8).tobytes()).hexdigest() == str(g["batch/obs_sha256"])
+    L = NullLogger()
+    captured = {}
+
+    def capture(name, module, opt, extra=None):
+        real = opt.step
+
+        def step():
+            captured[name] = grads_of(module)
+            if extra:
+                captured[name].update(extra())
+            real()
+        opt.step = step
+    capture("critic", agent.critic, agent.critic_optimizer)
+    capture("actor", agent.actor, agent.actor_optimizer)
+    capture("cpc", agent.critic.encoder, agent.encoder_optimizer, lambda: {"W": agent.CURL.W.grad.cpu().clone()})
+    agent.update_critic(obs, act, rew, nxt, nd, L, 0, noise=_t(g["noise/critic"]))
+    agent.update_actor_and_alpha(obs, L, 0, noise=_t(g["noise/actor"]))
+    agent.soft_update_targets()
+    agent.update_cpc(kw["obs_anchor"], kw["obs_pos"], kw, L, 0)
+    for key in ("train_critic/loss", "train_actor/loss", "train_alpha/loss", "train/curl_loss", "train_actor/entropy"):
+        check(f"c1shape {key}", L.scalars[key], g["scalar/" + key])
+    for k, v in sub(g, "sum/critic/grad/", as_torch=False).items():
+        check(f"c1shape critic grad {k}", summarize(captured["critic"][k]), v)
+    for k, v in sub(g, "sum/actor/grad/", as_torch=False).items():
+        check(f"c1shape actor grad {k}", summarize(captured["actor"][k]), v)
+    for k, v in sub(g, "sum/cpc/grad/", as_torch=False).items():
+        kk = k if k == "W" else k[len("encoder."):]
+        check(f"c1shape cpc grad {k}", summarize(captured["cpc"][kk]), v, 2e-4)
+
+
+def test_update_chain_vs_oracle_agent():
+    """3 consecutive update() calls (even, odd, even) from the same init against
+    the oracle agent fed the same minibatches and noise: losses per step."""
+    import curla_amd
+    from oracle import curla_oracle as O
+    torch.manual_seed(3)
+    np.random.seed(3)
+    in_hw, out_hw, B, hidden = (40, 44), (32, 36), 16, 96
+    agent, aug = make_agent((9,) + out_hw, in_hw, hidden)
+    oracle = O.OracleAgent((9,) + out_hw, (2,), hidden_dim=hidden, **{k: v for k, v in HP.items()
+                                                                      if k not in ("log_interval",)})
+    # identical weights: copy the agent's (reference-layout) state into the oracle
+    for dst, src in ((oracle.critic, agent.critic.state_dict()), (oracle.critic_target, agent.critic_target.state_dict()),
+                     (oracle.actor, agent.actor.state_dict())):
+        for k in dst:
+            dst[k].data.copy_(src[k].cpu())
+    oracle.W.data.copy_(agent.CURL.W.detach().cpu())
+    rb = curla_amd.ReplayBuffer((9,) + in_hw, (2,), 64, B, torch.device("cuda"), aug)
+    rs = np.random.RandomState(0)
+    n = 48
+    obs_all = rs.randint(0, 256, (n, 9) + in_hw, dtype=np.uint8)
+    nxt_all = rs.randint(0, 256, (n, 9) + in_hw, dtype=np.uint8)
+    act_all = rs.uniform(-1, 1, (n, 2)).astype(np.float32)
+    rew_all = rs.randn(n).astype(np.float32)
+    done_all = (np.arange(n) % 7) == 6
+    for i in range(n):  # the per-transition add() path
+        rb.add(obs_all[i], act_all[i], rew_all[i], nxt_all[i], bool(done_all[i]))
+    assert rb.idx == n and not rb.full
+    L = NullLogger()
+    for step in range(3):
+        idxs, offs = rb.draw_indices()
+        noise_c, noise_a = torch.randn(B, 2), torch.randn(B, 2)
+        crop = lambda src, j: torch.from_numpy(O.random_crop(src[idxs], offs[2 * j], offs[2 * j + 1], out_hw)).float()  # noqa: E731
+        ref = oracle.update(crop(obs_all, 0), torch.from_numpy(act_all[idxs]), torch.from_numpy(rew_all[idxs])[:, None],
+                            crop(nxt_all, 1), torch.from_numpy(1.0 - done_all[idxs].astype(np.float32))[:, None],
+                            crop(obs_all, 2), noise_c, noise_a, step)
+        obs, act, rew, nxt, nd, kw = rb.sample_cpc_refs(indices=(idxs, offs))
+        agent.update_critic(obs, act, rew, nxt, nd, L, step, noise=noise_c.cuda())
+        if step % 2 == 0:
+            agent.update_actor_and_alpha(obs, L, step, noise=noise_a.cuda())
+            agent.soft_update_targets()
+        agent.update_cpc(kw["obs_anchor"], kw["obs_pos"], kw, L, step)
+        # trajectories diverge chaotically: looser bar after the first step
+        tol = RTOL if step == 0 else 5e-3
+        check(f"chain step{step} critic loss", L.scalars["train_critic/loss"], ref["critic_loss"], tol)
+        check(f"chain step{step} curl loss", L.scalars["train/curl_loss"], ref["curl_loss"], tol)
+        if step % 2 == 0:
+            check(f"chain step{step} actor loss", L.scalars["train_actor/loss"], ref["actor_loss"], tol)
+    # parameters after 3 Adam-stepped updates stay close to the oracle's
+    sd = agent.critic.state_dict()
+    for k in ("encoder.convs.1.weight", "Q1.trunk.2.weight", "encoder.ln.weight"):
+        check(f"chain params {k}", sd[k].cpu(), oracle.critic[k].detach(), 2e-2)
+
+
+def test_update_entry_point_runs_from_ring():
+    """agent.update(replay_buffer, L, step) -- the reference's call (train.py:425) --
+    with NumPy-seeded sampling, finite losses, 5 conv forwards per update."""
+    import curla_amd
+    from curla_amd import _lib
+    np.random.seed(11)
+    agent, aug = make_agent((9, 28, 34), (34, 40), 64)
+    rb = curla_amd.ReplayBuffer((9, 34, 40), (2,), 32, 8, torch.device("cuda"), aug)
+    rs = np.random.RandomState(1)
+    for i in range(20):
+        rb.add(rs.randint(0, 256, (9, 34, 40), dtype=np.uint8), rs.uniform(-1, 1, 2), rs.randn(), rs.randint(0, 256, (9, 34, 40), dtype=np.uint8), i % 9 == 8)
+    L = NullLogger()
+    for step in range(4):
+        agent.update(rb, L, step)
+    torch.cuda.synchronize()
+    for k in ("train_critic/loss", "train_actor/loss", "train/curl_loss", "train/batch_reward", "train_alpha/value"):
+        assert np.isfinite(L.scalars[k]), k
+    assert _lib._lib is not None  # the native library is what ran

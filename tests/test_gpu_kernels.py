@@ -1,0 +1,335 @@
+"""Kernel-level parity on the MI355X: every HIP entry point against a plain
+PyTorch fp32 (CPU) statement of the same op, through the C ABI.  Integer work
+(crop, frame store) bit-exact; floating point within 1e-4 per tensor
+(tests/_util.RTOL).  Shapes include ragged tiles, rectangular images and the
+BASELINE geometries (84->76, 37/35/33 feature maps, 83-wide maps of config 5)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests._util import RTOL, rel_err
+
+pytestmark = pytest.mark.gpu
+
+REPORT = []
+
+
+def check(name, got, ref, tol=RTOL):
+    e = rel_err(got, ref)
+    REPORT.append((name, e))
+    assert np.isfinite(e) and e <= tol, f"{name}: rel err {e:.3e} > {tol:.1e}"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _report():
+    yield
+    import os
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/kernel_parity.txt", "a") as f:
+        for n, e in REPORT:
+            f.write(f"{n:60s} {e:.3e}\n")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from curla_amd import ops as o
+    return o
+
+
+def dev(x):
+    return torch.as_tensor(x).cuda().contiguous()
+
+
+def nhwc(x):  # NCHW cpu -> NHWC cuda
+    return x.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def nchw(x):  # NHWC cuda -> NCHW cpu
+    return x.permute(0, 3, 1, 2).contiguous().cpu()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 13, 16), (2, 37, 37), (5, 35, 35), (1, 83, 83), (2, 5, 41), (9, 17, 15)])
+def test_conv_s1_fwd(ops, B, H, W):
+    x, w, b = rnd(B, 32, H, W, seed=1), rnd(32, 32, 3, 3, seed=2, scale=0.1), rnd(32, seed=3, scale=0.1)
+    ref = torch.relu(F.conv2d(x, w, b))
+    out = torch.full((B, H - 2, W - 2, 32), float("nan"), device="cuda")
+    ops.conv_s1_fwd(nhwc(x), dev(w), dev(b), out)
+    check(f"conv_s1_fwd B{B} {H}x{W}", nchw(out), ref)
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 11, 14), (2, 35, 35), (1, 81, 81), (4, 3, 39), (7, 13, 13)])
+def test_conv_s1_dgrad(ops, B, H, W):
+    # g: gradient w.r.t. the conv output [B,32,H,W]; input was [B,32,H+2,W+2]
+    below = rnd(B, 32, H + 2, W + 2, seed=4)
+    act_below = torch.relu(below)
+    w = rnd(32, 32, 3, 3, seed=5, scale=0.1)
+    g = rnd(B, 32, H, W, seed=6)
+    ref = F.conv_transpose2d(g, w) * (act_below > 0)
+    gin = torch.full((B, H + 2, W + 2, 32), float("nan"), device="cuda")
+    ops.conv_s1_dgrad(nhwc(g), dev(w), nhwc(act_below), gin)
+    check(f"conv_s1_dgrad B{B} {H}x{W}", nchw(gin), ref)
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 13, 16), (2, 37, 37), (6, 35, 35), (1, 83, 83), (300, 9, 9)])
+def test_conv_s1_wgrad(ops, B, H, W):
+    x = torch.relu(rnd(B, 32, H, W, seed=7))
+    g = rnd(B, 32, H - 2, W - 2, seed=8) * (rnd(B, 32, H - 2, W - 2, seed=9) > 0)
+    w = torch.zeros(32, 32, 3, 3, requires_grad=True)
+    b = torch.zeros(32, requires_grad=True)
+    F.conv2d(x, w, b).backward(g)
+    dw = torch.full((32, 32, 3, 3), float("nan"), device="cuda")
+    db = torch.full((32,), float("nan"), device="cuda")
+    ws = torch.empty(ops.wgrad_workspace_floats(32), device="cuda")
+    ops.conv_s1_wgrad(nhwc(x), nhwc(g), dw, db, ws)
+    check(f"conv_s1_wgrad dW B{B} {H}x{W}", dw.cpu(), w.grad)
+    check(f"conv_s1_wgrad db B{B} {H}x{W}", db.cpu(), b.grad)
+
+
+def _ring(N, C, Hs, Ws, seed):
+    frames = np.random.RandomState(seed).randint(0, 256, (N, C, Hs, Ws), dtype=np.uint8)  # CHW like the reference
+    store = torch.zeros(N * C * Hs * Ws + 16, dtype=torch.uint8, device="cuda")
+    ring = store[:N * C * Hs * Ws].view(N, Hs, Ws, C)
+    ring.copy_(torch.from_numpy(frames).permute(0, 2, 3, 1))
+    return frames, ring
+
+
+CONV1_CASES = [  # C, Hs, Ws, Hc, Wc, B
+    (9, 34, 40, 28, 34, 8), (9, 84, 84, 76, 76, 4), (9, 84, 84, 84, 84, 3), (12, 50, 46, 41, 37, 5), (3, 20, 23, 17, 19, 6),
+]
+
+
+@pytest.mark.parametrize("C,Hs,Ws,Hc,Wc,B", CONV1_CASES)
+def test_crop_and_conv1_u8(ops, C, Hs, Ws, Hc, Wc, B):
+    from oracle import curla_oracle as O
+    N = 11
+    frames, ring = _ring(N, C, Hs, Ws, seed=C + Hs)
+    rs = np.random.RandomState(5)
+    idx = rs.randint(0, N, B)
+    h1 = rs.randint(0, Hs - Hc + 1, B).astype(np.int32)
+    w1 = rs.randint(0, Ws - Wc + 1, B).astype(np.int32)
+    ref_crop = O.random_crop(frames[idx], h1, w1, (Hc, Wc))
+    d_idx, d_h1, d_w1 = dev(idx.astype(np.int64)), dev(h1), dev(w1)
+    # integer path: bit-exact
+    out_u8 = torch.zeros((B, C, Hc, Wc), dtype=torch.uint8, device="cuda")
+    out_f = torch.zeros((B, C, Hc, Wc), dtype=torch.float32, device="cuda")
+    ops.crop_nchw(ring, d_idx, d_h1, d_w1, B, (Hc, Wc), out_f32=out_f, out_u8=out_u8)
+    assert np.array_equal(out_u8.cpu().numpy(), ref_crop)
+    assert np.array_equal(out_f.cpu().numpy(), ref_crop.astype(np.float32))
+    # fused gather + crop + /255 + conv1 + relu
+    w, b = rnd(32, C, 3, 3, seed=11, scale=0.2), rnd(32, seed=12, scale=0.1)
+    x = torch.from_numpy(ref_crop.astype(np.float32))
+    ref = torch.relu(F.conv2d(x / 255.0, w, b, stride=2))
+    Ho, Wo = ref.shape[2:]
+    obs = ops.ObsRef.from_ring(ring, d_idx, d_h1, d_w1, B, (Hc, Wc))
+    out = torch.full((B, Ho, Wo, 32), float("nan"), device="cuda")
+    ops.conv1_fwd(obs, dev(w), dev(b), out)
+    check(f"conv1_fwd u8 C{C} {Hs}x{Ws}->{Hc}x{Wc}", nchw(out), ref)
+    # float NCHW source (reference tensor contract)
+    out2 = torch.full((B, Ho, Wo, 32), float("nan"), device="cuda")
+    ops.conv1_fwd(ops.ObsRef.from_tensor(out_f), dev(w), dev(b), out2)
+    check(f"conv1_fwd f32 C{C} {Hc}x{Wc}", nchw(out2), ref)
+    # weight gradient, both sources
+    g = rnd(B, 32, Ho, Wo, seed=13) * (ref > 0)
+    wl = w.clone().requires_grad_(True)
+    bl = b.clone().requires_grad_(True)
+    F.conv2d(x / 255.0, wl, bl, stride=2).backward(g)
+    ws = torch.empty(ops.wgrad_workspace_floats(C), device="cuda")
+    for name, o in (("u8", obs), ("f32", ops.ObsRef.from_tensor(out_f))):
+        dw = torch.full((32, C, 3, 3), float("nan"), device="cuda")
+        db = torch.full((32,), float("nan"), device="cuda")
+        ops.conv1_wgrad(o, nhwc(g), dw, db, ws)
+        check(f"conv1_wgrad dW {name} C{C} {Hc}x{Wc}", dw.cpu(), wl.grad)
+        check(f"conv1_wgrad db {name} C{C} {Hc}x{Wc}", db.cpu(), bl.grad)
+
+
+def test_store_frame_bit_exact(ops):
+    C, H, W = 9, 34, 40
+    ring = torch.zeros((5, H, W, C), dtype=torch.uint8, device="cuda")
+    f = np.random.RandomState(2).randint(0, 256, (C, H, W), dtype=np.uint8)
+    ops.store_frame(dev(f).view(-1), ring, 3)
+    assert np.array_equal(ring[3].cpu().numpy(), f.transpose(1, 2, 0))
+    assert int(ring[2].sum()) == 0 and int(ring[4].sum()) == 0
+
+
+GEMM_CASES = [  # M, N, K, a_kmajor, b_kmajor, nbatch
+    (8, 50, 2240, 0, 0, 1), (70, 64, 50, 0, 0, 1), (512, 1024, 52, 0, 0, 2), (33, 17, 129, 0, 1, 1), (50, 301, 64, 1, 1, 1),
+    (64, 52, 100, 1, 1, 2), (5, 4, 64, 0, 0, 1), (128, 128, 128, 0, 1, 2), (1, 64, 50, 0, 0, 1),
+]
+
+
+@pytest.mark.parametrize("M,N,K,ak,bk,nb", GEMM_CASES)
+def test_gemm(ops, M, N, K, ak, bk, nb):
+    A = rnd(nb, M, K, seed=21)
+    Bm = rnd(nb, N, K, seed=22)
+    bias = rnd(nb, N, seed=23)
+    mask = rnd(nb, M, N, seed=24)
+    ref_plain = torch.einsum("zmk,znk->zmn", A, Bm)
+    Ad = dev(A.transpose(1, 2)) if ak else dev(A)
+    Bd = dev(Bm.transpose(1, 2)) if bk else dev(Bm)
+    lda, ldb = (M if ak else K), (N if bk else K)
+    C = torch.full((nb, M, N), float("nan"), device="cuda")
+    ops.gemm(Ad, ak, lda, M * K, Bd, bk, ldb, N * K, C, N, M * N, M, N, K, nb, alpha=0.5, bias=dev(bias), sBias=N, relu=1)
+    check(f"gemm bias+relu {M}x{N}x{K} ak{ak} bk{bk} nb{nb}", C.cpu(), torch.relu(0.5 * ref_plain + bias[:, None, :]))
+    C2 = torch.full((nb, M, N), float("nan"), device="cuda")
+    ops.gemm(Ad, ak, lda, M * K, Bd, bk, ldb, N * K, C2, N, M * N, M, N, K, nb, mask=dev(mask), ldmask=N, sMask=M * N)
+    check(f"gemm mask {M}x{N}x{K} ak{ak} bk{bk} nb{nb}", C2.cpu(), ref_plain * (mask > 0))
+
+
+def test_gemm_splitk_and_fc_ln(ops):
+    B, Fd, K = 24, 50, 3456
+    h, W, bias = rnd(B, K, seed=31), rnd(Fd, K, seed=32, scale=0.05), rnd(Fd, seed=33)
+    gamma, beta = 1 + 0.1 * rnd(Fd, seed=34), 0.1 * rnd(Fd, seed=35)
+    ks = 7
+    part = torch.full((ks, B, Fd), float("nan"), device="cuda")
+    ops.gemm(dev(h), 0, K, 0, dev(W), 0, K, 0, part, Fd, 0, B, Fd, K, 1, ksplit=ks, split_stride=B * Fd)
+    hl = h.clone().requires_grad_(True)
+    Wl, bl = W.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    gl, betal = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    fc = F.linear(hl, Wl, bl)
+    y_ref = F.layer_norm(fc, (Fd,), gl, betal, 1e-5)
+    y, fco, xhat = (torch.empty(B, Fd, device="cuda") for _ in range(3))
+    rstd = torch.empty(B, device="cuda")
+    ops.fc_ln_fwd(part, ks, B * Fd, Fd, dev(bias), dev(gamma), dev(beta), B, Fd, y, fc_out=fco, xhat=xhat, rstd=rstd)
+    check("fc splitk + bias", fco.cpu(), fc.detach())
+    check("layernorm fwd", y.cpu(), y_ref.detach())
+    dy = rnd(B, Fd, seed=36)
+    y_ref.backward(dy)
+    dx, dg, db_ = torch.empty(B, Fd, device="cuda"), torch.empty(Fd, device="cuda"), torch.empty(Fd, device="cuda")
+    ops.ln_bwd(dev(dy), xhat, rstd, dev(gamma), B, Fd, dx, dgamma=dg, dbeta=db_)
+    check("layernorm dgamma", dg.cpu(), gl.grad)
+    check("layernorm dbeta", db_.cpu(), betal.grad)
+    fcl = fc.detach().clone().requires_grad_(True)
+    (F.layer_norm(fcl, (Fd,), gamma, beta, 1e-5) * dy).sum().backward()
+    check("layernorm dx", dx.cpu(), fcl.grad)
+    # fc backward through the helpers used by the agent
+    dW = torch.empty(Fd, K, device="cuda")
+    ops.linear_dw(dx, 0, dev(h), 0, dW, 0, B, Fd, K)
+    check("fc dW (TN gemm)", dW.cpu(), Wl.grad)
+    dbias = torch.empty(Fd, device="cuda")
+    ops.colsum(dx, B, Fd, Fd, 0, dbias, 0)
+    check("fc dbias (colsum)", dbias.cpu(), bl.grad)
+    dh = torch.empty(B, K, device="cuda")
+    msk = rnd(B, K, seed=37)
+    ops.linear_dx(dx, 0, dev(W), 0, dh, 0, B, Fd, K, mask=dev(msk))
+    check("fc dh (NN gemm + relu mask)", dh.cpu(), hl.grad * (msk > 0))
+    red = torch.empty(B, Fd, device="cuda")
+    from curla_amd._lib import call, ptr, stream
+    call("curla_splitk_reduce", ptr(part), ks, B * Fd, B, Fd, Fd, ptr(red), Fd, ptr(dev(bias)), 0, stream())
+    check("splitk_reduce", red.cpu(), fc.detach())
+
+
+def _head_ref(out2a, noise, lo, hi):
+    A = noise.shape[1]
+    mu, ls = out2a.chunk(2, dim=-1)
+    t = torch.tanh(ls)
+    log_std = lo + 0.5 * (hi - lo) * (t + 1)
+    pi = mu + noise * log_std.exp()
+    log_pi = (-0.5 * noise.pow(2) - log_std).sum(-1, keepdim=True) - 0.5 * np.log(2 * np.pi) * A
+    mu_t, pi_t = torch.tanh(mu), torch.tanh(pi)
+    log_pi = log_pi - torch.log(F.relu(1 - pi_t.pow(2)) + 1e-6).sum(-1, keepdim=True)
+    return mu_t, pi_t, log_pi, log_std
+
+
+@pytest.mark.parametrize("B,A", [(8, 2), (300, 2), (17, 3)])
+def test_actor_head(ops, B, A):
+    lo, hi = -10.0, 2.0
+    out = rnd(B, 2 * A, seed=41).requires_grad_(True)
+    noise = rnd(B, A, seed=42)
+    mu_r, pi_r, lp_r, ls_r = _head_ref(out, noise, lo, hi)
+    mu, pi, ls, tl = (torch.empty(B, A, device="cuda") for _ in range(4))
+    lp = torch.empty(B, 1, device="cuda")
+    ops.actor_head_fwd(dev(out.detach()), dev(noise), B, A, lo, hi, mu=mu, pi=pi, log_pi=lp, log_std=ls, tanh_ls=tl)
+    for n, a, r in (("mu", mu, mu_r), ("pi", pi, pi_r), ("log_pi", lp, lp_r), ("log_std", ls, ls_r)):
+        check(f"actor_head_fwd {n} B{B}", a.cpu(), r.detach())
+    gpi = rnd(B, A, seed=43)
+    log_alpha = torch.tensor(np.log(0.1))
+    glp = float(log_alpha.exp()) / B
+    ((pi_r * gpi).sum() + glp * lp_r.sum()).backward()
+    dout = torch.empty(B, 2 * A, device="cuda")
+    ops.actor_head_bwd(dev(gpi), dev(log_alpha), 1.0 / B, dev(noise), pi, ls, tl, B, A, lo, hi, dout)
+    check(f"actor_head_bwd B{B}", dout.cpu(), out.grad)
+    # select_action form: no noise
+    mu2 = torch.empty(B, A, device="cuda")
+    ops.actor_head_fwd(dev(out.detach()), None, B, A, lo, hi, mu=mu2)
+    check(f"actor_head_fwd mu-only B{B}", mu2.cpu(), mu_r.detach())
+
+
+def test_losses(ops):
+    B, A = 70, 2
+    q = rnd(2, B, 1, seed=51).requires_grad_(True)
+    tq, lp = rnd(2, B, 1, seed=52), rnd(B, 1, seed=53)
+    r, nd = rnd(B, 1, seed=54), (rnd(B, 1, seed=55) > -1).float()
+    log_alpha = torch.tensor(np.log(0.1), requires_grad=True)
+    alpha = log_alpha.exp()
+    target = (r + nd * 0.99 * (torch.min(tq[0], tq[1]) - alpha.detach() * lp)).float()
+    tgt = torch.empty(B, 1, device="cuda")
+    d_la = dev(log_alpha.detach())
+    ops.td_target(dev(tq), B, dev(lp), dev(r), dev(nd), d_la, 0.99, B, tgt)
+    check("td_target", tgt.cpu(), target)
+    loss_ref = F.mse_loss(q[0], target) + F.mse_loss(q[1], target)
+    loss_ref.backward()
+    loss, dq = torch.empty(1, device="cuda"), torch.empty(2, B, 1, device="cuda")
+    ops.critic_loss(dev(q.detach()), B, tgt, B, loss, dq)
+    check("critic_loss", loss.cpu(), loss_ref.detach().reshape(1))
+    check("critic_loss dq", dq.cpu(), q.grad)
+    # actor / alpha
+    q2 = rnd(2, B, 1, seed=56).requires_grad_(True)
+    ls = rnd(B, A, seed=57)
+    actor_loss = (alpha.detach() * lp - torch.min(q2[0], q2[1])).mean()
+    actor_loss.backward()
+    alpha_loss = (alpha * (-lp - (-2.0)).detach()).mean()
+    alpha_loss.backward()
+    ent = (0.5 * A * (1.0 + np.log(2 * np.pi)) + ls.sum(-1)).mean()
+    sc, dq2 = torch.empty(4, device="cuda"), torch.empty(2, B, 1, device="cuda")
+    dla = torch.zeros((), dtype=torch.float64, device="cuda")
+    ops.actor_loss(dev(q2.detach()), B, dev(lp), dev(ls), A, d_la, -2.0, B, sc, dq2, dla)
+    check("actor_loss scalars", sc.cpu(), torch.stack([actor_loss.detach(), alpha_loss.detach(), ent, alpha.detach()]).float())
+    check("actor_loss dq", dq2.cpu(), q2.grad)
+    check("dlog_alpha", dla.cpu(), log_alpha.grad)
+
+
+@pytest.mark.parametrize("B", [8, 64, 200, 512])
+def test_curl_ce(ops, B):
+    logits = (rnd(B, B, seed=61) * 3).requires_grad_(True)
+    ref = F.cross_entropy(logits - logits.max(1)[0][:, None], torch.arange(B))
+    ref.backward()
+    rl, loss, dl = torch.empty(B, device="cuda"), torch.empty(1, device="cuda"), torch.empty(B, B, device="cuda")
+    ops.curl_ce(dev(logits.detach()), B, B, rl, loss, dl)
+    check(f"curl_ce loss B{B}", loss.cpu(), ref.detach().reshape(1))
+    check(f"curl_ce dlogits B{B}", dl.cpu(), logits.grad)
+
+
+def test_concat_split_softupdate_mean(ops):
+    B, Fd, A = 9, 50, 2
+    z, a = rnd(B, Fd, seed=71), rnd(B, A, seed=72)
+    xa = torch.empty(B, Fd + A, device="cuda")
+    ops.concat(dev(z), dev(a), B, Fd, A, xa)
+    assert torch.equal(xa.cpu(), torch.cat([z, a], 1))
+    dxa = rnd(2, B, Fd + A, seed=73)
+    dz, da = torch.empty(B, Fd, device="cuda"), torch.empty(B, A, device="cuda")
+    ops.split_sum(dev(dxa), B * (Fd + A), B, Fd, A, dz=dz, dact=da)
+    check("split_sum dz", dz.cpu(), (dxa[0] + dxa[1])[:, :Fd])
+    check("split_sum dact", da.cpu(), (dxa[0] + dxa[1])[:, Fd:])
+    p, t = rnd(100003, seed=74), rnd(100003, seed=75)
+    td = dev(t)
+    ops.soft_update(dev(p), td, 0.05)
+    check("soft_update", td.cpu(), 0.05 * p + (1 - 0.05) * t, 1e-6)
+    m = torch.empty(1, device="cuda")
+    ops.mean(dev(p[:777]), 777, m)
+    check("mean", m.cpu(), p[:777].mean().reshape(1), 1e-5)
+
+
+def test_bad_arguments_fail_loudly(ops):
+    from curla_amd._lib import CurlaHipError
+    x = torch.zeros(2, 9, 9, 16, device="cuda")  # 16 channels: not built
+    with pytest.raises(CurlaHipError):
+        ops.conv_s1_fwd(x, torch.zeros(16, 16, 3, 3, device="cuda"), torch.zeros(16, device="cuda"),
+                        torch.zeros(2, 7, 7, 16, device="cuda"))
+    with pytest.raises(CurlaHipError):
+        ops.ObsRef.from_tensor(torch.zeros(1, 9, 20, 20))  # CPU tensor
