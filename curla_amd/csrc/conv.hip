@@ -356,7 +356,7 @@ __global__ __launch_bounds__(512, 2) void wgrad_s1_kernel(WgradS1Args a) {
     const int tha = min(a.th, a.Ho - band * a.th);
     const int npix = tha * a.Wo;
     const float* ldsg = lds + (tha + 2) * a.Wi * kLdsPix;
-    const int nunits = (npix + 3) >> 2;  // 4 pixels per MFMA k-step
+    const int nunits = ((npix + 15) >> 4) << 2;  // 4 pixels per MFMA k-step, 4 k-steps per 16-pixel group
     for (int u = wave; u < nunits; u += 8) {
       // pixels of a k-step are 4 apart so the two lane groups of an LDS half hit disjoint banks
       const int p = (u >> 2) * 16 + (u & 3) + 4 * kq;
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(Wgrad1Args a) {
     }
     __syncthreads();
     const int npix = tha * a.Wo;
-    const int nunits = (npix + 3) >> 2;
+    const int nunits = ((npix + 15) >> 4) << 2;
     for (int u = wave; u < nunits; u += 8) {
       const int p = (u >> 2) * 16 + (u & 3) + 4 * kq;
       const bool pv = p < npix;

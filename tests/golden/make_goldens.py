@@ -276,6 +276,15 @@ def gen_tiny():
     in_hw, out_hw, B = (34, 40), (28, 34), 8
     aug = make_crop_augmentor(in_hw, out_hw)
     agent = build_agent((9, 84, 84), out_hw, hidden=64, num_layers=4, seed=1, aug=aug)
+    # construction parity (CurlSacAgent.__init__ + weight_init, curl_sac.py:38-54,226-318): summaries of the
+    # freshly initialised parameters for seed 1
+    init = {}
+    for name, mod in (("actor", agent.actor), ("critic", agent.critic), ("critic_target", agent.critic_target)):
+        for k, v in mod.state_dict().items():
+            init[f"{name}/{k}"] = summarize(v.numpy())
+    init["W"] = summarize(agent.CURL.W.detach().numpy())
+    init["log_alpha"] = agent.log_alpha.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "init_tiny.npz"), **init)
     rb = utils.ReplayBuffer((9,) + in_hw, (2,), 64, B, torch.device("cpu"), aug)
     fill_buffer(rb, 40, (9,) + in_hw, seed=0)
     L = NullLogger()

@@ -1,0 +1,243 @@
+"""Host-side logic of the drop-in surface, on CPU: construction parity with the
+reference (same seed => same initial parameters), state_dict layout, weight
+tying, replay ring bookkeeping and RNG order, the kernel launch schedule of
+update() (via the trace hook: nothing is computed), error behaviour."""
+import collections
+
+import numpy as np
+import pytest
+import torch
+
+import curla_amd
+from curla_amd import _lib
+from oracle import curla_oracle as O
+from tests._util import assert_close, load, sub, summarize
+
+HP = dict(discount=0.99, init_temperature=0.1, alpha_lr=1e-4, alpha_beta=0.5, actor_lr=1e-3, actor_beta=0.9,
+          actor_log_std_min=-10, actor_log_std_max=2, actor_update_freq=2, critic_lr=1e-3, critic_beta=0.9,
+          critic_tau=0.01, critic_target_update_freq=2, encoder_feature_dim=50, encoder_lr=1e-3, encoder_tau=0.05,
+          num_layers=4, num_filters=32, log_interval=1)
+
+
+class NullLogger:
+    def log(self, *a, **k):
+        pass
+
+
+def tiny_agent(**kw):
+    aug = curla_amd.RandomCrop((34, 40), (28, 34))
+    curla_amd.set_seed_everywhere(1)
+    return curla_amd.CurlSacAgent((9, 28, 34), (2,), "cpu", aug, hidden_dim=64, **{**HP, **kw}), aug
+
+
+def test_construction_matches_reference_init():
+    """Same seed, same construction order, same init functions => the reference's
+    initial parameters (curl_sac.py:38-54,226-318), bit for bit in summary."""
+    g = load("init_tiny.npz")
+    agent, _ = tiny_agent()
+    for name, mod in (("actor", agent.actor), ("critic", agent.critic), ("critic_target", agent.critic_target)):
+        sd = mod.state_dict()
+        ref = sub(g, name + "/", as_torch=False)
+        assert list(sd.keys()) == list(ref.keys())
+        for k, v in ref.items():
+            assert_close(summarize(sd[k]), v, 1e-6, f"init {name}/{k}")
+    assert_close(summarize(agent.CURL.W), g["W"], 1e-6, "init W")
+    assert agent.log_alpha.dtype == torch.float64 and float(agent.log_alpha) == float(g["log_alpha"])
+    assert agent.target_entropy == -2
+
+
+def test_parameter_sharing_and_optimizer_groups():
+    agent, _ = tiny_agent()
+    for i in range(4):  # curl_sac.py:290 / encoder.py:112-116
+        assert agent.actor.encoder.convs[i].weight is agent.critic.encoder.convs[i].weight
+        assert agent.actor.encoder.convs[i].bias is agent.critic.encoder.convs[i].bias
+    assert agent.actor.encoder.fc.weight is not agent.critic.encoder.fc.weight
+    assert agent.CURL.encoder is agent.critic.encoder and agent.CURL.encoder_target is agent.critic_target.encoder
+    n = lambda opt: sum(len(g["params"]) for g in opt.param_groups)  # noqa: E731
+    # tensors that ever receive a gradient in each optimizer (18/24/1/12/25 minus the
+    # never-stepped tied convs (8) and target-encoder tensors (12))
+    assert (n(agent.actor_optimizer), n(agent.critic_optimizer), n(agent.log_alpha_optimizer),
+            n(agent.encoder_optimizer), n(agent.cpc_optimizer)) == (10, 24, 1, 12, 13)
+    assert agent.critic_optimizer.param_groups[0]["betas"] == (0.9, 0.999)
+    assert agent.log_alpha_optimizer.param_groups[0]["betas"] == (0.5, 0.999)
+    assert curla_amd.PixelEncoder is curla_amd.CNNEncoder
+
+
+def test_flat_layout_and_twin_stride():
+    agent, _ = tiny_agent()
+    lay = agent._lay
+    flat, gflat = agent._critic_flat, agent._critic_gflat
+    assert flat.numel() == lay["total"] == gflat.numel()
+    q1, q2 = agent.critic.Q1.trunk, agent.critic.Q2.trunk
+    for j in (0, 2, 4):
+        for a, b in ((q1[j].weight, q2[j].weight), (q1[j].bias, q2[j].bias)):
+            assert (b.data_ptr() - a.data_ptr()) // 4 == agent.critic.twin_stride
+            assert a.data_ptr() % 16 == 0 and a.grad.data_ptr() % 16 == 0
+    # parameters are views into the flat buffer; grads into its mirror
+    w = agent.critic.encoder.convs[2].weight
+    off = (w.data_ptr() - flat.data_ptr()) // 4
+    assert lay["enc"][0] <= off < lay["enc"][1]
+    assert (w.grad.data_ptr() - gflat.data_ptr()) // 4 == off
+    assert (agent.CURL.W.data_ptr() - flat.data_ptr()) == 0
+    # target has the same layout
+    tw = agent.critic_target.encoder.convs[2].weight
+    assert (tw.data_ptr() - agent._target_flat.data_ptr()) // 4 == off
+
+
+def test_fc_weight_checkpoint_layout_roundtrip():
+    """fc.weight is held (y,x,c)-ordered; state_dict()/load_state_dict() speak the
+    reference's (c,y,x) order (encoder.py:89 flatten of NCHW)."""
+    agent, _ = tiny_agent()
+    enc = agent.critic.encoder
+    c, h, w = 32, *enc.out_dim
+    ref_w = torch.arange(50 * c * h * w, dtype=torch.float32).reshape(50, c * h * w)
+    sd = agent.critic.state_dict()
+    sd["encoder.fc.weight"] = ref_w.clone()
+    agent.critic.load_state_dict(sd)
+    internal = enc.fc.weight.detach()
+    # element (f, c, y, x) of the reference weight sits at column (y*W + x)*C + c internally
+    f_, c_, y_, x_ = 7, 5, 3, 2
+    assert internal[f_, (y_ * w + x_) * c + c_] == ref_w[f_, (c_ * h + y_) * w + x_]
+    assert torch.equal(agent.critic.state_dict()["encoder.fc.weight"], ref_w)
+    agent.critic_target.load_state_dict(agent.critic.state_dict())
+    assert torch.equal(agent.critic_target.encoder.fc.weight, enc.fc.weight)
+
+
+def test_encoder_shapes_and_errors():
+    for (h, w), L, want in (((76, 135), 4, (31, 61)), ((90, 160), 4, (38, 73)), ((84, 84), 4, (35, 35)),
+                            ((76, 76), 4, (31, 31)), ((168, 168), 6, (73, 73)), ((64, 64), 2, (29, 29))):
+        e = curla_amd.CNNEncoder((9, h, w), 50, num_layers=L)
+        assert tuple(e.out_dim) == want == O.conv_out_hw(h, w, L)
+        assert e.fc.in_features == 32 * want[0] * want[1]
+    with pytest.raises(NotImplementedError):  # encoder.py:46-47
+        curla_amd.CNNEncoder((9, 8, 8), 50, num_layers=4)
+    with pytest.raises(ValueError):  # augmentations.py:220
+        curla_amd.make_augmentor("nope", (84, 84))
+    assert curla_amd.make_augmentor("random_crop", (84, 84)).output_shape == (71, 71)  # augmentations.py:23-24
+    assert curla_amd.make_augmentor("random_crop", (90, 160)).output_shape == (76, 135)
+    assert curla_amd.make_augmentor("identity", (84, 84)).output_shape == (84, 84)
+
+
+def test_random_crop_host_path_bit_exact():
+    g = load("crop84.npz")
+    aug = curla_amd.RandomCrop((84, 84), (76, 76))
+    imgs = np.random.RandomState(int(g["imgs_seed"])).randint(0, 256, (16, 9, 84, 84), dtype=np.uint8)
+    np.random.seed(int(g["numpy_seed"]))
+    out = aug.training_augmentation(imgs)
+    assert np.array_equal(out[:2], g["out_first2"])
+    import hashlib
+    assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest() == str(g["out_sha256"])
+    assert np.array_equal(aug.evaluation_augmentation(imgs[0]), g["center_crop0"])
+
+
+def test_replay_ring_bookkeeping_and_rng_order():
+    aug = curla_amd.RandomCrop((34, 40), (28, 34))
+    rb = curla_amd.ReplayBuffer((9, 34, 40), (2,), 5, 8, "cpu", aug)
+    rs = np.random.RandomState(0)
+    frames = rs.randint(0, 256, (7, 9, 34, 40), dtype=np.uint8)
+    for i in range(7):  # wraps: capacity 5
+        assert rb.full == (i >= 5)
+        rb.add(frames[i], [0.1 * i, -0.1 * i], float(i), frames[(i + 1) % 7], i == 3)
+    assert rb.idx == 2 and rb.full and len(rb) == 5
+    # slot 0 and 1 were overwritten by transitions 5 and 6; frames are stored HWC
+    assert np.array_equal(rb.obses[1].numpy(), frames[6].transpose(1, 2, 0))
+    assert np.array_equal(rb.next_obses[4].numpy(), frames[5].transpose(1, 2, 0))
+    assert float(rb.rewards[0]) == 5.0 and float(rb.not_dones[3]) == 0.0 and float(rb.not_dones[4]) == 1.0
+    assert np.allclose(rb.actions[1].numpy(), [0.6, -0.6])
+    # RNG order == the reference's (golden stream replay, utils.py:147 + augmentations.py:66-67 x3)
+    g = load("tiny.npz")
+    rb2 = curla_amd.ReplayBuffer((9, 34, 40), (2,), 64, 8, "cpu", aug)
+    rb2.idx = int(g["meta/n_valid"])
+    st = list(np.random.get_state())
+    st[1], st[2] = g["meta/numpy_state_keys"], int(g["meta/numpy_state_pos"])
+    np.random.set_state(tuple(st))
+    idxs, offs = rb2.draw_indices()
+    assert np.array_equal(idxs, g["rng/idxs"])
+    for j, nm in enumerate(("obs", "next_obs", "pos")):
+        assert np.array_equal(offs[2 * j], g[f"rng/h1_{nm}"]) and np.array_equal(offs[2 * j + 1], g[f"rng/w1_{nm}"])
+    # identity augmentation draws only the indices (utils.py:168-182)
+    rb3 = curla_amd.ReplayBuffer((9, 34, 40), (2,), 64, 8, "cpu", curla_amd.IdentityAugmentation((34, 40)))
+    rb3.idx = 40
+    np.random.seed(3)
+    a, offs3 = rb3.draw_indices()
+    np.random.seed(3)
+    assert np.array_equal(a, np.random.randint(0, 40, size=8)) and not offs3.any()
+
+
+def test_sampling_pixels_without_gpu_fails_loudly():
+    aug = curla_amd.RandomCrop((34, 40), (28, 34))
+    rb = curla_amd.ReplayBuffer((9, 34, 40), (2,), 8, 4, "cpu", aug)
+    rb.add(np.zeros((9, 34, 40), np.uint8), [0, 0], 0.0, np.zeros((9, 34, 40), np.uint8), False)
+    with pytest.raises(RuntimeError):
+        rb.sample_cpc()
+    agent, _ = tiny_agent()
+    with pytest.raises(RuntimeError):
+        agent.update(rb, NullLogger(), 0)
+
+
+def _trace_updates(agent, rb, steps, **kw):
+    calls = []
+    _lib.set_trace_hook(lambda n, a: calls.append(n))
+    try:
+        out = []
+        for s in steps:
+            calls.clear()
+            agent.update(rb, NullLogger(), s, **kw)
+            out.append(collections.Counter(calls))
+        return out
+    finally:
+        _lib.set_trace_hook(None)
+
+
+def _filled_rb(aug, hw=(34, 40)):
+    rb = curla_amd.ReplayBuffer((9,) + hw, (2,), 32, 8, "cpu", aug)
+    for i in range(12):
+        rb.add(np.zeros((9,) + hw, np.uint8), [0, 0], 0.0, np.zeros((9,) + hw, np.uint8), False)
+    return rb
+
+
+def test_update_schedule_launch_counts():
+    """curl_sac.py:426-451 schedule, with the conv passes the build shares:
+    5 conv-stack forwards + 2 backwards on every step."""
+    agent, aug = tiny_agent()
+    even, odd = _trace_updates(agent, _filled_rb(aug), [0, 1])
+    for c in (even, odd):
+        assert c["curla_conv1_fwd"] == 5 and c["curla_conv3x3_s1_fwd"] == 15
+        assert c["curla_conv1_wgrad"] == 2 and c["curla_conv3x3_s1_wgrad"] == 6 and c["curla_conv3x3_s1_dgrad"] == 6
+        assert c["curla_curl_ce"] == 1 and c["curla_critic_loss"] == 1
+    assert even["curla_actor_loss"] == 1 and odd["curla_actor_loss"] == 0       # actor_update_freq = 2
+    assert even["curla_soft_update"] == 2 and odd["curla_soft_update"] == 0     # critic_target_update_freq = 2
+    # only_cpc (train.py:425): no SAC phases
+    (c,) = _trace_updates(agent, _filled_rb(aug), [2], only_cpc=True)
+    assert c["curla_critic_loss"] == 0 and c["curla_actor_loss"] == 0 and c["curla_curl_ce"] == 1
+    assert c["curla_conv1_fwd"] == 2 and c["curla_conv1_wgrad"] == 1
+
+
+def test_update_schedule_pixel_sac():
+    """--pixel_sac forces identity augmentation and skips CURL (train.py:262-264, curl_sac.py:448)."""
+    aug = curla_amd.IdentityAugmentation((34, 40))
+    curla_amd.set_seed_everywhere(1)
+    agent = curla_amd.CurlSacAgent((9, 34, 40), (2,), "cpu", aug, hidden_dim=64, pixel_sac=True, **HP)
+    even, odd = _trace_updates(agent, _filled_rb(aug), [0, 1])
+    assert even["curla_conv1_fwd"] == 4 and odd["curla_conv1_fwd"] == 3
+    assert even["curla_conv1_wgrad"] == 1 and odd["curla_conv1_wgrad"] == 1
+    assert even["curla_curl_ce"] == 0
+
+
+def test_reference_style_buffer_goes_through_tensor_contract():
+    """A buffer that only offers the reference's sample_cpc() (float NCHW tensors)
+    drives the same phases through the f32 loader."""
+    agent, aug = tiny_agent()
+
+    class RefStyle:
+        def sample_cpc(self):
+            o = torch.zeros(8, 9, 28, 34)
+            return o, torch.zeros(8, 2), torch.zeros(8, 1), o.clone(), torch.ones(8, 1), dict(obs_anchor=o, obs_pos=o.clone())
+    seen = []
+    _lib.set_trace_hook(lambda n, a: seen.append((n, a)))
+    try:
+        agent.update(RefStyle(), NullLogger(), 0)
+    finally:
+        _lib.set_trace_hook(None)
+    conv1 = [a for n, a in seen if n == "curla_conv1_fwd"]
+    assert len(conv1) == 5 and all(a[1] == 0 for a in conv1)  # src_is_u8 == 0
