@@ -12,18 +12,29 @@
 // per lane instead of 2 per FMA.  GEMM view of the forward:
 //   D[cout (16 per m-tile, 2 tiles)][pixel (16 per n-tile)] += W[cout][k] * X[k][pixel],
 //   k = (tap, cin).  A 512-thread workgroup stages a band of input rows in LDS
-// (pixel stride padded 32 -> 36 floats) and its 8 waves walk the band's
-// 16-pixel tiles; the next band is prefetched into registers while the MFMAs
-// of the current one run.
+// (pixel stride padded 32 -> 36 floats) and its 4 waves walk the band's
+// 16-pixel tiles.  Two such workgroups share a CU (<= 80 KB LDS, <= 256 VGPRs
+// each): their load / barrier stalls are uncorrelated, so one wave per SIMD is
+// always ready to feed the matrix pipe.
 #include "common.h"
 
 namespace {
 
 constexpr int kLdsPix = 36;   // floats per pixel in LDS (32 channels + 4 pad: conflict-free b128 reads)
 constexpr int kWStride = 289; // LDS row stride while re-gathering the OIHW weights
-constexpr int kMaxPf = 12;    // float4 prefetch registers per thread (band <= 512*12/8 = 768 pixels)
+constexpr int kMaxPf = 18;    // float4 staging registers per thread (band <= 256*18/8 = 576 pixels, 81 KB of LDS)
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+// Timing-only ablations for tools/kbench.py (results are wrong when set); compiled out of the product library.
+#ifdef CURLA_ABLATE
+int g_ablate = 0;
+#define ABL(bit) (a.dbg & (bit))
+#define ABL_HOST g_ablate
+#else
+#define ABL(bit) 0
+#define ABL_HOST 0
+#endif
 
 struct ConvS1Args {
   const float* in;   // [B][Hs][Ws][32]
@@ -31,6 +42,7 @@ struct ConvS1Args {
   const float* aux;  // FWD: bias[32]; DGRAD: activation below, [B][Ho][Wo][32] (ReLU mask)
   float* out;        // [B][Ho][Wo][32]
   int B, Hs, Ws, Ho, Wo, pad, th, nbands;
+  int dbg;
 };
 
 // ---------------------------------------------------------------------------
@@ -38,7 +50,7 @@ struct ConvS1Args {
 // with the flipped/transposed filter, ReLU mask of the layer below fused in).
 // ---------------------------------------------------------------------------
 template <int MODE>
-__global__ __launch_bounds__(512, 2) void conv_s1_kernel(ConvS1Args a) {
+__global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
@@ -49,7 +61,7 @@ __global__ __launch_bounds__(512, 2) void conv_s1_kernel(ConvS1Args a) {
   // wave pairs (2p, 2p+1) share pixel tiles.  k-step (q,e) of tap t covers
   // cin = 16q + 4kq' + e over the four lane groups kq'.
   const int mt = wave & 1, tslot = wave >> 1;
-  for (int i = tid; i < 32 * 288; i += 512) {
+  for (int i = tid; i < 32 * 288; i += 256) {
     int r = i / 288;
     lds[r * kWStride + (i - r * 288)] = a.w[i];
   }
@@ -68,77 +80,76 @@ __global__ __launch_bounds__(512, 2) void conv_s1_kernel(ConvS1Args a) {
   __syncthreads();
 
   const int nitems = a.B * a.nbands;
-  f32x4 pf[kMaxPf];
-
-  auto issue = [&](int item) {
-    const int b = item / a.nbands, band = item - b * a.nbands;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int band = item / a.B, b = item - band * a.B;  // band-major: every workgroup sees every band size
     const int y0 = band * a.th;
-    const int rows = min(a.th, a.Ho - y0) + 2;
-    const int n4 = rows * WT * 8;
+    const int tha = min(a.th, a.Ho - y0);
+    // ---- stage the band: all loads in flight at once, then the LDS writes.  The
+    // exposed latency is covered by the CU's second workgroup, whose phases are
+    // not synchronised with this one's.
+    {
+      const int n4 = (tha + 2) * WT * 8;
+      f32x4 pf[kMaxPf];
 #pragma unroll
-    for (int u = 0; u < kMaxPf; ++u) {
-      const int f = tid + u * 512;
-      f32x4 v = {0, 0, 0, 0};
-      if (f < n4) {
-        const int pix = f >> 3, ch = f & 7;
-        const int r = pix / WT, c = pix - r * WT;
-        const int sy = y0 + r - a.pad, sx = c - a.pad;
-        if (sy >= 0 && sy < a.Hs && sx >= 0 && sx < a.Ws)
-          v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(b * a.Hs + sy) * a.Ws + sx) * 32 + ch * 4);
+      for (int u = 0; u < kMaxPf; ++u) {
+        const int f = tid + u * 256;
+        f32x4 v = {0, 0, 0, 0};
+        if (f < n4 && !(ABL(1) && item != (int)blockIdx.x)) {
+          const int pix = f >> 3, ch = f & 7;
+          const int r = pix / WT, c = pix - r * WT;
+          const int sy = y0 + r - a.pad, sx = c - a.pad;
+          if (sy >= 0 && sy < a.Hs && sx >= 0 && sx < a.Ws)
+            v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(b * a.Hs + sy) * a.Ws + sx) * 32 + ch * 4);
+        }
+        pf[u] = v;
       }
-      pf[u] = v;
-    }
-  };
-  auto commit = [&](int item) {
-    const int b = item / a.nbands, band = item - b * a.nbands;
-    const int rows = min(a.th, a.Ho - band * a.th) + 2;
-    const int n4 = rows * WT * 8;
 #pragma unroll
-    for (int u = 0; u < kMaxPf; ++u) {
-      const int f = tid + u * 512;
-      if (f < n4) *reinterpret_cast<f32x4*>(lds + (f >> 3) * kLdsPix + (f & 7) * 4) = pf[u];
+      for (int u = 0; u < kMaxPf; ++u) {
+        const int f = tid + u * 256;
+        if (f < n4 && !(ABL(2) && item != (int)blockIdx.x))
+          *reinterpret_cast<f32x4*>(lds + (f >> 3) * kLdsPix + (f & 7) * 4) = pf[u];
+      }
     }
-  };
-
-  int item = blockIdx.x;
-  if (item < nitems) issue(item);
-  while (item < nitems) {
-    commit(item);
     __syncthreads();
-    const int next = item + gridDim.x;
-    if (next < nitems) issue(next);
 
-    const int b = item / a.nbands, band = item - b * a.nbands;
-    const int y0 = band * a.th;
-    const int npix = min(a.th, a.Ho - y0) * a.Wo;
+    const int npix = tha * a.Wo;
     const int ntiles = (npix + 15) >> 4;
-    for (int t = tslot; t < ntiles; t += 4) {
+    for (int t = tslot; t < ntiles; t += 2) {
       const int p = t * 16 + li;
       const bool pv = p < npix;
       const int pc = pv ? p : 0;
       const int ty = pc / a.Wo, x = pc - ty * a.Wo;
       const float* base = lds + (ty * WT + x) * kLdsPix + 4 * kq;
-      // two accumulation chains so dependent MFMAs never wait on each other
+      // two accumulation chains so dependent MFMAs never wait on each other; the LDS
+      // reads of tap t+1 are issued before the MFMAs of tap t (software pipeline,
+      // pinned with sched_group_barrier: hipcc otherwise sinks each read to its use)
       f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+      f32x4 nb0 = *reinterpret_cast<const f32x4*>(base);
+      f32x4 nb1 = *reinterpret_cast<const f32x4*>(base + 16);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // tap 0 reads
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
+      for (int t = 0; t < 9; ++t) {
+        const f32x4 b0 = nb0, b1 = nb1;
+        if (t < 8) {
+          const int dy = (t + 1) / 3, dx = (t + 1) - 3 * dy;
           const float* ptr = base + (dy * WT + dx) * kLdsPix;
-          const f32x4 b0 = *reinterpret_cast<const f32x4*>(ptr);
-          const f32x4 b1 = *reinterpret_cast<const f32x4*>(ptr + 16);
-#pragma unroll
-          for (int e = 0; e < 4; e += 2) {
-            acc0 = mfma16(wr[dy * 3 + dx][e], b0[e], acc0);
-            acc1 = mfma16(wr[dy * 3 + dx][e + 1], b0[e + 1], acc1);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; e += 2) {
-            acc0 = mfma16(wr[dy * 3 + dx][4 + e], b1[e], acc0);
-            acc1 = mfma16(wr[dy * 3 + dx][5 + e], b1[e + 1], acc1);
-          }
+          nb0 = *reinterpret_cast<const f32x4*>(ptr);
+          nb1 = *reinterpret_cast<const f32x4*>(ptr + 16);
         }
-      if (pv) {
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          acc0 = mfma16(wr[t][e], b0[e], acc0);
+          acc1 = mfma16(wr[t][e + 1], b0[e + 1], acc1);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          acc0 = mfma16(wr[t][4 + e], b1[e], acc0);
+          acc1 = mfma16(wr[t][5 + e], b1[e + 1], acc1);
+        }
+        if (t < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads (next tap) ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);             // ... then 8 MFMAs (this tap)
+      }
+      if (pv && !ABL(4)) {
         const size_t g = ((size_t)(b * a.Ho + y0 + ty) * a.Wo + x) * 32 + mt * 16 + 4 * kq;
         f32x4 v = acc0 + acc1;
         if (MODE == MODE_FWD) {
@@ -154,7 +165,6 @@ __global__ __launch_bounds__(512, 2) void conv_s1_kernel(ConvS1Args a) {
       }
     }
     __syncthreads();
-    item = next;
   }
 }
 
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(512) void conv1_fwd_kernel(Conv1Args a) {
   __syncthreads();
 
   const int item = blockIdx.x;
-  const int b = item / a.nbands, band = item - b * a.nbands;
+  const int band = item / a.B, b = item - band * a.B;  // band-major: every workgroup sees every band size
   const int y0 = band * a.th;
   const int tha = min(a.th, a.Ho - y0);
   conv1_stage<SRC>(lds, a.src, a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Hc, a.Wc, 2 * y0, 2 * tha + 1, RS, a.scale, tid,
@@ -299,123 +309,118 @@ struct WgradS1Args {
 };
 constexpr int kPartialS1 = 32 * 288 + 32;
 
-__global__ __launch_bounds__(512, 2) void wgrad_s1_kernel(WgradS1Args a) {
+__global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
-  f32x4 acc[2][2][9];
+  // a wave owns the 16 output channels mt*16.. of dW (18 accumulator tiles); wave pairs share pixels
+  const int mt = wave & 1, uslot = wave >> 1;
+  f32x4 acc[2][9];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int t = 0; t < 9; ++t) acc[i][j][t] = f32x4{0, 0, 0, 0};
-  float bsum[2] = {0.f, 0.f};
+    for (int t = 0; t < 9; ++t) acc[j][t] = f32x4{0, 0, 0, 0};
+  float bsum = 0.f;
 
   const int nitems = a.B * a.nbands;
-  f32x4 pf[kMaxPf];
-  // band = (tha+2) input rows followed by tha gradient rows, both contiguous in HBM
-  auto issue = [&](int item) {
-    const int b = item / a.nbands, band = item - b * a.nbands;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int band = item / a.B, b = item - band * a.B;  // band-major: every workgroup sees every band size
     const int y0 = band * a.th;
     const int tha = min(a.th, a.Ho - y0);
+    // band = (tha+2) input rows followed by tha gradient rows, both contiguous in HBM
     const int nin = (tha + 2) * a.Wi * 8, ng = tha * a.Wo * 8;
-    const float* pin = a.in + ((size_t)(b * a.Hi + y0) * a.Wi) * 32;
-    const float* pg = a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
+    {
+      const float* pin = a.in + ((size_t)(b * a.Hi + y0) * a.Wi) * 32;
+      const float* pg = a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
+      f32x4 pf[kMaxPf];
 #pragma unroll
-    for (int u = 0; u < kMaxPf; ++u) {
-      const int f = tid + u * 512;
-      f32x4 v = {0, 0, 0, 0};
-      if (f < nin)
-        v = *reinterpret_cast<const f32x4*>(pin + (size_t)f * 4);
-      else if (f < nin + ng)
-        v = *reinterpret_cast<const f32x4*>(pg + (size_t)(f - nin) * 4);
-      pf[u] = v;
-    }
-  };
-  auto commit = [&](int item) {
-    const int b = item / a.nbands, band = item - b * a.nbands;
-    const int tha = min(a.th, a.Ho - band * a.th);
-    const int nin = (tha + 2) * a.Wi * 8, ng = tha * a.Wo * 8;
+      for (int u = 0; u < kMaxPf; ++u) {
+        const int f = tid + u * 256;
+        f32x4 v = {0, 0, 0, 0};
+        if (f < nin)
+          v = *reinterpret_cast<const f32x4*>(pin + (size_t)f * 4);
+        else if (f < nin + ng)
+          v = *reinterpret_cast<const f32x4*>(pg + (size_t)(f - nin) * 4);
+        pf[u] = v;
+      }
 #pragma unroll
-    for (int u = 0; u < kMaxPf; ++u) {
-      const int f = tid + u * 512;
-      if (f < nin + ng) *reinterpret_cast<f32x4*>(lds + (f >> 3) * kLdsPix + (f & 7) * 4) = pf[u];
+      for (int u = 0; u < kMaxPf; ++u) {
+        const int f = tid + u * 256;
+        if (f < nin + ng) *reinterpret_cast<f32x4*>(lds + (f >> 3) * kLdsPix + (f & 7) * 4) = pf[u];
+      }
     }
-  };
-
-  int item = blockIdx.x;
-  if (item < nitems) issue(item);
-  while (item < nitems) {
-    commit(item);
     __syncthreads();
-    const int next = item + gridDim.x;
-    if (next < nitems) issue(next);
 
-    const int band = item % a.nbands;
-    const int tha = min(a.th, a.Ho - band * a.th);
     const int npix = tha * a.Wo;
     const float* ldsg = lds + (tha + 2) * a.Wi * kLdsPix;
     const int nunits = ((npix + 15) >> 4) << 2;  // 4 pixels per MFMA k-step, 4 k-steps per 16-pixel group
-    for (int u = wave; u < nunits; u += 8) {
+    // operand fetch of one k-step: 1 gradient value (A) + 18 input values (B: 9 taps x 2 cin tiles)
+    auto fetch = [&](int u, float& av, float (&bv)[18]) {
       // pixels of a k-step are 4 apart so the two lane groups of an LDS half hit disjoint banks
       const int p = (u >> 2) * 16 + (u & 3) + 4 * kq;
-      const bool pv = p < npix;
+      const bool pv = (u < nunits) && (p < npix);
       const int pc = pv ? p : 0;
       const int ty = pc / a.Wo, x = pc - ty * a.Wo;
-      const float* gp = ldsg + (ty * a.Wo + x) * kLdsPix + li;
-      const float a0 = pv ? gp[0] : 0.f, a1 = pv ? gp[16] : 0.f;
-      bsum[0] += a0;
-      bsum[1] += a1;
+      av = pv ? ldsg[(ty * a.Wo + x) * kLdsPix + mt * 16 + li] : 0.f;
       const float* ip = lds + (ty * a.Wi + x) * kLdsPix + li;
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
           const float* q = ip + (dy * a.Wi + dx) * kLdsPix;
-          const float b0 = q[0], b1 = q[16];
-          const int t = dy * 3 + dx;
-          acc[0][0][t] = mfma16(a0, b0, acc[0][0][t]);
-          acc[0][1][t] = mfma16(a0, b1, acc[0][1][t]);
-          acc[1][0][t] = mfma16(a1, b0, acc[1][0][t]);
-          acc[1][1][t] = mfma16(a1, b1, acc[1][1][t]);
+          bv[2 * (dy * 3 + dx)] = q[0];
+          bv[2 * (dy * 3 + dx) + 1] = q[16];
         }
+    };
+    auto mma = [&](float av, const float (&bv)[18]) {
+      bsum += av;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        acc[0][t] = mfma16(av, bv[2 * t], acc[0][t]);
+        acc[1][t] = mfma16(av, bv[2 * t + 1], acc[1][t]);
+      }
+    };
+    // software pipeline over this wave's k-steps (two register sets, no copies): the LDS
+    // reads of the next step are in flight while the 18 MFMAs of the current one issue
+    float avA, avB, bvA[18], bvB[18];
+    fetch(uslot, avA, bvA);
+    for (int u = uslot; u < nunits; u += 4) {
+      fetch(u + 2, avB, bvB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(avA, bvA);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(u + 4, avA, bvA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(avB, bvB);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
-    item = next;
   }
 
   // cross-wave sum in a fixed order (deterministic), then one slab per workgroup
-  bsum[0] += __shfl_xor(bsum[0], 16);
-  bsum[0] += __shfl_xor(bsum[0], 32);
-  bsum[1] += __shfl_xor(bsum[1], 16);
-  bsum[1] += __shfl_xor(bsum[1], 32);
-  for (int w = 0; w < 8; ++w) {
-    if (wave == w) {
+  bsum += __shfl_xor(bsum, 16);
+  bsum += __shfl_xor(bsum, 32);
+  for (int w = 0; w < 2; ++w) {
+    if (uslot == w) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-          for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int co = mt * 16 + 4 * kq + r, ci = ct * 16 + li;
-              float* d = lds + co * 288 + ci * 9 + t;
-              *d = (w == 0) ? acc[mt][ct][t][r] : *d + acc[mt][ct][t][r];
-            }
+          for (int r = 0; r < 4; ++r) {
+            const int co = mt * 16 + 4 * kq + r, ci = ct * 16 + li;
+            float* d = lds + co * 288 + ci * 9 + t;
+            *d = (w == 0) ? acc[ct][t][r] : *d + acc[ct][t][r];
+          }
       if (kq == 0) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          float* d = lds + 32 * 288 + mt * 16 + li;
-          *d = (w == 0) ? bsum[mt] : *d + bsum[mt];
-        }
+        float* d = lds + 32 * 288 + mt * 16 + li;
+        *d = (w == 0) ? bsum : *d + bsum;
       }
     }
     __syncthreads();
   }
   float* slab = a.partial + (size_t)blockIdx.x * kPartialS1;
-  for (int i = tid; i < kPartialS1; i += 512) slab[i] = lds[i];
+  for (int i = tid; i < kPartialS1; i += 256) slab[i] = lds[i];
 }
 
 // ---------------------------------------------------------------------------
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(Wgrad1Args a) {
   const int nitems = a.B * a.nbands;
   const int in_floats = (2 * a.th + 1) * RS;  // LDS offset of the gradient band
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const int b = item / a.nbands, band = item - b * a.nbands;
+    const int band = item / a.B, b = item - band * a.B;  // band-major: every workgroup sees every band size
     const int y0 = band * a.th;
     const int tha = min(a.th, a.Ho - y0);
     conv1_stage<SRC>(lds, a.src, a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Hc, a.Wc, 2 * y0, 2 * tha + 1, RS, a.scale,
@@ -531,40 +536,60 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(Wgrad1Args a) {
   for (int i = tid; i < nw + 32; i += 512) slab[i] = lds[i];
 }
 
-// second pass: dW = sum over workgroup slabs, in slab order
-__global__ void wgrad_reduce_kernel(const float* partial, int nslabs, int nw, float* dw, float* db) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nw + 32) return;
+// second pass: dW = sum over workgroup slabs.  32 elements x 8 slab-groups per
+// block; each group adds its slabs in slab order, the 8 group sums are added in
+// group order (fixed order => bitwise reproducible).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, int nslabs, int nw, float* dw,
+                                                           float* db) {
+  __shared__ float sm[8][32];
+  const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + c;
+  const int n = nw + 32;
   float s = 0.f;
-  for (int k = 0; k < nslabs; ++k) s += partial[(size_t)k * (nw + 32) + i];
-  if (i < nw)
-    dw[i] = s;
-  else
-    db[i - nw] = s;
+  if (i < n)
+    for (int k = part; k < nslabs; k += 8) s += partial[(size_t)k * n + i];
+  sm[part][c] = s;
+  __syncthreads();
+  if (part == 0 && i < n) {
+    float t = sm[0][c];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += sm[k][c];
+    if (i < nw)
+      dw[i] = t;
+    else
+      db[i - nw] = t;
+  }
 }
 
 // ------------------------------ host-side planning ------------------------------
 constexpr int kMaxLds = 160 * 1024;
+constexpr int kBandPx = 568;  // pixels a band may hold: 568 * 144 B = 79.9 KB of LDS -> 2 workgroups per CU
+static_assert(kBandPx * 8 <= 256 * kMaxPf, "band must fit the staging registers");
 
-// rows per band for the prefetching stride-1 kernels: the band must fit the
-// prefetch registers (768 pixels); among the fitting values pick the one
-// that wastes the fewest 16-pixel tile slots over the 8 waves.
+// Rows per band for the stride-1 kernels.  The band (th+2 input rows, plus th
+// gradient rows for wgrad) must fit kBandPx pixels.  Candidates split Ho into
+// nb near-equal bands; the score is the fraction of useful 16-pixel tile slots
+// (tiles are dealt to `nslots` wave groups) times the halo re-read factor.
 int plan_band_s1(int Ho, int Wo, int px_per_row_extra, int budget_px, int unit_px, int nslots) {
-  int best = 1;
+  int th_max = 0;
+  for (int th = 1; th <= Ho; ++th)
+    if ((th + 2) * (Wo + 2) + px_per_row_extra * th <= budget_px) th_max = th;
+  if (th_max == 0) return 1;
+  int best = th_max;
   double best_eff = -1.0;
-  for (int th = 1; th <= Ho; ++th) {
-    const int px = (th + 2) * (Wo + 2) + px_per_row_extra * th;
-    if (px > budget_px) break;
-    const int nb = (Ho + th - 1) / th;
+  const int nb0 = (Ho + th_max - 1) / th_max;
+  for (int nb = nb0; nb <= nb0 + 3 && nb <= Ho; ++nb) {
+    const int th = (Ho + nb - 1) / nb;
+    if (th > th_max) continue;
+    const int nbands = (Ho + th - 1) / th;
     double work = 0, slots = 0;
-    for (int bnd = 0; bnd < nb; ++bnd) {
-      const int tha = (bnd == nb - 1) ? Ho - bnd * th : th;
+    for (int bnd = 0; bnd < nbands; ++bnd) {
+      const int tha = (bnd == nbands - 1) ? Ho - bnd * th : th;
       const int tiles = (tha * Wo + unit_px - 1) / unit_px;
       work += tha * Wo / (double)unit_px;
       slots += ((tiles + nslots - 1) / nslots) * nslots;
     }
-    // halo rows are re-read per band: mild preference for taller bands
-    const double eff = work / slots * (double)th / (th + 2 + 4);
+    const double eff = work / slots * (double)th / (th + 2) * (1.0 - 0.01 * nbands);  // small per-band fixed cost
     if (eff > best_eff) best_eff = eff, best = th;
   }
   return best;
@@ -587,21 +612,22 @@ int launch_conv_s1(int mode, const float* in, const float* w, const float* aux, 
   a.pad = mode == MODE_FWD ? 0 : 2;
   a.Ho = mode == MODE_FWD ? Hs - 2 : Hs + 2;
   a.Wo = mode == MODE_FWD ? Ws - 2 : Ws + 2;
-  if (a.Ho <= 0 || a.Wo <= 0 || (a.Wo + 2) * 3 > 512 * kMaxPf / 8) return CURLA_ERR_UNSUPPORTED;
-  a.th = plan_band_s1(a.Ho, a.Wo, 0, 512 * kMaxPf / 8, 16, 4);
+  if (a.Ho <= 0 || a.Wo <= 0 || (a.Wo + 2) * 3 > kBandPx) return CURLA_ERR_UNSUPPORTED;
+  a.th = plan_band_s1(a.Ho, a.Wo, 0, kBandPx, 16, 2);
   a.nbands = (a.Ho + a.th - 1) / a.th;
+  a.dbg = ABL_HOST;
   size_t lds = (size_t)(a.th + 2) * (a.Wo + 2) * kLdsPix * sizeof(float);
   const size_t wl = (size_t)32 * kWStride * sizeof(float);
   if (lds < wl) lds = wl;
   const int nitems = B * a.nbands;
-  const int grid = nitems < curla_cu_count() ? nitems : curla_cu_count();
+  const int grid = nitems < 2 * curla_cu_count() ? nitems : 2 * curla_cu_count();
   int rc;
   if (mode == MODE_FWD) {
     if ((rc = set_lds(conv_s1_kernel<MODE_FWD>, lds)) != CURLA_OK) return rc;
-    hipLaunchKernelGGL(conv_s1_kernel<MODE_FWD>, dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(conv_s1_kernel<MODE_FWD>, dim3(grid), dim3(256), lds, st, a);
   } else {
     if ((rc = set_lds(conv_s1_kernel<MODE_DGRAD>, lds)) != CURLA_OK) return rc;
-    hipLaunchKernelGGL(conv_s1_kernel<MODE_DGRAD>, dim3(grid), dim3(512), lds, st, a);
+    hipLaunchKernelGGL(conv_s1_kernel<MODE_DGRAD>, dim3(grid), dim3(256), lds, st, a);
   }
   return curla_launch_status();
 }
@@ -631,6 +657,10 @@ int plan_band_conv1(int Ho, int Wo, int Wc, int C, int g_px_per_row, size_t lds_
 
 // ------------------------------------ C ABI ------------------------------------
 extern "C" {
+
+#ifdef CURLA_ABLATE
+void curla_debug_ablate(int flags) { g_ablate = flags; }
+#endif
 
 int curla_conv3x3_s1_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Hi, int Wi,
                          int channels, void* stream) {
@@ -706,7 +736,7 @@ int curla_conv1_fwd(const void* src, int src_is_u8, const int64_t* idx, const in
 
 // workspace (floats) the weight-gradient kernels need for their per-workgroup slabs
 size_t curla_conv_wgrad_workspace_floats(int cin) {
-  return (size_t)curla_cu_count() * ((size_t)32 * cin * 9 + 32);
+  return (size_t)2 * curla_cu_count() * ((size_t)32 * cin * 9 + 32);
 }
 
 int curla_conv3x3_s1_wgrad(const float* in, const float* g, float* dw, float* db, float* workspace, int B, int Hi,
@@ -717,19 +747,19 @@ int curla_conv3x3_s1_wgrad(const float* in, const float* g, float* dw, float* db
   WgradS1Args a;
   a.in = in, a.g = g, a.partial = workspace;
   a.B = B, a.Hi = Hi, a.Wi = Wi, a.Ho = Hi - 2, a.Wo = Wi - 2;
-  if ((a.Wo + 2) * 3 + a.Wo > 512 * kMaxPf / 8) return CURLA_ERR_UNSUPPORTED;
-  a.th = plan_band_s1(a.Ho, a.Wo, a.Wo, 512 * kMaxPf / 8, 4, 8);
+  if ((a.Wo + 2) * 3 + a.Wo > kBandPx) return CURLA_ERR_UNSUPPORTED;
+  a.th = plan_band_s1(a.Ho, a.Wo, a.Wo, kBandPx, 16, 2);
   a.nbands = (a.Ho + a.th - 1) / a.th;
   size_t lds = (size_t)((a.th + 2) * Wi + a.th * a.Wo) * kLdsPix * sizeof(float);
   if (lds < kPartialS1 * sizeof(float)) lds = kPartialS1 * sizeof(float);
   const int nitems = B * a.nbands;
-  const int grid = nitems < curla_cu_count() ? nitems : curla_cu_count();
+  const int grid = nitems < 2 * curla_cu_count() ? nitems : 2 * curla_cu_count();
   int rc = set_lds(wgrad_s1_kernel, lds);
   if (rc != CURLA_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(wgrad_s1_kernel, dim3(grid), dim3(512), lds, st, a);
+  hipLaunchKernelGGL(wgrad_s1_kernel, dim3(grid), dim3(256), lds, st, a);
   if ((rc = curla_launch_status()) != CURLA_OK) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kPartialS1 + 255) / 256), dim3(256), 0, st, workspace, grid, 32 * 288,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kPartialS1 + 31) / 32), dim3(256), 0, st, workspace, grid, 32 * 288,
                      dw, db);
   return curla_launch_status();
 }
@@ -765,7 +795,7 @@ int curla_conv1_wgrad(const void* src, int src_is_u8, const int64_t* idx, const 
   CURLA_DISPATCH_C(C, src_is_u8, WGRAD1_LAUNCH, grid, lds, st, a);
   if (rc != CURLA_OK) return rc;
   if ((rc = curla_launch_status()) != CURLA_OK) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nw + 32 + 255) / 256), dim3(256), 0, st, workspace, grid, nw, dw, db);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nw + 32 + 31) / 32), dim3(256), 0, st, workspace, grid, nw, dw, db);
   return curla_launch_status();
 }
 

@@ -31,12 +31,12 @@ struct GemmArgs {
   int relu, vecA, vecB;
 };
 
-// load one BK x 64 operand tile into registers (2 float4 per thread)
-template <bool KMAJOR>
+// load one BK x ROWS operand tile into registers (ROWS/32 float4 per thread)
+template <bool KMAJOR, int ROWS>
 __device__ __forceinline__ void tile_load(const float* __restrict__ P, int ld, int rows_total, int r0, int k0, int kend,
-                                          int vec, int tid, f32x4 (&reg)[2]) {
+                                          int vec, int tid, f32x4 (&reg)[ROWS / 32]) {
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < ROWS / 32; ++u) {
     f32x4 v = {0, 0, 0, 0};
     if (!KMAJOR) {
       const int row = (tid >> 3) + 32 * u, k4 = (tid & 7) * 4;
@@ -52,7 +52,8 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ P, int ld, i
         }
       }
     } else {
-      const int k = (tid >> 4) + 16 * u, r4 = (tid & 15) * 4;
+      constexpr int TPR = ROWS / 4;  // threads per k-row
+      const int k = tid / TPR + (256 / TPR) * u, r4 = (tid % TPR) * 4;
       const int gk = k0 + k, gr = r0 + r4;
       if (gk < kend) {
         const float* p = P + (size_t)gk * ld + gr;
@@ -69,16 +70,17 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ P, int ld, i
   }
 }
 
-template <bool KMAJOR>
-__device__ __forceinline__ void tile_store(float* __restrict__ S, int tid, const f32x4 (&reg)[2]) {
+template <bool KMAJOR, int ROWS>
+__device__ __forceinline__ void tile_store(float* __restrict__ S, int tid, const f32x4 (&reg)[ROWS / 32]) {
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
+  for (int u = 0; u < ROWS / 32; ++u) {
     if (!KMAJOR) {
       const int row = (tid >> 3) + 32 * u, k4 = (tid & 7) * 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i) S[row * RSTR + k4 + i] = reg[u][i];
     } else {
-      const int k = (tid >> 4) + 16 * u, r4 = (tid & 15) * 4;
+      constexpr int TPR = ROWS / 4;
+      const int k = tid / TPR + (256 / TPR) * u, r4 = (tid % TPR) * 4;
       *reinterpret_cast<f32x4*>(S + k * KSTR + r4) = reg[u];
     }
   }
@@ -89,8 +91,13 @@ __device__ __forceinline__ float frag(const float* __restrict__ S, int row, int 
   return KMAJOR ? S[k * KSTR + row] : S[row * RSTR + k];
 }
 
-template <bool AK, bool BKM>
+// 256 threads = 2 x 2 waves; a wave computes 32 x (TBN/2) of the 64 x TBN tile.
+// TBN = 32 doubles the workgroup count for the mid-sized GEMMs of the heads
+// (512 x 1024 x 1024 is only 128 tiles of 64 x 64 on a 256-CU chip).
+template <bool AK, bool BKM, int TBN>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  constexpr int NJ = TBN / 32;
+  constexpr int WN = TBN / 2;  // columns per wave
   __shared__ __attribute__((aligned(16))) float As[BK * KSTR];
   __shared__ __attribute__((aligned(16))) float Bs[BK * KSTR];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -98,43 +105,43 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int z = blockIdx.z;
   const int batch = z / g.ksplit, ks = z - batch * g.ksplit;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * TBN;
   const float* A = g.A + batch * g.sA;
   const float* B = g.B + batch * g.sB;
   float* C = g.C + batch * g.sC + ks * g.sSplit;
   const int kbeg = ks * g.kchunk;
   const int kend = min(g.K, kbeg + g.kchunk);
 
-  f32x4 acc[2][2];
+  f32x4 acc[2][NJ];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-  f32x4 ra[2], rb[2];
+  f32x4 ra[2], rb[TBN / 32];
   if (kbeg < kend) {
-    tile_load<AK>(A, g.lda, g.M, m0, kbeg, kend, g.vecA, tid, ra);
-    tile_load<BKM>(B, g.ldb, g.N, n0, kbeg, kend, g.vecB, tid, rb);
+    tile_load<AK, BM>(A, g.lda, g.M, m0, kbeg, kend, g.vecA, tid, ra);
+    tile_load<BKM, TBN>(B, g.ldb, g.N, n0, kbeg, kend, g.vecB, tid, rb);
   }
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    tile_store<AK>(As, tid, ra);
-    tile_store<BKM>(Bs, tid, rb);
+    tile_store<AK, BM>(As, tid, ra);
+    tile_store<BKM, TBN>(Bs, tid, rb);
     __syncthreads();
     if (k0 + BK < kend) {
-      tile_load<AK>(A, g.lda, g.M, m0, k0 + BK, kend, g.vecA, tid, ra);
-      tile_load<BKM>(B, g.ldb, g.N, n0, k0 + BK, kend, g.vecB, tid, rb);
+      tile_load<AK, BM>(A, g.lda, g.M, m0, k0 + BK, kend, g.vecA, tid, ra);
+      tile_load<BKM, TBN>(B, g.ldb, g.N, n0, k0 + BK, kend, g.vecB, tid, rb);
     }
 #pragma unroll
     for (int s = 0; s < BK / 4; ++s) {
-      float fa[2], fb[2];
+      float fa[2], fb[NJ];
 #pragma unroll
       for (int i = 0; i < 2; ++i) fa[i] = frag<AK>(As, wm * 32 + i * 16 + li, 4 * s + kq);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) fb[j] = frag<BKM>(Bs, wn * 32 + j * 16 + li, 4 * s + kq);
+      for (int j = 0; j < NJ; ++j) fb[j] = frag<BKM>(Bs, wn * WN + j * 16 + li, 4 * s + kq);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = mfma16(fa[i], fb[j], acc[i][j]);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(fa[i], fb[j], acc[i][j]);
     }
     __syncthreads();
   }
@@ -145,8 +152,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + wn * 32 + j * 16 + li;
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * WN + j * 16 + li;
       if (n >= g.N) continue;
       const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
@@ -195,16 +202,27 @@ int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const f
   g.alpha = alpha, g.relu = relu;
   g.vecA = (lda % 4 == 0) && (strideA % 4 == 0) && aligned16(A);
   g.vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && aligned16(B);
-  dim3 grid((N + BN - 1) / BN, (M + BM - 1) / BM, nbatch * ksplit);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long wgs64 = (long long)((N + 63) / 64) * ((M + BM - 1) / BM) * nbatch * ksplit;
+  const bool narrow = wgs64 < 2LL * curla_cu_count() && N > 32;  // not enough 64x64 tiles to fill the chip twice
+#define CURLA_GEMM_LAUNCH(AKM, BKMAJ)                                                                       \
+  do {                                                                                                      \
+    if (narrow)                                                                                             \
+      hipLaunchKernelGGL((gemm_kernel<AKM, BKMAJ, 32>), dim3((N + 31) / 32, (M + BM - 1) / BM, nbatch * ksplit), \
+                         dim3(256), 0, st, g);                                                              \
+    else                                                                                                    \
+      hipLaunchKernelGGL((gemm_kernel<AKM, BKMAJ, 64>), dim3((N + 63) / 64, (M + BM - 1) / BM, nbatch * ksplit), \
+                         dim3(256), 0, st, g);                                                              \
+  } while (0)
   if (a_kmajor && b_kmajor)
-    hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, st, g);
+    CURLA_GEMM_LAUNCH(true, true);
   else if (a_kmajor)
-    hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, st, g);
+    CURLA_GEMM_LAUNCH(true, false);
   else if (b_kmajor)
-    hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, st, g);
+    CURLA_GEMM_LAUNCH(false, true);
   else
-    hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, st, g);
+    CURLA_GEMM_LAUNCH(false, false);
+#undef CURLA_GEMM_LAUNCH
   return curla_launch_status();
 }
 

@@ -71,13 +71,14 @@ __global__ void ln_bwd_kernel(const float* dy, const float* xhat, const float* r
   if (f < F) dx[(size_t)row * F + f] = rstd[row] * (g - m1 - xh * m2);
 }
 
-// dgamma[f] = sum_b dy*xhat ; dbeta[f] = sum_b dy   (single block, F <= 64)
-__global__ void ln_param_grad_kernel(const float* dy, const float* xhat, int B, int F, float* dgamma, float* dbeta) {
-  __shared__ float sg[4][64], sb[4][64];
+// dgamma[f] = sum_b dy*xhat ; dbeta[f] = sum_b dy   (single block of 1024, F <= 64)
+__global__ __launch_bounds__(1024) void ln_param_grad_kernel(const float* dy, const float* xhat, int B, int F,
+                                                             float* dgamma, float* dbeta) {
+  __shared__ float sg[16][64], sb[16][64];
   const int f = threadIdx.x & 63, part = threadIdx.x >> 6;
   float ag = 0.f, ab = 0.f;
   if (f < F)
-    for (int b = part; b < B; b += 4) {
+    for (int b = part; b < B; b += 16) {
       const float d = dy[(size_t)b * F + f];
       ag += d * xhat[(size_t)b * F + f];
       ab += d;
@@ -85,23 +86,32 @@ __global__ void ln_param_grad_kernel(const float* dy, const float* xhat, int B, 
   sg[part][f] = ag, sb[part][f] = ab;
   __syncthreads();
   if (part == 0 && f < F) {
-    dgamma[f] = (sg[0][f] + sg[1][f]) + (sg[2][f] + sg[3][f]);
-    dbeta[f] = (sb[0][f] + sb[1][f]) + (sb[2][f] + sb[3][f]);
+    float g = sg[0][f], bsum = sb[0][f];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) g += sg[k][f], bsum += sb[k][f];
+    dgamma[f] = g;
+    dbeta[f] = bsum;
   }
 }
 
-// out[z][n] = sum_m X[z][m][n]  (bias gradients); 64 columns x 4 row-parts per block
-__global__ void colsum_kernel(const float* X, int M, int N, int ldx, long long sX, float* out, long long sOut) {
-  __shared__ float sm[4][64];
-  const int c = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + c;
+// out[z][n] = sum_m X[z][m][n]  (bias gradients); 32 columns x 32 row-parts per block, fixed order
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* X, int M, int N, int ldx, long long sX, float* out,
+                                                      long long sOut) {
+  __shared__ float sm[32][33];
+  const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + c;
   const float* x = X + blockIdx.y * sX;
   float a = 0.f;
   if (n < N)
-    for (int m = part; m < M; m += 4) a += x[(size_t)m * ldx + n];
+    for (int m = part; m < M; m += 32) a += x[(size_t)m * ldx + n];
   sm[part][c] = a;
   __syncthreads();
-  if (part == 0 && n < N) out[blockIdx.y * sOut + n] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
+  if (part == 0 && n < N) {
+    float t = sm[0][c];
+#pragma unroll
+    for (int k = 1; k < 32; ++k) t += sm[k][c];
+    out[blockIdx.y * sOut + n] = t;
+  }
 }
 
 // ---- policy head ----
@@ -344,14 +354,14 @@ int curla_ln_bwd(const float* dy, const float* xhat, const float* rstd, const fl
   if (F > 64) return CURLA_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(ln_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, dy, xhat, rstd, gamma, B, F, dx);
-  if (dgamma && dbeta) hipLaunchKernelGGL(ln_param_grad_kernel, dim3(1), dim3(256), 0, st, dy, xhat, B, F, dgamma, dbeta);
+  if (dgamma && dbeta) hipLaunchKernelGGL(ln_param_grad_kernel, dim3(1), dim3(1024), 0, st, dy, xhat, B, F, dgamma, dbeta);
   return curla_launch_status();
 }
 
 int curla_colsum(const float* X, int M, int N, int ldx, long long strideX, float* out, long long strideOut, int nbatch,
                  void* stream) {
   CURLA_REQUIRE(X && out && M > 0 && N > 0 && nbatch > 0);
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, nbatch), dim3(256), 0, static_cast<hipStream_t>(stream), X, M,
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32, nbatch), dim3(1024), 0, static_cast<hipStream_t>(stream), X, M,
                      N, ldx, strideX, out, strideOut);
   return curla_launch_status();
 }

@@ -72,7 +72,7 @@ def conv_s1_wgrad(x, g, dw, db, ws):
 
 def wgrad_workspace_floats(cin):
     if _lib._trace_hook is not None:
-        return 256 * (32 * cin * 9 + 32)
+        return 512 * (32 * cin * 9 + 32)
     return int(_lib.load().curla_conv_wgrad_workspace_floats(cin))
 
 

@@ -1,0 +1,132 @@
+#!/usr/bin/env python3
+"""Per-kernel timing at the BASELINE configs[1] shapes (B=512), with optional
+timing-only ablations of the stride-1 conv kernel (needs the -DCURLA_ABLATE
+build: tools/kbench.py --build-ablate).  Prints one line per kernel: avg us,
+TFLOP/s, fraction of the 157.3 TF fp32 MFMA peak."""
+import argparse
+import ctypes
+import os
+import subprocess
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+PEAK = 157.3e12
+
+
+def build_ablate():
+    out = os.path.join(ROOT, "tools", "_build")
+    os.makedirs(out, exist_ok=True)
+    lib = os.path.join(out, "libcurla_ablate.so")
+    srcs = [os.path.join(ROOT, "curla_amd", "csrc", f) for f in ("conv.hip", "gemm.hip", "heads.hip")]
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
+                           "-DCURLA_ABLATE", "-o", lib] + srcs)
+    return lib
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--build-ablate", action="store_true")
+    ap.add_argument("--ablate", type=str, default="")
+    ap.add_argument("--B", type=int, default=512)
+    ap.add_argument("--what", type=str, default="conv,gemm,misc")
+    args = ap.parse_args()
+    if args.build_ablate:
+        print(build_ablate())
+        return
+    from curla_amd import _lib, ops
+    flags = [int(x) for x in args.ablate.split(",") if x] or [0]
+    if flags != [0]:
+        _lib.LIB_PATH = os.path.join(ROOT, "tools", "_build", "libcurla_ablate.so")
+        _lib.SIGNATURES["curla_debug_ablate"] = [ctypes.c_int]
+    lib = _lib.load()
+    B = args.B
+    dev = "cuda"
+    r = lambda *s: torch.randn(*s, device=dev)  # noqa: E731
+
+    def report(name, us, flop):
+        print(f"{name:46s} {us:9.1f} us  {flop / us / 1e6:7.1f} TF  {flop / us * 1e6 / PEAK * 100:5.1f}%", flush=True)
+
+    if "conv" in args.what:
+        w, b = r(32, 32, 3, 3) * 0.1, r(32) * 0.1
+        for fl in flags:
+            if flags != [0]:
+                lib.curla_debug_ablate(fl)
+            for H in (37, 35, 33):
+                x = torch.relu(r(B, H, H, 32))
+                out = torch.empty(B, H - 2, H - 2, 32, device=dev)
+                fl_ = 2.0 * B * (H - 2) ** 2 * 32 * 32 * 9
+                report(f"[abl {fl}] conv_s1_fwd {H}->{H - 2}", timeit(lambda: ops.conv_s1_fwd(x, w, b, out)), fl_)
+            for H in (35, 33, 31):
+                g = r(B, H, H, 32)
+                below = torch.relu(r(B, H + 2, H + 2, 32))
+                gin = torch.empty_like(below)
+                fl_ = 2.0 * B * H * H * 32 * 32 * 9
+                report(f"[abl {fl}] conv_s1_dgrad {H}->{H + 2}", timeit(lambda: ops.conv_s1_dgrad(g, w, below, gin)), fl_)
+        if flags != [0]:
+            lib.curla_debug_ablate(0)
+        ws = torch.empty(ops.wgrad_workspace_floats(32), device=dev)
+        dw, db = torch.empty(32, 32, 3, 3, device=dev), torch.empty(32, device=dev)
+        for H in (37, 35, 33):
+            x = torch.relu(r(B, H, H, 32))
+            g = r(B, H - 2, H - 2, 32)
+            fl_ = 2.0 * B * (H - 2) ** 2 * 32 * 32 * 9
+            report(f"conv_s1_wgrad(+reduce) {H}", timeit(lambda: ops.conv_s1_wgrad(x, g, dw, db, ws)), fl_)
+        ring = torch.randint(0, 256, (2048, 84, 84, 9), dtype=torch.uint8, device=dev)
+        idx = torch.randint(0, 2048, (B,), device=dev)
+        h1 = torch.randint(0, 8, (B,), device=dev, dtype=torch.int32)
+        w1 = torch.randint(0, 8, (B,), device=dev, dtype=torch.int32)
+        obs = ops.ObsRef.from_ring(ring, idx, h1, w1, B, (76, 76))
+        w0 = r(32, 9, 3, 3) * 0.1
+        out = torch.empty(B, 37, 37, 32, device=dev)
+        fl_ = 2.0 * B * 37 * 37 * 32 * 9 * 9
+        report("conv1_fwd u8 84->76->37", timeit(lambda: ops.conv1_fwd(obs, w0, b, out)), fl_)
+        g = r(B, 37, 37, 32)
+        dw0 = torch.empty(32, 9, 3, 3, device=dev)
+        ws0 = torch.empty(ops.wgrad_workspace_floats(9), device=dev)
+        report("conv1_wgrad(+reduce) u8", timeit(lambda: ops.conv1_wgrad(obs, g, dw0, db, ws0)), fl_)
+
+    if "gemm" in args.what:
+        H, F, K = 1024, 50, 30752
+        for nb in (1, 2):
+            x, W, bb, out = r(nb, B, H), r(nb, H, H), r(nb, H), torch.empty(nb, B, H, device=dev)
+            fl_ = 2.0 * nb * B * H * H
+            report(f"linear_fwd {B}x{H}x{H} nb{nb}", timeit(lambda: ops.linear_fwd(x, B * H, W, H * H, bb, H, out, B * H, B, H, H, nb, relu=1)), fl_)
+            report(f"linear_dx  {B}x{H}x{H} nb{nb}", timeit(lambda: ops.linear_dx(x, B * H, W, H * H, out, B * H, B, H, H, nb, mask=x, smask=B * H)), fl_)
+            report(f"linear_dw  {B}x{H}x{H} nb{nb}", timeit(lambda: ops.linear_dw(x, B * H, out, B * H, W, H * H, B, H, H, nb)), fl_)
+        h, Wf = r(B, K), r(F, K)
+        for ks in (16, 32, 64):
+            part = torch.empty(ks, B, F, device=dev)
+            report(f"fc fwd split-K {ks} [{B}x{K}]x[{K}x{F}]",
+                   timeit(lambda: ops.gemm(h, 0, K, 0, Wf, 0, K, 0, part, F, 0, B, F, K, 1, ksplit=ks, split_stride=B * F)), 2.0 * B * F * K)
+        dz, dW, dh = r(B, F), torch.empty(F, K, device=dev), torch.empty(B, K, device=dev)
+        report("fc dW (TN)", timeit(lambda: ops.linear_dw(dz, 0, h, 0, dW, 0, B, F, K)), 2.0 * B * F * K)
+        report("fc dh (NN + mask)", timeit(lambda: ops.linear_dx(dz, 0, Wf, 0, dh, 0, B, F, K, mask=h)), 2.0 * B * F * K)
+
+    if "misc" in args.what:
+        X = r(2, B, 1024)
+        o = torch.empty(2, 1024, device=dev)
+        report("colsum 2x512x1024", timeit(lambda: ops.colsum(X, B, 1024, 1024, B * 1024, o, 1024, 2)), 2.0 * B * 1024)
+        part = r(64, B, 50)
+        y = torch.empty(B, 50, device=dev)
+        bi, ga, be = r(50), r(50), r(50)
+        report("fc_ln_fwd ks64", timeit(lambda: ops.fc_ln_fwd(part, 64, B * 50, 50, bi, ga, be, B, 50, y)), 64.0 * B * 50)
+
+
+if __name__ == "__main__":
+    main()
