@@ -90,18 +90,31 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
     {
       const int n4 = (tha + 2) * WT * 8;
       f32x4 pf[kMaxPf];
+      if (MODE == MODE_FWD) {
+        // the band (tha+2 full rows) is one contiguous run of HBM: no index arithmetic
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.in + ((size_t)(b * a.Hs + y0) * a.Ws) * 32);
 #pragma unroll
-      for (int u = 0; u < kMaxPf; ++u) {
-        const int f = tid + u * 256;
-        f32x4 v = {0, 0, 0, 0};
-        if (f < n4 && !(ABL(1) && item != (int)blockIdx.x)) {
-          const int pix = f >> 3, ch = f & 7;
-          const int r = pix / WT, c = pix - r * WT;
-          const int sy = y0 + r - a.pad, sx = c - a.pad;
-          if (sy >= 0 && sy < a.Hs && sx >= 0 && sx < a.Ws)
-            v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(b * a.Hs + sy) * a.Ws + sx) * 32 + ch * 4);
+        for (int u = 0; u < kMaxPf; ++u) {
+          const int f = tid + u * 256;
+          f32x4 v = {0, 0, 0, 0};
+          if (f < n4 && !(ABL(1) && item != (int)blockIdx.x)) v = src[f];
+          pf[u] = v;
         }
-        pf[u] = v;
+      } else {
+        // zero-padded band: walk (row, col) incrementally (32 pixels per step), no divisions
+        int r = (tid >> 3) / WT, c = (tid >> 3) - r * WT;
+        const int ch = tid & 7;
+#pragma unroll
+        for (int u = 0; u < kMaxPf; ++u) {
+          const int f = tid + u * 256;
+          f32x4 v = {0, 0, 0, 0};
+          const int sy = y0 + r - a.pad, sx = c - a.pad;
+          if (f < n4 && sy >= 0 && sy < a.Hs && sx >= 0 && sx < a.Ws && !(ABL(1) && item != (int)blockIdx.x))
+            v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(b * a.Hs + sy) * a.Ws + sx) * 32 + ch * 4);
+          pf[u] = v;
+          c += 32;
+          while (c >= WT) c -= WT, ++r;
+        }
       }
 #pragma unroll
       for (int u = 0; u < kMaxPf; ++u) {
@@ -114,11 +127,11 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
 
     const int npix = tha * a.Wo;
     const int ntiles = (npix + 15) >> 4;
+    // this lane's pixel walks the band 32 pixels per iteration: (ty, x) kept incrementally
+    int ty = (tslot * 16 + li) / a.Wo, x = (tslot * 16 + li) - ty * a.Wo;
     for (int t = tslot; t < ntiles; t += 2) {
-      const int p = t * 16 + li;
-      const bool pv = p < npix;
-      const int pc = pv ? p : 0;
-      const int ty = pc / a.Wo, x = pc - ty * a.Wo;
+      const bool pv = t * 16 + li < npix;
+      if (!pv) ty = 0, x = 0;
       const float* base = lds + (ty * WT + x) * kLdsPix + 4 * kq;
       // two accumulation chains so dependent MFMAs never wait on each other; the LDS
       // reads of tap t+1 are issued before the MFMAs of tap t (software pipeline,
@@ -163,6 +176,8 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
         }
         *reinterpret_cast<f32x4*>(a.out + g) = v;
       }
+      x += 32;
+      while (x >= a.Wo) x -= a.Wo, ++ty;
     }
     __syncthreads();
   }
@@ -355,12 +370,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) {
     const float* ldsg = lds + (tha + 2) * a.Wi * kLdsPix;
     const int nunits = ((npix + 15) >> 4) << 2;  // 4 pixels per MFMA k-step, 4 k-steps per 16-pixel group
     // operand fetch of one k-step: 1 gradient value (A) + 18 input values (B: 9 taps x 2 cin tiles)
+    // fetch() is called for u = uslot, uslot+2, ... in order; the lane's pixel
+    // p(u) = (u>>2)*16 + (u&3) + 4*kq advances by 2 or 14, so (fy, fx) are kept incrementally
+    int fy = (uslot + 4 * kq) / a.Wo, fx = (uslot + 4 * kq) - fy * a.Wo;
     auto fetch = [&](int u, float& av, float (&bv)[18]) {
       // pixels of a k-step are 4 apart so the two lane groups of an LDS half hit disjoint banks
       const int p = (u >> 2) * 16 + (u & 3) + 4 * kq;
       const bool pv = (u < nunits) && (p < npix);
-      const int pc = pv ? p : 0;
-      const int ty = pc / a.Wo, x = pc - ty * a.Wo;
+      const int ty = pv ? fy : 0, x = pv ? fx : 0;
       av = pv ? ldsg[(ty * a.Wo + x) * kLdsPix + mt * 16 + li] : 0.f;
       const float* ip = lds + (ty * a.Wi + x) * kLdsPix + li;
 #pragma unroll
@@ -371,6 +388,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) {
           bv[2 * (dy * 3 + dx)] = q[0];
           bv[2 * (dy * 3 + dx) + 1] = q[16];
         }
+      fx += (u & 2) ? 14 : 2;
+      while (fx >= a.Wo) fx -= a.Wo, ++fy;
     };
     auto mma = [&](float av, const float (&bv)[18]) {
       bsum += av;
