@@ -15,7 +15,7 @@
 namespace {
 
 constexpr int BM = 64, BN = 64, BK = 32;
-constexpr int RSTR = BK + 1;   // LDS stride, row-major tile [64][BK]
+constexpr int RSTR = BK + 8;   // LDS stride, row-major tile [64][BK]: 40 floats -> 16-B aligned rows, ds_read_b128 of 16 rows x 4 k-quarters conflict-free
 constexpr int KSTR = BM + 16;  // LDS stride, k-major tile [BK][64]  (80 = 16 mod 32: the two lane groups of a half are disjoint)
 
 struct GemmArgs {
@@ -76,8 +76,7 @@ __device__ __forceinline__ void tile_store(float* __restrict__ S, int tid, const
   for (int u = 0; u < ROWS / 32; ++u) {
     if (!KMAJOR) {
       const int row = (tid >> 3) + 32 * u, k4 = (tid & 7) * 4;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) S[row * RSTR + k4 + i] = reg[u][i];
+      *reinterpret_cast<f32x4*>(S + row * RSTR + k4) = reg[u];
     } else {
       constexpr int TPR = ROWS / 4;
       const int k = tid / TPR + (256 / TPR) * u, r4 = (tid % TPR) * 4;
@@ -86,9 +85,22 @@ __device__ __forceinline__ void tile_store(float* __restrict__ S, int tid, const
   }
 }
 
+// MFMA operand values of one lane for the 8 k-steps of a BK=32 tile.  k-step (j, e) multiplies
+// k = 16j + 4kq + e on lane group kq (any k order is fine as long as A and B agree): a row-major
+// tile delivers them with two ds_read_b128, a k-major tile with eight ds_read_b32.
 template <bool KMAJOR>
-__device__ __forceinline__ float frag(const float* __restrict__ S, int row, int k) {
-  return KMAJOR ? S[k * KSTR + row] : S[row * RSTR + k];
+__device__ __forceinline__ void frags(const float* __restrict__ S, int row, int kq, float (&v)[8]) {
+  if (!KMAJOR) {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(S + row * RSTR + 4 * kq);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(S + row * RSTR + 16 + 4 * kq);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = lo[e], v[4 + e] = hi[e];
+  } else {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[4 * j + e] = S[(16 * j + 4 * kq + e) * KSTR + row];
+  }
 }
 
 // 256 threads = 2 x 2 waves; a wave computes 32 x (TBN/2) of the 64 x TBN tile.
@@ -131,18 +143,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       tile_load<AK, BM>(A, g.lda, g.M, m0, k0 + BK, kend, g.vecA, tid, ra);
       tile_load<BKM, TBN>(B, g.ldb, g.N, n0, k0 + BK, kend, g.vecB, tid, rb);
     }
+    float fa[2][8], fb[NJ][8];
 #pragma unroll
-    for (int s = 0; s < BK / 4; ++s) {
-      float fa[2], fb[NJ];
+    for (int i = 0; i < 2; ++i) frags<AK>(As, wm * 32 + i * 16 + li, kq, fa[i]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i) fa[i] = frag<AK>(As, wm * 32 + i * 16 + li, 4 * s + kq);
+    for (int j = 0; j < NJ; ++j) frags<BKM>(Bs, wn * WN + j * 16 + li, kq, fb[j]);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) fb[j] = frag<BKM>(Bs, wn * WN + j * 16 + li, 4 * s + kq);
+    for (int s = 0; s < BK / 4; ++s)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(fa[i], fb[j], acc[i][j]);
-    }
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(fa[i][s], fb[j][s], acc[i][j]);
     __syncthreads();
   }
 

@@ -339,3 +339,89 @@ def test_update_entry_point_runs_from_ring():
     for k in ("train_critic/loss", "train_actor/loss", "train/curl_loss", "train/batch_reward", "train_alpha/value"):
         assert np.isfinite(L.scalars[k]), k
     assert _lib._lib is not None  # the native library is what ran
+
+
+@pytest.mark.parametrize("name,obs_shape,layers,pixel_sac,B", [
+    ("c3_pixel_sac_84", (9, 84, 84), 4, True, 6),        # BASELINE configs[2]: identity aug, no CURL head
+    ("c5_geometry_168x12_L6", (12, 168, 168), 6, False, 3),  # BASELINE configs[4] geometry (augmentation-free)
+    ("rect_76x135", (9, 76, 135), 4, False, 4),          # the reference's own thesis shape (encoder.py:42-43)
+])
+def test_other_config_geometries_vs_oracle(name, obs_shape, layers, pixel_sac, B):
+    """One even-step update() on the other BASELINE geometries against the oracle
+    agent (same weights, minibatch, noise): per-phase losses and the gradients
+    that reach Adam."""
+    import curla_amd
+    from oracle import curla_oracle as O
+    torch.manual_seed(11)
+    np.random.seed(11)
+    hw = obs_shape[1:]
+    aug = curla_amd.IdentityAugmentation(hw)
+    hp = {**HP, "num_layers": layers}
+    agent = curla_amd.CurlSacAgent(obs_shape, (2,), torch.device("cuda"), aug, hidden_dim=64, pixel_sac=pixel_sac, **hp)
+    oracle = O.OracleAgent(obs_shape, (2,), hidden_dim=64, pixel_sac=pixel_sac,
+                           **{k: v for k, v in hp.items() if k != "log_interval"})
+    for dst, src in ((oracle.critic, agent.critic.state_dict()), (oracle.critic_target, agent.critic_target.state_dict()),
+                     (oracle.actor, agent.actor.state_dict())):
+        for k in dst:
+            dst[k].data.copy_(src[k].cpu())
+    # move the convs off the delta-orthogonal init (all taps live) -- same perturbation on both sides
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for i in range(layers):
+            for nm in ("weight", "bias"):
+                k = f"encoder.convs.{i}.{nm}"
+                d = 0.05 * torch.randn(oracle.critic[k].shape, generator=g)
+                oracle.critic[k].add_(d)
+                oracle.critic_target[k].add_(0.5 * d)
+        sd = {k: v.detach().clone() for k, v in oracle.critic.items()}
+        agent.critic.load_state_dict(sd)
+        agent.critic_target.load_state_dict({k: v.detach().clone() for k, v in oracle.critic_target.items()})
+    oracle.W.data.copy_(agent.CURL.W.detach().cpu())
+    rb = curla_amd.ReplayBuffer(obs_shape, (2,), 8, B, torch.device("cuda"), aug)
+    rs = np.random.RandomState(2)
+    n = 8
+    obs_all = rs.randint(0, 256, (n,) + obs_shape, dtype=np.uint8)
+    nxt_all = rs.randint(0, 256, (n,) + obs_shape, dtype=np.uint8)
+    act_all = rs.uniform(-1, 1, (n, 2)).astype(np.float32)
+    rew_all = rs.randn(n).astype(np.float32)
+    rb.add_batch(obs_all, act_all, rew_all, nxt_all, np.zeros(n, bool))
+    idxs, offs = rb.draw_indices()
+    assert not offs.any()
+    nc, na = torch.randn(B, 2), torch.randn(B, 2)
+    f = lambda a: torch.from_numpy(a[idxs]).float()  # noqa: E731
+    # reference gradients of the critic phase from the pre-update state (functional oracle)
+    ref_critic = O.critic_phase(oracle.actor, oracle.critic, oracle.critic_target, oracle.log_alpha, f(obs_all),
+                                torch.from_numpy(act_all[idxs]), torch.from_numpy(rew_all[idxs])[:, None], f(nxt_all),
+                                torch.ones(B, 1), nc, num_layers=layers, discount=0.99, log_std_min=-10, log_std_max=2)
+    ref = oracle.update(f(obs_all), torch.from_numpy(act_all[idxs]), torch.from_numpy(rew_all[idxs])[:, None], f(nxt_all),
+                        torch.ones(B, 1), f(obs_all), nc, na, step=0)
+    L = NullLogger()
+    grads = {}
+
+    def capture(nm, module, opt):
+        real = opt.step
+
+        def step():
+            grads[nm] = grads_of(module)
+            real()
+        opt.step = step
+    capture("critic", agent.critic, agent.critic_optimizer)
+    obs, act, rew, nxt, nd, kw = rb.sample_cpc_refs(indices=(idxs, offs))
+    agent.update_critic(obs, act, rew, nxt, nd, L, 0, noise=nc.cuda())
+    agent.update_actor_and_alpha(obs, L, 0, noise=na.cuda())
+    agent.soft_update_targets()
+    if not pixel_sac:
+        agent.update_cpc(kw["obs_anchor"], kw["obs_pos"], kw, L, 0)
+    check(f"{name} critic loss", L.scalars["train_critic/loss"], ref["critic_loss"])
+    check(f"{name} actor loss", L.scalars["train_actor/loss"], ref["actor_loss"])
+    if not pixel_sac:
+        check(f"{name} curl loss", L.scalars["train/curl_loss"], ref["curl_loss"])
+    for k, v in ref_critic["grads"].items():
+        check(f"{name} critic grad {k}", grads["critic"][k], v)
+    # post-Adam conv parameters (fc.weight is left out: its entries are ~lr-sized, so one Adam step of a
+    # near-zero gradient element is chaotic -- SURVEY.md D11)
+    sd = agent.critic.state_dict()
+    for k in ("encoder.convs.0.weight", f"encoder.convs.{layers - 1}.weight"):
+        check(f"{name} params after update {k}", sd[k].cpu(), oracle.critic[k].detach(), 1e-3)
+    assert len(grads["critic"]) == 8 + 2 * layers + 8
+
