@@ -46,11 +46,14 @@ class NullLogger:
     log_histogram = log_param = log_image = log
 
 
-def cpu_baseline(calls=4):
+def cpu_baseline(budget_s=20.0, max_calls=4):
     """The oracle (CPU restatement pinned to the reference) on the host cores:
-    a bounded sample of the same workload (same shapes, B=512)."""
+    a bounded sample of the same workload (same shapes, B=512).  Thread count
+    is capped at 32: torch's CPU conv kernels get slower, not faster, beyond
+    that on a 256-thread host."""
     from oracle import curla_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
     rs = np.random.RandomState(0)
     ag = O.OracleAgent((FRAMES_C,) + CROP_HW, (2,), hidden_dim=HIDDEN)
     B = BATCH
@@ -60,14 +63,20 @@ def cpu_baseline(calls=4):
         return (f(), torch.from_numpy(rs.uniform(-1, 1, (B, 2)).astype(np.float32)),
                 torch.from_numpy(rs.randn(B, 1).astype(np.float32)), f(), torch.ones(B, 1), f(),
                 torch.randn(B, 2), torch.randn(B, 2))
-    ag.update(*batch(), step=0)  # warm-up
-    t0 = time.perf_counter()
-    for s in range(1, calls + 1):
-        ag.update(*batch(), step=s)
-    dt = time.perf_counter() - t0
-    return {"value": calls / dt, "unit": "batch-512 gradient updates/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{calls} OracleAgent.update() calls at B=512, 76x76x9, hidden 1024 "
-            f"(steps 1..{calls}, after 1 warm-up), torch {torch.__version__} CPU"}
+    times = []
+    t_start = time.perf_counter()
+    for s in range(max_calls + 1):  # call 0 is the warm-up unless it alone exhausts the budget
+        bt = batch()
+        t0 = time.perf_counter()
+        ag.update(*bt, step=s)
+        times.append(time.perf_counter() - t0)
+        if time.perf_counter() - t_start > budget_s:
+            break
+    timed = times[1:] if len(times) > 1 else times
+    return {"value": len(timed) / sum(timed), "unit": "batch-512 gradient updates/s", "cores": threads,
+            "kind": "port", "sample": f"{len(timed)} OracleAgent.update() call(s) at B=512, 76x76x9, hidden 1024 "
+            f"({'after 1 warm-up call' if len(times) > 1 else 'first call, no warm-up: budget exhausted'}; "
+            f"{threads} of {os.cpu_count()} host threads), torch {torch.__version__} CPU"}
 
 
 def main():
@@ -146,14 +155,17 @@ def main():
         agent.update(rb, L, step)
         step += 1
     barrier()
-    recording[0] = True
+    # event pairs are taken on a sample of the timed steps spread over the whole region (<= 32 steps = 480
+    # launches): thousands of pending HIP events slow the runtime itself and would perturb the measurement
+    rec_stride = max(1, args.steps // 32)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        recording[0] = (i % rec_stride == 0)
         agent.update(rb, L, step)
         step += 1
+    recording[0] = False
     barrier()
     dt = time.perf_counter() - t0
-    recording[0] = False
 
     if distributed:
         import torch.distributed as dist
@@ -167,6 +179,15 @@ def main():
         achieved = kflops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         updates_per_s = world * args.steps / dt
         per_update = BATCH * (5 * sum(flops) + 2 * (2 * sum(flops) - flops[0]))  # n_f=5, n_b=2
+        # HBM traffic of the dominant kernel per launch: measured offline with rocprofv3 PMC counters
+        # (tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as gfx950 needs),
+        # summary committed under profiles/; null if that file is absent
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["conv_s1_kernel<0>"]["traffic_bytes"]
+        except Exception:
+            pass
         out = {
             "metric": "SAC+CURL gradient updates/sec, batch=512 84x84x9",
             "value": updates_per_s,
@@ -184,7 +205,9 @@ def main():
             "conv_roofline_frac_whole_update": per_update * (args.steps / dt) / (PEAK_F32_TFLOPS * 1e12),
             "roofline": {"bound": "mfma", "kernel": "conv_s1_kernel<FWD> (3x3 s1 32->32 + bias + ReLU, f32 MFMA 16x16x4)",
                          "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": traffic,
+                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json); "
+                                         "algorithmic in+out = 152 MB per launch (mean of the 3 layers)",
                          "launches": len(ev_pairs), "avg_launch_ms": kms / max(1, len(ev_pairs))},
         }
         if not args.no_cpu_baseline and world == 1:
