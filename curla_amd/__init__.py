@@ -1,11 +1,11 @@
 """curla_amd: MI355X-native CURL + SAC learner (drop-in for the learner path of
 paulvantieghem/curla: CurlSacAgent.update & friends, CNNEncoder/PixelEncoder,
 ReplayBuffer, random_crop)."""
-from .augmentations import IdentityAugmentation, RandomCrop, make_augmentor  # noqa: F401
+from .augmentations import ColorJiggle, IdentityAugmentation, NoisyCover, RandomCrop, make_augmentor  # noqa: F401
 from .curl_sac import Actor, Critic, CURL, CurlSacAgent, QFunction  # noqa: F401
 from .encoder import CNNEncoder, PixelEncoder  # noqa: F401
 from .utils import ReplayBuffer, eval_mode, set_seed_everywhere, soft_update_params  # noqa: F401
 
 __all__ = ["CurlSacAgent", "Actor", "Critic", "QFunction", "CURL", "CNNEncoder", "PixelEncoder", "ReplayBuffer",
-           "RandomCrop", "IdentityAugmentation", "make_augmentor", "eval_mode", "set_seed_everywhere",
+           "RandomCrop", "IdentityAugmentation", "ColorJiggle", "NoisyCover", "make_augmentor", "eval_mode", "set_seed_everywhere",
            "soft_update_params"]

@@ -65,15 +65,55 @@ class RandomCrop(IdentityAugmentation):
         return out
 
 
+class ColorJiggle(IdentityAugmentation):
+    """augmentations.py:78-136: every RGB frame of the stack is jittered independently with probability
+    0.85 -- contrast U(0.8,1.2), saturation U(0.5,1.5), hue U(-0.5,0.5) turns, brightness 0 -- the four
+    operations applied in one random order per call.
+
+    PARITY UNPINNED: the reference delegates the arithmetic to kornia (not vendored, version un-pinned).
+    The arithmetic here (curla_amd/csrc/augment.hip, restated in oracle/curla_oracle.py) follows kornia's
+    documented ColorJiggle: brightness additive (0 -> identity), contrast x*c clamped to [0,1], saturation
+    and hue through HSV.  Random parameters are drawn on the host from torch's CPU generator."""
+
+    p, contrast, saturation, hue = 0.85, 0.2, 0.5, 0.5
+
+    def draw_params(self, n_images):
+        """(params [n_images, 4] = apply, contrast, saturation, hue in radians; order [4])."""
+        import torch
+        apply = (torch.rand(n_images) < self.p).float()
+        con = torch.empty(n_images).uniform_(1 - self.contrast, 1 + self.contrast)
+        sat = torch.empty(n_images).uniform_(1 - self.saturation, 1 + self.saturation)
+        hue = torch.empty(n_images).uniform_(-self.hue, self.hue) * (2 * np.pi)
+        order = torch.randperm(4).int()
+        return torch.stack([apply, con, sat, hue], 1).contiguous(), order
+
+
+class NoisyCover(IdentityAugmentation):
+    """augmentations.py:138-205: rows [0, ceil(0.31 h)) and [h - ceil(0.20 h), h) of every frame are painted
+    with one random colour per RGB channel (np.random.randint(0, 255) x3 per call, shared by the batch),
+    Gaussian noise N(0, 10) is added and the result clamped to [0, 255].  Noise: torch generator of the
+    device (kornia's RandomGaussianNoise in the reference; PARITY UNPINNED for the noise stream only)."""
+
+    def __init__(self, input_shape):
+        super().__init__(input_shape)
+        self.h = self.input_shape[0]
+        self.top = int(np.ceil(self.h * 0.31))
+        self.bottom = int(np.ceil(self.h * 0.20))
+        self.std = 10.0
+
+    def draw_colors(self):
+        return [np.random.randint(0, 255) for _ in range(3)]
+
+
 def make_augmentor(name, input_shape, output_shape=None):
-    """augmentations.py:208-221.  ``color_jiggle`` / ``noisy_cover`` need kornia
-    (not vendored by the reference, parity unpinned -- SURVEY.md D9) and are not
-    part of this build yet."""
+    """augmentations.py:208-221."""
     print(f'CHOSEN AUGMENTATION: {name}')
     if name == 'identity':
         return IdentityAugmentation(input_shape)
     if name == 'random_crop':
         return RandomCrop(input_shape, output_shape)
-    if name in ('color_jiggle', 'noisy_cover'):
-        raise NotImplementedError(f'augmentation {name} is not available in curla_amd yet')
+    if name == 'color_jiggle':
+        return ColorJiggle(input_shape)
+    if name == 'noisy_cover':
+        return NoisyCover(input_shape)
     raise ValueError('augmentation is not supported: %s' % name)

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcurla_hip.so")
-SOURCES = ["conv.hip", "gemm.hip", "heads.hip"]
+SOURCES = ["conv.hip", "gemm.hip", "heads.hip", "augment.hip"]
 ARCH = "gfx950"  # MI355X only
 
 

@@ -1,0 +1,160 @@
+// Pixel augmentations that produce float observations (reference: augmentations.py:78-205).
+//
+// The reference implements ColorJiggle / NoisyCover with kornia (un-vendored, version un-pinned), so there is
+// no reference arithmetic to pin against: the algorithm below is this build's own statement of kornia's
+// documented behaviour (oracle/curla_oracle.py restates it on the CPU; parity is to that restatement only).
+// Both kernels read the uint8 NHWC replay ring directly (gather by frame index fused in) and write the
+// float32 NHWC minibatch [B][H][W][C] in [0,255] that the first conv kernel consumes (src kind 2).
+#include "common.h"
+
+namespace {
+
+constexpr float kTwoPi = 6.283185307179586f;
+
+__device__ __forceinline__ void rgb_to_hsv(float r, float g, float b, float& h, float& s, float& v) {
+  const float mx = fmaxf(r, fmaxf(g, b)), mn = fminf(r, fminf(g, b));
+  v = mx;
+  float d = mx - mn;
+  s = d / (mx + 1e-8f);
+  if (d == 0.f) d = 1.f;
+  const float rc = mx - r, gc = mx - g, bc = mx - b;
+  float hh;
+  if (r == mx)          // first maximum wins, as argmax does
+    hh = bc - gc;
+  else if (g == mx)
+    hh = (rc - bc) + 2.f * d;
+  else
+    hh = (gc - rc) + 4.f * d;
+  hh = hh / d / 6.f;
+  hh = hh - floorf(hh);  // python-style % 1
+  h = kTwoPi * hh;
+}
+
+__device__ __forceinline__ void hsv_to_rgb(float h, float s, float v, float& r, float& g, float& b) {
+  const float h6 = h / kTwoPi * 6.f;
+  const float fl = floorf(h6);
+  const int hi = ((int)fl % 6 + 6) % 6;
+  const float f = (h6 - 6.f * floorf(h6 / 6.f)) - (float)hi;
+  const float p = v * (1.f - s), q = v * (1.f - f * s), t = v * (1.f - (1.f - f) * s);
+  switch (hi) {
+    case 0: r = v, g = t, b = p; break;
+    case 1: r = q, g = v, b = p; break;
+    case 2: r = p, g = v, b = t; break;
+    case 3: r = p, g = q, b = v; break;
+    case 4: r = t, g = p, b = v; break;
+    default: r = v, g = p, b = q; break;
+  }
+}
+
+// params[img] = (apply, contrast, saturation, hue_radians); order[4] = permutation of {0 brightness(identity),
+// 1 contrast, 2 saturation, 3 hue}; one image = one RGB frame of the stack (augmentations.py:124-128).
+__global__ void color_jiggle_kernel(const uint8_t* frames, const int64_t* idx, const float* params, const int* order,
+                                    int B, int C, int H, int W, float* out) {
+  const int k = C / 3;
+  const size_t n = (size_t)B * H * W * k;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const int o0 = order[0], o1 = order[1], o2 = order[2], o3 = order[3];
+  for (; i < n; i += stride) {
+    const int fr = i % k;
+    const size_t pix = i / k;  // (b, y, x) flattened
+    const int b = pix / ((size_t)H * W);
+    const size_t yx = pix - (size_t)b * H * W;
+    const int64_t fi = idx ? idx[b] : b;
+    const uint8_t* src = frames + ((size_t)fi * H * W + yx) * C + 3 * fr;
+    float r = src[0] * (1.f / 255.f), g = src[1] * (1.f / 255.f), bl = src[2] * (1.f / 255.f);
+    const float* p = params + ((size_t)b * k + fr) * 4;
+    if (p[0] != 0.f) {
+      const float con = p[1], sat = p[2], hue = p[3];
+#pragma unroll
+      for (int step = 0; step < 4; ++step) {
+        const int op = step == 0 ? o0 : step == 1 ? o1 : step == 2 ? o2 : o3;
+        if (op == 1) {
+          r = fminf(fmaxf(r * con, 0.f), 1.f);
+          g = fminf(fmaxf(g * con, 0.f), 1.f);
+          bl = fminf(fmaxf(bl * con, 0.f), 1.f);
+        } else if (op == 2) {
+          float h, s, v;
+          rgb_to_hsv(r, g, bl, h, s, v);
+          s = fminf(fmaxf(s * sat, 0.f), 1.f);
+          hsv_to_rgb(h, s, v, r, g, bl);
+        } else if (op == 3) {
+          float h, s, v;
+          rgb_to_hsv(r, g, bl, h, s, v);
+          h = h + hue;
+          h = h - kTwoPi * floorf(h / kTwoPi);  // fmod into [0, 2pi)
+          hsv_to_rgb(h, s, v, r, g, bl);
+        }
+      }
+    }
+    float* dst = out + pix * C + 3 * fr;
+    dst[0] = r * 255.f, dst[1] = g * 255.f, dst[2] = bl * 255.f;
+  }
+}
+
+// rows [0,top) and [H-bottom,H) of every frame are painted with colors[c%3], then noise is added and the
+// result clamped to [0,255] (augmentations.py:185-203)
+__global__ void noisy_cover_kernel(const uint8_t* frames, const int64_t* idx, const float* noise, float c0, float c1,
+                                   float c2, int top, int bottom, int B, int C, int H, int W, float* out) {
+  const size_t n = (size_t)B * H * W * C;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int c = i % C;
+    const size_t pix = i / C;
+    const int b = pix / ((size_t)H * W);
+    const size_t yx = pix - (size_t)b * H * W;
+    const int y = yx / W;
+    const int64_t fi = idx ? idx[b] : b;
+    float v = (float)frames[((size_t)fi * H * W + yx) * C + c];
+    if (y < top || y >= H - bottom) v = (c % 3 == 0) ? c0 : (c % 3 == 1) ? c1 : c2;
+    v += noise[i];
+    out[i] = fminf(fmaxf(v, 0.f), 255.f);
+  }
+}
+
+// plain gather + u8 -> f32 (identity augmentation materialised as NHWC floats)
+__global__ void gather_nhwc_kernel(const uint8_t* frames, const int64_t* idx, int B, size_t frame, float* out) {
+  const size_t n = (size_t)B * frame;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int b = i / frame;
+    const int64_t fi = idx ? idx[b] : b;
+    out[i] = (float)frames[(size_t)fi * frame + (i - (size_t)b * frame)];
+  }
+}
+
+inline int blocks_for(size_t n) {
+  size_t b = (n + 255) / 256;
+  return (int)(b < 8192 ? b : 8192);
+}
+
+}  // namespace
+
+extern "C" {
+
+int curla_color_jiggle(const uint8_t* frames, const int64_t* idx, const float* params, const int32_t* order, int B,
+                       int C, int H, int W, float* out, void* stream) {
+  CURLA_REQUIRE(frames && params && order && out && B > 0 && C > 0 && C % 3 == 0 && H > 0 && W > 0);
+  hipLaunchKernelGGL(color_jiggle_kernel, dim3(blocks_for((size_t)B * H * W * (C / 3))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), frames, idx, params, order, B, C, H, W, out);
+  return curla_launch_status();
+}
+
+int curla_noisy_cover(const uint8_t* frames, const int64_t* idx, const float* noise, float c0, float c1, float c2,
+                      int top, int bottom, int B, int C, int H, int W, float* out, void* stream) {
+  CURLA_REQUIRE(frames && noise && out && B > 0 && C > 0 && H > 0 && W > 0 && top >= 0 && bottom >= 0);
+  hipLaunchKernelGGL(noisy_cover_kernel, dim3(blocks_for((size_t)B * H * W * C)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), frames, idx, noise, c0, c1, c2, top, bottom, B, C, H, W, out);
+  return curla_launch_status();
+}
+
+int curla_gather_nhwc(const uint8_t* frames, const int64_t* idx, int B, int C, int H, int W, float* out, void* stream) {
+  CURLA_REQUIRE(frames && out && B > 0 && C > 0 && H > 0 && W > 0);
+  hipLaunchKernelGGL(gather_nhwc_kernel, dim3(blocks_for((size_t)B * H * W * C)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), frames, idx, B, (size_t)C * H * W, out);
+  return curla_launch_status();
+}
+
+}  // extern "C"

@@ -202,9 +202,10 @@ struct Conv1Args {
   float scale;
 };
 
-enum { SRC_U8 = 0, SRC_F32 = 1 };
+enum { SRC_U8 = 0, SRC_F32 = 1, SRC_NHWC = 2 };  // u8 ring / float NCHW tensor / float NHWC tensor
 
 __device__ __forceinline__ int conv1_row_stride(int Wc, int C) { return ((Wc * C + 3) & ~3) + 4; }
+__device__ __forceinline__ bool aligned16_dev(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // Stage input rows [r0, r0+rows) of sample b's (cropped) image into LDS as
 // f32 HWC rows of stride RS, scaled by `scale`.
@@ -233,6 +234,22 @@ __device__ __forceinline__ void conv1_stage(float* lds, const void* src, const i
       o[2] = (float)((v >> 16) & 0xff) * scale;
       o[3] = (float)(v >> 24) * scale;
       *reinterpret_cast<f32x4*>(lds + r * RS + 4 * g) = o;
+    }
+  } else if (SRC == SRC_NHWC) {
+    // float NHWC minibatch (augmented observations): rows are contiguous runs of Wc*C floats
+    const float* img = static_cast<const float*>(src) + ((size_t)b * Hc + r0) * rowf;
+    if ((rowf & 3) == 0 && aligned16_dev(img)) {
+      const int G = rowf >> 2;
+      for (int i = tid; i < rows * G; i += nthreads) {
+        const int r = i / G, g = i - r * G;
+        f32x4 v = *reinterpret_cast<const f32x4*>(img + (size_t)r * rowf + 4 * g);
+        *reinterpret_cast<f32x4*>(lds + r * RS + 4 * g) = v * scale;
+      }
+    } else {
+      for (int i = tid; i < rows * rowf; i += nthreads) {
+        const int r = i / rowf, e = i - r * rowf;
+        lds[r * RS + e] = img[(size_t)r * rowf + e] * scale;
+      }
     }
   } else {
     const float* img = static_cast<const float*>(src) + (size_t)b * C * Hc * Wc;
@@ -699,9 +716,9 @@ int curla_conv3x3_s1_dgrad(const float* g, const float* w, const float* act_belo
 
 static int conv1_common_check(const void* src, int src_is_u8, int B, int C, int Hs, int Ws, int Hc, int Wc,
                               const int32_t* h1, const int32_t* w1) {
-  CURLA_REQUIRE(src && B > 0 && Hc >= 3 && Wc >= 3);
+  CURLA_REQUIRE(src && B > 0 && Hc >= 3 && Wc >= 3 && src_is_u8 >= 0 && src_is_u8 <= 2);
   if (C != 9 && C != 12 && C != 3) return CURLA_ERR_UNSUPPORTED;
-  if (src_is_u8) {
+  if (src_is_u8 == 1) {
     CURLA_REQUIRE(Hs >= Hc && Ws >= Wc);
     // dword-aligned frame starts are what the byte-aligning loader assumes
     CURLA_REQUIRE(((size_t)Hs * Ws * C) % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0);
@@ -710,15 +727,25 @@ static int conv1_common_check(const void* src, int src_is_u8, int B, int C, int 
   return CURLA_OK;
 }
 
-#define CURLA_DISPATCH_C(C, SRCU8, KERNEL, ...)                                   \
-  do {                                                                            \
-    if ((C) == 9) {                                                               \
-      if (SRCU8) { KERNEL(SRC_U8, 9, __VA_ARGS__); } else { KERNEL(SRC_F32, 9, __VA_ARGS__); } \
-    } else if ((C) == 12) {                                                       \
-      if (SRCU8) { KERNEL(SRC_U8, 12, __VA_ARGS__); } else { KERNEL(SRC_F32, 12, __VA_ARGS__); } \
-    } else {                                                                      \
-      if (SRCU8) { KERNEL(SRC_U8, 3, __VA_ARGS__); } else { KERNEL(SRC_F32, 3, __VA_ARGS__); } \
-    }                                                                             \
+#define CURLA_DISPATCH_SRC(CC, KIND, KERNEL, ...)                  \
+  do {                                                             \
+    if ((KIND) == 1) {                                             \
+      KERNEL(SRC_U8, CC, __VA_ARGS__);                             \
+    } else if ((KIND) == 2) {                                      \
+      KERNEL(SRC_NHWC, CC, __VA_ARGS__);                           \
+    } else {                                                       \
+      KERNEL(SRC_F32, CC, __VA_ARGS__);                            \
+    }                                                              \
+  } while (0)
+#define CURLA_DISPATCH_C(C, KIND, KERNEL, ...)                     \
+  do {                                                             \
+    if ((C) == 9) {                                                \
+      CURLA_DISPATCH_SRC(9, KIND, KERNEL, __VA_ARGS__);            \
+    } else if ((C) == 12) {                                        \
+      CURLA_DISPATCH_SRC(12, KIND, KERNEL, __VA_ARGS__);           \
+    } else {                                                       \
+      CURLA_DISPATCH_SRC(3, KIND, KERNEL, __VA_ARGS__);            \
+    }                                                              \
   } while (0)
 
 #define CONV1_FWD_LAUNCH(SRC, CC, grid, lds, st, a)                                       \
@@ -727,12 +754,12 @@ static int conv1_common_check(const void* src, int src_is_u8, int B, int C, int 
     if (rc == CURLA_OK) hipLaunchKernelGGL((conv1_fwd_kernel<SRC, CC>), dim3(grid), dim3(512), lds, st, a); \
   }
 
-int curla_conv1_fwd(const void* src, int src_is_u8, const int64_t* idx, const int32_t* h1, const int32_t* w1,
+int curla_conv1_fwd(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1,
                     const float* w, const float* bias, float* out, int B, int C, int Hs, int Ws, int Hc, int Wc,
                     int channels, float scale, void* stream) {
   CURLA_REQUIRE(w && bias && out);
   if (channels != 32) return CURLA_ERR_UNSUPPORTED;
-  int rc = conv1_common_check(src, src_is_u8, B, C, Hs, Ws, Hc, Wc, h1, w1);
+  int rc = conv1_common_check(src, src_kind, B, C, Hs, Ws, Hc, Wc, h1, w1);
   if (rc != CURLA_OK) return rc;
   Conv1Args a;
   a.src = src, a.idx = idx, a.h1 = h1, a.w1 = w1, a.w = w, a.bias = bias, a.out = out;
@@ -748,7 +775,7 @@ int curla_conv1_fwd(const void* src, int src_is_u8, const int64_t* idx, const in
   if (lds < wl) lds = wl;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int grid = B * a.nbands;
-  CURLA_DISPATCH_C(C, src_is_u8, CONV1_FWD_LAUNCH, grid, lds, st, a);
+  CURLA_DISPATCH_C(C, src_kind, CONV1_FWD_LAUNCH, grid, lds, st, a);
   if (rc != CURLA_OK) return rc;
   return curla_launch_status();
 }
@@ -789,12 +816,12 @@ int curla_conv3x3_s1_wgrad(const float* in, const float* g, float* dw, float* db
     if (rc == CURLA_OK) hipLaunchKernelGGL((wgrad1_kernel<SRC, CC>), dim3(grid), dim3(512), lds, st, a); \
   }
 
-int curla_conv1_wgrad(const void* src, int src_is_u8, const int64_t* idx, const int32_t* h1, const int32_t* w1,
+int curla_conv1_wgrad(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1,
                       const float* g, float* dw, float* db, float* workspace, int B, int C, int Hs, int Ws, int Hc,
                       int Wc, int channels, float scale, void* stream) {
   CURLA_REQUIRE(g && dw && db && workspace);
   if (channels != 32) return CURLA_ERR_UNSUPPORTED;
-  int rc = conv1_common_check(src, src_is_u8, B, C, Hs, Ws, Hc, Wc, h1, w1);
+  int rc = conv1_common_check(src, src_kind, B, C, Hs, Ws, Hc, Wc, h1, w1);
   if (rc != CURLA_OK) return rc;
   CURLA_REQUIRE(aligned16(g));
   Wgrad1Args a;
@@ -811,7 +838,7 @@ int curla_conv1_wgrad(const void* src, int src_is_u8, const int64_t* idx, const 
   const int nitems = B * a.nbands;
   const int grid = nitems < curla_cu_count() ? nitems : curla_cu_count();
   hipStream_t st = static_cast<hipStream_t>(stream);
-  CURLA_DISPATCH_C(C, src_is_u8, WGRAD1_LAUNCH, grid, lds, st, a);
+  CURLA_DISPATCH_C(C, src_kind, WGRAD1_LAUNCH, grid, lds, st, a);
   if (rc != CURLA_OK) return rc;
   if ((rc = curla_launch_status()) != CURLA_OK) return rc;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nw + 32 + 31) / 32), dim3(256), 0, st, workspace, grid, nw, dw, db);

@@ -20,9 +20,10 @@ def _dev(t, dtype=F32):
 
 
 class ObsRef:
-    """Where a minibatch's pixels live: either the uint8 NHWC replay ring plus
-    per-sample frame indices and crop offsets (fused gather+crop, the fast path)
-    or a float NCHW tensor in [0,255] (the reference's tensor contract)."""
+    """Where a minibatch's pixels live: the uint8 NHWC replay ring plus per-sample
+    frame indices and crop offsets (is_u8 = 1: fused gather+crop, the fast path),
+    a float NCHW tensor in [0,255] (is_u8 = 0: the reference's tensor contract) or
+    a float NHWC tensor (is_u8 = 2: output of the float augmentations)."""
 
     __slots__ = ("src", "is_u8", "idx", "h1", "w1", "B", "C", "Hs", "Ws", "Hc", "Wc")
 
@@ -33,6 +34,16 @@ class ObsRef:
         o.src, o.is_u8, o.idx, o.h1, o.w1, o.B = frames, 1, idx, h1, w1, B
         _, o.Hs, o.Ws, o.C = frames.shape
         o.Hc, o.Wc = crop_hw
+        return o
+
+    @staticmethod
+    def from_nhwc(x):
+        """float32 NHWC minibatch [B, H, W, C] in [0,255] (augmented observations)."""
+        o = ObsRef()
+        _dev(x)
+        o.src, o.is_u8, o.idx, o.h1, o.w1 = x, 2, None, None, None
+        o.B, o.Hc, o.Wc, o.C = x.shape
+        o.Hs, o.Ws = o.Hc, o.Wc
         return o
 
     @staticmethod
@@ -171,3 +182,19 @@ def store_frame(chw_u8, frames, slot):
 def nhwc_to_nchw(x, out):
     B, H, W, C = x.shape
     call("curla_nhwc_to_nchw", ptr(x), ptr(out), B, H, W, C, stream())
+
+
+def color_jiggle(frames, idx, params, order, B, out):
+    _, H, W, C = frames.shape
+    call("curla_color_jiggle", ptr(frames), ptr(idx), ptr(params), ptr(order), B, C, H, W, ptr(out), stream())
+
+
+def noisy_cover(frames, idx, noise, colors, top, bottom, B, out):
+    _, H, W, C = frames.shape
+    call("curla_noisy_cover", ptr(frames), ptr(idx), ptr(noise), float(colors[0]), float(colors[1]), float(colors[2]),
+         int(top), int(bottom), B, C, H, W, ptr(out), stream())
+
+
+def gather_nhwc(frames, idx, B, out):
+    _, H, W, C = frames.shape
+    call("curla_gather_nhwc", ptr(frames), ptr(idx), B, C, H, W, ptr(out), stream())

@@ -173,9 +173,31 @@ class ReplayBuffer(object):
             for j in range(3):
                 h1, w1 = self.augmentor.draw_offsets(B)
                 offs[2 * j], offs[2 * j + 1] = h1, w1
-        elif type(self.augmentor) is not augmentations.IdentityAugmentation:
-            raise NotImplementedError("only identity / random_crop augmentations are built")
+        elif not isinstance(self.augmentor, (augmentations.ColorJiggle, augmentations.NoisyCover)) and \
+                type(self.augmentor) is not augmentations.IdentityAugmentation:
+            raise NotImplementedError("unknown augmentation object: %r" % (self.augmentor,))
         return idxs, offs
+
+    def _float_augmented(self, ring):
+        """One augmented float NHWC minibatch [B, H, W, C] from ``ring`` at the uploaded indices
+        (utils.py:168-182 branch: the torch/kornia augmentations)."""
+        B = self.batch_size
+        c, h, w = self.obs_shape
+        out = torch.empty((B, h, w, c), dtype=torch.float32, device=self.device)
+        aug = self.augmentor
+        if isinstance(aug, augmentations.ColorJiggle):
+            params, order = aug.draw_params(B * (c // 3))
+            ops.color_jiggle(ring, self._d_idx, params.to(self.device), order.to(self.device), B, out)
+        elif isinstance(aug, augmentations.NoisyCover):
+            colors = aug.draw_colors()
+            noise = torch.randn((B, h, w, c), device=self.device) * aug.std
+            ops.noisy_cover(ring, self._d_idx, noise, colors, aug.top, aug.bottom, B, out)
+        else:
+            ops.gather_nhwc(ring, self._d_idx, B, out)
+        return out
+
+    def _is_float_aug(self):
+        return isinstance(self.augmentor, (augmentations.ColorJiggle, augmentations.NoisyCover))
 
     def _upload_indices(self, idxs, offs):
         B = self.batch_size
@@ -211,9 +233,15 @@ class ReplayBuffer(object):
         B = self.batch_size
         crop = tuple(self.augmentor.output_shape)
         off = self._d_off
-        obses = ops.ObsRef.from_ring(self.obses, self._d_idx, off[0], off[1], B, crop)
-        next_obses = ops.ObsRef.from_ring(self.next_obses, self._d_idx, off[2], off[3], B, crop)
-        pos = ops.ObsRef.from_ring(self.obses, self._d_idx, off[4], off[5], B, crop)
+        if self._is_float_aug():
+            # obs, next_obs and pos (= a copy of obs) are augmented independently (utils.py:173-182)
+            obses = ops.ObsRef.from_nhwc(self._float_augmented(self.obses))
+            next_obses = ops.ObsRef.from_nhwc(self._float_augmented(self.next_obses))
+            pos = ops.ObsRef.from_nhwc(self._float_augmented(self.obses))
+        else:
+            obses = ops.ObsRef.from_ring(self.obses, self._d_idx, off[0], off[1], B, crop)
+            next_obses = ops.ObsRef.from_ring(self.next_obses, self._d_idx, off[2], off[3], B, crop)
+            pos = ops.ObsRef.from_ring(self.obses, self._d_idx, off[4], off[5], B, crop)
         actions, rewards, not_dones = self._scalars()
         cpc_kwargs = dict(obs_anchor=obses, obs_pos=pos, time_anchor=None, time_pos=None)
         return obses, actions, rewards, next_obses, not_dones, cpc_kwargs
@@ -231,7 +259,10 @@ class ReplayBuffer(object):
         outs = []
         for ring, j in ((self.obses, 0), (self.next_obses, 1), (self.obses, 2)):
             t = torch.empty((B, c, oh, ow), dtype=torch.float32, device=self.device)
-            ops.crop_nchw(ring, self._d_idx, off[2 * j], off[2 * j + 1], B, (oh, ow), out_f32=t)
+            if self._is_float_aug():
+                ops.nhwc_to_nchw(self._float_augmented(ring), t)
+            else:
+                ops.crop_nchw(ring, self._d_idx, off[2 * j], off[2 * j + 1], B, (oh, ow), out_f32=t)
             outs.append(t)
         obses, next_obses, pos = outs
         actions, rewards, not_dones = self._scalars()

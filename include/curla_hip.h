@@ -37,13 +37,15 @@ const char* curla_version(void);
 /* ---- encoder convolutions (encoder.py:54-63 construction, :77-90 forward) ---- */
 
 /* First layer: 3x3 stride 2, C -> 32, + bias + ReLU, with the minibatch assembly
- * fused into the load.  src_is_u8 = 1: `src` is the uint8 replay ring
+ * fused into the load.  src_kind = 1: `src` is the uint8 replay ring
  * [N][Hs][Ws][C]; sample b reads frame idx[b] (NULL: b) cropped at
  * (h1[b], w1[b]) (NULL: 0) to Hc x Wc -- replaces utils.py:151-166 (gather,
  * RandomCrop.training_augmentation augmentations.py:47-75, .float()) and
- * encoder.py:78 (`obs / 255.`, pass scale = 1/255).  src_is_u8 = 0: `src` is the
- * reference's float NCHW tensor [B][C][Hc][Wc] in [0,255].  C in {3, 9, 12}. */
-int curla_conv1_fwd(const void* src, int src_is_u8, const int64_t* idx, const int32_t* h1, const int32_t* w1,
+ * encoder.py:78 (`obs / 255.`, pass scale = 1/255).  src_kind = 0: `src` is the
+ * reference's float NCHW tensor [B][C][Hc][Wc] in [0,255]; src_kind = 2: a float
+ * NHWC tensor [B][Hc][Wc][C] in [0,255] (what curla_color_jiggle / curla_noisy_cover
+ * write).  C in {3, 9, 12}. */
+int curla_conv1_fwd(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1,
                     const float* w, const float* bias, float* out, int B, int C, int Hs, int Ws, int Hc, int Wc,
                     int channels, float scale, void* stream);
 
@@ -59,7 +61,7 @@ int curla_conv3x3_s1_dgrad(const float* g, const float* w, const float* act_belo
                            int channels, void* stream);
 int curla_conv3x3_s1_wgrad(const float* in, const float* g, float* dw, float* db, float* workspace, int B, int Hi,
                            int Wi, int channels, void* stream);
-int curla_conv1_wgrad(const void* src, int src_is_u8, const int64_t* idx, const int32_t* h1, const int32_t* w1,
+int curla_conv1_wgrad(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1,
                       const float* g, float* dw, float* db, float* workspace, int B, int C, int Hs, int Ws, int Hc,
                       int Wc, int channels, float scale, void* stream);
 /* floats of `workspace` the two wgrad entry points need (per-workgroup partial slabs) */
@@ -124,6 +126,18 @@ int curla_mean(const float* x, int n, float* out, void* stream);
 
 /* target <- tau*param + (1-tau)*target over a flat parameter block (utils.py:37-41) */
 int curla_soft_update(const float* param, float* target, size_t n, float tau, float one_minus_tau, void* stream);
+
+/* ---- augmentations that produce float observations (augmentations.py:78-205; kornia arithmetic is not
+ * vendored by the reference: PARITY UNPINNED, the algorithm is this build's statement of kornia's documented
+ * behaviour, see oracle/curla_oracle.py color_jiggle / noisy_cover).  Output: float NHWC [B][H][W][C] in [0,255].
+ * color_jiggle: params[B*C/3][4] = (apply, contrast, saturation, hue_radians) per RGB frame, order[4] = permutation
+ * of {0 brightness (identity), 1 contrast, 2 saturation, 3 hue}.  noisy_cover: rows [0,top) and [H-bottom,H) painted
+ * with (c0,c1,c2) per RGB channel, + noise (float NHWC), clamped to [0,255].  gather_nhwc: identity (u8 -> float). */
+int curla_color_jiggle(const uint8_t* frames, const int64_t* idx, const float* params, const int32_t* order, int B,
+                       int C, int H, int W, float* out, void* stream);
+int curla_noisy_cover(const uint8_t* frames, const int64_t* idx, const float* noise, float c0, float c1, float c2,
+                      int top, int bottom, int B, int C, int H, int W, float* out, void* stream);
+int curla_gather_nhwc(const uint8_t* frames, const int64_t* idx, int B, int C, int H, int W, float* out, void* stream);
 
 /* ---- replay ring helpers ---- */
 /* float/uint8 NCHW crops exactly as sample_cpc returns them (utils.py:151-166) */

@@ -89,6 +89,81 @@ def center_crop(img: np.ndarray, out_hw: Tuple[int, int]) -> np.ndarray:
 
 
 # --------------------------------------------------------------------------
+# float augmentations
+# --------------------------------------------------------------------------
+def noisy_cover(imgs: torch.Tensor, colors, noise: torch.Tensor, top_ratio=0.31, bottom_ratio=0.20) -> torch.Tensor:
+    """NoisyCover.training_augmentation (augmentations.py:138-205) with the noise
+    tensor explicit: rows [0, ceil(.31 h)) and [h - ceil(.20 h), h) of every RGB
+    frame get colors[c % 3]; + noise; clamp to [0, 255].  imgs: float [B, C, H, W].
+    The cover logic is the reference's own code (pinned by noisy_cover.npz); the
+    noise distribution is kornia's RandomGaussianNoise(std=10) there."""
+    h = imgs.shape[2]
+    top, bottom = int(np.ceil(h * top_ratio)), int(np.ceil(h * bottom_ratio))
+    out = imgs.clone().float()
+    rows = list(range(0, top)) + list(range(h - bottom, h))
+    for c in range(out.shape[1]):
+        out[:, c, rows, :] = float(colors[c % 3])
+    return torch.clamp(out + noise, 0, 255)
+
+
+def _rgb_to_hsv(img: torch.Tensor):
+    """kornia-style RGB->HSV on [..., 3, H, W] in [0,1]: h in [0, 2pi)."""
+    r, g, b = img[..., 0, :, :], img[..., 1, :, :], img[..., 2, :, :]
+    mx, arg = img.max(-3)
+    mn = img.min(-3)[0]
+    v = mx
+    d = mx - mn
+    s = d / (mx + 1e-8)
+    d = torch.where(d == 0, torch.ones_like(d), d)
+    rc, gc, bc = mx - r, mx - g, mx - b
+    h = torch.stack([bc - gc, (rc - bc) + 2.0 * d, (gc - rc) + 4.0 * d], -3)
+    h = torch.gather(h, -3, arg.unsqueeze(-3)).squeeze(-3) / d
+    h = (h / 6.0) % 1.0
+    return 2.0 * math.pi * h, s, v
+
+
+def _hsv_to_rgb(h, s, v):
+    h6 = h / (2.0 * math.pi) * 6.0
+    hi = torch.floor(h6) % 6
+    f = (h6 % 6) - hi
+    p, q, t = v * (1 - s), v * (1 - f * s), v * (1 - (1 - f) * s)
+    hi = hi.long()
+    sel = lambda a0, a1, a2, a3, a4, a5: torch.stack([a0, a1, a2, a3, a4, a5], 0).gather(0, hi.unsqueeze(0)).squeeze(0)  # noqa: E731
+    return torch.stack([sel(v, q, p, p, t, v), sel(t, v, v, q, p, p), sel(p, p, t, v, v, q)], -3)
+
+
+def color_jiggle(imgs_u8: np.ndarray, params: torch.Tensor, order) -> torch.Tensor:
+    """ColorJiggle.training_augmentation (augmentations.py:78-136) -- PARITY UNPINNED:
+    the reference calls kornia.augmentation.ColorJiggle(brightness 0, contrast .2,
+    saturation .5, hue .5, p .85), whose source is not part of the reference and whose
+    version is not pinned.  This restates kornia's documented behaviour: each RGB
+    frame of the stack is one image; with probability p the four operations run in
+    the (per call) random ``order``: 0 brightness (additive, factor 0 -> identity),
+    1 contrast (x*c, clamp [0,1]), 2 saturation (HSV, s*f clamp [0,1]), 3 hue (HSV,
+    h + d mod 2pi).  params [B*k, 4] = (apply, contrast, saturation, hue_rad).
+    imgs_u8 [B, C, H, W] -> float [B, C, H, W] in [0, 255]."""
+    x = torch.from_numpy(np.ascontiguousarray(imgs_u8)).float() / 255.0
+    B, C, H, W = x.shape
+    x = x.reshape(B * (C // 3), 3, H, W)
+    out = x.clone()
+    for i in range(x.shape[0]):
+        if params[i, 0] == 0:
+            continue
+        im = x[i]
+        for op in [int(o) for o in order]:
+            if op == 1:
+                im = torch.clamp(im * params[i, 1], 0, 1)
+            elif op == 2:
+                h, s_, v = _rgb_to_hsv(im)
+                im = _hsv_to_rgb(h, torch.clamp(s_ * params[i, 2], 0, 1), v)
+            elif op == 3:
+                h, s_, v = _rgb_to_hsv(im)
+                im = _hsv_to_rgb(torch.fmod(torch.fmod(h + params[i, 3], 2 * math.pi) + 2 * math.pi, 2 * math.pi), s_, v)
+        out[i] = im
+    return (out * 255.0).reshape(B, C, H, W)
+
+
+# --------------------------------------------------------------------------
 # networks (PyTorch CPU fp32)
 # --------------------------------------------------------------------------
 def encoder_forward(p: Params, prefix: str, obs: torch.Tensor, num_layers: int,

@@ -406,7 +406,26 @@ def gen_c1shape():
     np.savez_compressed(os.path.join(HERE, "c1shape.npz"), **out)
 
 
+def gen_noisy_cover():
+    """NoisyCover.training_augmentation: the cover rows / colours / clamp are the reference's own code;
+    kornia's RandomGaussianNoise (absent) is replaced by a recorded additive-noise stand-in, so this
+    pins everything except the noise distribution."""
+    aug = augmentations.NoisyCover((34, 40))
+    rs = np.random.RandomState(21)
+    imgs = rs.randint(0, 256, (5, 9, 34, 40), dtype=np.uint8)
+    noise = torch.from_numpy(rs.randn(5, 9, 34, 40).astype(np.float32) * 10.0)
+    aug.aug = lambda x: x + noise.reshape(x.shape)
+    np.random.seed(77)
+    out = aug.training_augmentation(torch.from_numpy(imgs).float())
+    np.random.seed(77)
+    colors = np.array([np.random.randint(0, 255) for _ in range(3)])
+    np.savez_compressed(os.path.join(HERE, "noisy_cover.npz"), imgs_seed=np.int64(21), numpy_seed=np.int64(77),
+                        colors=colors, top=np.int64(aug.top), bottom=np.int64(aug.bottom),
+                        out=out.numpy().astype(np.float16), out_sum=np.float64(out.double().sum().item()))
+
+
 if __name__ == "__main__":
+    gen_noisy_cover()
     gen_tiny()
     gen_crop84()
     gen_c1shape()
