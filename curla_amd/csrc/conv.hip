@@ -61,9 +61,18 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
   // wave pairs (2p, 2p+1) share pixel tiles.  k-step (q,e) of tap t covers
   // cin = 16q + 4kq' + e over the four lane groups kq'.
   const int mt = wave & 1, tslot = wave >> 1;
-  for (int i = tid; i < 32 * 288; i += 256) {
-    int r = i / 288;
-    lds[r * kWStride + (i - r * 288)] = a.w[i];
+  {
+    // 9216 weights = 2304 float4, 9 per thread, all in flight at once (OIHW rows are 288 floats = 72 float4)
+    f32x4 wv[9];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) wv[u] = reinterpret_cast<const f32x4*>(a.w)[tid + u * 256];
+#pragma unroll
+    for (int u = 0; u < 9; ++u) {
+      const int i4 = tid + u * 256;
+      const int r = i4 / 72, c = (i4 - r * 72) * 4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) lds[r * kWStride + c + e] = wv[u][e];
+    }
   }
   __syncthreads();
   float wr[9][8];
@@ -572,24 +581,24 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(Wgrad1Args a) {
   for (int i = tid; i < nw + 32; i += 512) slab[i] = lds[i];
 }
 
-// second pass: dW = sum over workgroup slabs.  32 elements x 8 slab-groups per
-// block; each group adds its slabs in slab order, the 8 group sums are added in
+// second pass: dW = sum over workgroup slabs.  32 elements x 32 slab-groups per
+// block; each group adds its slabs in slab order, the 32 group sums are added in
 // group order (fixed order => bitwise reproducible).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* partial, int nslabs, int nw, float* dw,
-                                                           float* db) {
-  __shared__ float sm[8][32];
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* partial, int nslabs, int nw, float* dw,
+                                                            float* db) {
+  __shared__ float sm[32][33];
   const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + c;
   const int n = nw + 32;
   float s = 0.f;
   if (i < n)
-    for (int k = part; k < nslabs; k += 8) s += partial[(size_t)k * n + i];
+    for (int k = part; k < nslabs; k += 32) s += partial[(size_t)k * n + i];
   sm[part][c] = s;
   __syncthreads();
   if (part == 0 && i < n) {
     float t = sm[0][c];
 #pragma unroll
-    for (int k = 1; k < 8; ++k) t += sm[k][c];
+    for (int k = 1; k < 32; ++k) t += sm[k][c];
     if (i < nw)
       dw[i] = t;
     else
@@ -702,7 +711,7 @@ int curla_conv3x3_s1_fwd(const float* in, const float* w, const float* bias, flo
                          int channels, void* stream) {
   CURLA_REQUIRE(in && w && bias && out && B > 0 && Hi >= 3 && Wi >= 3);
   if (channels != 32) return CURLA_ERR_UNSUPPORTED;
-  CURLA_REQUIRE(aligned16(in) && aligned16(out) && aligned16(bias));
+  CURLA_REQUIRE(aligned16(in) && aligned16(out) && aligned16(bias) && aligned16(w));
   return launch_conv_s1(MODE_FWD, in, w, bias, out, B, Hi, Wi, static_cast<hipStream_t>(stream));
 }
 
@@ -710,7 +719,7 @@ int curla_conv3x3_s1_dgrad(const float* g, const float* w, const float* act_belo
                            int channels, void* stream) {
   CURLA_REQUIRE(g && w && act_below && gin && B > 0 && Ho >= 1 && Wo >= 1);
   if (channels != 32) return CURLA_ERR_UNSUPPORTED;
-  CURLA_REQUIRE(aligned16(g) && aligned16(gin) && aligned16(act_below));
+  CURLA_REQUIRE(aligned16(g) && aligned16(gin) && aligned16(act_below) && aligned16(w));
   return launch_conv_s1(MODE_DGRAD, g, w, act_below, gin, B, Ho, Wo, static_cast<hipStream_t>(stream));
 }
 
@@ -805,7 +814,7 @@ int curla_conv3x3_s1_wgrad(const float* in, const float* g, float* dw, float* db
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(wgrad_s1_kernel, dim3(grid), dim3(256), lds, st, a);
   if ((rc = curla_launch_status()) != CURLA_OK) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kPartialS1 + 31) / 32), dim3(256), 0, st, workspace, grid, 32 * 288,
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kPartialS1 + 31) / 32), dim3(1024), 0, st, workspace, grid, 32 * 288,
                      dw, db);
   return curla_launch_status();
 }
@@ -841,7 +850,7 @@ int curla_conv1_wgrad(const void* src, int src_kind, const int64_t* idx, const i
   CURLA_DISPATCH_C(C, src_kind, WGRAD1_LAUNCH, grid, lds, st, a);
   if (rc != CURLA_OK) return rc;
   if ((rc = curla_launch_status()) != CURLA_OK) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nw + 32 + 31) / 32), dim3(256), 0, st, workspace, grid, nw, dw, db);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nw + 32 + 31) / 32), dim3(1024), 0, st, workspace, grid, nw, dw, db);
   return curla_launch_status();
 }
 
