@@ -337,6 +337,107 @@ __global__ __launch_bounds__(512) void conv1_fwd_kernel(Conv1Args a) {
 }
 
 // ---------------------------------------------------------------------------
+// first layer, uint8 ring source, bytes kept as bytes in LDS (4x less LDS than the float band: a whole
+// 76x76x9 crop is 52 KB, so a workgroup takes one sample with no halo re-reads and two workgroups share a
+// CU).  Staging is a pure byte copy: 16-byte runs of the (arbitrarily aligned) crop row are rebuilt from
+// aligned dword loads with v_alignbyte; u8 -> f32 and the /255 happen when the MFMA B operand is read.
+// k = 4s + kq of the GEMM is (dy, rr) = (s / (KR/4), 4 (s % (KR/4)) + kq): since KR is a multiple of 4 the
+// tap row dy is wave-uniform per k-step and the byte offset inside the row differs per lane only by kq.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int conv1_row_bytes(int Wc, int C) { return ((Wc * C + 15) & ~15) + 16; }
+
+__device__ __forceinline__ void conv1_stage_u8(uint8_t* lds, const uint8_t* frames, const int64_t* idx,
+                                               const int32_t* h1, const int32_t* w1, int b, int C, int Hs, int Ws,
+                                               int Wc, int r0, int rows, int RSb, int tid, int nthreads) {
+  const int64_t fi = idx ? idx[b] : b;
+  const int oh = h1 ? h1[b] : 0, ow = w1 ? w1[b] : 0;
+  const uint8_t* frame = frames + (size_t)fi * Hs * Ws * C;
+  const int runs = (Wc * C + 15) >> 4;  // 16-byte runs per row
+  for (int i = tid; i < rows * runs; i += nthreads) {
+    const int r = i / runs, g = i - r * runs;
+    const uint8_t* p = frame + ((size_t)(oh + r0 + r) * Ws + ow) * C + 16 * g;
+    const uintptr_t ad = reinterpret_cast<uintptr_t>(p);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(ad & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(ad & 3);
+    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
+    const uint32_t d4 = sh ? q[4] : 0u;  // only touch the fifth dword when the run straddles it
+    uint4 o;
+    o.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
+    o.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    o.z = __builtin_amdgcn_alignbyte(d3, d2, sh);
+    o.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
+    *reinterpret_cast<uint4*>(lds + r * RSb + 16 * g) = o;
+  }
+}
+
+template <int C>
+__global__ __launch_bounds__(512) void conv1_fwd_u8_kernel(Conv1Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int KR = (3 * C + 3) & ~3;
+  constexpr int KQ = KR / 4;      // k-steps per tap row
+  constexpr int NS = 3 * KQ;      // k-steps
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int RSb = conv1_row_bytes(a.Wc, C);
+
+  for (int i = tid; i < 32 * C * 9; i += 512) lds[i] = a.w[i];
+  __syncthreads();
+  float wr[NS][2];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const int dy = s / KQ, rr = 4 * (s - dy * KQ) + kq;
+    const bool ok = rr < 3 * C;
+    const int dx = ok ? rr / C : 0, c = ok ? rr - dx * C : 0;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) wr[s][mt] = ok ? lds[((mt * 16 + li) * C + c) * 9 + dy * 3 + dx] : 0.f;
+  }
+  f32x4 bias4[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) bias4[mt] = *reinterpret_cast<const f32x4*>(a.bias + mt * 16 + 4 * kq);
+  __syncthreads();
+
+  const int item = blockIdx.x;
+  const int band = item / a.B, b = item - band * a.B;
+  const int y0 = band * a.th;
+  const int tha = min(a.th, a.Ho - y0);
+  uint8_t* ldsb = reinterpret_cast<uint8_t*>(lds);
+  conv1_stage_u8(ldsb, static_cast<const uint8_t*>(a.src), a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Wc, 2 * y0,
+                 2 * tha + 1, RSb, tid, 512);
+  __syncthreads();
+
+  const int npix = tha * a.Wo;
+  const int ntiles = (npix + 15) >> 4;
+  int ty = (wave * 16 + li) / a.Wo, x = (wave * 16 + li) - ty * a.Wo;
+  for (int t = wave; t < ntiles; t += 8) {
+    const bool pv = t * 16 + li < npix;
+    if (!pv) ty = 0, x = 0;
+    const uint8_t* base = ldsb + 2 * ty * RSb + 2 * x * C + kq;
+    float bv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) bv[s] = (float)base[(s / KQ) * RSb + 4 * (s % KQ)];
+    f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const float v = bv[s] * a.scale;
+      acc[0] = mfma16(wr[s][0], v, acc[0]);
+      acc[1] = mfma16(wr[s][1], v, acc[1]);
+    }
+    if (pv) {
+      const size_t g = ((size_t)(b * a.Ho + y0 + ty) * a.Wo + x) * 32 + 4 * kq;
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        f32x4 v = acc[mt] + bias4[mt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        *reinterpret_cast<f32x4*>(a.out + g + mt * 16) = v;
+      }
+    }
+    x += 128;
+    while (x >= a.Wo) x -= a.Wo, ++ty;
+  }
+}
+
+// ---------------------------------------------------------------------------
 // weight gradient, stride-1 32->32:  dW[co][ci][tap] = sum_pixels g[p][co] * in[p+tap][ci]
 // GEMM view: D[co][ci] per tap, K = pixels (4 per MFMA).  36 accumulator tiles
 // (2 x 2 x 9) live in registers for the whole persistent workgroup; partial
@@ -581,6 +682,109 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(Wgrad1Args a) {
   for (int i = tid; i < nw + 32; i += 512) slab[i] = lds[i];
 }
 
+// first-layer weight gradient from the uint8 ring with the input band kept as bytes in LDS (see
+// conv1_fwd_u8_kernel); the gradient band stays float (pixel stride kLdsPix).
+template <int C>
+__global__ __launch_bounds__(512) void wgrad1_u8_kernel(Wgrad1Args a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int KR = (3 * C + 3) & ~3;
+  constexpr int NT = (3 * KR + 15) / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int RSb = conv1_row_bytes(a.Wc, C);
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
+  float bsum[2] = {0.f, 0.f};
+  int koff[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int k = t * 16 + li;
+    const int dy = k / KR, rr = k - dy * KR;
+    koff[t] = (dy < 3) ? dy * RSb + rr : 0;
+  }
+  const int nitems = a.B * a.nbands;
+  const int in_bytes = ((2 * a.th + 1) * RSb + 15) & ~15;  // LDS byte offset of the gradient band
+  uint8_t* ldsb = reinterpret_cast<uint8_t*>(lds);
+  float* ldsg = reinterpret_cast<float*>(ldsb + in_bytes);
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int band = item / a.B, b = item - band * a.B;
+    const int y0 = band * a.th;
+    const int tha = min(a.th, a.Ho - y0);
+    conv1_stage_u8(ldsb, static_cast<const uint8_t*>(a.src), a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Wc, 2 * y0,
+                   2 * tha + 1, RSb, tid, 512);
+    {
+      const float* pg = a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
+      const int ng = tha * a.Wo * 8;
+      for (int f = tid; f < ng; f += 512)
+        *reinterpret_cast<f32x4*>(ldsg + (f >> 3) * kLdsPix + (f & 7) * 4) =
+            *reinterpret_cast<const f32x4*>(pg + (size_t)f * 4);
+    }
+    __syncthreads();
+    const int npix = tha * a.Wo;
+    const int nunits = ((npix + 15) >> 4) << 2;
+    for (int u = wave; u < nunits; u += 8) {
+      const int p = (u >> 2) * 16 + (u & 3) + 4 * kq;
+      const bool pv = p < npix;
+      const int pc = pv ? p : 0;
+      const int ty = pc / a.Wo, x = pc - ty * a.Wo;
+      const float* gp = ldsg + (ty * a.Wo + x) * kLdsPix + li;
+      const float a0 = pv ? gp[0] : 0.f, a1 = pv ? gp[16] : 0.f;
+      bsum[0] += a0;
+      bsum[1] += a1;
+      const uint8_t* ip = ldsb + 2 * ty * RSb + 2 * x * C;
+      float bv[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[t] = (float)ip[koff[t]];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float v = bv[t] * a.scale;
+        acc[0][t] = mfma16(a0, v, acc[0][t]);
+        acc[1][t] = mfma16(a1, v, acc[1][t]);
+      }
+    }
+    __syncthreads();
+  }
+
+  bsum[0] += __shfl_xor(bsum[0], 16);
+  bsum[0] += __shfl_xor(bsum[0], 32);
+  bsum[1] += __shfl_xor(bsum[1], 16);
+  bsum[1] += __shfl_xor(bsum[1], 32);
+  const int nw = 32 * C * 9;
+  for (int w = 0; w < 8; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const int k = t * 16 + li;
+          const int dy = k / KR, rr = k - dy * KR;
+          if (dy < 3 && rr < 3 * C) {
+            const int dx = rr / C, c = rr - dx * C;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int co = mt * 16 + 4 * kq + r;
+              float* d = lds + (co * C + c) * 9 + dy * 3 + dx;
+              *d = (w == 0) ? acc[mt][t][r] : *d + acc[mt][t][r];
+            }
+          }
+        }
+      if (kq == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          float* d = lds + nw + mt * 16 + li;
+          *d = (w == 0) ? bsum[mt] : *d + bsum[mt];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* slab = a.partial + (size_t)blockIdx.x * (nw + 32);
+  for (int i = tid; i < nw + 32; i += 512) slab[i] = lds[i];
+}
+
 // second pass: dW = sum over workgroup slabs.  32 elements x 32 slab-groups per
 // block; each group adds its slabs in slab order, the 32 group sums are added in
 // group order (fixed order => bitwise reproducible).
@@ -775,14 +979,34 @@ int curla_conv1_fwd(const void* src, int src_kind, const int64_t* idx, const int
   a.B = B, a.C = C, a.Hs = Hs, a.Ws = Ws, a.Hc = Hc, a.Wc = Wc;
   a.Ho = (Hc - 3) / 2 + 1, a.Wo = (Wc - 3) / 2 + 1;
   a.scale = scale;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const size_t wl = (size_t)32 * C * 9 * sizeof(float);
+  if (src_kind == 1) {
+    // uint8 ring: the band stays bytes in LDS; the tallest band that leaves room for two workgroups per CU
+    const int RSb = ((Wc * C + 15) & ~15) + 16;
+    int th = a.Ho;
+    while (th > 1 && (size_t)(2 * th + 1) * RSb > 76 * 1024) --th;
+    a.nbands = (a.Ho + th - 1) / th;
+    a.th = (a.Ho + a.nbands - 1) / a.nbands;  // near-equal bands
+    size_t lds = (size_t)(2 * a.th + 1) * RSb + 32;
+    if (lds < wl) lds = wl;
+    const int grid = B * a.nbands;
+#define CONV1_U8_LAUNCH(CC)                                                                                 \
+  {                                                                                                         \
+    rc = set_lds(conv1_fwd_u8_kernel<CC>, lds);                                                             \
+    if (rc == CURLA_OK) hipLaunchKernelGGL((conv1_fwd_u8_kernel<CC>), dim3(grid), dim3(512), lds, st, a);   \
+  }
+    if (C == 9) CONV1_U8_LAUNCH(9) else if (C == 12) CONV1_U8_LAUNCH(12) else CONV1_U8_LAUNCH(3)
+#undef CONV1_U8_LAUNCH
+    if (rc != CURLA_OK) return rc;
+    return curla_launch_status();
+  }
   // two workgroups per CU so one stages while the other computes
   a.th = plan_band_conv1(a.Ho, a.Wo, Wc, C, 0, 76 * 1024);
   a.nbands = (a.Ho + a.th - 1) / a.th;
   const int RS = ((Wc * C + 3) & ~3) + 4;
   size_t lds = ((size_t)(2 * a.th + 1) * RS + 8) * sizeof(float);
-  const size_t wl = (size_t)32 * C * 9 * sizeof(float);
   if (lds < wl) lds = wl;
-  hipStream_t st = static_cast<hipStream_t>(stream);
   const int grid = B * a.nbands;
   CURLA_DISPATCH_C(C, src_kind, CONV1_FWD_LAUNCH, grid, lds, st, a);
   if (rc != CURLA_OK) return rc;
@@ -838,16 +1062,36 @@ int curla_conv1_wgrad(const void* src, int src_kind, const int64_t* idx, const i
   a.B = B, a.C = C, a.Hs = Hs, a.Ws = Ws, a.Hc = Hc, a.Wc = Wc;
   a.Ho = (Hc - 3) / 2 + 1, a.Wo = (Wc - 3) / 2 + 1;
   a.scale = scale;
-  a.th = plan_band_conv1(a.Ho, a.Wo, Wc, C, a.Wo, 150 * 1024);
-  a.nbands = (a.Ho + a.th - 1) / a.th;
-  const int RS = ((Wc * C + 3) & ~3) + 4;
   const int nw = 32 * C * 9;
-  size_t lds = ((size_t)(2 * a.th + 1) * RS + (size_t)a.th * a.Wo * kLdsPix + 8) * sizeof(float);
-  if (lds < (size_t)(nw + 32) * sizeof(float)) lds = (size_t)(nw + 32) * sizeof(float);
-  const int nitems = B * a.nbands;
-  const int grid = nitems < curla_cu_count() ? nitems : curla_cu_count();
   hipStream_t st = static_cast<hipStream_t>(stream);
-  CURLA_DISPATCH_C(C, src_kind, WGRAD1_LAUNCH, grid, lds, st, a);
+  int grid;
+  if (src_kind == 1) {
+    const int RSb = ((Wc * C + 15) & ~15) + 16;
+    int th = a.Ho;
+    while (th > 1 && (size_t)(2 * th + 1) * RSb + (size_t)th * a.Wo * kLdsPix * sizeof(float) > 76 * 1024) --th;
+    a.nbands = (a.Ho + th - 1) / th;
+    a.th = (a.Ho + a.nbands - 1) / a.nbands;
+    size_t lds = (((size_t)(2 * a.th + 1) * RSb + 15) & ~(size_t)15) + (size_t)a.th * a.Wo * kLdsPix * sizeof(float) + 32;
+    if (lds < (size_t)(nw + 32) * sizeof(float)) lds = (size_t)(nw + 32) * sizeof(float);
+    const int nitems = B * a.nbands;
+    grid = nitems < 2 * curla_cu_count() ? nitems : 2 * curla_cu_count();
+#define WGRAD1_U8_LAUNCH(CC)                                                                             \
+  {                                                                                                      \
+    rc = set_lds(wgrad1_u8_kernel<CC>, lds);                                                             \
+    if (rc == CURLA_OK) hipLaunchKernelGGL((wgrad1_u8_kernel<CC>), dim3(grid), dim3(512), lds, st, a);   \
+  }
+    if (C == 9) WGRAD1_U8_LAUNCH(9) else if (C == 12) WGRAD1_U8_LAUNCH(12) else WGRAD1_U8_LAUNCH(3)
+#undef WGRAD1_U8_LAUNCH
+  } else {
+    a.th = plan_band_conv1(a.Ho, a.Wo, Wc, C, a.Wo, 150 * 1024);
+    a.nbands = (a.Ho + a.th - 1) / a.th;
+    const int RS = ((Wc * C + 3) & ~3) + 4;
+    size_t lds = ((size_t)(2 * a.th + 1) * RS + (size_t)a.th * a.Wo * kLdsPix + 8) * sizeof(float);
+    if (lds < (size_t)(nw + 32) * sizeof(float)) lds = (size_t)(nw + 32) * sizeof(float);
+    const int nitems = B * a.nbands;
+    grid = nitems < curla_cu_count() ? nitems : curla_cu_count();
+    CURLA_DISPATCH_C(C, src_kind, WGRAD1_LAUNCH, grid, lds, st, a);
+  }
   if (rc != CURLA_OK) return rc;
   if ((rc = curla_launch_status()) != CURLA_OK) return rc;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nw + 32 + 31) / 32), dim3(1024), 0, st, workspace, grid, nw, dw, db);

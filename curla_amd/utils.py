@@ -79,9 +79,9 @@ class ReplayBuffer(object):
             free, _ = torch.cuda.mem_get_info(self.device)
             if total_bytes > free:
                 raise ValueError('Replay buffer size exceeds available memory')  # utils.py:112-113
-        # ring storage: NHWC uint8 frames (+16 B slack: the dword-aligning loader may touch one dword past a row)
-        self._obs_store = torch.zeros(capacity * frame + 16, dtype=torch.uint8, device=self.device)
-        self._next_store = torch.zeros(capacity * frame + 16, dtype=torch.uint8, device=self.device)
+        # ring storage: NHWC uint8 frames (+32 B slack: the aligning loader reads whole 16-byte runs plus one dword)
+        self._obs_store = torch.zeros(capacity * frame + 32, dtype=torch.uint8, device=self.device)
+        self._next_store = torch.zeros(capacity * frame + 32, dtype=torch.uint8, device=self.device)
         self.obses = self._obs_store[:capacity * frame].view(capacity, h, w, c)
         self.next_obses = self._next_store[:capacity * frame].view(capacity, h, w, c)
         self.actions = torch.empty((capacity, *action_shape), dtype=torch.float32, device=self.device)

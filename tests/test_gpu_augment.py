@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 def _ring(frames_chw):
     n, c, h, w = frames_chw.shape
-    store = torch.zeros(n * c * h * w + 16, dtype=torch.uint8, device="cuda")
+    store = torch.zeros(n * c * h * w + 32, dtype=torch.uint8, device="cuda")
     ring = store[:n * c * h * w].view(n, h, w, c)
     ring.copy_(torch.from_numpy(frames_chw).permute(0, 2, 3, 1))
     return ring

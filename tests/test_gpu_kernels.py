@@ -93,7 +93,7 @@ def test_conv_s1_wgrad(ops, B, H, W):
 
 def _ring(N, C, Hs, Ws, seed):
     frames = np.random.RandomState(seed).randint(0, 256, (N, C, Hs, Ws), dtype=np.uint8)  # CHW like the reference
-    store = torch.zeros(N * C * Hs * Ws + 16, dtype=torch.uint8, device="cuda")
+    store = torch.zeros(N * C * Hs * Ws + 32, dtype=torch.uint8, device="cuda")
     ring = store[:N * C * Hs * Ws].view(N, Hs, Ws, C)
     ring.copy_(torch.from_numpy(frames).permute(0, 2, 3, 1))
     return frames, ring

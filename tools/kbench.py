@@ -87,7 +87,8 @@ def main():
             g = r(B, H - 2, H - 2, 32)
             fl_ = 2.0 * B * (H - 2) ** 2 * 32 * 32 * 9
             report(f"conv_s1_wgrad(+reduce) {H}", timeit(lambda: ops.conv_s1_wgrad(x, g, dw, db, ws)), fl_)
-        ring = torch.randint(0, 256, (2048, 84, 84, 9), dtype=torch.uint8, device=dev)
+        store = torch.randint(0, 256, (2048 * 84 * 84 * 9 + 32,), dtype=torch.uint8, device=dev)
+        ring = store[:2048 * 84 * 84 * 9].view(2048, 84, 84, 9)
         idx = torch.randint(0, 2048, (B,), device=dev)
         h1 = torch.randint(0, 8, (B,), device=dev, dtype=torch.int32)
         w1 = torch.randint(0, 8, (B,), device=dev, dtype=torch.int32)
