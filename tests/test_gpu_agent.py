@@ -425,3 +425,87 @@ def test_other_config_geometries_vs_oracle(name, obs_shape, layers, pixel_sac, B
         check(f"{name} params after update {k}", sd[k].cpu(), oracle.critic[k].detach(), 1e-3)
     assert len(grads["critic"]) == 8 + 2 * layers + 8
 
+
+
+def test_detach_encoder_and_only_cpc_modes(tiny):
+    """--detach_encoder (curl_sac.py:358: h.detach() between conv and fc): conv tensors get no gradient, so
+    Adam must leave them untouched while fc/ln/Q still move; only_cpc (train.py:425) touches only the encoder/W."""
+    import curla_amd
+    from oracle import curla_oracle as O
+    g = tiny
+    aug = curla_amd.RandomCrop((34, 40), (28, 34))
+    torch.manual_seed(0)
+    agent = curla_amd.CurlSacAgent((9, 28, 34), (2,), torch.device("cuda"), aug, hidden_dim=64, detach_encoder=True, **HP)
+    load_state(agent, sub(g, "state0/actor/"), sub(g, "state0/critic/"), sub(g, "state0/critic_target/"),
+               g["state0/W"], g["state0/log_alpha"])
+    before = {k: v.clone() for k, v in agent.critic.state_dict().items()}
+    L = NullLogger()
+    obs, nxt = _t(g["batch/obs"]).float(), _t(g["batch/next_obs"]).float()
+    act, rew, nd = _t(g["batch/action"]), _t(g["batch/reward"]), _t(g["batch/not_done"])
+    ref = O.critic_phase(sub(g, "state0/actor/"), sub(g, "state0/critic/"), sub(g, "state0/critic_target/"),
+                         torch.from_numpy(g["state0/log_alpha"]), obs.cpu(), act.cpu(), rew.cpu(), nxt.cpu(), nd.cpu(),
+                         torch.from_numpy(g["noise/critic"]), num_layers=4, discount=0.99, log_std_min=-10,
+                         log_std_max=2, detach_encoder=True)
+    grads = {}
+    real = agent.critic_optimizer.step
+
+    def step():
+        grads.update({n: (None if p.grad is None else 1) for n, p in agent.critic.named_parameters()})
+        real()
+    agent.critic_optimizer.step = step
+    agent.update_critic(obs, act, rew, nxt, nd, L, 4, noise=_t(g["noise/critic"]))
+    check("detach critic loss", L.scalars["train_critic/loss"], ref["loss"])
+    got = grads_of(agent.critic)
+    for k, v in ref["grads"].items():
+        if v is None:
+            assert ".convs." in k and grads[k] is None  # Adam saw no gradient for the convs
+        else:
+            check(f"detach critic grad {k}", got[k], v)
+    after = agent.critic.state_dict()
+    for k in before:
+        same = torch.equal(before[k], after[k])
+        assert same == (".convs." in k), k
+    # only_cpc: the SAC phases are skipped entirely
+    agent2, _ = _tiny_agent(g)
+    rb = curla_amd.ReplayBuffer((9, 34, 40), (2,), 16, 8, torch.device("cuda"), aug)
+    fill_ring(rb, g["batch/obs_full"], g["batch/next_obs_full"])
+    q_before = agent2.critic.Q1.trunk[0].weight.detach().clone()
+    conv_before = agent2.critic.encoder.convs[1].weight.detach().clone()
+    np.random.seed(0)
+    agent2.update(rb, L, 3, only_cpc=True)
+    assert torch.equal(q_before, agent2.critic.Q1.trunk[0].weight)
+    assert not torch.equal(conv_before, agent2.critic.encoder.convs[1].weight)
+
+
+def test_checkpoint_and_buffer_persistence(tmp_path, tiny):
+    """save/load (curl_sac.py:453-465) and the replay chunk format (utils.py:189-216)."""
+    import curla_amd
+    agent, aug = _tiny_agent(tiny)
+    agent.save(str(tmp_path), "random_crop", 7)
+    sd = torch.load(tmp_path / "random_crop_critic_7.pt")
+    ref = sub(tiny, "state0/critic/")
+    assert list(sd.keys()) == list(ref.keys())
+    for k in ref:  # files hold the reference layouts
+        assert torch.equal(sd[k].cpu(), ref[k]), k
+    assert list(torch.load(tmp_path / "random_crop_curl_7.pt").keys())[0] == "W"
+    other, _ = make_agent((9, 28, 34), (34, 40), 64)
+    other.load(str(tmp_path), "random_crop", 7)
+    for k, v in agent.actor.state_dict().items():
+        assert torch.equal(v, other.actor.state_dict()[k]), k
+    for k, v in agent.critic.state_dict().items():
+        assert torch.equal(v, other.critic_target.state_dict()[k]), k  # load() re-syncs the target (curl_sac.py:464)
+    # replay buffer chunks
+    rb = curla_amd.ReplayBuffer((9, 34, 40), (2,), 16, 4, torch.device("cuda"), aug)
+    rs = np.random.RandomState(3)
+    frames = rs.randint(0, 256, (6, 9, 34, 40), dtype=np.uint8)
+    for i in range(5):
+        rb.add(frames[i], [0.1 * i, 0.2], float(i), frames[i + 1], i == 4)
+    d = tmp_path / "buf"
+    d.mkdir()
+    rb.save(str(d))
+    payload = torch.load(d / "0_5.pt", weights_only=False)
+    assert payload[0].shape == (5, 9, 34, 40) and np.array_equal(payload[0], frames[:5])  # CHW like the reference
+    assert np.array_equal(payload[1], frames[1:6]) and payload[4][4, 0] == 0.0
+    rb2 = curla_amd.ReplayBuffer((9, 34, 40), (2,), 16, 4, torch.device("cuda"), aug)
+    rb2.load(str(d))
+    assert rb2.idx == 5 and torch.equal(rb2.obses[:5], rb.obses[:5]) and torch.equal(rb2.rewards[:5], rb.rewards[:5])
