@@ -70,6 +70,23 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ P, int ld, i
   }
 }
 
+// interior, aligned tiles: no bounds or alignment tests in the k loop
+template <bool KMAJOR, int ROWS>
+__device__ __forceinline__ void tile_load_fast(const float* __restrict__ P, int ld, int r0, int k0, int tid,
+                                               f32x4 (&reg)[ROWS / 32]) {
+#pragma unroll
+  for (int u = 0; u < ROWS / 32; ++u) {
+    if (!KMAJOR) {
+      const int row = (tid >> 3) + 32 * u, k4 = (tid & 7) * 4;
+      reg[u] = *reinterpret_cast<const f32x4*>(P + (size_t)(r0 + row) * ld + k0 + k4);
+    } else {
+      constexpr int TPR = ROWS / 4;
+      const int k = tid / TPR + (256 / TPR) * u, r4 = (tid % TPR) * 4;
+      reg[u] = *reinterpret_cast<const f32x4*>(P + (size_t)(k0 + k) * ld + r0 + r4);
+    }
+  }
+}
+
 template <bool KMAJOR, int ROWS>
 __device__ __forceinline__ void tile_store(float* __restrict__ S, int tid, const f32x4 (&reg)[ROWS / 32]) {
 #pragma unroll
@@ -106,8 +123,10 @@ __device__ __forceinline__ void frags(const float* __restrict__ S, int row, int 
 // 256 threads = 2 x 2 waves; a wave computes 32 x (TBN/2) of the 64 x TBN tile.
 // TBN = 32 doubles the workgroup count for the mid-sized GEMMs of the heads
 // (512 x 1024 x 1024 is only 128 tiles of 64 x 64 on a 256-CU chip).
-template <bool AK, bool BKM, int TBN>
+template <bool AK, bool BKM, int TBM, int TBN, bool FAST>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  constexpr int MI = TBM / 32;  // 16-row fragments per wave
+  constexpr int WM = TBM / 2;   // rows per wave
   constexpr int NJ = TBN / 32;
   constexpr int WN = TBN / 2;  // columns per wave
   __shared__ __attribute__((aligned(16))) float As[BK * KSTR];
@@ -117,41 +136,44 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int wm = wave >> 1, wn = wave & 1;
   const int z = blockIdx.z;
   const int batch = z / g.ksplit, ks = z - batch * g.ksplit;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * TBN;
+  const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
   const float* A = g.A + batch * g.sA;
   const float* B = g.B + batch * g.sB;
   float* C = g.C + batch * g.sC + ks * g.sSplit;
   const int kbeg = ks * g.kchunk;
   const int kend = min(g.K, kbeg + g.kchunk);
 
-  f32x4 acc[2][NJ];
+  f32x4 acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-  f32x4 ra[2], rb[TBN / 32];
-  if (kbeg < kend) {
-    tile_load<AK, BM>(A, g.lda, g.M, m0, kbeg, kend, g.vecA, tid, ra);
-    tile_load<BKM, TBN>(B, g.ldb, g.N, n0, kbeg, kend, g.vecB, tid, rb);
-  }
+  f32x4 ra[TBM / 32], rb[TBN / 32];
+  auto load = [&](int k0) {
+    if (FAST) {
+      tile_load_fast<AK, TBM>(A, g.lda, m0, k0, tid, ra);
+      tile_load_fast<BKM, TBN>(B, g.ldb, n0, k0, tid, rb);
+    } else {
+      tile_load<AK, TBM>(A, g.lda, g.M, m0, k0, kend, g.vecA, tid, ra);
+      tile_load<BKM, TBN>(B, g.ldb, g.N, n0, k0, kend, g.vecB, tid, rb);
+    }
+  };
+  if (kbeg < kend) load(kbeg);
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    tile_store<AK, BM>(As, tid, ra);
+    tile_store<AK, TBM>(As, tid, ra);
     tile_store<BKM, TBN>(Bs, tid, rb);
     __syncthreads();
-    if (k0 + BK < kend) {
-      tile_load<AK, BM>(A, g.lda, g.M, m0, k0 + BK, kend, g.vecA, tid, ra);
-      tile_load<BKM, TBN>(B, g.ldb, g.N, n0, k0 + BK, kend, g.vecB, tid, rb);
-    }
-    float fa[2][8], fb[NJ][8];
+    if (k0 + BK < kend) load(k0 + BK);
+    float fa[MI][8], fb[NJ][8];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) frags<AK>(As, wm * 32 + i * 16 + li, kq, fa[i]);
+    for (int i = 0; i < MI; ++i) frags<AK>(As, wm * WM + i * 16 + li, kq, fa[i]);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) frags<BKM>(Bs, wn * WN + j * 16 + li, kq, fb[j]);
 #pragma unroll
     for (int s = 0; s < BK / 4; ++s)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(fa[i][s], fb[j][s], acc[i][j]);
     __syncthreads();
@@ -161,7 +183,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const float* bias = (epi && g.bias) ? g.bias + batch * g.sBias : nullptr;
   const float* mask = (epi && g.mask) ? g.mask + batch * g.sMask : nullptr;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int n = n0 + wn * WN + j * 16 + li;
@@ -169,7 +191,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       const float bv = bias ? bias[n] : 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 32 + i * 16 + 4 * kq + r;
+        const int m = m0 + wm * WM + i * 16 + 4 * kq + r;
         if (m >= g.M) continue;
         float v = g.alpha * acc[i][j][r] + bv;
         if (epi && g.relu) v = fmaxf(v, 0.f);
@@ -214,16 +236,35 @@ int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const f
   g.vecA = (lda % 4 == 0) && (strideA % 4 == 0) && aligned16(A);
   g.vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && aligned16(B);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const long long wgs64 = (long long)((N + 63) / 64) * ((M + BM - 1) / BM) * nbatch * ksplit;
-  const bool narrow = wgs64 < 2LL * curla_cu_count() && N > 32;  // not enough 64x64 tiles to fill the chip twice
-#define CURLA_GEMM_LAUNCH(AKM, BKMAJ)                                                                       \
-  do {                                                                                                      \
-    if (narrow)                                                                                             \
-      hipLaunchKernelGGL((gemm_kernel<AKM, BKMAJ, 32>), dim3((N + 31) / 32, (M + BM - 1) / BM, nbatch * ksplit), \
-                         dim3(256), 0, st, g);                                                              \
-    else                                                                                                    \
-      hipLaunchKernelGGL((gemm_kernel<AKM, BKMAJ, 64>), dim3((N + 63) / 64, (M + BM - 1) / BM, nbatch * ksplit), \
-                         dim3(256), 0, st, g);                                                              \
+  // tile shape: 64x64 when that already fills the chip twice, else 64x32, else 32x32 (more, smaller
+  // workgroups: at one workgroup per CU nothing hides the L2 latency of the single-buffered k loop)
+  const long long cu2 = 2LL * curla_cu_count();
+  const long long zb = (long long)nbatch * ksplit;
+  const long long wgs64 = (long long)((N + 63) / 64) * ((M + 63) / 64) * zb;
+  const long long wgs6432 = (long long)((N + 31) / 32) * ((M + 63) / 64) * zb;
+  int tbm = 64, tbn = 64;
+  if (wgs64 < cu2 && N > 32) tbn = 32;
+  if (tbn == 32 && wgs6432 < cu2 && M > 32) tbm = 32;
+  // interior + aligned everywhere: the k loop runs without bounds / alignment tests
+  const bool fast = g.vecA && g.vecB && (M % tbm == 0) && (N % tbn == 0) && (K % BK == 0) && (g.kchunk % BK == 0);
+#define CURLA_GEMM_LAUNCH3(AKM, BKMAJ, TM, TN, FS)                                                          \
+  hipLaunchKernelGGL((gemm_kernel<AKM, BKMAJ, TM, TN, FS>), dim3((N + TN - 1) / TN, (M + TM - 1) / TM, nbatch * ksplit), \
+                     dim3(256), 0, st, g)
+#define CURLA_GEMM_LAUNCH2(AKM, BKMAJ, TM, TN)               \
+  do {                                                       \
+    if (fast)                                                \
+      CURLA_GEMM_LAUNCH3(AKM, BKMAJ, TM, TN, true);          \
+    else                                                     \
+      CURLA_GEMM_LAUNCH3(AKM, BKMAJ, TM, TN, false);         \
+  } while (0)
+#define CURLA_GEMM_LAUNCH(AKM, BKMAJ)                        \
+  do {                                                       \
+    if (tbm == 32)                                           \
+      CURLA_GEMM_LAUNCH2(AKM, BKMAJ, 32, 32);                \
+    else if (tbn == 32)                                      \
+      CURLA_GEMM_LAUNCH2(AKM, BKMAJ, 64, 32);                \
+    else                                                     \
+      CURLA_GEMM_LAUNCH2(AKM, BKMAJ, 64, 64);                \
   } while (0)
   if (a_kmajor && b_kmajor)
     CURLA_GEMM_LAUNCH(true, true);
@@ -233,6 +274,8 @@ int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const f
     CURLA_GEMM_LAUNCH(false, true);
   else
     CURLA_GEMM_LAUNCH(false, false);
+#undef CURLA_GEMM_LAUNCH3
+#undef CURLA_GEMM_LAUNCH2
 #undef CURLA_GEMM_LAUNCH
   return curla_launch_status();
 }
