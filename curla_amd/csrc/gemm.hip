@@ -72,13 +72,14 @@ __device__ __forceinline__ void tile_load(const float* __restrict__ P, int ld, i
 
 // interior, aligned tiles: no bounds or alignment tests in the k loop
 template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ void tile_load_fast(const float* __restrict__ P, int ld, int r0, int k0, int tid,
-                                               f32x4 (&reg)[ROWS / 32]) {
+__device__ __forceinline__ void tile_load_fast(const float* __restrict__ P, int ld, int rows_total, int r0, int k0,
+                                               int tid, f32x4 (&reg)[ROWS / 32]) {
 #pragma unroll
   for (int u = 0; u < ROWS / 32; ++u) {
     if (!KMAJOR) {
-      const int row = (tid >> 3) + 32 * u, k4 = (tid & 7) * 4;
-      reg[u] = *reinterpret_cast<const f32x4*>(P + (size_t)(r0 + row) * ld + k0 + k4);
+      // rows past the matrix edge re-read the last row (their products are discarded by the epilogue)
+      const int row = min(r0 + (tid >> 3) + 32 * u, rows_total - 1), k4 = (tid & 7) * 4;
+      reg[u] = *reinterpret_cast<const f32x4*>(P + (size_t)row * ld + k0 + k4);
     } else {
       constexpr int TPR = ROWS / 4;
       const int k = tid / TPR + (256 / TPR) * u, r4 = (tid % TPR) * 4;
@@ -152,8 +153,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   f32x4 ra[TBM / 32], rb[TBN / 32];
   auto load = [&](int k0) {
     if (FAST) {
-      tile_load_fast<AK, TBM>(A, g.lda, m0, k0, tid, ra);
-      tile_load_fast<BKM, TBN>(B, g.ldb, n0, k0, tid, rb);
+      tile_load_fast<AK, TBM>(A, g.lda, g.M, m0, k0, tid, ra);
+      tile_load_fast<BKM, TBN>(B, g.ldb, g.N, n0, k0, tid, rb);
     } else {
       tile_load<AK, TBM>(A, g.lda, g.M, m0, k0, kend, g.vecA, tid, ra);
       tile_load<BKM, TBN>(B, g.ldb, g.N, n0, k0, kend, g.vecB, tid, rb);
@@ -175,28 +176,49 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(fa[i][s], fb[j][s], acc[i][j]);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(fb[j][s], fa[i][s], acc[i][j]);
     __syncthreads();
   }
 
   const bool epi = g.ksplit == 1;
   const float* bias = (epi && g.bias) ? g.bias + batch * g.sBias : nullptr;
   const float* mask = (epi && g.mask) ? g.mask + batch * g.sMask : nullptr;
+  // The MFMA is issued with the N-side operand as its row operand, so a lane holds 4 CONSECUTIVE n
+  // (rows 4kq..4kq+3 of the 16x16 tile) of ONE m (column li): C, bias and mask move as float4.
+  const bool vec_c = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                     (!mask || ((g.ldmask % 4 == 0) && ((reinterpret_cast<uintptr_t>(mask) & 15) == 0)));
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int n = n0 + wn * WN + j * 16 + li;
-      if (n >= g.N) continue;
-      const float bv = bias ? bias[n] : 0.f;
+      const int m = m0 + wm * WM + i * 16 + li;
+      const int n = n0 + wn * WN + j * 16 + 4 * kq;
+      if (m >= g.M || n >= g.N) continue;
+      f32x4 v = acc[i][j] * g.alpha;
+      if (vec_c && n + 3 < g.N) {
+        if (bias) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * WM + i * 16 + 4 * kq + r;
-        if (m >= g.M) continue;
-        float v = g.alpha * acc[i][j][r] + bv;
-        if (epi && g.relu) v = fmaxf(v, 0.f);
-        if (mask) v = mask[(size_t)m * g.ldmask + n] > 0.f ? v : 0.f;
-        C[(size_t)m * g.ldc + n] = v;
+          for (int r = 0; r < 4; ++r) v[r] += bias[n + r];
+        }
+        if (epi && g.relu) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if (mask) {
+          const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + (size_t)m * g.ldmask + n);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(C + (size_t)m * g.ldc + n) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= g.N) continue;
+          float x = v[r] + (bias ? bias[n + r] : 0.f);
+          if (epi && g.relu) x = fmaxf(x, 0.f);
+          if (mask) x = mask[(size_t)m * g.ldmask + n + r] > 0.f ? x : 0.f;
+          C[(size_t)m * g.ldc + n + r] = x;
+        }
       }
     }
 }
@@ -246,7 +268,9 @@ int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const f
   if (wgs64 < cu2 && N > 32) tbn = 32;
   if (tbn == 32 && wgs6432 < cu2 && M > 32) tbm = 32;
   // interior + aligned everywhere: the k loop runs without bounds / alignment tests
-  const bool fast = g.vecA && g.vecB && (M % tbm == 0) && (N % tbn == 0) && (K % BK == 0) && (g.kchunk % BK == 0);
+  // (a k-major operand still needs whole tiles: its float4 runs along the rows)
+  const bool fast = g.vecA && g.vecB && (K % BK == 0) && (g.kchunk % BK == 0) && (!a_kmajor || M % tbm == 0) &&
+                    (!b_kmajor || N % tbn == 0);
 #define CURLA_GEMM_LAUNCH3(AKM, BKMAJ, TM, TN, FS)                                                          \
   hipLaunchKernelGGL((gemm_kernel<AKM, BKMAJ, TM, TN, FS>), dim3((N + TN - 1) / TN, (M + TM - 1) / TM, nbatch * ksplit), \
                      dim3(256), 0, st, g)

@@ -119,7 +119,7 @@ class CNNEncoder(nn.Module):
         """Split-K factor of the fc GEMM ([B, flat] x [flat, F]): enough
         workgroups to fill 256 CUs about twice."""
         mt = (B + 63) // 64
-        ks = max(1, min(64, 512 // mt))
+        ks = max(1, min(32, 512 // mt))
         return min(ks, max(1, self.flat_dim // 256))
 
     def partial(self, B):
