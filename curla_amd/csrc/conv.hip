@@ -48,6 +48,9 @@ struct ConvS1Args {
 // ---------------------------------------------------------------------------
 // stride-1 32->32 conv: forward (bias+ReLU) and data-gradient (full correlation
 // with the flipped/transposed filter, ReLU mask of the layer below fused in).
+// The x direction uses Winograd F(2,3) (4 MFMA products per two outputs instead of 6): the input
+// transform is 4 vector adds on the LDS window right before the MFMAs, the output transform 4 adds
+// per pair; the y direction and the channel sums are the plain accumulation.
 // ---------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
@@ -75,14 +78,26 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
     }
   }
   __syncthreads();
-  float wr[9][8];
+  // 1-D Winograd F(2,3) along x: two adjacent outputs share one 4-pixel window and need 4 products
+  // per (row tap, cin) instead of 6.  Filter transform per row tap dy (g0,g1,g2 = the three x taps):
+  //   U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2
+  float wu[3][4][8];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
       const int co = mt * 16 + li;
       const int ci = 16 * (s >> 2) + 4 * kq + (s & 3);
-      wr[t][s] = (MODE == MODE_FWD) ? lds[co * kWStride + ci * 9 + t] : lds[ci * kWStride + co * 9 + (8 - t)];
+      float gx[3];
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int t = dy * 3 + dx;
+        gx[dx] = (MODE == MODE_FWD) ? lds[co * kWStride + ci * 9 + t] : lds[ci * kWStride + co * 9 + (8 - t)];
+      }
+      wu[dy][0][s] = gx[0];
+      wu[dy][1][s] = 0.5f * (gx[0] + gx[1] + gx[2]);
+      wu[dy][2][s] = 0.5f * (gx[0] - gx[1] + gx[2]);
+      wu[dy][3][s] = gx[2];
     }
   f32x4 bias4 = {0, 0, 0, 0};
   if (MODE == MODE_FWD) bias4 = *reinterpret_cast<const f32x4*>(a.aux + mt * 16 + 4 * kq);
@@ -134,59 +149,69 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
     }
     __syncthreads();
 
-    const int npix = tha * a.Wo;
-    const int ntiles = (npix + 15) >> 4;
-    // this lane's pixel walks the band 32 pixels per iteration: (ty, x) kept incrementally
-    int ty = (tslot * 16 + li) / a.Wo, x = (tslot * 16 + li) - ty * a.Wo;
+    // a lane owns a horizontal PAIR of output pixels (x0 = 2j, 2j+1); a tile is 16 pairs
+    const int PW = (a.Wo + 1) >> 1;            // pairs per output row (the last one is half valid when Wo is odd)
+    const int npairs = tha * PW;
+    const int ntiles = (npairs + 15) >> 4;
+    int ty = (tslot * 16 + li) / PW, j = (tslot * 16 + li) - ty * PW;
     for (int t = tslot; t < ntiles; t += 2) {
-      const bool pv = t * 16 + li < npix;
-      if (!pv) ty = 0, x = 0;
-      const float* base = lds + (ty * WT + x) * kLdsPix + 4 * kq;
-      // two accumulation chains so dependent MFMAs never wait on each other; the LDS
-      // reads of tap t+1 are issued before the MFMAs of tap t (software pipeline,
-      // pinned with sched_group_barrier: hipcc otherwise sinks each read to its use)
-      f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-      f32x4 nb0 = *reinterpret_cast<const f32x4*>(base);
-      f32x4 nb1 = *reinterpret_cast<const f32x4*>(base + 16);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // tap 0 reads
+      const bool pv = t * 16 + li < npairs;
+      if (!pv) ty = 0, j = 0;
+      const float* base = lds + (ty * WT + 2 * j) * kLdsPix + 4 * kq;
+      f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+      // 6 half-steps (3 row taps x 2 cin halves); the 4 window reads of the next half-step are issued
+      // before the 16 MFMAs of the current one
+      f32x4 d[2][4];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const f32x4 b0 = nb0, b1 = nb1;
-        if (t < 8) {
-          const int dy = (t + 1) / 3, dx = (t + 1) - 3 * dy;
-          const float* ptr = base + (dy * WT + dx) * kLdsPix;
-          nb0 = *reinterpret_cast<const f32x4*>(ptr);
-          nb1 = *reinterpret_cast<const f32x4*>(ptr + 16);
-        }
+      for (int c = 0; c < 4; ++c) d[0][c] = *reinterpret_cast<const f32x4*>(base + c * kLdsPix);
 #pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-          acc0 = mfma16(wr[t][e], b0[e], acc0);
-          acc1 = mfma16(wr[t][e + 1], b0[e + 1], acc1);
-        }
+      for (int h = 0; h < 6; ++h) {
+        const int dy = h >> 1, q = h & 1;
+        if (h < 5) {
+          const int ndy = (h + 1) >> 1, nq = (h + 1) & 1;
 #pragma unroll
-        for (int e = 0; e < 4; e += 2) {
-          acc0 = mfma16(wr[t][4 + e], b1[e], acc0);
-          acc1 = mfma16(wr[t][5 + e], b1[e + 1], acc1);
+          for (int c = 0; c < 4; ++c)
+            d[(h + 1) & 1][c] = *reinterpret_cast<const f32x4*>(base + (ndy * WT + c) * kLdsPix + 16 * nq);
         }
-        if (t < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // 2 DS reads (next tap) ...
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);             // ... then 8 MFMAs (this tap)
+        __builtin_amdgcn_sched_barrier(0);
+        const f32x4 d0 = d[h & 1][0], d1 = d[h & 1][1], d2 = d[h & 1][2], d3 = d[h & 1][3];
+        const f32x4 v0 = d0 - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - d3;  // input transform B^T d
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[0] = mfma16(wu[dy][0][4 * q + e], v0[e], acc[0]);
+          acc[1] = mfma16(wu[dy][1][4 * q + e], v1[e], acc[1]);
+          acc[2] = mfma16(wu[dy][2][4 * q + e], v2[e], acc[2]);
+          acc[3] = mfma16(wu[dy][3][4 * q + e], v3[e], acc[3]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (pv && !ABL(4)) {
-        const size_t g = ((size_t)(b * a.Ho + y0 + ty) * a.Wo + x) * 32 + mt * 16 + 4 * kq;
-        f32x4 v = acc0 + acc1;
+        // output transform A^T m: y(x0) = m0+m1+m2, y(x0+1) = m1-m2-m3
+        const int x0 = 2 * j;
+        const size_t g = ((size_t)(b * a.Ho + y0 + ty) * a.Wo + x0) * 32 + mt * 16 + 4 * kq;
+        f32x4 ya = acc[0] + acc[1] + acc[2];
+        f32x4 yb = acc[1] - acc[2] - acc[3];
+        const bool second = x0 + 1 < a.Wo;
         if (MODE == MODE_FWD) {
-          v += bias4;
+          ya += bias4;
+          yb += bias4;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          for (int r = 0; r < 4; ++r) ya[r] = fmaxf(ya[r], 0.f), yb[r] = fmaxf(yb[r], 0.f);
         } else {
-          const f32x4 m = *reinterpret_cast<const f32x4*>(a.aux + g);
+          const f32x4 ma = *reinterpret_cast<const f32x4*>(a.aux + g);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = m[r] > 0.f ? v[r] : 0.f;
+          for (int r = 0; r < 4; ++r) ya[r] = ma[r] > 0.f ? ya[r] : 0.f;
+          if (second) {
+            const f32x4 mb = *reinterpret_cast<const f32x4*>(a.aux + g + 32);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yb[r] = mb[r] > 0.f ? yb[r] : 0.f;
+          }
         }
-        *reinterpret_cast<f32x4*>(a.out + g) = v;
+        *reinterpret_cast<f32x4*>(a.out + g) = ya;
+        if (second) *reinterpret_cast<f32x4*>(a.out + g + 32) = yb;
       }
-      x += 32;
-      while (x >= a.Wo) x -= a.Wo, ++ty;
+      j += 32;
+      while (j >= PW) j -= PW, ++ty;
     }
     __syncthreads();
   }
@@ -812,14 +837,14 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* partial
 
 // ------------------------------ host-side planning ------------------------------
 constexpr int kMaxLds = 160 * 1024;
-constexpr int kBandPx = 568;  // pixels a band may hold: 568 * 144 B = 79.9 KB of LDS -> 2 workgroups per CU
+constexpr int kBandPx = 567;  // pixels a band may hold: (567 + 1 slack) * 144 B = 79.9 KB of LDS -> 2 workgroups per CU
 static_assert(kBandPx * 8 <= 256 * kMaxPf, "band must fit the staging registers");
 
 // Rows per band for the stride-1 kernels.  The band (th+2 input rows, plus th
 // gradient rows for wgrad) must fit kBandPx pixels.  Candidates split Ho into
 // nb near-equal bands; the score is the fraction of useful 16-pixel tile slots
 // (tiles are dealt to `nslots` wave groups) times the halo re-read factor.
-int plan_band_s1(int Ho, int Wo, int px_per_row_extra, int budget_px, int unit_px, int nslots) {
+int plan_band_s1(int Ho, int Wo, int px_per_row_extra, int budget_px, int unit_px, int nslots, bool pairs = false) {
   int th_max = 0;
   for (int th = 1; th <= Ho; ++th)
     if ((th + 2) * (Wo + 2) + px_per_row_extra * th <= budget_px) th_max = th;
@@ -834,8 +859,9 @@ int plan_band_s1(int Ho, int Wo, int px_per_row_extra, int budget_px, int unit_p
     double work = 0, slots = 0;
     for (int bnd = 0; bnd < nbands; ++bnd) {
       const int tha = (bnd == nbands - 1) ? Ho - bnd * th : th;
-      const int tiles = (tha * Wo + unit_px - 1) / unit_px;
-      work += tha * Wo / (double)unit_px;
+      const int units = pairs ? tha * ((Wo + 1) / 2) : tha * Wo;  // work items per band (pixel pairs or pixels)
+      const int tiles = (units + unit_px - 1) / unit_px;
+      work += (pairs ? tha * Wo / 2.0 : tha * Wo) / (double)unit_px;
       slots += ((tiles + nslots - 1) / nslots) * nslots;
     }
     const double eff = work / slots * (double)th / (th + 2) * (1.0 - 0.01 * nbands);  // small per-band fixed cost
@@ -862,10 +888,10 @@ int launch_conv_s1(int mode, const float* in, const float* w, const float* aux, 
   a.Ho = mode == MODE_FWD ? Hs - 2 : Hs + 2;
   a.Wo = mode == MODE_FWD ? Ws - 2 : Ws + 2;
   if (a.Ho <= 0 || a.Wo <= 0 || (a.Wo + 2) * 3 > kBandPx) return CURLA_ERR_UNSUPPORTED;
-  a.th = plan_band_s1(a.Ho, a.Wo, 0, kBandPx, 16, 2);
+  a.th = plan_band_s1(a.Ho, a.Wo, 0, kBandPx, 16, 2, /*pairs=*/true);
   a.nbands = (a.Ho + a.th - 1) / a.th;
   a.dbg = ABL_HOST;
-  size_t lds = (size_t)(a.th + 2) * (a.Wo + 2) * kLdsPix * sizeof(float);
+  size_t lds = ((size_t)(a.th + 2) * (a.Wo + 2) + 1) * kLdsPix * sizeof(float);  // +1 pixel: 4th window pixel of the last pair
   const size_t wl = (size_t)32 * kWStride * sizeof(float);
   if (lds < wl) lds = wl;
   const int nitems = B * a.nbands;
