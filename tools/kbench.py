@@ -20,7 +20,7 @@ def build_ablate():
     out = os.path.join(ROOT, "tools", "_build")
     os.makedirs(out, exist_ok=True)
     lib = os.path.join(out, "libcurla_ablate.so")
-    srcs = [os.path.join(ROOT, "curla_amd", "csrc", f) for f in ("conv.hip", "gemm.hip", "heads.hip")]
+    srcs = [os.path.join(ROOT, "curla_amd", "csrc", f) for f in ("conv.hip", "gemm.hip", "heads.hip", "augment.hip")]
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared",
                            "-DCURLA_ABLATE", "-o", lib] + srcs)
     return lib
