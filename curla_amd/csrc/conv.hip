@@ -480,15 +480,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
-  // a wave owns the 16 output channels mt*16.. of dW (18 accumulator tiles); wave pairs share pixels
+  // a wave owns the 16 output channels mt*16.. of dW; wave pairs share pixels.
+  // Winograd F(3,2) along x (the transpose of the forward's F(2,3)): for a horizontal pair of
+  // gradient pixels (g0,g1) and its 4-pixel input window (d0..d3), the three x taps need 4 products
+  //   M0 += g0 (d0-d2), M1 += (g0+g1)(d1+d2), M2 += (g0-g1)(d2-d1), M3 += -g1 (d1-d3)
+  // summed over all pairs; dW(dx=0,1,2) = M0+(M1+M2)/2, (M1-M2)/2, (M1+M2)/2+M3 once at the end.
   const int mt = wave & 1, uslot = wave >> 1;
-  f32x4 acc[2][9];
+  f32x4 acc[3][4][2];  // [dy][k][cin tile]
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[j][t] = f32x4{0, 0, 0, 0};
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) acc[dy][k][ct] = f32x4{0, 0, 0, 0};
   float bsum = 0.f;
 
+  const int PW = (a.Wo + 1) >> 1;  // pixel pairs per gradient row
   const int nitems = a.B * a.nbands;
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int band = item / a.B, b = item - band * a.B;  // band-major: every workgroup sees every band size
@@ -518,71 +525,85 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) {
     }
     __syncthreads();
 
-    const int npix = tha * a.Wo;
+    const int npairs = tha * PW;
     const float* ldsg = lds + (tha + 2) * a.Wi * kLdsPix;
-    const int nunits = ((npix + 15) >> 4) << 2;  // 4 pixels per MFMA k-step, 4 k-steps per 16-pixel group
-    // operand fetch of one k-step: 1 gradient value (A) + 18 input values (B: 9 taps x 2 cin tiles)
-    // fetch() is called for u = uslot, uslot+2, ... in order; the lane's pixel
-    // p(u) = (u>>2)*16 + (u&3) + 4*kq advances by 2 or 14, so (fy, fx) are kept incrementally
-    int fy = (uslot + 4 * kq) / a.Wo, fx = (uslot + 4 * kq) - fy * a.Wo;
-    auto fetch = [&](int u, float& av, float (&bv)[18]) {
-      // pixels of a k-step are 4 apart so the two lane groups of an LDS half hit disjoint banks
-      const int p = (u >> 2) * 16 + (u & 3) + 4 * kq;
-      const bool pv = (u < nunits) && (p < npix);
-      const int ty = pv ? fy : 0, x = pv ? fx : 0;
-      av = pv ? ldsg[(ty * a.Wo + x) * kLdsPix + mt * 16 + li] : 0.f;
-      const float* ip = lds + (ty * a.Wi + x) * kLdsPix + li;
+    const int nunits = ((npairs + 7) >> 3) << 1;  // 4 pairs per MFMA k-step, 2 k-steps per group of 8 pairs
+    // fetch() runs for u = uslot, uslot+2, ... in order; the lane's pair q(u) = (u>>1)*8 + (u&1) + 2*kq
+    // (pairs of a k-step are 2 apart = 4 pixels: the two lane groups of an LDS half hit disjoint banks)
+    // advances by 8 pairs per call, so (fy, fj) are kept incrementally
+    int fy = ((uslot & 1) + 2 * kq) / PW, fj = ((uslot & 1) + 2 * kq) - fy * PW;
+    auto fetch = [&](int u, float (&gv)[2], float (&dv)[3][4][2]) {
+      const int q = (u >> 1) * 8 + (u & 1) + 2 * kq;
+      const bool pv = (u < nunits) && (q < npairs);
+      const int ty = pv ? fy : 0, x0 = pv ? 2 * fj : 0;
+      const float* gp = ldsg + (ty * a.Wo + x0) * kLdsPix + mt * 16 + li;
+      gv[0] = pv ? gp[0] : 0.f;
+      gv[1] = (pv && x0 + 1 < a.Wo) ? gp[kLdsPix] : 0.f;
+      const float* ip = lds + (ty * a.Wi + x0) * kLdsPix + li;
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const float* q = ip + (dy * a.Wi + dx) * kLdsPix;
-          bv[2 * (dy * 3 + dx)] = q[0];
-          bv[2 * (dy * 3 + dx) + 1] = q[16];
+        for (int c = 0; c < 4; ++c) {
+          const float* qd = ip + (dy * a.Wi + c) * kLdsPix;
+          dv[dy][c][0] = qd[0];
+          dv[dy][c][1] = qd[16];
         }
-      fx += (u & 2) ? 14 : 2;
-      while (fx >= a.Wo) fx -= a.Wo, ++fy;
+      fj += 8;
+      while (fj >= PW) fj -= PW, ++fy;
     };
-    auto mma = [&](float av, const float (&bv)[18]) {
-      bsum += av;
+    auto mma = [&](const float (&gv)[2], const float (&dv)[3][4][2]) {
+      bsum += gv[0] + gv[1];
+      const float g0 = gv[0], g1 = gv[0] + gv[1], g2 = gv[0] - gv[1], g3 = -gv[1];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        acc[0][t] = mfma16(av, bv[2 * t], acc[0][t]);
-        acc[1][t] = mfma16(av, bv[2 * t + 1], acc[1][t]);
-      }
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const float d0 = dv[dy][0][ct], d1 = dv[dy][1][ct], d2 = dv[dy][2][ct], d3 = dv[dy][3][ct];
+          acc[dy][0][ct] = mfma16(g0, d0 - d2, acc[dy][0][ct]);
+          acc[dy][1][ct] = mfma16(g1, d1 + d2, acc[dy][1][ct]);
+          acc[dy][2][ct] = mfma16(g2, d2 - d1, acc[dy][2][ct]);
+          acc[dy][3][ct] = mfma16(g3, d1 - d3, acc[dy][3][ct]);
+        }
     };
-    // software pipeline over this wave's k-steps (two register sets, no copies): the LDS
-    // reads of the next step are in flight while the 18 MFMAs of the current one issue
-    float avA, avB, bvA[18], bvB[18];
-    fetch(uslot, avA, bvA);
+    // software pipeline over this wave's k-steps (two register sets, no copies): the LDS reads of the
+    // next step are in flight while the 24 MFMAs of the current one issue
+    float gA[2], gB[2], dA[3][4][2], dB[3][4][2];
+    fetch(uslot, gA, dA);
     for (int u = uslot; u < nunits; u += 4) {
-      fetch(u + 2, avB, bvB);
+      fetch(u + 2, gB, dB);
       __builtin_amdgcn_sched_barrier(0);
-      mma(avA, bvA);
+      mma(gA, dA);
       __builtin_amdgcn_sched_barrier(0);
-      fetch(u + 4, avA, bvA);
+      fetch(u + 4, gA, dA);
       __builtin_amdgcn_sched_barrier(0);
-      mma(avB, bvB);
+      mma(gB, dB);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
 
-  // cross-wave sum in a fixed order (deterministic), then one slab per workgroup
+  // output transform (linear, so applied once to the accumulated products), then the cross-wave
+  // sum in a fixed order (deterministic) and one slab per workgroup
   bsum += __shfl_xor(bsum, 16);
   bsum += __shfl_xor(bsum, 32);
   for (int w = 0; w < 2; ++w) {
     if (uslot == w) {
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct)
+      for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
-        for (int t = 0; t < 9; ++t)
+        for (int ct = 0; ct < 2; ++ct) {
+          const f32x4 hs = 0.5f * (acc[dy][1][ct] + acc[dy][2][ct]);
+          const f32x4 hd = 0.5f * (acc[dy][1][ct] - acc[dy][2][ct]);
+          const f32x4 dw[3] = {acc[dy][0][ct] + hs, hd, hs + acc[dy][3][ct]};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int co = mt * 16 + 4 * kq + r, ci = ct * 16 + li;
-            float* d = lds + co * 288 + ci * 9 + t;
-            *d = (w == 0) ? acc[ct][t][r] : *d + acc[ct][t][r];
-          }
+          for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int co = mt * 16 + 4 * kq + r, ci = ct * 16 + li;
+              float* d = lds + co * 288 + ci * 9 + dy * 3 + dx;
+              *d = (w == 0) ? dw[dx][r] : *d + dw[dx][r];
+            }
+        }
       if (kq == 0) {
         float* d = lds + 32 * 288 + mt * 16 + li;
         *d = (w == 0) ? bsum : *d + bsum;
@@ -1053,7 +1074,7 @@ int curla_conv3x3_s1_wgrad(const float* in, const float* g, float* dw, float* db
   a.in = in, a.g = g, a.partial = workspace;
   a.B = B, a.Hi = Hi, a.Wi = Wi, a.Ho = Hi - 2, a.Wo = Wi - 2;
   if ((a.Wo + 2) * 3 + a.Wo > kBandPx) return CURLA_ERR_UNSUPPORTED;
-  a.th = plan_band_s1(a.Ho, a.Wo, a.Wo, kBandPx, 16, 2);
+  a.th = plan_band_s1(a.Ho, a.Wo, a.Wo, kBandPx, 8, 1, /*pairs=*/true);
   a.nbands = (a.Ho + a.th - 1) / a.th;
   size_t lds = (size_t)((a.th + 2) * Wi + a.th * a.Wo) * kLdsPix * sizeof(float);
   if (lds < kPartialS1 * sizeof(float)) lds = kPartialS1 * sizeof(float);
