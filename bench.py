@@ -166,6 +166,9 @@ def main():
     recording[0] = False
     barrier()
     dt = time.perf_counter() - t0
+    # the timed updates must have produced finite numbers (a NaN run would be meaningless)
+    ws = agent._ws(BATCH)
+    assert bool(torch.isfinite(ws.scalars).all()) and bool(torch.isfinite(agent._critic_flat).all()), "non-finite state"
 
     if distributed:
         import torch.distributed as dist
