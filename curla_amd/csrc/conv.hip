@@ -137,7 +137,13 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
             v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(b * a.Hs + sy) * a.Ws + sx) * 32 + ch * 4);
           pf[u] = v;
           c += 32;
-          while (c >= WT) c -= WT, ++r;
+          if (WT >= 32) {  // wave-uniform: at most one row wrap per 32-pixel step
+            const bool wrap = c >= WT;
+            c = wrap ? c - WT : c;
+            r = wrap ? r + 1 : r;
+          } else {
+            while (c >= WT) c -= WT, ++r;
+          }
         }
       }
 #pragma unroll
