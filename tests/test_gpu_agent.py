@@ -210,6 +210,13 @@ def test_acting_path_vs_reference(tiny):
     agent, aug = _tiny_agent(g)
     check("select_action", agent.select_action(aug.evaluation_augmentation(g["act/obs"])), g["act/select"])
     check("sample_action", agent.sample_action(g["act/obs"], noise=_t(g["act/noise"])), g["act/sample"])
+    # uint8 frames take the pinned one-slot-ring route, anything else the reference's FloatTensor route
+    assert g["act/obs"].dtype == np.uint8 and agent._act_stage
+    obs_f = g["act/obs"].astype(np.float32)
+    check("select_action (float obs)", agent.select_action(aug.evaluation_augmentation(obs_f)), g["act/select"])
+    check("sample_action (float obs)", agent.sample_action(obs_f, noise=_t(g["act/noise"])), g["act/sample"])
+    for _ in range(3):  # staging buffers are reused call after call
+        check("sample_action (repeat)", agent.sample_action(g["act/obs"], noise=_t(g["act/noise"])), g["act/sample"])
     # module-level callables used by plot_tsne (latent_data.py:83,93)
     x = _t(aug.evaluation_augmentation(g["act/obs"]).copy()).float()[None]
     z = agent.actor.encoder(x)

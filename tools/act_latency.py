@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Latency of the acting path (sample_action / select_action, B=1) -- SURVEY.md 8f rank 1."""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import curla_amd
+dev = torch.device("cuda")
+aug = curla_amd.RandomCrop((84, 84), (76, 76))
+agent = curla_amd.CurlSacAgent((9, 76, 76), (2,), dev, aug, hidden_dim=1024)
+obs = np.random.randint(0, 256, (9, 84, 84), dtype=np.uint8)
+for _ in range(20):
+    agent.sample_action(obs)
+t0 = time.perf_counter()
+for _ in range(200):
+    agent.sample_action(obs)
+t1 = time.perf_counter()
+for _ in range(200):
+    agent.select_action(aug.evaluation_augmentation(obs))
+t2 = time.perf_counter()
+print(f"sample_action {(t1 - t0) / 200 * 1e6:.0f} us   select_action {(t2 - t1) / 200 * 1e6:.0f} us (host->device->host, B=1)")
