@@ -150,8 +150,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-  f32x4 ra[TBM / 32], rb[TBN / 32];
-  auto load = [&](int k0) {
+  // Two operand tiles are kept in flight in registers (prefetch distance 2): most of these GEMMs run at two
+  // workgroups per CU, where one tile (12-16 KB per workgroup) in flight does not cover the HBM/L2 latency.
+  f32x4 ra0[TBM / 32], rb0[TBN / 32], ra1[TBM / 32], rb1[TBN / 32];
+  auto load = [&](int k0, f32x4 (&ra)[TBM / 32], f32x4 (&rb)[TBN / 32]) {
     if (FAST) {
       tile_load_fast<AK, TBM>(A, g.lda, g.M, m0, k0, tid, ra);
       tile_load_fast<BKM, TBN>(B, g.ldb, g.N, n0, k0, tid, rb);
@@ -160,12 +162,12 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       tile_load<BKM, TBN>(B, g.ldb, g.N, n0, k0, kend, g.vecB, tid, rb);
     }
   };
-  if (kbeg < kend) load(kbeg);
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+  // one k tile: registers -> LDS, refill the registers with the tile two ahead, multiply
+  auto step = [&](int k0, f32x4 (&ra)[TBM / 32], f32x4 (&rb)[TBN / 32], bool refill) {
     tile_store<AK, TBM>(As, tid, ra);
     tile_store<BKM, TBN>(Bs, tid, rb);
     __syncthreads();
-    if (k0 + BK < kend) load(k0 + BK);
+    if (refill) load(k0 + 2 * BK, ra, rb);
     float fa[MI][8], fb[NJ][8];
 #pragma unroll
     for (int i = 0; i < MI; ++i) frags<AK>(As, wm * WM + i * 16 + li, kq, fa[i]);
@@ -178,6 +180,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(fb[j][s], fa[i][s], acc[i][j]);
     __syncthreads();
+  };
+  const int ntiles = (kend - kbeg + BK - 1) / BK;
+  if (ntiles > 0) {
+    load(kbeg, ra0, rb0);
+    load(ntiles > 1 ? kbeg + BK : kbeg, ra1, rb1);  // (a single-tile product re-reads its tile: keeps this branch-free)
+    int k0 = kbeg, t = 0;
+    // steady state: pairs of tiles with no exit between the halves, so that the compiler's vmcnt bookkeeping
+    // keeps the younger tile's loads in flight across each LDS store
+    for (; t + 3 < ntiles; t += 2, k0 += 2 * BK) {
+      step(k0, ra0, rb0, true);
+      step(k0 + BK, ra1, rb1, true);
+    }
+    const int rem = ntiles - t;  // 1..3 tiles left, the first two already in registers
+    step(k0, ra0, rb0, rem >= 3);
+    if (rem >= 2) step(k0 + BK, ra1, rb1, false);
+    if (rem >= 3) step(k0 + 2 * BK, ra0, rb0, false);
   }
 
   const bool epi = g.ksplit == 1;
