@@ -160,11 +160,60 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
     const int npairs = tha * PW;
     const int ntiles = (npairs + 15) >> 4;
     int ty = (tslot * 16 + li) / PW, j = (tslot * 16 + li) - ty * PW;
-    for (int t = tslot; t < ntiles; t += 2) {
+    // The output transform + bias/ReLU (mask) + stores of a tile are deferred into the second half-step of the
+    // NEXT tile: there they issue between that tile's MFMAs instead of waiting for the matrix pipe to drain
+    // with nothing else to do (the epilogue at the tile's own end cost 17 % of the kernel).
+    // Two accumulator sets alternate between consecutive tiles, so the deferred epilogue reads registers no
+    // MFMA of the current tile writes (a copy would wait for the pipe all the same).
+    f32x4 accA[4], accB[4], pma = {0, 0, 0, 0}, pmb = {0, 0, 0, 0};
+    size_t pg = 0;
+    bool ppv = false, psecond = false;
+    auto epilogue = [&](const f32x4 (&pacc)[4]) {
+      if (ppv && !ABL(4)) {
+        // output transform A^T m: y(x0) = m0+m1+m2, y(x0+1) = m1-m2-m3
+        f32x4 ya = pacc[0] + pacc[1] + pacc[2];
+        f32x4 yb = pacc[1] - pacc[2] - pacc[3];
+        if (MODE == MODE_FWD) {
+          ya += bias4;
+          yb += bias4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ya[r] = fmaxf(ya[r], 0.f), yb[r] = fmaxf(yb[r], 0.f);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ya[r] = pma[r] > 0.f ? ya[r] : 0.f, yb[r] = pmb[r] > 0.f ? yb[r] : 0.f;
+        }
+        if (ABL(8) && ya[0] != 12345.678f) return;  // timing only: transforms without the stores
+        if (ABL(16)) {  // timing only: each wave writes whole 128-B lines (wrong placement)
+          float* q = a.out + (pg - mt * 16 - 4 * kq) + mt * 32 + 4 * kq;
+          *reinterpret_cast<f32x4*>(q) = ya;
+          *reinterpret_cast<f32x4*>(q + 16) = yb;
+          return;
+        }
+        // streaming stores: the 64-B half lines a wave writes are not read again by this kernel; keeping them
+        // out of the L2's way is worth 6-9 % of the kernel
+        if (ABL(32)) {  // timing only: ordinary (L2 write-back) stores
+          *reinterpret_cast<f32x4*>(a.out + pg) = ya;
+          if (psecond) *reinterpret_cast<f32x4*>(a.out + pg + 32) = yb;
+          return;
+        }
+        __builtin_nontemporal_store(ya, reinterpret_cast<f32x4*>(a.out + pg));
+        if (psecond) __builtin_nontemporal_store(yb, reinterpret_cast<f32x4*>(a.out + pg + 32));
+      }
+    };
+    auto tile = [&](f32x4 (&acc)[4], const f32x4 (&pacc)[4], int t, bool have_prev) {
       const bool pv = t * 16 + li < npairs;
       if (!pv) ty = 0, j = 0;
       const float* base = lds + (ty * WT + 2 * j) * kLdsPix + 4 * kq;
-      f32x4 acc[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+      const int x0 = 2 * j;
+      const size_t g = ((size_t)(b * a.Ho + y0 + ty) * a.Wo + x0) * 32 + mt * 16 + 4 * kq;
+      const bool second = x0 + 1 < a.Wo;
+      f32x4 ma = {0, 0, 0, 0}, mb = {0, 0, 0, 0};
+      if (MODE == MODE_DGRAD && pv && !ABL(4)) {  // ReLU mask of the layer below: in flight for a whole tile
+        ma = *reinterpret_cast<const f32x4*>(a.aux + g);
+        if (second) mb = *reinterpret_cast<const f32x4*>(a.aux + g + 32);
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = f32x4{0, 0, 0, 0};
       // 6 half-steps (3 row taps x 2 cin halves); the 4 window reads of the next half-step are issued
       // before the 16 MFMAs of the current one
       f32x4 d[2][4];
@@ -189,36 +238,26 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
           acc[2] = mfma16(wu[dy][2][4 * q + e], v2[e], acc[2]);
           acc[3] = mfma16(wu[dy][3][4 * q + e], v3[e], acc[3]);
         }
+        if (h == 1 && have_prev) epilogue(pacc);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (pv && !ABL(4)) {
-        // output transform A^T m: y(x0) = m0+m1+m2, y(x0+1) = m1-m2-m3
-        const int x0 = 2 * j;
-        const size_t g = ((size_t)(b * a.Ho + y0 + ty) * a.Wo + x0) * 32 + mt * 16 + 4 * kq;
-        f32x4 ya = acc[0] + acc[1] + acc[2];
-        f32x4 yb = acc[1] - acc[2] - acc[3];
-        const bool second = x0 + 1 < a.Wo;
-        if (MODE == MODE_FWD) {
-          ya += bias4;
-          yb += bias4;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ya[r] = fmaxf(ya[r], 0.f), yb[r] = fmaxf(yb[r], 0.f);
-        } else {
-          const f32x4 ma = *reinterpret_cast<const f32x4*>(a.aux + g);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ya[r] = ma[r] > 0.f ? ya[r] : 0.f;
-          if (second) {
-            const f32x4 mb = *reinterpret_cast<const f32x4*>(a.aux + g + 32);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) yb[r] = mb[r] > 0.f ? yb[r] : 0.f;
-          }
-        }
-        *reinterpret_cast<f32x4*>(a.out + g) = ya;
-        if (second) *reinterpret_cast<f32x4*>(a.out + g + 32) = yb;
-      }
+      pma = ma, pmb = mb, pg = g, ppv = pv, psecond = second;
       j += 32;
       while (j >= PW) j -= PW, ++ty;
+    };
+    int t = tslot, done = 0;
+    for (; t < ntiles; t += 4) {
+      tile(accA, accB, t, done > 0);
+      ++done;
+      if (t + 2 < ntiles) {
+        tile(accB, accA, t + 2, true);
+        ++done;
+      }
     }
+    if (done & 1)
+      epilogue(accA);
+    else if (done)
+      epilogue(accB);
     __syncthreads();
   }
 }
@@ -361,7 +400,7 @@ __global__ __launch_bounds__(512) void conv1_fwd_kernel(Conv1Args a) {
         f32x4 v = acc[mt] + bias4[mt];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        *reinterpret_cast<f32x4*>(a.out + g + mt * 16) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + g + mt * 16));
       }
     }
   }
@@ -460,7 +499,7 @@ __global__ __launch_bounds__(512) void conv1_fwd_u8_kernel(Conv1Args a) {
         f32x4 v = acc[mt] + bias4[mt];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        *reinterpret_cast<f32x4*>(a.out + g + mt * 16) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + g + mt * 16));
       }
     }
     x += 128;

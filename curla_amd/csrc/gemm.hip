@@ -29,6 +29,7 @@ struct GemmArgs {
   int nbatch, ksplit, kchunk;
   float alpha;
   int relu, vecA, vecB;
+  int stream_c;  // output far larger than the L2s (fc data gradient): streaming stores
 };
 
 // load one BK x ROWS operand tile into registers (ROWS/32 float4 per thread)
@@ -227,7 +228,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
         }
-        *reinterpret_cast<f32x4*>(C + (size_t)m * g.ldc + n) = v;
+        if (g.stream_c)
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(C + (size_t)m * g.ldc + n));
+        else
+          *reinterpret_cast<f32x4*>(C + (size_t)m * g.ldc + n) = v;
       } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -273,6 +277,7 @@ int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const f
   kc = (kc + BK - 1) / BK * BK;  // chunk boundaries stay float4-aligned
   g.kchunk = kc;
   g.alpha = alpha, g.relu = relu;
+  g.stream_c = (long long)M * N * nbatch * (long long)sizeof(float) >= (32LL << 20);
   g.vecA = (lda % 4 == 0) && (strideA % 4 == 0) && aligned16(A);
   g.vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && aligned16(B);
   hipStream_t st = static_cast<hipStream_t>(stream);
