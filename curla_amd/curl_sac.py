@@ -691,3 +691,61 @@ class CurlSacAgent(object):
         self.critic.load_state_dict(torch.load('%s/%s_critic_%s.pt' % (model_dir, augmentation, step)))
         self.critic_target.load_state_dict(self.critic.state_dict())
         print('Loaded model %s/%s_critic_%s.pt' % (model_dir, augmentation, step))
+
+    # -- full training state (the reference only writes the three state_dicts above and
+    #    cannot resume; this adds log_alpha, the target critic, the five Adam states, the RNG streams and the step)
+    def _optimizers(self):
+        return {"actor": self.actor_optimizer, "critic": self.critic_optimizer, "log_alpha": self.log_alpha_optimizer,
+                "encoder": self.encoder_optimizer, "cpc": self.cpc_optimizer}
+
+    def _convert_opt_state(self, opt, sd, to_reference):
+        """Adam moments of an encoder fc.weight follow the weight's column order: (c,y,x) on disk like the
+        reference's Parameter, (y,x,c) in HBM."""
+        fc_of = {id(e.fc.weight): e.fc for e in (self.actor.encoder, self.critic.encoder, self.critic_target.encoder)}
+        params = [q for g in opt.param_groups for q in g["params"]]
+        state = {}
+        for i, st in sd["state"].items():
+            st = dict(st)
+            fc = fc_of.get(id(params[i]))
+            for k, v in st.items():
+                if torch.is_tensor(v):
+                    if fc is not None and v.dim() == 2:
+                        v = (fc.to_reference_layout(v) if to_reference else fc.from_reference_layout(v)).contiguous()
+                    st[k] = v.detach().cpu() if to_reference else v
+            state[i] = st
+        return {"state": state, "param_groups": sd["param_groups"]}
+
+    def save_checkpoint(self, path, step):
+        rng = {"torch": torch.get_rng_state(), "numpy": np.random.get_state()}
+        if self.device.type == "cuda":
+            rng["cuda"] = torch.cuda.get_rng_state(self.device)
+        torch.save({
+            "format": "curla_amd.checkpoint.v1", "step": int(step),
+            "actor": self.actor.state_dict(), "critic": self.critic.state_dict(),
+            "critic_target": self.critic_target.state_dict(), "curl": self.CURL.state_dict(),
+            "log_alpha": self.log_alpha.detach().cpu(),
+            "optimizers": {k: self._convert_opt_state(o, o.state_dict(), True) for k, o in self._optimizers().items()},
+            "rng": rng,
+        }, path)
+
+    def load_checkpoint(self, path, restore_rng=True):
+        """Returns the step the checkpoint was written at."""
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        if ck.get("format") != "curla_amd.checkpoint.v1":
+            raise ValueError("not a curla_amd checkpoint: %r" % (path,))
+        self.CURL.load_state_dict(ck["curl"])
+        self.actor.load_state_dict(ck["actor"])
+        self.critic.load_state_dict(ck["critic"])
+        self.critic_target.load_state_dict(ck["critic_target"])
+        with torch.no_grad():
+            self.log_alpha.copy_(ck["log_alpha"])
+        for k, o in self._optimizers().items():
+            o.load_state_dict(self._convert_opt_state(o, ck["optimizers"][k], False))
+        if restore_rng:
+            torch.set_rng_state(ck["rng"]["torch"])
+            np.random.set_state(ck["rng"]["numpy"])
+            if self.device.type == "cuda" and "cuda" in ck["rng"]:
+                torch.cuda.set_rng_state(ck["rng"]["cuda"], self.device)
+        self._anchor_cache = None
+        return ck["step"]
+

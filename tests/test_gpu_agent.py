@@ -516,3 +516,51 @@ def test_checkpoint_and_buffer_persistence(tmp_path, tiny):
     rb2 = curla_amd.ReplayBuffer((9, 34, 40), (2,), 16, 4, torch.device("cuda"), aug)
     rb2.load(str(d))
     assert rb2.idx == 5 and torch.equal(rb2.obses[:5], rb.obses[:5]) and torch.equal(rb2.rewards[:5], rb.rewards[:5])
+
+
+def test_full_checkpoint_resumes_bitwise(tmp_path):
+    """save_checkpoint / load_checkpoint: parameters, targets, log_alpha, the five Adam
+    states and the RNG streams -- a resumed run continues bit-for-bit (the kernels are deterministic)."""
+    import curla_amd
+
+    def ring(aug):
+        rb = curla_amd.ReplayBuffer((9, 34, 40), (2,), 32, 8, torch.device("cuda"), aug)
+        rs = np.random.RandomState(1)
+        for i in range(20):
+            rb.add(rs.randint(0, 256, (9, 34, 40), dtype=np.uint8), rs.uniform(-1, 1, 2), rs.randn(),
+                   rs.randint(0, 256, (9, 34, 40), dtype=np.uint8), i % 9 == 8)
+        return rb
+
+    np.random.seed(5)
+    torch.manual_seed(5)
+    agent, aug = make_agent((9, 28, 34), (34, 40), 64)
+    rb, L = ring(aug), NullLogger()
+    for step in range(3):
+        agent.update(rb, L, step)
+    ck = tmp_path / "resume.pt"
+    agent.save_checkpoint(str(ck), 3)
+    for step in range(3, 6):
+        agent.update(rb, L, step)
+    want = {k: v.clone() for k, v in agent.critic.state_dict().items()}
+    want_actor = {k: v.clone() for k, v in agent.actor.state_dict().items()}
+    want_alpha = agent.log_alpha.detach().clone()
+
+    np.random.seed(99)  # a different process state: everything must come from the file
+    torch.manual_seed(99)
+    other, aug2 = make_agent((9, 28, 34), (34, 40), 64)
+    rb2 = ring(aug2)
+    assert other.load_checkpoint(str(ck)) == 3
+    # Adam moments of fc.weight are stored in the reference column order and converted back
+    st = torch.load(ck, weights_only=False)["optimizers"]["critic"]["state"]
+    assert any(v["exp_avg"].dim() == 2 and v["exp_avg"].shape[0] == 50 for v in st.values())
+    for step in range(3, 6):
+        other.update(rb2, L, step)
+    torch.cuda.synchronize()
+    for k, v in want.items():
+        assert torch.equal(v, other.critic.state_dict()[k]), k
+    for k, v in want_actor.items():
+        assert torch.equal(v, other.actor.state_dict()[k]), k
+    assert torch.equal(want_alpha, other.log_alpha.detach())
+    with pytest.raises(ValueError):
+        torch.save({"format": "something else"}, tmp_path / "bad.pt")
+        other.load_checkpoint(str(tmp_path / "bad.pt"))

@@ -241,3 +241,23 @@ def test_reference_style_buffer_goes_through_tensor_contract():
         _lib.set_trace_hook(None)
     conv1 = [a for n, a in seen if n == "curla_conv1_fwd"]
     assert len(conv1) == 5 and all(a[1] == 0 for a in conv1)  # src_is_u8 == 0
+
+
+def test_full_checkpoint_file_layout(tmp_path):
+    """save_checkpoint writes reference-layout tensors (+ optimizer, RNG, step) and load_checkpoint refuses other files."""
+    import curla_amd
+    aug = curla_amd.RandomCrop((40, 40), (34, 34))
+    a = curla_amd.CurlSacAgent((9, 34, 34), (2,), torch.device("cpu"), aug, hidden_dim=32)
+    p = tmp_path / "ck.pt"
+    a.save_checkpoint(str(p), 11)
+    ck = torch.load(p, weights_only=False)
+    assert ck["format"] == "curla_amd.checkpoint.v1" and ck["step"] == 11
+    assert set(ck["optimizers"]) == {"actor", "critic", "log_alpha", "encoder", "cpc"}
+    assert list(ck["critic"].keys()) == list(a.critic.state_dict().keys())
+    b = curla_amd.CurlSacAgent((9, 34, 34), (2,), torch.device("cpu"), aug, hidden_dim=32)
+    assert b.load_checkpoint(str(p)) == 11
+    for k, v in a.actor.state_dict().items():
+        assert torch.equal(v, b.actor.state_dict()[k]), k
+    torch.save({"format": "x"}, tmp_path / "bad.pt")
+    with pytest.raises(ValueError):
+        b.load_checkpoint(str(tmp_path / "bad.pt"))
