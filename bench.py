@@ -91,7 +91,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    # CURLA_BENCH_FORCE_DIST=1: take the RCCL code path with a single rank (1-GPU check of the N>1 branch)
+    distributed = world > 1 or os.environ.get("CURLA_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if distributed:
@@ -170,11 +171,33 @@ def main():
     ws = agent._ws(BATCH)
     assert bool(torch.isfinite(ws.scalars).all()) and bool(torch.isfinite(agent._critic_flat).all()), "non-finite state"
 
+    allreduce = None
     if distributed:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # outside the timed region: cost of the three gradient all-reduces of one update, each timed alone
+        # (SURVEY.md 8e reporting: all-reduce time per phase and the bus bandwidth it reaches)
+        lay = agent._lay
+        buckets = {"critic": agent._critic_gflat[lay["enc"][0]:lay["total"]], "actor": agent._actor_gflat,
+                   "cpc": agent._critic_gflat[0:lay["enc"][1]]}
+        allreduce = {}
+        for name, buf in buckets.items():
+            scratch = torch.zeros_like(buf)
+            for _ in range(3):
+                dist.all_reduce(scratch)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                dist.all_reduce(scratch)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 10
+            nbytes = scratch.numel() * 4
+            allreduce[name] = {"bytes": nbytes, "ms": ms,
+                               "bus_GBps": 2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9}
 
     if rank == 0:
         kflops = sum(p[2] for p in ev_pairs)
@@ -213,6 +236,8 @@ def main():
                                          "algorithmic in+out = 152 MB per launch (mean of the 3 layers)",
                          "launches": len(ev_pairs), "avg_launch_ms": kms / max(1, len(ev_pairs))},
         }
+        if allreduce is not None:
+            out["allreduce"] = allreduce
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
