@@ -6,10 +6,27 @@
 #include "../../include/curla_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// v_mfma_f32_16x16x4_f32: D(16x16) += A(16x4) * B(4x16), exact f32 (a k-ordered
-// fmaf chain).  Lane l holds A[i = l&15][k = l>>4] and B[k = l>>4][j = l&15];
-// D element (row = 4*(l>>4) + r, col = l&15) is register r of lane l.
+// 1-D Winograd input transform B^T d = (d0-d2, d1+d2, d2-d1, d1-d3) on two channels at once with packed fp32
+// adds (4 VALU issues instead of 8; the compiler scalarises vector arithmetic whose components feed separate
+// MFMAs).  In place: v0 -> d0, v2 -> d2, v3 -> d3, v1 -> t.  The block is inline asm, which the compiler's hazard
+// recogniser cannot look into, so the two MFMA hazards a VALU write can hit are handled here by construction:
+//   * VALU write -> MFMA read within 2 wait states: the trailing s_nop 1;
+//   * MFMA SrcC read -> VALU write of that VGPR within 7 wait states: every register written here is either an
+//     LDS-read destination (d0, d2, d3: the read's latency separates it from any earlier MFMA) or `t`, which the
+//     caller keeps alive for the whole kernel so that it can never be a just-released accumulator.
+// tools/check_asm_hazards.py scans the generated ISA for both (tests/test_capi.py runs it).
+__device__ __forceinline__ void winograd_bt_pk(f32x2& d0, const f32x2& d1, f32x2& d2, f32x2& d3, f32x2& t) {
+  asm("v_pk_add_f32 %0, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %2, %4, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %3, %4, %1\n\t"
+      "v_pk_add_f32 %1, %1, %4 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_nop 1"
+      : "+v"(d0), "+v"(d2), "+v"(d3), "+v"(t)
+      : "v"(d1));
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
   if (MODE == MODE_FWD) bias4 = *reinterpret_cast<const f32x4*>(a.aux + mt * 16 + 4 * kq);
   __syncthreads();
 
+  f32x2 wt = {0, 0};  // winograd_bt_pk's temporary, live for the whole kernel (see common.h)
   const int nitems = a.B * a.nbands;
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int band = item / a.B, b = item - band * a.B;  // band-major: every workgroup sees every band size
@@ -230,13 +231,20 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         const f32x4 d0 = d[h & 1][0], d1 = d[h & 1][1], d2 = d[h & 1][2], d3 = d[h & 1][3];
-        const f32x4 v0 = d0 - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - d3;  // input transform B^T d
+        // input transform B^T d = (d0-d2, d1+d2, d2-d1, d1-d3), two channels per packed VALU op
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc[0] = mfma16(wu[dy][0][4 * q + e], v0[e], acc[0]);
-          acc[1] = mfma16(wu[dy][1][4 * q + e], v1[e], acc[1]);
-          acc[2] = mfma16(wu[dy][2][4 * q + e], v2[e], acc[2]);
-          acc[3] = mfma16(wu[dy][3][4 * q + e], v3[e], acc[3]);
+        for (int p = 0; p < 2; ++p) {
+          f32x2 v0 = {d0[2 * p], d0[2 * p + 1]}, e1 = {d1[2 * p], d1[2 * p + 1]};
+          f32x2 v2 = {d2[2 * p], d2[2 * p + 1]}, v3 = {d3[2 * p], d3[2 * p + 1]};
+          winograd_bt_pk(v0, e1, v2, v3, wt);
+#pragma unroll
+          for (int r = 0; r < 2; ++r) {
+            const int e = 2 * p + r;
+            acc[0] = mfma16(wu[dy][0][4 * q + e], v0[r], acc[0]);
+            acc[1] = mfma16(wu[dy][1][4 * q + e], wt[r], acc[1]);
+            acc[2] = mfma16(wu[dy][2][4 * q + e], v2[r], acc[2]);
+            acc[3] = mfma16(wu[dy][3][4 * q + e], v3[r], acc[3]);
+          }
         }
         if (h == 1 && have_prev) epilogue(pacc);
         __builtin_amdgcn_sched_barrier(0);

@@ -46,3 +46,20 @@ def test_missing_library_fails_loudly(monkeypatch):
         _lib.load()
     with pytest.raises(_lib.CurlaHipError):
         _lib.call("curla_mean", None, 1, None, None)
+
+
+def test_inline_asm_vector_ops_clear_of_mfma_hazards(tmp_path):
+    """common.h's packed Winograd transform is inline asm, invisible to the compiler's hazard recogniser; the
+    generated ISA must keep every such VALU write clear of the MFMA RAW / SrcC-WAR windows."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    asm = tmp_path / "conv.s"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S",
+                           "--cuda-device-only", "-o", str(asm), os.path.join(root, "curla_amd/csrc/conv.hip")],
+                          stderr=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools/check_asm_hazards.py"), str(asm)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "inline-asm VALU ops checked, 0 hazard(s)" in r.stdout and not r.stdout.startswith("0 inline")
