@@ -251,7 +251,16 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
       }
       pma = ma, pmb = mb, pg = g, ppv = pv, psecond = second;
       j += 32;
-      while (j >= PW) j -= PW, ++ty;
+      if (PW >= 16) {  // wave-uniform: at most two row wraps per tile step, done without a divergent loop
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+          const bool wrap = j >= PW;
+          j = wrap ? j - PW : j;
+          ty = wrap ? ty + 1 : ty;
+        }
+      } else {
+        while (j >= PW) j -= PW, ++ty;
+      }
     };
     int t = tslot, done = 0;
     for (; t < ntiles; t += 4) {
@@ -547,6 +556,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) {
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) acc[dy][k][ct] = f32x4{0, 0, 0, 0};
   float bsum = 0.f;
+  f32x2 wt = {0, 0};  // winograd_bt_pk's temporary, live for the whole kernel (see common.h)
 
   const int PW = (a.Wo + 1) >> 1;  // pixel pairs per gradient row
   const int nitems = a.B * a.nbands;
@@ -585,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) {
     // (pairs of a k-step are 2 apart = 4 pixels: the two lane groups of an LDS half hit disjoint banks)
     // advances by 8 pairs per call, so (fy, fj) are kept incrementally
     int fy = ((uslot & 1) + 2 * kq) / PW, fj = ((uslot & 1) + 2 * kq) - fy * PW;
-    auto fetch = [&](int u, float (&gv)[2], float (&dv)[3][4][2]) {
+    auto fetch = [&](int u, float (&gv)[2], f32x2 (&dv)[3][4]) {
       const int q = (u >> 1) * 8 + (u & 1) + 2 * kq;
       const bool pv = (u < nunits) && (q < npairs);
       const int ty = pv ? fy : 0, x0 = pv ? 2 * fj : 0;
@@ -598,29 +608,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const float* qd = ip + (dy * a.Wi + c) * kLdsPix;
-          dv[dy][c][0] = qd[0];
-          dv[dy][c][1] = qd[16];
+          dv[dy][c] = f32x2{qd[0], qd[16]};  // the two cin tiles of one window pixel (one ds_read2_b32)
         }
       fj += 8;
-      while (fj >= PW) fj -= PW, ++fy;
+      if (PW >= 8) {  // wave-uniform: at most one row wrap per step, done without a divergent loop
+        const bool wrap = fj >= PW;
+        fj = wrap ? fj - PW : fj;
+        fy = wrap ? fy + 1 : fy;
+      } else {
+        while (fj >= PW) fj -= PW, ++fy;
+      }
     };
-    auto mma = [&](const float (&gv)[2], const float (&dv)[3][4][2]) {
+    auto mma = [&](const float (&gv)[2], f32x2 (&dv)[3][4]) {
       bsum += gv[0] + gv[1];
       const float g0 = gv[0], g1 = gv[0] + gv[1], g2 = gv[0] - gv[1], g3 = -gv[1];
 #pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
+      for (int dy = 0; dy < 3; ++dy) {
+        // (d0-d2, d1+d2, d2-d1, d1-d3) for both cin tiles with 4 packed adds
+        winograd_bt_pk(dv[dy][0], dv[dy][1], dv[dy][2], dv[dy][3], wt);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
-          const float d0 = dv[dy][0][ct], d1 = dv[dy][1][ct], d2 = dv[dy][2][ct], d3 = dv[dy][3][ct];
-          acc[dy][0][ct] = mfma16(g0, d0 - d2, acc[dy][0][ct]);
-          acc[dy][1][ct] = mfma16(g1, d1 + d2, acc[dy][1][ct]);
-          acc[dy][2][ct] = mfma16(g2, d2 - d1, acc[dy][2][ct]);
-          acc[dy][3][ct] = mfma16(g3, d1 - d3, acc[dy][3][ct]);
+          acc[dy][0][ct] = mfma16(g0, dv[dy][0][ct], acc[dy][0][ct]);
+          acc[dy][1][ct] = mfma16(g1, wt[ct], acc[dy][1][ct]);
+          acc[dy][2][ct] = mfma16(g2, dv[dy][2][ct], acc[dy][2][ct]);
+          acc[dy][3][ct] = mfma16(g3, dv[dy][3][ct], acc[dy][3][ct]);
         }
+      }
     };
     // software pipeline over this wave's k-steps (two register sets, no copies): the LDS reads of the
     // next step are in flight while the 24 MFMAs of the current one issue
-    float gA[2], gB[2], dA[3][4][2], dB[3][4][2];
+    float gA[2], gB[2];
+    f32x2 dA[3][4], dB[3][4];
     fetch(uslot, gA, dA);
     for (int u = uslot; u < nunits; u += 4) {
       fetch(u + 2, gB, dB);

@@ -62,6 +62,13 @@ def main():
     def report(name, us, flop):
         print(f"{name:46s} {us:9.1f} us  {flop / us / 1e6:7.1f} TF  {flop / us * 1e6 / PEAK * 100:5.1f}%", flush=True)
 
+    # the first ~0.5 s of MFMA work in a process runs ~8 % slow (clock ramp): burn it before measuring
+    xw, ww, bw = torch.relu(r(B, 37, 37, 32)), r(32, 32, 3, 3) * 0.1, r(32) * 0.1
+    ow = torch.empty(B, 35, 35, 32, device=dev)
+    for _ in range(6000):
+        ops.conv_s1_fwd(xw, ww, bw, ow)
+    torch.cuda.synchronize()
+
     if "conv" in args.what:
         w, b = r(32, 32, 3, 3) * 0.1, r(32) * 0.1
         for fl in flags:
