@@ -296,6 +296,7 @@ struct Conv1Args {
   float* out;          // [B][Ho][Wo][32]
   int B, C, Hs, Ws, Hc, Wc, Ho, Wo, th, nbands;
   float scale;
+  int dbg;
 };
 
 enum { SRC_U8 = 0, SRC_F32 = 1, SRC_NHWC = 2 };  // u8 ring / float NCHW tensor / float NHWC tensor
@@ -433,27 +434,82 @@ __global__ __launch_bounds__(512) void conv1_fwd_kernel(Conv1Args a) {
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int conv1_row_bytes(int Wc, int C) { return ((Wc * C + 15) & ~15) + 16; }
 
-__device__ __forceinline__ void conv1_stage_u8(uint8_t* lds, const uint8_t* frames, const int64_t* idx,
-                                               const int32_t* h1, const int32_t* w1, int b, int C, int Hs, int Ws,
-                                               int Wc, int r0, int rows, int RSb, int tid, int nthreads) {
-  const int64_t fi = idx ? idx[b] : b;
-  const int oh = h1 ? h1[b] : 0, ow = w1 ? w1[b] : 0;
-  const uint8_t* frame = frames + (size_t)fi * Hs * Ws * C;
+// One pass of the byte staging, split into its two halves so that a kernel can put other work between the
+// loads and the LDS stores: U 16-byte runs per thread, all their dword loads in flight together.
+template <int U>
+struct Conv1StageRegs {
+  uint32_t dw[U][5], sh[U];
+  int dst[U];
+};
+
+template <int U>
+__device__ __forceinline__ void conv1_stage_u8_issue(Conv1StageRegs<U>& rg, const uint8_t* frame, int oh, int ow, int C,
+                                                     int Ws, int Wc, int r0, int rows, int RSb, int i0, int tid,
+                                                     int nthreads) {
   const int runs = (Wc * C + 15) >> 4;  // 16-byte runs per row
-  for (int i = tid; i < rows * runs; i += nthreads) {
-    const int r = i / runs, g = i - r * runs;
+  const int total = rows * runs;
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    const int i = i0 + tid + k * nthreads;
+    const bool ok = i < total;
+    const int ic = ok ? i : 0;
+    const int r = ic / runs, g = ic - r * runs;
     const uint8_t* p = frame + ((size_t)(oh + r0 + r) * Ws + ow) * C + 16 * g;
     const uintptr_t ad = reinterpret_cast<uintptr_t>(p);
     const uint32_t* q = reinterpret_cast<const uint32_t*>(ad & ~(uintptr_t)3);
-    const uint32_t sh = (uint32_t)(ad & 3);
-    const uint32_t d0 = q[0], d1 = q[1], d2 = q[2], d3 = q[3];
-    const uint32_t d4 = sh ? q[4] : 0u;  // only touch the fifth dword when the run straddles it
+    rg.sh[k] = (uint32_t)(ad & 3);
+    rg.dst[k] = ok ? r * RSb + 16 * g : -1;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rg.dw[k][e] = ok ? q[e] : 0u;
+    rg.dw[k][4] = (ok && rg.sh[k]) ? q[4] : 0u;  // only touch the fifth dword when the run straddles it
+  }
+}
+
+template <int U>
+__device__ __forceinline__ void conv1_stage_u8_commit(const Conv1StageRegs<U>& rg, uint8_t* lds) {
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
     uint4 o;
-    o.x = __builtin_amdgcn_alignbyte(d1, d0, sh);
-    o.y = __builtin_amdgcn_alignbyte(d2, d1, sh);
-    o.z = __builtin_amdgcn_alignbyte(d3, d2, sh);
-    o.w = __builtin_amdgcn_alignbyte(d4, d3, sh);
-    *reinterpret_cast<uint4*>(lds + r * RSb + 16 * g) = o;
+    o.x = __builtin_amdgcn_alignbyte(rg.dw[k][1], rg.dw[k][0], rg.sh[k]);
+    o.y = __builtin_amdgcn_alignbyte(rg.dw[k][2], rg.dw[k][1], rg.sh[k]);
+    o.z = __builtin_amdgcn_alignbyte(rg.dw[k][3], rg.dw[k][2], rg.sh[k]);
+    o.w = __builtin_amdgcn_alignbyte(rg.dw[k][4], rg.dw[k][3], rg.sh[k]);
+    if (rg.dst[k] >= 0) *reinterpret_cast<uint4*>(lds + rg.dst[k]) = o;
+  }
+}
+
+__device__ __forceinline__ void conv1_stage_u8(uint8_t* lds, const uint8_t* frames, const int64_t* idx,
+                                               const int32_t* h1, const int32_t* w1, int b, int C, int Hs, int Ws,
+                                               int Wc, int r0, int rows, int RSb, int tid, int nthreads,
+                                               int first_run = 0) {
+  const int64_t fi = idx ? idx[b] : b;
+  const int oh = h1 ? h1[b] : 0, ow = w1 ? w1[b] : 0;
+  const uint8_t* frame = frames + (size_t)fi * Hs * Ws * C;
+  const int total = rows * ((Wc * C + 15) >> 4);
+  constexpr int U = 4;
+  for (int i0 = first_run; i0 < total; i0 += nthreads * U) {
+    Conv1StageRegs<U> rg;
+    conv1_stage_u8_issue<U>(rg, frame, oh, ow, C, Ws, Wc, r0, rows, RSb, i0, tid, nthreads);
+    conv1_stage_u8_commit<U>(rg, lds);
+  }
+}
+
+// float4 copy of `n4` contiguous float4 from HBM into the pixel-padded LDS band layout (8 float4 per pixel ->
+// stride kLdsPix floats), U loads in flight per thread per pass
+__device__ __forceinline__ void stage_band_f32(float* lds_band, const float* src, int n4, int tid, int nthreads) {
+  constexpr int U = 6;
+  for (int f0 = 0; f0 < n4; f0 += nthreads * U) {
+    f32x4 v[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int f = f0 + tid + k * nthreads;
+      v[k] = f < n4 ? *reinterpret_cast<const f32x4*>(src + (size_t)f * 4) : f32x4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int f = f0 + tid + k * nthreads;
+      if (f < n4) *reinterpret_cast<f32x4*>(lds_band + (f >> 3) * kLdsPix + (f & 7) * 4) = v[k];
+    }
   }
 }
 
@@ -466,6 +522,23 @@ __global__ __launch_bounds__(512) void conv1_fwd_u8_kernel(Conv1Args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int RSb = conv1_row_bytes(a.Wc, C);
+
+  const int item = blockIdx.x;
+  const int band = item / a.B, b = item - band * a.B;
+  const int y0 = band * a.th;
+  const int tha = min(a.th, a.Ho - y0);
+  // the first staging pass (7 x 512 runs: a whole 76x76x9 crop) is issued before the weight phase, whose two
+  // barriers and LDS gather then run under the loads' latency; its LDS stores come after (same LDS region)
+  constexpr int U0 = 7;
+  Conv1StageRegs<U0> rg0;
+  const uint8_t* frame0;
+  int oh0, ow0;
+  {
+    const int64_t fi = a.idx ? a.idx[b] : b;
+    oh0 = a.h1 ? a.h1[b] : 0, ow0 = a.w1 ? a.w1[b] : 0;
+    frame0 = static_cast<const uint8_t*>(a.src) + (size_t)fi * a.Hs * a.Ws * C;
+    if (!ABL(1)) conv1_stage_u8_issue<U0>(rg0, frame0, oh0, ow0, C, a.Ws, a.Wc, 2 * y0, 2 * tha + 1, RSb, 0, tid, 512);
+  }
 
   for (int i = tid; i < 32 * C * 9; i += 512) lds[i] = a.w[i];
   __syncthreads();
@@ -483,17 +556,16 @@ __global__ __launch_bounds__(512) void conv1_fwd_u8_kernel(Conv1Args a) {
   for (int mt = 0; mt < 2; ++mt) bias4[mt] = *reinterpret_cast<const f32x4*>(a.bias + mt * 16 + 4 * kq);
   __syncthreads();
 
-  const int item = blockIdx.x;
-  const int band = item / a.B, b = item - band * a.B;
-  const int y0 = band * a.th;
-  const int tha = min(a.th, a.Ho - y0);
   uint8_t* ldsb = reinterpret_cast<uint8_t*>(lds);
-  conv1_stage_u8(ldsb, static_cast<const uint8_t*>(a.src), a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Wc, 2 * y0,
-                 2 * tha + 1, RSb, tid, 512);
+  if (!ABL(1)) {
+    conv1_stage_u8_commit<U0>(rg0, ldsb);
+    conv1_stage_u8(ldsb, static_cast<const uint8_t*>(a.src), a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Wc, 2 * y0,
+                   2 * tha + 1, RSb, tid, 512, /*first_run=*/U0 * 512);  // taller bands: the rest
+  }
   __syncthreads();
 
   const int npix = tha * a.Wo;
-  const int ntiles = (npix + 15) >> 4;
+  const int ntiles = ABL(64) ? 0 : (npix + 15) >> 4;
   int ty = (wave * 16 + li) / a.Wo, x = (wave * 16 + li) - ty * a.Wo;
   for (int t = wave; t < ntiles; t += 8) {
     const bool pv = t * 16 + li < npix;
@@ -509,7 +581,7 @@ __global__ __launch_bounds__(512) void conv1_fwd_u8_kernel(Conv1Args a) {
       acc[0] = mfma16(wr[s][0], v, acc[0]);
       acc[1] = mfma16(wr[s][1], v, acc[1]);
     }
-    if (pv) {
+    if (pv && !ABL(4)) {
       const size_t g = ((size_t)(b * a.Ho + y0 + ty) * a.Wo + x) * 32 + 4 * kq;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
@@ -832,38 +904,63 @@ __global__ __launch_bounds__(512) void wgrad1_u8_kernel(Wgrad1Args a) {
     const int tha = min(a.th, a.Ho - y0);
     conv1_stage_u8(ldsb, static_cast<const uint8_t*>(a.src), a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Wc, 2 * y0,
                    2 * tha + 1, RSb, tid, 512);
-    {
-      const float* pg = a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
-      const int ng = tha * a.Wo * 8;
-      for (int f = tid; f < ng; f += 512)
-        *reinterpret_cast<f32x4*>(ldsg + (f >> 3) * kLdsPix + (f & 7) * 4) =
-            *reinterpret_cast<const f32x4*>(pg + (size_t)f * 4);
-    }
+    stage_band_f32(ldsg, a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32, tha * a.Wo * 8, tid, 512);
     __syncthreads();
     const int npix = tha * a.Wo;
     const int nunits = ((npix + 15) >> 4) << 2;
-    for (int u = wave; u < nunits; u += 8) {
+    // the lane's pixel p(u) = (u>>2)*16 + (u&3) + 4*kq advances by 32 per iteration: (ty, x) are kept
+    // incrementally (no division in the loop); the bytes are multiplied unscaled, `scale` is applied once to
+    // the accumulated sums
+    int ty = ((wave >> 2) * 16 + (wave & 3) + 4 * kq) / a.Wo, x = ((wave >> 2) * 16 + (wave & 3) + 4 * kq) - ty * a.Wo;
+    // fetch() runs for u = wave, wave+8, ... in order and leaves (ty, x) at the next unit's pixel
+    auto fetch = [&](int u, float (&av)[2], float (&bv)[NT]) {
       const int p = (u >> 2) * 16 + (u & 3) + 4 * kq;
-      const bool pv = p < npix;
-      const int pc = pv ? p : 0;
-      const int ty = pc / a.Wo, x = pc - ty * a.Wo;
-      const float* gp = ldsg + (ty * a.Wo + x) * kLdsPix + li;
-      const float a0 = pv ? gp[0] : 0.f, a1 = pv ? gp[16] : 0.f;
-      bsum[0] += a0;
-      bsum[1] += a1;
-      const uint8_t* ip = ldsb + 2 * ty * RSb + 2 * x * C;
-      float bv[NT];
+      const bool pv = (u < nunits) && (p < npix);
+      const int cy = pv ? ty : 0, cx = pv ? x : 0;
+      const float* gp = ldsg + (cy * a.Wo + cx) * kLdsPix + li;
+      av[0] = pv ? gp[0] : 0.f;
+      av[1] = pv ? gp[16] : 0.f;
+      const uint8_t* ip = ldsb + 2 * cy * RSb + 2 * cx * C;
 #pragma unroll
       for (int t = 0; t < NT; ++t) bv[t] = (float)ip[koff[t]];
+      x += 32;
+      if (a.Wo >= 32) {  // wave-uniform: one wrap at most
+        const bool wrap = x >= a.Wo;
+        x = wrap ? x - a.Wo : x;
+        ty = wrap ? ty + 1 : ty;
+      } else {
+        while (x >= a.Wo) x -= a.Wo, ++ty;
+      }
+    };
+    auto mma = [&](const float (&av)[2], const float (&bv)[NT]) {
+      bsum[0] += av[0];
+      bsum[1] += av[1];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const float v = bv[t] * a.scale;
-        acc[0][t] = mfma16(a0, v, acc[0][t]);
-        acc[1][t] = mfma16(a1, v, acc[1][t]);
+        acc[0][t] = mfma16(av[0], bv[t], acc[0][t]);
+        acc[1][t] = mfma16(av[1], bv[t], acc[1][t]);
       }
+    };
+    // two register sets: the LDS reads (and byte -> float conversions) of the next unit are in flight while the
+    // MFMAs of the current one issue
+    float aA[2], aB[2], bA[NT], bB[NT];
+    fetch(wave, aA, bA);
+    for (int u = wave; u < nunits; u += 16) {
+      fetch(u + 8, aB, bB);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(aA, bA);
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(u + 16, aA, bA);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(aB, bB);
+      __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
   }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[i][t] *= a.scale;
 
   bsum[0] += __shfl_xor(bsum[0], 16);
   bsum[0] += __shfl_xor(bsum[0], 32);
@@ -1097,6 +1194,7 @@ int curla_conv1_fwd(const void* src, int src_kind, const int64_t* idx, const int
   a.B = B, a.C = C, a.Hs = Hs, a.Ws = Ws, a.Hc = Hc, a.Wc = Wc;
   a.Ho = (Hc - 3) / 2 + 1, a.Wo = (Wc - 3) / 2 + 1;
   a.scale = scale;
+  a.dbg = ABL_HOST;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t wl = (size_t)32 * C * 9 * sizeof(float);
   if (src_kind == 1) {

@@ -103,7 +103,12 @@ def main():
         w0 = r(32, 9, 3, 3) * 0.1
         out = torch.empty(B, 37, 37, 32, device=dev)
         fl_ = 2.0 * B * 37 * 37 * 32 * 9 * 9
-        report("conv1_fwd u8 84->76->37", timeit(lambda: ops.conv1_fwd(obs, w0, b, out)), fl_)
+        for fl in flags:
+            if flags != [0]:
+                lib.curla_debug_ablate(fl)
+            report(f"[abl {fl}] conv1_fwd u8 84->76->37", timeit(lambda: ops.conv1_fwd(obs, w0, b, out)), fl_)
+        if flags != [0]:
+            lib.curla_debug_ablate(0)
         g = r(B, 37, 37, 32)
         dw0 = torch.empty(32, 9, 3, 3, device=dev)
         ws0 = torch.empty(ops.wgrad_workspace_floats(9), device=dev)
