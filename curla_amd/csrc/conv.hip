@@ -549,7 +549,8 @@ __global__ __launch_bounds__(512) void conv1_fwd_u8_kernel(Conv1Args a) {
     const bool ok = rr < 3 * C;
     const int dx = ok ? rr / C : 0, c = ok ? rr - dx * C : 0;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) wr[s][mt] = ok ? lds[((mt * 16 + li) * C + c) * 9 + dy * 3 + dx] : 0.f;
+    // the 1/255 of `obs / 255.` (encoder.py:78) is folded into the weights: the bytes go to the MFMA unscaled
+    for (int mt = 0; mt < 2; ++mt) wr[s][mt] = ok ? lds[((mt * 16 + li) * C + c) * 9 + dy * 3 + dx] * a.scale : 0.f;
   }
   f32x4 bias4[2];
 #pragma unroll
@@ -577,9 +578,8 @@ __global__ __launch_bounds__(512) void conv1_fwd_u8_kernel(Conv1Args a) {
     f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      const float v = bv[s] * a.scale;
-      acc[0] = mfma16(wr[s][0], v, acc[0]);
-      acc[1] = mfma16(wr[s][1], v, acc[1]);
+      acc[0] = mfma16(wr[s][0], bv[s], acc[0]);
+      acc[1] = mfma16(wr[s][1], bv[s], acc[1]);
     }
     if (pv && !ABL(4)) {
       const size_t g = ((size_t)(b * a.Ho + y0 + ty) * a.Wo + x) * 32 + 4 * kq;
