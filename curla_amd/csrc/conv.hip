@@ -1009,8 +1009,17 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* partial
   const int i = blockIdx.x * 32 + c;
   const int n = nw + 32;
   float s = 0.f;
-  if (i < n)
-    for (int k = part; k < nslabs; k += 32) s += partial[(size_t)k * n + i];
+  if (i < n) {
+    int k = part;
+    for (; k + 7 * 32 < nslabs; k += 8 * 32) {  // 8 slabs in flight, added in slab order
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = partial[(size_t)(k + 32 * u) * n + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; k < nslabs; k += 32) s += partial[(size_t)k * n + i];
+  }
   sm[part][c] = s;
   __syncthreads();
   if (part == 0 && i < n) {

@@ -37,7 +37,17 @@ __global__ void fc_ln_fwd_kernel(const float* P, int nsplit, long long sSplit, i
   if (row >= B) return;
   float v = 0.f;
   if (f < F) {
-    for (int s = 0; s < nsplit; ++s) v += P[s * sSplit + (size_t)row * ldp + f];
+    // same summation order as a plain loop, but 8 partials are fetched together (the loop is pure load latency)
+    const float* p = P + (size_t)row * ldp + f;
+    int s = 0;
+    for (; s + 8 <= nsplit; s += 8) {
+      float t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = p[(s + k) * sSplit];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v += t[k];
+    }
+    for (; s < nsplit; ++s) v += p[s * sSplit];
     v += bias[f];
   }
   const float mean = wave_sum(f < F ? v : 0.f) / F;
@@ -77,12 +87,21 @@ __global__ __launch_bounds__(1024) void ln_param_grad_kernel(const float* dy, co
   __shared__ float sg[16][64], sb[16][64];
   const int f = threadIdx.x & 63, part = threadIdx.x >> 6;
   float ag = 0.f, ab = 0.f;
-  if (f < F)
-    for (int b = part; b < B; b += 16) {
+  if (f < F) {
+    int b = part;
+    for (; b + 7 * 16 < B; b += 8 * 16) {  // 8 rows in flight, accumulated in row order
+      float d[8], x[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) d[k] = dy[(size_t)(b + 16 * k) * F + f], x[k] = xhat[(size_t)(b + 16 * k) * F + f];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) ag += d[k] * x[k], ab += d[k];
+    }
+    for (; b < B; b += 16) {
       const float d = dy[(size_t)b * F + f];
       ag += d * xhat[(size_t)b * F + f];
       ab += d;
     }
+  }
   sg[part][f] = ag, sb[part][f] = ab;
   __syncthreads();
   if (part == 0 && f < F) {
@@ -102,8 +121,17 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* X, int M, int
   const int n = blockIdx.x * 32 + c;
   const float* x = X + blockIdx.y * sX;
   float a = 0.f;
-  if (n < N)
-    for (int m = part; m < M; m += 32) a += x[(size_t)m * ldx + n];
+  if (n < N) {
+    int m = part;
+    for (; m + 7 * 32 < M; m += 8 * 32) {  // 8 rows in flight, accumulated in row order
+      float t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = x[(size_t)(m + 32 * k) * ldx + n];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a += t[k];
+    }
+    for (; m < M; m += 32) a += x[(size_t)m * ldx + n];
+  }
   sm[part][c] = a;
   __syncthreads();
   if (part == 0 && n < N) {
