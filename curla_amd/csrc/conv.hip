@@ -167,16 +167,17 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
     // Two accumulator sets alternate between consecutive tiles, so the deferred epilogue reads registers no
     // MFMA of the current tile writes (a copy would wait for the pipe all the same).
     f32x4 accA[4], accB[4], pma = {0, 0, 0, 0}, pmb = {0, 0, 0, 0};
-    size_t pg = 0;
+    // per-item (wave-uniform) base pointers: a tile only adds a 32-bit element offset
+    float* const out_item = a.out + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
+    const float* const aux_item = a.aux + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
+    int pg = 0;
     bool ppv = false, psecond = false;
     auto epilogue = [&](const f32x4 (&pacc)[4]) {
       if (ppv && !ABL(4)) {
         // output transform A^T m: y(x0) = m0+m1+m2, y(x0+1) = m1-m2-m3
         f32x4 ya = pacc[0] + pacc[1] + pacc[2];
         f32x4 yb = pacc[1] - pacc[2] - pacc[3];
-        if (MODE == MODE_FWD) {
-          ya += bias4;
-          yb += bias4;
+        if (MODE == MODE_FWD) {  // (the bias came in through the accumulators' initial values)
 #pragma unroll
           for (int r = 0; r < 4; ++r) ya[r] = fmaxf(ya[r], 0.f), yb[r] = fmaxf(yb[r], 0.f);
         } else {
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
         }
         if (ABL(8) && ya[0] != 12345.678f) return;  // timing only: transforms without the stores
         if (ABL(16)) {  // timing only: each wave writes whole 128-B lines (wrong placement)
-          float* q = a.out + (pg - mt * 16 - 4 * kq) + mt * 32 + 4 * kq;
+          float* q = out_item + pg - mt * 16 - 4 * kq + mt * 32 + 4 * kq;
           *reinterpret_cast<f32x4*>(q) = ya;
           *reinterpret_cast<f32x4*>(q + 16) = yb;
           return;
@@ -193,12 +194,12 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
         // streaming stores: the 64-B half lines a wave writes are not read again by this kernel; keeping them
         // out of the L2's way is worth 6-9 % of the kernel
         if (ABL(32)) {  // timing only: ordinary (L2 write-back) stores
-          *reinterpret_cast<f32x4*>(a.out + pg) = ya;
-          if (psecond) *reinterpret_cast<f32x4*>(a.out + pg + 32) = yb;
+          *reinterpret_cast<f32x4*>(out_item + pg) = ya;
+          if (psecond) *reinterpret_cast<f32x4*>(out_item + pg + 32) = yb;
           return;
         }
-        __builtin_nontemporal_store(ya, reinterpret_cast<f32x4*>(a.out + pg));
-        if (psecond) __builtin_nontemporal_store(yb, reinterpret_cast<f32x4*>(a.out + pg + 32));
+        __builtin_nontemporal_store(ya, reinterpret_cast<f32x4*>(out_item + pg));
+        if (psecond) __builtin_nontemporal_store(yb, reinterpret_cast<f32x4*>(out_item + pg + 32));
       }
     };
     auto tile = [&](f32x4 (&acc)[4], const f32x4 (&pacc)[4], int t, bool have_prev) {
@@ -206,15 +207,15 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
       if (!pv) ty = 0, j = 0;
       const float* base = lds + (ty * WT + 2 * j) * kLdsPix + 4 * kq;
       const int x0 = 2 * j;
-      const size_t g = ((size_t)(b * a.Ho + y0 + ty) * a.Wo + x0) * 32 + mt * 16 + 4 * kq;
+      const int g = (ty * a.Wo + x0) * 32 + mt * 16 + 4 * kq;  // element offset inside the item's output band
       const bool second = x0 + 1 < a.Wo;
       f32x4 ma = {0, 0, 0, 0}, mb = {0, 0, 0, 0};
       if (MODE == MODE_DGRAD && pv && !ABL(4)) {  // ReLU mask of the layer below: in flight for a whole tile
-        ma = *reinterpret_cast<const f32x4*>(a.aux + g);
-        if (second) mb = *reinterpret_cast<const f32x4*>(a.aux + g + 32);
+        ma = *reinterpret_cast<const f32x4*>(aux_item + g);
+        if (second) mb = *reinterpret_cast<const f32x4*>(aux_item + g + 32);
       }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] = f32x4{0, 0, 0, 0};
+      // y(x0) = m0+m1+m2 and y(x0+1) = m1-m2-m3: starting m0 at +bias and m3 at -bias adds the bias to both
+      acc[0] = bias4, acc[1] = f32x4{0, 0, 0, 0}, acc[2] = f32x4{0, 0, 0, 0}, acc[3] = -bias4;
       // 6 half-steps (3 row taps x 2 cin halves); the 4 window reads of the next half-step are issued
       // before the 16 MFMAs of the current one
       f32x4 d[2][4];
