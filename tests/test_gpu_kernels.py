@@ -333,3 +333,90 @@ def test_bad_arguments_fail_loudly(ops):
                         torch.zeros(2, 7, 7, 16, device="cuda"))
     with pytest.raises(CurlaHipError):
         ops.ObsRef.from_tensor(torch.zeros(1, 9, 20, 20))  # CPU tensor
+
+
+def test_full_size_batch_independence(ops):
+    """BASELINE.json's full size (B=512, 84x84x9 ring -> 76x76 crop, 37/35/33/31 maps): a sample's result must
+    not depend on what else is in the minibatch.  The conv stack, the fc split-K product and the data gradient
+    of the full batch equal, bit for bit, the same kernels run on the two halves; weight gradients (whose
+    fixed summation order follows the work split) agree to 1e-5; and a handful of samples are checked against
+    the PyTorch statement of the layer."""
+    B, C = 512, 9
+    g = torch.Generator(device="cuda").manual_seed(7)
+    store = torch.randint(0, 256, (1024 * 84 * 84 * C + 32,), dtype=torch.uint8, device="cuda", generator=g)
+    ring = store[:1024 * 84 * 84 * C].view(1024, 84, 84, C)
+    idx = torch.randint(0, 1024, (B,), device="cuda", generator=g)
+    h1 = torch.randint(0, 9, (B,), device="cuda", generator=g).int()
+    w1 = torch.randint(0, 9, (B,), device="cuda", generator=g).int()
+    w0, b0 = dev(rnd(32, C, 3, 3, seed=1, scale=0.1)), dev(rnd(32, seed=2, scale=0.1))
+    ws, bs = dev(rnd(32, 32, 3, 3, seed=3, scale=0.1)), dev(rnd(32, seed=4, scale=0.1))
+
+    def stack(lo, hi):
+        n = hi - lo
+        ref = ops.ObsRef.from_ring(ring, idx[lo:hi].contiguous(), h1[lo:hi].contiguous(), w1[lo:hi].contiguous(), n, (76, 76))
+        a1 = torch.empty(n, 37, 37, 32, device="cuda")
+        ops.conv1_fwd(ref, w0, b0, a1)
+        acts = [a1]
+        for hw in (35, 33, 31):
+            o = torch.empty(n, hw, hw, 32, device="cuda")
+            ops.conv_s1_fwd(acts[-1], ws, bs, o)
+            acts.append(o)
+        return ref, acts
+
+    ref_full, full = stack(0, B)
+    _, lo = stack(0, B // 2)
+    _, hi = stack(B // 2, B)
+    for l, (f, a, b) in enumerate(zip(full, lo, hi)):
+        assert torch.equal(f[:B // 2], a) and torch.equal(f[B // 2:], b), f"conv layer {l + 1} depends on the batch"
+    # a few samples against PyTorch (crop -> /255 -> conv stack)
+    pick = [0, 255, 511]
+    x = torch.stack([ring[idx[i], h1[i]:h1[i] + 76, w1[i]:w1[i] + 76] for i in pick]).permute(0, 3, 1, 2).float().cpu() / 255.0
+    r = torch.relu(F.conv2d(x, w0.cpu(), b0.cpu(), stride=2))
+    for _ in range(3):
+        r = torch.relu(F.conv2d(r, ws.cpu(), bs.cpu()))
+    check("full-size conv stack (3 samples of 512)", nchw(full[3][pick]), r)
+
+    # fc split-K product: rows are independent
+    K, Fd = 31 * 31 * 32, 50
+    Wfc = dev(rnd(Fd, K, seed=5, scale=0.01))
+    hflat = full[3].view(B, K)
+    part = torch.empty(32, B, Fd, device="cuda")
+    ops.gemm(hflat, 0, K, 0, Wfc, 0, K, 0, part, Fd, 0, B, Fd, K, 1, ksplit=32, split_stride=B * Fd)
+    part_lo = torch.empty(32, B // 2, Fd, device="cuda")
+    ops.gemm(lo[3].view(B // 2, K), 0, K, 0, Wfc, 0, K, 0, part_lo, Fd, 0, B // 2, Fd, K, 1, ksplit=32,
+             split_stride=(B // 2) * Fd)
+    assert torch.equal(part[:, :B // 2], part_lo), "fc product of a row depends on the batch"
+
+    # backward of the last conv layer
+    gy = torch.randn(B, 31, 31, 32, device="cuda", generator=g) * (full[3] > 0)
+    gin = torch.empty(B, 33, 33, 32, device="cuda")
+    ops.conv_s1_dgrad(gy, ws, full[2], gin)
+    gin_lo = torch.empty(B // 2, 33, 33, 32, device="cuda")
+    ops.conv_s1_dgrad(gy[:B // 2].contiguous(), ws, lo[2], gin_lo)
+    assert torch.equal(gin[:B // 2], gin_lo), "dgrad of a sample depends on the batch"
+    wsp = torch.empty(ops.wgrad_workspace_floats(32), device="cuda")
+    dw, db = torch.empty(32, 32, 3, 3, device="cuda"), torch.empty(32, device="cuda")
+    dwa, dba, dwb, dbb = torch.empty_like(dw), torch.empty_like(db), torch.empty_like(dw), torch.empty_like(db)
+    ops.conv_s1_wgrad(full[2], gy, dw, db, wsp)
+    ops.conv_s1_wgrad(lo[2], gy[:B // 2].contiguous(), dwa, dba, wsp)
+    ops.conv_s1_wgrad(hi[2], gy[B // 2:].contiguous(), dwb, dbb, wsp)
+    check("full-size wgrad = sum over halves", dw.cpu(), (dwa + dwb).cpu(), 1e-5)
+    check("full-size bias grad = sum over halves", db.cpu(), (dba + dbb).cpu(), 1e-5)
+    dw2, db2 = torch.empty_like(dw), torch.empty_like(db)
+    ops.conv_s1_wgrad(full[2], gy, dw2, db2, wsp)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "wgrad is not run-to-run reproducible"
+    # first-layer weight gradient from the ring
+    g1 = torch.randn(B, 37, 37, 32, device="cuda", generator=g)
+    ws1 = torch.empty(ops.wgrad_workspace_floats(C), device="cuda")
+    dw1, db1 = torch.empty(32, C, 3, 3, device="cuda"), torch.empty(32, device="cuda")
+    ops.conv1_wgrad(ref_full, g1, dw1, db1, ws1)
+    xs = torch.stack([ring[idx[i], h1[i]:h1[i] + 76, w1[i]:w1[i] + 76] for i in range(0, B, 64)]).permute(0, 3, 1, 2).float() / 255.0
+    # linearity spot check: gradient of 8 samples alone, against autograd
+    sel = list(range(0, B, 64))
+    sub = ops.ObsRef.from_ring(ring, idx[sel].contiguous(), h1[sel].contiguous(), w1[sel].contiguous(), len(sel), (76, 76))
+    dws, dbs = torch.empty_like(dw1), torch.empty_like(db1)
+    ops.conv1_wgrad(sub, g1[sel].contiguous(), dws, dbs, ws1)
+    wref = w0.cpu().clone().requires_grad_(True)
+    F.conv2d(xs.cpu(), wref, None, stride=2).backward(g1[sel].permute(0, 3, 1, 2).cpu())
+    check("conv1 wgrad from the ring (8 of 512)", dws.cpu(), wref.grad)
+    assert torch.isfinite(dw1).all() and float(dw1.abs().max()) > 0
