@@ -564,3 +564,52 @@ def test_full_checkpoint_resumes_bitwise(tmp_path):
     with pytest.raises(ValueError):
         torch.save({"format": "something else"}, tmp_path / "bad.pt")
         other.load_checkpoint(str(tmp_path / "bad.pt"))
+
+
+def test_full_size_gradients_are_the_mean_over_shards():
+    """BASELINE configs[1] shapes (B=512, 84x84x9 -> 76x76, hidden 1024) and the data-parallel definition at
+    that size: the critic and actor/alpha gradients of a 512-minibatch equal the mean of the
+    gradients of its two 256-halves (what two ranks would all-reduce).  Learning rates are 0 so the three
+    evaluations see the same parameters."""
+    import curla_amd
+    from curla_amd import ops
+    hp = dict(HP)
+    for k in ("alpha_lr", "actor_lr", "critic_lr", "encoder_lr"):
+        hp[k] = 0.0
+    torch.manual_seed(3)
+    aug = curla_amd.RandomCrop((84, 84), (76, 76))
+    agent = curla_amd.CurlSacAgent((9, 76, 76), (2,), torch.device("cuda"), aug, hidden_dim=1024, **hp)
+    B = 512
+    g = torch.Generator(device="cuda").manual_seed(11)
+    store = torch.randint(0, 256, (2, 1024 * 84 * 84 * 9 + 32), dtype=torch.uint8, device="cuda", generator=g)
+    rings = [s[:1024 * 84 * 84 * 9].view(1024, 84, 84, 9) for s in store]
+    idx = torch.randint(0, 1024, (B,), device="cuda", generator=g)
+    offs = [torch.randint(0, 9, (B,), device="cuda", generator=g).int() for _ in range(4)]
+    action = torch.rand(B, 2, device="cuda", generator=g) * 2 - 1
+    reward = torch.randn(B, 1, device="cuda", generator=g)
+    not_done = (torch.rand(B, 1, device="cuda", generator=g) > 0.02).float()
+    noise_c = torch.randn(B, 2, device="cuda", generator=g)
+    noise_a = torch.randn(B, 2, device="cuda", generator=g)
+    L = NullLogger()
+
+    def grads(lo, hi):
+        n = hi - lo
+        sl = lambda t: t[lo:hi].contiguous()  # noqa: E731
+        obs = ops.ObsRef.from_ring(rings[0], sl(idx), sl(offs[0]), sl(offs[1]), n, (76, 76))
+        nxt = ops.ObsRef.from_ring(rings[1], sl(idx), sl(offs[2]), sl(offs[3]), n, (76, 76))
+        agent.update_critic(obs, sl(action), sl(reward), nxt, sl(not_done), L, 1, noise=sl(noise_c))
+        gc = agent._critic_gflat.clone()
+        closs = L.scalars["train_critic/loss"]
+        agent.update_actor_and_alpha(obs, L, 1, noise=sl(noise_a))
+        return gc, agent._actor_gflat.clone(), agent.log_alpha.grad.clone(), closs, L.scalars["train_actor/loss"]
+
+    full = grads(0, B)
+    a, b = grads(0, B // 2), grads(B // 2, B)
+    lay = agent._lay
+    live = slice(lay["enc"][0], lay["total"])  # the critic phase writes [encoder | Q1 | Q2]
+    check("critic grads: 512 = mean of 2 x 256", full[0][live].cpu(), (0.5 * (a[0] + b[0]))[live].cpu(), 1e-5)
+    check("actor grads: 512 = mean of 2 x 256", full[1].cpu(), (0.5 * (a[1] + b[1])).cpu(), 1e-5)
+    check("log_alpha grad: 512 = mean of 2 x 256", full[2].cpu().float().reshape(1), (0.5 * (a[2] + b[2])).cpu().float().reshape(1), 1e-5)
+    assert abs(full[3] - 0.5 * (a[3] + b[3])) <= 1e-5 * abs(full[3])
+    assert abs(full[4] - 0.5 * (a[4] + b[4])) <= 1e-5 * max(1.0, abs(full[4]))
+    assert float(full[0][live].abs().max()) > 0 and torch.isfinite(full[0]).all()
