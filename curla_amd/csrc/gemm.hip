@@ -289,6 +289,9 @@ int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const f
   const long long wgs6432 = (long long)((N + 31) / 32) * ((M + 63) / 64) * zb;
   int tbm = 64, tbn = 64;
   if (wgs64 < cu2 && N > 32) tbn = 32;
+  // a single row of tiles streaming a k-major B (the fc weight gradient, M = 50): the wider tile reads 256-B
+  // instead of 128-B pieces of each HBM row and is faster even at one workgroup per CU
+  if (tbn == 32 && M <= 64 && a_kmajor && b_kmajor && 2 * wgs64 >= cu2) tbn = 64;
   if (tbn == 32 && wgs6432 < cu2 && M > 32) tbm = 32;
   // interior + aligned everywhere: the k loop runs without bounds / alignment tests
   // (a k-major operand still needs whole tiles: its float4 runs along the rows)
