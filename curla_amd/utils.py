@@ -84,17 +84,31 @@ class ReplayBuffer(object):
         self._next_store = torch.zeros(capacity * frame + 32, dtype=torch.uint8, device=self.device)
         self.obses = self._obs_store[:capacity * frame].view(capacity, h, w, c)
         self.next_obses = self._next_store[:capacity * frame].view(capacity, h, w, c)
-        self.actions = torch.empty((capacity, *action_shape), dtype=torch.float32, device=self.device)
-        self.rewards = torch.empty((capacity, 1), dtype=torch.float32, device=self.device)
-        self.not_dones = torch.empty((capacity, 1), dtype=torch.float32, device=self.device)
+        # action | reward | not_done of a transition sit in one row, so add() writes them with one small copy;
+        # the three reference attributes are column views of it
+        A = int(np.prod(action_shape))
+        self._n_act = A
+        self._sc = torch.empty((capacity, A + 2), dtype=torch.float32, device=self.device)
+        self.actions = self._sc[:, :A].unflatten(1, tuple(action_shape)) if len(action_shape) != 1 else self._sc[:, :A]
+        self.rewards = self._sc[:, A:A + 1]
+        self.not_dones = self._sc[:, A + 1:A + 2]
         self.idx = 0
         self.last_save = 0
         self.full = False
         # staging: pinned host rows for add(), static device index buffers for sampling
         pin = self.device.type == "cuda"
-        self._h_frames = torch.empty((2, frame), dtype=torch.uint8, pin_memory=pin)
-        self._d_frames = torch.empty((2, frame), dtype=torch.uint8, device=self.device)
-        self._h_scalars = torch.empty(int(np.prod(action_shape)) + 2, dtype=torch.float32, pin_memory=pin)
+        # add(): one pinned block per slot = [obs frame | next_obs frame | pad | action, reward, not_done], a few
+        # slots guarded by events so that add() never waits for the GPU; one device block receives the copy
+        self._frame = frame
+        self._sc_off = (2 * frame + 15) & ~15
+        blk = self._sc_off + 4 * (A + 2)
+        self._n_add, self._add_slot = 4, 0
+        self._h_add = torch.empty((self._n_add, blk), dtype=torch.uint8, pin_memory=pin)
+        self._h_add_np = self._h_add.numpy()
+        self._add_events = [None] * self._n_add
+        self._d_add = torch.empty(blk, dtype=torch.uint8, device=self.device)
+        self._d_add_frames = self._d_add[:2 * frame].view(2, frame)
+        self._d_add_sc = self._d_add[self._sc_off:].view(torch.float32)
         B = batch_size
         # the host may run several updates ahead of the GPU: a small ring of pinned slots, each guarded by an
         # event, keeps an index upload's source intact until its async copy has executed
@@ -107,31 +121,36 @@ class ReplayBuffer(object):
 
     # ------------------------------------------------------------------ writing
     def add(self, obs, action, reward, next_obs, done):
-        """utils.py:120-128: store one transition at ``idx`` (async H2D of the two
-        frames, CHW -> HWC on the device)."""
+        """utils.py:120-128: store one transition at ``idx``.  The two frames and the scalars travel in one
+        pinned block and one async copy; two kernels turn CHW into the ring's HWC, one row copy stores the
+        scalars.  Nothing here waits for the GPU (a slot is reused only after its copy has executed)."""
         i = self.idx
-        self._h_frames[0].copy_(torch.from_numpy(np.ascontiguousarray(obs, dtype=np.uint8).reshape(-1)))
-        self._h_frames[1].copy_(torch.from_numpy(np.ascontiguousarray(next_obs, dtype=np.uint8).reshape(-1)))
-        a = np.asarray(action, dtype=np.float32).reshape(-1)
-        self._h_scalars[:a.size] = torch.from_numpy(a)
-        self._h_scalars[a.size] = float(reward)
-        self._h_scalars[a.size + 1] = float(not done)
+        k = self._add_slot
+        self._add_slot = (k + 1) % self._n_add
+        if self._add_events[k] is not None:
+            self._add_events[k].synchronize()
+        fr, A = self._frame, self._n_act
+        row = self._h_add_np[k]
+        row[:fr] = np.asarray(obs, dtype=np.uint8).reshape(-1)
+        row[fr:2 * fr] = np.asarray(next_obs, dtype=np.uint8).reshape(-1)
+        sc = row[self._sc_off:].view(np.float32)
+        sc[:A] = np.asarray(action, dtype=np.float32).reshape(-1)
+        sc[A] = float(reward)
+        sc[A + 1] = float(not done)
         if self.device.type == "cuda":
-            self._d_frames.copy_(self._h_frames, non_blocking=True)
-            ops.store_frame(self._d_frames[0], self.obses, i)
-            ops.store_frame(self._d_frames[1], self.next_obses, i)
-            sc = self._h_scalars.to(self.device, non_blocking=True)
-            # the pinned staging rows are reused by the next add(): wait for the copies (tiny; add() runs
-            # once per environment step, off the learner's critical path)
-            torch.cuda.current_stream().synchronize()
+            self._d_add.copy_(self._h_add[k], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._add_events[k] = ev
+            ops.store_frame(self._d_add_frames[0], self.obses, i)
+            ops.store_frame(self._d_add_frames[1], self.next_obses, i)
+            self._sc[i].copy_(self._d_add_sc)
         else:  # host-side bookkeeping only (index logic tests); pixels are still stored, HWC
             c, h, w = self.obs_shape
-            self.obses[i] = self._h_frames[0].view(c, h, w).permute(1, 2, 0)
-            self.next_obses[i] = self._h_frames[1].view(c, h, w).permute(1, 2, 0)
-            sc = self._h_scalars
-        self.actions[i] = sc[:a.size].view(self.actions.shape[1:])
-        self.rewards[i] = sc[a.size]
-        self.not_dones[i] = sc[a.size + 1]
+            blk = self._h_add[k]
+            self.obses[i] = blk[:fr].view(c, h, w).permute(1, 2, 0)
+            self.next_obses[i] = blk[fr:2 * fr].view(c, h, w).permute(1, 2, 0)
+            self._sc[i] = torch.from_numpy(sc.copy())
         self.idx = (self.idx + 1) % self.capacity
         self.full = self.full or self.idx == 0
 
