@@ -111,7 +111,7 @@ def main():
         alpha_beta=0.5, actor_lr=1e-3, actor_beta=0.9, critic_lr=1e-3, critic_beta=0.9, critic_tau=0.01,
         encoder_feature_dim=50, encoder_lr=1e-3, encoder_tau=0.05, num_layers=4, num_filters=32, log_interval=10 ** 9)
     if distributed:
-        agent.enable_data_parallel()
+        agent.enable_data_parallel(single_rank_collectives=(world == 1))
     curla_amd.set_seed_everywhere(1 + rank)
 
     # replay ring shard, pre-filled on the device with i.i.d. uniform bytes (worst case for any compression)

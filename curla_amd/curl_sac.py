@@ -346,6 +346,8 @@ class CurlSacAgent(object):
         self._anchor_cache = None
         self._dp_group = None
         self._dp_world = 1
+        self._dp_active = False
+        self._dp_avg = False
         self.train()
         self.critic_target.train()
 
@@ -419,22 +421,30 @@ class CurlSacAgent(object):
         return self._workspaces[B]
 
     # --------------------------------------------------------------- data parallel
-    def enable_data_parallel(self, process_group=None):
+    def enable_data_parallel(self, process_group=None, single_rank_collectives=False):
         """Synchronous data parallelism (one process per GPU): before every
-        optimizer step the freshly written flat gradient bucket is summed over
-        ranks with one all-reduce (RCCL over xGMI) and divided by the world size
-        (SURVEY.md 8e).  Ranks must hold identical parameters (same seed)."""
+        optimizer step the freshly written flat gradient bucket is averaged over
+        ranks with one all-reduce (RCCL over xGMI).  Ranks must hold
+        identical parameters (same seed).  RCCL averages inside the collective
+        (ncclAvg); other backends (gloo in the CPU tests) sum and divide.
+        ``single_rank_collectives`` issues the collectives even in a world of one
+        (a 1-GPU check of the exact calls an N-GPU run makes)."""
         import torch.distributed as dist
         self._dp_group = process_group if process_group is not None else dist.group.WORLD
         self._dp_world = dist.get_world_size(self._dp_group)
+        self._dp_active = self._dp_world > 1 or single_rank_collectives
+        self._dp_avg = dist.get_backend(self._dp_group) == "nccl"
 
     def _allreduce(self, *buckets):
-        if self._dp_world == 1:
+        if not self._dp_active:
             return
         import torch.distributed as dist
         for t in buckets:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._dp_group)
-            t.div_(self._dp_world)
+            if self._dp_avg:
+                dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self._dp_group)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._dp_group)
+                t.div_(self._dp_world)
 
     # ------------------------------------------------------------------ reference API
     def train(self, training=True):
