@@ -1,27 +1,33 @@
-// checks the inline-asm packed add/sub helpers of common.h on the device
+// checks common.h's packed Winograd input transform (inline-asm block) on the device against scalar arithmetic
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include "../../curla_amd/csrc/common.h"
-__global__ void k(const float* a, const float* b, float* c) {
-  int i = threadIdx.x;
-  f32x2 x = {a[2 * i], a[2 * i + 1]}, y = {b[2 * i], b[2 * i + 1]};
-  f32x2 s = pk_sub(x, y), t = pk_add(x, y);
-  c[4 * i] = s[0], c[4 * i + 1] = s[1], c[4 * i + 2] = t[0], c[4 * i + 3] = t[1];
+__global__ void k(const float* in, float* out) {
+  const int i = threadIdx.x;
+  f32x2 d0 = {in[8 * i], in[8 * i + 1]}, d1 = {in[8 * i + 2], in[8 * i + 3]};
+  f32x2 d2 = {in[8 * i + 4], in[8 * i + 5]}, d3 = {in[8 * i + 6], in[8 * i + 7]}, t = {0, 0};
+  winograd_bt_pk(d0, d1, d2, d3, t);  // d0 <- d0-d2, t <- d1+d2, d2 <- d2-d1, d3 <- d1-d3
+  out[8 * i] = d0[0], out[8 * i + 1] = d0[1], out[8 * i + 2] = t[0], out[8 * i + 3] = t[1];
+  out[8 * i + 4] = d2[0], out[8 * i + 5] = d2[1], out[8 * i + 6] = d3[0], out[8 * i + 7] = d3[1];
 }
 int main() {
-  float ha[128], hb[128], hc[256];
-  for (int i = 0; i < 128; ++i) ha[i] = i * 1.5f, hb[i] = 100.f - i;
-  float *a, *b, *c;
-  hipMalloc(&a, 512); hipMalloc(&b, 512); hipMalloc(&c, 1024);
-  hipMemcpy(a, ha, 512, hipMemcpyHostToDevice); hipMemcpy(b, hb, 512, hipMemcpyHostToDevice);
-  hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, a, b, c);
-  hipMemcpy(hc, c, 1024, hipMemcpyDeviceToHost);
+  float h[512], o[512];
+  for (int i = 0; i < 512; ++i) h[i] = (float)((i * 37) % 101) * 0.25f - 7.f;
+  float *a, *b;
+  (void)hipMalloc(&a, sizeof h);
+  (void)hipMalloc(&b, sizeof o);
+  (void)hipMemcpy(a, h, sizeof h, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, a, b);
+  (void)hipMemcpy(o, b, sizeof o, hipMemcpyDeviceToHost);
   int bad = 0;
   for (int i = 0; i < 64; ++i)
     for (int r = 0; r < 2; ++r) {
-      if (hc[4 * i + r] != ha[2 * i + r] - hb[2 * i + r]) ++bad;
-      if (hc[4 * i + 2 + r] != ha[2 * i + r] + hb[2 * i + r]) ++bad;
+      const float d0 = h[8 * i + r], d1 = h[8 * i + 2 + r], d2 = h[8 * i + 4 + r], d3 = h[8 * i + 6 + r];
+      bad += o[8 * i + r] != d0 - d2;
+      bad += o[8 * i + 2 + r] != d1 + d2;
+      bad += o[8 * i + 4 + r] != d2 - d1;
+      bad += o[8 * i + 6 + r] != d1 - d3;
     }
-  printf("bad=%d  c[0..3]=%g %g %g %g (want %g %g %g %g)\n", bad, hc[0], hc[1], hc[2], hc[3], ha[0] - hb[0], ha[1] - hb[1], ha[0] + hb[0], ha[1] + hb[1]);
+  printf("winograd_bt_pk: %d mismatches of 512\n", bad);
   return bad != 0;
 }
