@@ -42,6 +42,7 @@ struct ConvS1Args {
   const float* aux;  // FWD: bias[32]; DGRAD: activation below, [B][Ho][Wo][32] (ReLU mask)
   float* out;        // [B][Ho][Wo][32]
   int B, Hs, Ws, Ho, Wo, pad, th, nbands;
+  int h1;  // height of band 0 (>= th; the other bands are th rows, the last one what is left)
   int dbg;
 };
 
@@ -107,8 +108,8 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
   const int nitems = a.B * a.nbands;
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int band = item / a.B, b = item - band * a.B;  // band-major: every workgroup sees every band size
-    const int y0 = band * a.th;
-    const int tha = min(a.th, a.Ho - y0);
+    const int y0 = band == 0 ? 0 : a.h1 + (band - 1) * a.th;
+    const int tha = band == 0 ? a.h1 : min(a.th, a.Ho - y0);
     // ---- stage the band: all loads in flight at once, then the LDS writes.  The
     // exposed latency is covered by the CU's second workgroup, whose phases are
     // not synchronised with this one's.
@@ -1069,6 +1070,47 @@ int plan_band_s1(int Ho, int Wo, int px_per_row_extra, int budget_px, int unit_p
   return best;
 }
 
+// Bands of the forward / data-gradient kernel: band 0 has h1 rows, the others th (the last what is left), all
+// within the LDS budget.  A band's 16-pair tiles are dealt to two wave pairs, so an odd tile count idles one of
+// them for a tile; letting band 0 differ (31 rows = 11 + 10 + 10 instead of 11 + 11 + 9) buys even counts.
+// Score = useful tile slots / dealt tile slots x rows / staged rows (halo), minus a small per-band cost.
+void plan_bands_conv_s1(int Ho, int Wo, int budget_px, int* th_out, int* h1_out, int* nb_out) {
+  const int PW = (Wo + 1) / 2;
+  int th_max = 0;
+  for (int th = 1; th <= Ho; ++th)
+    if ((th + 2) * (Wo + 2) <= budget_px) th_max = th;
+  if (th_max == 0) {
+    *th_out = 1, *h1_out = 1, *nb_out = Ho;
+    return;
+  }
+  double best = -1.0;
+  auto slots = [&](int rows) {
+    const int tiles = (rows * PW + 15) / 16;
+    return (double)((tiles + 1) / 2 * 2);
+  };
+  for (int th = 1; th <= th_max; ++th)
+    for (int variant = 0; variant < 2; ++variant) {
+      int h1, nb;
+      if (variant == 0) {
+        h1 = th, nb = (Ho + th - 1) / th;  // uniform, last band short
+      } else {
+        nb = (Ho - th) / th + 1;  // first band takes the remainder: th <= h1 < 2 th
+        h1 = Ho - (nb - 1) * th;
+        if (nb < 2 || h1 > th_max) continue;
+      }
+      if (h1 >= Ho) h1 = Ho, nb = 1;
+      double s = slots(h1);
+      int rows_left = Ho - h1;
+      for (int b = 1; b < nb; ++b) {
+        const int r = rows_left < th ? rows_left : th;
+        s += slots(r);
+        rows_left -= r;
+      }
+      const double eff = (Ho * Wo / 32.0) / s * (double)Ho / (Ho + 2.0 * nb) * (1.0 - 0.01 * nb);
+      if (eff > best) best = eff, *th_out = th, *h1_out = h1, *nb_out = nb;
+    }
+}
+
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
   if (bytes > (size_t)kMaxLds) return CURLA_ERR_UNSUPPORTED;
@@ -1087,10 +1129,9 @@ int launch_conv_s1(int mode, const float* in, const float* w, const float* aux, 
   a.Ho = mode == MODE_FWD ? Hs - 2 : Hs + 2;
   a.Wo = mode == MODE_FWD ? Ws - 2 : Ws + 2;
   if (a.Ho <= 0 || a.Wo <= 0 || (a.Wo + 2) * 3 > kBandPx) return CURLA_ERR_UNSUPPORTED;
-  a.th = plan_band_s1(a.Ho, a.Wo, 0, kBandPx, 16, 2, /*pairs=*/true);
-  a.nbands = (a.Ho + a.th - 1) / a.th;
+  plan_bands_conv_s1(a.Ho, a.Wo, kBandPx, &a.th, &a.h1, &a.nbands);
   a.dbg = ABL_HOST;
-  size_t lds = ((size_t)(a.th + 2) * (a.Wo + 2) + 1) * kLdsPix * sizeof(float);  // +1 pixel: 4th window pixel of the last pair
+  size_t lds = ((size_t)(a.h1 + 2) * (a.Wo + 2) + 1) * kLdsPix * sizeof(float);  // +1 pixel: 4th window pixel of the last pair
   const size_t wl = (size_t)32 * kWStride * sizeof(float);
   if (lds < wl) lds = wl;
   const int nitems = B * a.nbands;
