@@ -214,6 +214,15 @@ def main():
                 traffic = json.load(f)["conv_s1_kernel<0>"]["traffic_bytes"]
         except Exception:
             pass
+        # matrix-pipe utilisation of the same kernel from the shader-core PMC pass (tools/pmc_sq.sh), if committed
+        mfma_busy = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_sq.json")) as f:
+                c = json.load(f)["conv_s1_kernel<0>"]
+                mfma_busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_BUSY_CU_CYCLES"])
+        except Exception:
+            pass
+        avg_ms = kms / max(1, len(ev_pairs))
         out = {
             "metric": "SAC+CURL gradient updates/sec, batch=512 84x84x9",
             "value": updates_per_s,
@@ -234,7 +243,10 @@ def main():
                          "frac": achieved / PEAK_F32_TFLOPS, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json); "
                                          "algorithmic in+out = 152 MB per launch (mean of the 3 layers)",
-                         "launches": len(ev_pairs), "avg_launch_ms": kms / max(1, len(ev_pairs))},
+                         "launches": len(ev_pairs), "avg_launch_ms": avg_ms,
+                         "hbm_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
+                         "hbm_peak_GBps": 8000.0,
+                         "mfma_busy_frac_pmc": mfma_busy},
         }
         if allreduce is not None:
             out["allreduce"] = allreduce
