@@ -1199,8 +1199,9 @@ static int conv1_common_check(const void* src, int src_is_u8, int B, int C, int 
   if (C != 9 && C != 12 && C != 3) return CURLA_ERR_UNSUPPORTED;
   if (src_is_u8 == 1) {
     CURLA_REQUIRE(Hs >= Hc && Ws >= Wc);
-    // dword-aligned frame starts are what the byte-aligning loader assumes
-    CURLA_REQUIRE(((size_t)Hs * Ws * C) % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0);
+    // the loader rebuilds every 16-byte run from aligned dwords whatever its byte address, so frames of any size
+    // work; only the ring's base must be dword-aligned (the first run would otherwise start before the buffer)
+    CURLA_REQUIRE((reinterpret_cast<uintptr_t>(src) & 3) == 0);
     (void)h1, (void)w1;
   }
   return CURLA_OK;

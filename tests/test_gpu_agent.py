@@ -348,12 +348,13 @@ def test_update_entry_point_runs_from_ring():
     assert _lib._lib is not None  # the native library is what ran
 
 
-@pytest.mark.parametrize("name,obs_shape,layers,pixel_sac,B", [
-    ("c3_pixel_sac_84", (9, 84, 84), 4, True, 6),        # BASELINE configs[2]: identity aug, no CURL head
-    ("c5_geometry_168x12_L6", (12, 168, 168), 6, False, 3),  # BASELINE configs[4] geometry (augmentation-free)
-    ("rect_76x135", (9, 76, 135), 4, False, 4),          # the reference's own thesis shape (encoder.py:42-43)
+@pytest.mark.parametrize("name,obs_shape,layers,pixel_sac,B,A,hidden,feat", [
+    ("c3_pixel_sac_84", (9, 84, 84), 4, True, 6, 2, 64, 50),        # BASELINE configs[2]: identity aug, no CURL head
+    ("c5_geometry_168x12_L6", (12, 168, 168), 6, False, 3, 2, 64, 50),  # BASELINE configs[4] geometry (augmentation-free)
+    ("rect_76x135", (9, 76, 135), 4, False, 4, 2, 64, 50),          # the reference's own thesis shape (encoder.py:42-43)
+    ("odd_sizes", (3, 31, 45), 3, False, 5, 3, 96, 37),             # nothing a multiple of a tile: |A|=3, hidden 96, feature 37
 ])
-def test_other_config_geometries_vs_oracle(name, obs_shape, layers, pixel_sac, B):
+def test_other_config_geometries_vs_oracle(name, obs_shape, layers, pixel_sac, B, A, hidden, feat):
     """One even-step update() on the other BASELINE geometries against the oracle
     agent (same weights, minibatch, noise): per-phase losses and the gradients
     that reach Adam."""
@@ -363,9 +364,9 @@ def test_other_config_geometries_vs_oracle(name, obs_shape, layers, pixel_sac, B
     np.random.seed(11)
     hw = obs_shape[1:]
     aug = curla_amd.IdentityAugmentation(hw)
-    hp = {**HP, "num_layers": layers}
-    agent = curla_amd.CurlSacAgent(obs_shape, (2,), torch.device("cuda"), aug, hidden_dim=64, pixel_sac=pixel_sac, **hp)
-    oracle = O.OracleAgent(obs_shape, (2,), hidden_dim=64, pixel_sac=pixel_sac,
+    hp = {**HP, "num_layers": layers, "encoder_feature_dim": feat}
+    agent = curla_amd.CurlSacAgent(obs_shape, (A,), torch.device("cuda"), aug, hidden_dim=hidden, pixel_sac=pixel_sac, **hp)
+    oracle = O.OracleAgent(obs_shape, (A,), hidden_dim=hidden, pixel_sac=pixel_sac,
                            **{k: v for k, v in hp.items() if k != "log_interval"})
     for dst, src in ((oracle.critic, agent.critic.state_dict()), (oracle.critic_target, agent.critic_target.state_dict()),
                      (oracle.actor, agent.actor.state_dict())):
@@ -384,17 +385,17 @@ def test_other_config_geometries_vs_oracle(name, obs_shape, layers, pixel_sac, B
         agent.critic.load_state_dict(sd)
         agent.critic_target.load_state_dict({k: v.detach().clone() for k, v in oracle.critic_target.items()})
     oracle.W.data.copy_(agent.CURL.W.detach().cpu())
-    rb = curla_amd.ReplayBuffer(obs_shape, (2,), 8, B, torch.device("cuda"), aug)
+    rb = curla_amd.ReplayBuffer(obs_shape, (A,), 8, B, torch.device("cuda"), aug)
     rs = np.random.RandomState(2)
     n = 8
     obs_all = rs.randint(0, 256, (n,) + obs_shape, dtype=np.uint8)
     nxt_all = rs.randint(0, 256, (n,) + obs_shape, dtype=np.uint8)
-    act_all = rs.uniform(-1, 1, (n, 2)).astype(np.float32)
+    act_all = rs.uniform(-1, 1, (n, A)).astype(np.float32)
     rew_all = rs.randn(n).astype(np.float32)
     rb.add_batch(obs_all, act_all, rew_all, nxt_all, np.zeros(n, bool))
     idxs, offs = rb.draw_indices()
     assert not offs.any()
-    nc, na = torch.randn(B, 2), torch.randn(B, 2)
+    nc, na = torch.randn(B, A), torch.randn(B, A)
     f = lambda a: torch.from_numpy(a[idxs]).float()  # noqa: E731
     # reference gradients of the critic phase from the pre-update state (functional oracle)
     ref_critic = O.critic_phase(oracle.actor, oracle.critic, oracle.critic_target, oracle.log_alpha, f(obs_all),
