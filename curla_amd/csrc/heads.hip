@@ -28,64 +28,97 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm) {
   return (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
-// ---- fc split-K reduce + bias + LayerNorm (one wave per row, F <= 64) ----
+// ---- fc split-K reduce + bias + LayerNorm (one wave per row; a lane holds features lane, lane+64, ...:
+// NF = ceil(F / 64) <= 4, i.e. F <= 256) ----
+template <int NF>
 __global__ void fc_ln_fwd_kernel(const float* P, int nsplit, long long sSplit, int ldp, const float* bias,
                                  const float* gamma, const float* beta, int B, int F, float eps, float* fc_out,
                                  float* y, float* xhat, float* rstd, int tanh_out) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int f = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63;
   if (row >= B) return;
-  float v = 0.f;
-  if (f < F) {
-    // same summation order as a plain loop, but 8 partials are fetched together (the loop is pure load latency)
-    const float* p = P + (size_t)row * ldp + f;
-    int s = 0;
-    for (; s + 8 <= nsplit; s += 8) {
-      float t[8];
+  float v[NF];
+  float tot = 0.f;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t[k] = p[(s + k) * sSplit];
+  for (int j = 0; j < NF; ++j) {
+    const int f = lane + 64 * j;
+    v[j] = 0.f;
+    if (f < F) {
+      // same summation order as a plain loop, but 8 partials are fetched together (the loop is pure load latency)
+      const float* p = P + (size_t)row * ldp + f;
+      float a = 0.f;
+      int s = 0;
+      for (; s + 8 <= nsplit; s += 8) {
+        float t[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) v += t[k];
+        for (int k = 0; k < 8; ++k) t[k] = p[(s + k) * sSplit];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a += t[k];
+      }
+      for (; s < nsplit; ++s) a += p[s * sSplit];
+      v[j] = a + bias[f];
     }
-    for (; s < nsplit; ++s) v += p[s * sSplit];
-    v += bias[f];
+    tot += v[j];
   }
-  const float mean = wave_sum(f < F ? v : 0.f) / F;
-  const float d = f < F ? v - mean : 0.f;
-  const float var = wave_sum(d * d) / F;
+  const float mean = wave_sum(tot) / F;
+  float d[NF], sq = 0.f;
+#pragma unroll
+  for (int j = 0; j < NF; ++j) {
+    d[j] = lane + 64 * j < F ? v[j] - mean : 0.f;
+    sq += d[j] * d[j];
+  }
+  const float var = wave_sum(sq) / F;
   const float rs = 1.0f / sqrtf(var + eps);
-  if (f < F) {
-    const float xh = d * rs;
-    float o = xh * gamma[f] + beta[f];
-    if (tanh_out) o = tanhf(o);
-    if (fc_out) fc_out[(size_t)row * F + f] = v;
-    y[(size_t)row * F + f] = o;
-    if (xhat) xhat[(size_t)row * F + f] = xh;
+#pragma unroll
+  for (int j = 0; j < NF; ++j) {
+    const int f = lane + 64 * j;
+    if (f < F) {
+      const float xh = d[j] * rs;
+      float o = xh * gamma[f] + beta[f];
+      if (tanh_out) o = tanhf(o);
+      if (fc_out) fc_out[(size_t)row * F + f] = v[j];
+      y[(size_t)row * F + f] = o;
+      if (xhat) xhat[(size_t)row * F + f] = xh;
+    }
   }
-  if (f == 0 && rstd) rstd[row] = rs;
+  if (lane == 0 && rstd) rstd[row] = rs;
 }
 
 // dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat))
+template <int NF>
 __global__ void ln_bwd_kernel(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int F,
                               float* dx) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int f = threadIdx.x & 63;
+  const int lane = threadIdx.x & 63;
   if (row >= B) return;
-  float g = 0.f, xh = 0.f;
-  if (f < F) {
-    g = dy[(size_t)row * F + f] * gamma[f];
-    xh = xhat[(size_t)row * F + f];
+  float g[NF], xh[NF], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < NF; ++j) {
+    const int f = lane + 64 * j;
+    g[j] = 0.f, xh[j] = 0.f;
+    if (f < F) {
+      g[j] = dy[(size_t)row * F + f] * gamma[f];
+      xh[j] = xhat[(size_t)row * F + f];
+    }
+    s1 += g[j];
+    s2 += g[j] * xh[j];
   }
-  const float m1 = wave_sum(g) / F;
-  const float m2 = wave_sum(g * xh) / F;
-  if (f < F) dx[(size_t)row * F + f] = rstd[row] * (g - m1 - xh * m2);
+  const float m1 = wave_sum(s1) / F;
+  const float m2 = wave_sum(s2) / F;
+  const float rs = rstd[row];
+#pragma unroll
+  for (int j = 0; j < NF; ++j) {
+    const int f = lane + 64 * j;
+    if (f < F) dx[(size_t)row * F + f] = rs * (g[j] - m1 - xh[j] * m2);
+  }
 }
 
-// dgamma[f] = sum_b dy*xhat ; dbeta[f] = sum_b dy   (single block of 1024, F <= 64)
+// dgamma[f] = sum_b dy*xhat ; dbeta[f] = sum_b dy   (one block of 1024 per 64 features)
 __global__ __launch_bounds__(1024) void ln_param_grad_kernel(const float* dy, const float* xhat, int B, int F,
                                                              float* dgamma, float* dbeta) {
   __shared__ float sg[16][64], sb[16][64];
-  const int f = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int fl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int f = blockIdx.x * 64 + fl;
   float ag = 0.f, ab = 0.f;
   if (f < F) {
     int b = part;
@@ -102,12 +135,12 @@ __global__ __launch_bounds__(1024) void ln_param_grad_kernel(const float* dy, co
       ab += d;
     }
   }
-  sg[part][f] = ag, sb[part][f] = ab;
+  sg[part][fl] = ag, sb[part][fl] = ab;
   __syncthreads();
   if (part == 0 && f < F) {
-    float g = sg[0][f], bsum = sb[0][f];
+    float g = sg[0][fl], bsum = sb[0][fl];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) g += sg[k][f], bsum += sb[k][f];
+    for (int k = 1; k < 16; ++k) g += sg[k][fl], bsum += sb[k][fl];
     dgamma[f] = g;
     dbeta[f] = bsum;
   }
@@ -370,19 +403,37 @@ int curla_fc_ln_fwd(const float* partial, int nsplit, long long split_stride, in
                     const float* gamma, const float* beta, int B, int F, float eps, float* fc_out, float* y,
                     float* xhat, float* rstd, int tanh_out, void* stream) {
   CURLA_REQUIRE(partial && bias && gamma && beta && y && B > 0 && F > 0 && nsplit > 0);
-  if (F > 64) return CURLA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(fc_ln_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), partial,
-                     nsplit, split_stride, ldp, bias, gamma, beta, B, F, eps, fc_out, y, xhat, rstd, tanh_out);
+  if (F > 256) return CURLA_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define CURLA_FC_LN(NF)                                                                                         \
+  hipLaunchKernelGGL(fc_ln_fwd_kernel<NF>, dim3((B + 3) / 4), dim3(256), 0, st, partial, nsplit, split_stride, ldp, \
+                     bias, gamma, beta, B, F, eps, fc_out, y, xhat, rstd, tanh_out)
+  switch ((F + 63) / 64) {
+    case 1: CURLA_FC_LN(1); break;
+    case 2: CURLA_FC_LN(2); break;
+    case 3: CURLA_FC_LN(3); break;
+    default: CURLA_FC_LN(4); break;
+  }
+#undef CURLA_FC_LN
   return curla_launch_status();
 }
 
 int curla_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int F, float* dx,
                  float* dgamma, float* dbeta, void* stream) {
   CURLA_REQUIRE(dy && xhat && rstd && gamma && dx && B > 0 && F > 0);
-  if (F > 64) return CURLA_ERR_UNSUPPORTED;
+  if (F > 256) return CURLA_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, st, dy, xhat, rstd, gamma, B, F, dx);
-  if (dgamma && dbeta) hipLaunchKernelGGL(ln_param_grad_kernel, dim3(1), dim3(1024), 0, st, dy, xhat, B, F, dgamma, dbeta);
+#define CURLA_LN_BWD(NF) \
+  hipLaunchKernelGGL(ln_bwd_kernel<NF>, dim3((B + 3) / 4), dim3(256), 0, st, dy, xhat, rstd, gamma, B, F, dx)
+  switch ((F + 63) / 64) {
+    case 1: CURLA_LN_BWD(1); break;
+    case 2: CURLA_LN_BWD(2); break;
+    case 3: CURLA_LN_BWD(3); break;
+    default: CURLA_LN_BWD(4); break;
+  }
+#undef CURLA_LN_BWD
+  if (dgamma && dbeta)
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((F + 63) / 64), dim3(1024), 0, st, dy, xhat, B, F, dgamma, dbeta);
   return curla_launch_status();
 }
 

@@ -82,7 +82,7 @@ int curla_splitk_reduce(const float* partial, int nsplit, long long split_stride
                         int ldc, const float* bias, int relu, void* stream);
 
 /* fc split-K reduce + bias + LayerNorm(eps) [+ tanh] (encoder.py:98-107).  Saves
- * xhat / rstd for the backward when non-NULL.  F <= 64. */
+ * xhat / rstd for the backward when non-NULL.  F <= 256. */
 int curla_fc_ln_fwd(const float* partial, int nsplit, long long split_stride, int ldp, const float* bias,
                     const float* gamma, const float* beta, int B, int F, float eps, float* fc_out, float* y,
                     float* xhat, float* rstd, int tanh_out, void* stream);

@@ -181,8 +181,8 @@ def test_gemm(ops, M, N, K, ak, bk, nb):
     check(f"gemm mask {M}x{N}x{K} ak{ak} bk{bk} nb{nb}", C2.cpu(), ref_plain * (mask > 0))
 
 
-def test_gemm_splitk_and_fc_ln(ops):
-    B, Fd, K = 24, 50, 3456
+@pytest.mark.parametrize("B,Fd,K", [(24, 50, 3456), (9, 130, 800), (5, 64, 288), (3, 256, 512)])
+def test_gemm_splitk_and_fc_ln(ops, B, Fd, K):
     h, W, bias = rnd(B, K, seed=31), rnd(Fd, K, seed=32, scale=0.05), rnd(Fd, seed=33)
     gamma, beta = 1 + 0.1 * rnd(Fd, seed=34), 0.1 * rnd(Fd, seed=35)
     ks = 7
