@@ -1196,7 +1196,7 @@ int curla_conv3x3_s1_dgrad(const float* g, const float* w, const float* act_belo
 static int conv1_common_check(const void* src, int src_is_u8, int B, int C, int Hs, int Ws, int Hc, int Wc,
                               const int32_t* h1, const int32_t* w1) {
   CURLA_REQUIRE(src && B > 0 && Hc >= 3 && Wc >= 3 && src_is_u8 >= 0 && src_is_u8 <= 2);
-  if (C != 9 && C != 12 && C != 3) return CURLA_ERR_UNSUPPORTED;
+  if (C != 9 && C != 12 && C != 6 && C != 3) return CURLA_ERR_UNSUPPORTED;  // 3 x frame_stack of 1..4
   if (src_is_u8 == 1) {
     CURLA_REQUIRE(Hs >= Hc && Ws >= Wc);
     // the loader rebuilds every 16-byte run from aligned dwords whatever its byte address, so frames of any size
@@ -1223,6 +1223,8 @@ static int conv1_common_check(const void* src, int src_is_u8, int B, int C, int 
       CURLA_DISPATCH_SRC(9, KIND, KERNEL, __VA_ARGS__);            \
     } else if ((C) == 12) {                                        \
       CURLA_DISPATCH_SRC(12, KIND, KERNEL, __VA_ARGS__);           \
+    } else if ((C) == 6) {                                         \
+      CURLA_DISPATCH_SRC(6, KIND, KERNEL, __VA_ARGS__);            \
     } else {                                                       \
       CURLA_DISPATCH_SRC(3, KIND, KERNEL, __VA_ARGS__);            \
     }                                                              \
@@ -1264,7 +1266,7 @@ int curla_conv1_fwd(const void* src, int src_kind, const int64_t* idx, const int
     rc = set_lds(conv1_fwd_u8_kernel<CC>, lds);                                                             \
     if (rc == CURLA_OK) hipLaunchKernelGGL((conv1_fwd_u8_kernel<CC>), dim3(grid), dim3(512), lds, st, a);   \
   }
-    if (C == 9) CONV1_U8_LAUNCH(9) else if (C == 12) CONV1_U8_LAUNCH(12) else CONV1_U8_LAUNCH(3)
+    if (C == 9) CONV1_U8_LAUNCH(9) else if (C == 12) CONV1_U8_LAUNCH(12) else if (C == 6) CONV1_U8_LAUNCH(6) else CONV1_U8_LAUNCH(3)
 #undef CONV1_U8_LAUNCH
     if (rc != CURLA_OK) return rc;
     return curla_launch_status();
@@ -1348,7 +1350,7 @@ int curla_conv1_wgrad(const void* src, int src_kind, const int64_t* idx, const i
     rc = set_lds(wgrad1_u8_kernel<CC>, lds);                                                             \
     if (rc == CURLA_OK) hipLaunchKernelGGL((wgrad1_u8_kernel<CC>), dim3(grid), dim3(512), lds, st, a);   \
   }
-    if (C == 9) WGRAD1_U8_LAUNCH(9) else if (C == 12) WGRAD1_U8_LAUNCH(12) else WGRAD1_U8_LAUNCH(3)
+    if (C == 9) WGRAD1_U8_LAUNCH(9) else if (C == 12) WGRAD1_U8_LAUNCH(12) else if (C == 6) WGRAD1_U8_LAUNCH(6) else WGRAD1_U8_LAUNCH(3)
 #undef WGRAD1_U8_LAUNCH
   } else {
     a.th = plan_band_conv1(a.Ho, a.Wo, Wc, C, a.Wo, 150 * 1024);

@@ -44,7 +44,7 @@ const char* curla_version(void);
  * encoder.py:78 (`obs / 255.`, pass scale = 1/255).  src_kind = 0: `src` is the
  * reference's float NCHW tensor [B][C][Hc][Wc] in [0,255]; src_kind = 2: a float
  * NHWC tensor [B][Hc][Wc][C] in [0,255] (what curla_color_jiggle / curla_noisy_cover
- * write).  C in {3, 9, 12}.  The uint8 ring must be followed by >= 32 readable bytes (the row loader reads
+ * write).  C in {3, 6, 9, 12}.  The uint8 ring must be followed by >= 32 readable bytes (the row loader reads
  * whole aligned 16-byte runs) and start on a 4-byte boundary; frames may have any size. */
 int curla_conv1_fwd(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1,
                     const float* w, const float* bias, float* out, int B, int C, int Hs, int Ws, int Hc, int Wc,

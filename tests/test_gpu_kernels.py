@@ -101,6 +101,8 @@ def _ring(N, C, Hs, Ws, seed):
 
 CONV1_CASES = [  # C, Hs, Ws, Hc, Wc, B
     (9, 34, 40, 28, 34, 8), (9, 84, 84, 76, 76, 4), (9, 84, 84, 84, 84, 3), (12, 50, 46, 41, 37, 5), (3, 20, 23, 17, 19, 6),
+    (6, 31, 45, 25, 39, 7),  # frame_stack 2; 31*45*6 bytes per frame is not a multiple of 4
+    (3, 21, 21, 21, 21, 5),  # odd-sized frames, no crop
 ]
 
 
