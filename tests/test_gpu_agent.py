@@ -354,6 +354,7 @@ def test_update_entry_point_runs_from_ring():
     ("rect_76x135", (9, 76, 135), 4, False, 4, 2, 64, 50),          # the reference's own thesis shape (encoder.py:42-43)
     ("odd_sizes", (3, 31, 45), 3, False, 5, 3, 96, 37),             # nothing a multiple of a tile: |A|=3, hidden 96, feature 37
     ("wide_feature", (9, 40, 40), 2, False, 4, 2, 64, 130),         # encoder_feature_dim > 64 (LayerNorm over 3 values per lane)
+    ("one_layer_stack2", (6, 33, 29), 1, False, 4, 2, 64, 50),      # a single (stride-2) conv layer, frame_stack 2
 ])
 def test_other_config_geometries_vs_oracle(name, obs_shape, layers, pixel_sac, B, A, hidden, feat):
     """One even-step update() on the other BASELINE geometries against the oracle
