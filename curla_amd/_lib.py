@@ -25,8 +25,9 @@ SIGNATURES = {
                    c_ll, c_float, vp, c_ll, c_int, vp, c_int, c_ll, vp],
     "curla_splitk_reduce": [vp, c_int, c_ll, c_int, c_int, c_int, vp, c_int, vp, c_int, vp],
     "curla_fc_ln_fwd": [vp, c_int, c_ll, c_int, vp, vp, vp, c_int, c_int, c_float, vp, vp, vp, vp, c_int, vp],
-    "curla_ln_bwd": [vp, vp, vp, vp, c_int, c_int, vp, vp, vp, vp],
+    "curla_ln_bwd": [vp, vp, vp, vp, c_int, c_int, vp, vp, vp, vp, vp],
     "curla_colsum": [vp, c_int, c_int, c_int, c_ll, vp, c_ll, c_int, vp],
+    "curla_colsum3": [vp, c_int, vp, c_int, vp, c_int, c_int, vp, vp, vp, c_ll, c_int, vp],
     "curla_actor_head_fwd": [vp, vp, c_int, c_int, c_float, c_float, vp, vp, vp, vp, vp, vp],
     "curla_actor_head_bwd": [vp, vp, vp, c_float, vp, vp, vp, vp, c_int, c_int, c_float, c_float, vp, vp],
     "curla_concat": [vp, vp, c_int, c_int, c_int, vp, vp],

@@ -113,36 +113,42 @@ __global__ void ln_bwd_kernel(const float* dy, const float* xhat, const float* r
   }
 }
 
-// dgamma[f] = sum_b dy*xhat ; dbeta[f] = sum_b dy   (one block of 1024 per 64 features)
-__global__ __launch_bounds__(1024) void ln_param_grad_kernel(const float* dy, const float* xhat, int B, int F,
-                                                             float* dgamma, float* dbeta) {
-  __shared__ float sg[16][64], sb[16][64];
+// dgamma[f] = sum_b dy*xhat ; dbeta[f] = sum_b dy ; optionally dbias[f] = sum_b dx (the gradient of the fc bias
+// that feeds the LayerNorm: the same walk over the rows)   (one block of 1024 per 64 features)
+__global__ __launch_bounds__(1024) void ln_param_grad_kernel(const float* dy, const float* xhat, const float* dx, int B,
+                                                             int F, float* dgamma, float* dbeta, float* dbias) {
+  __shared__ float sg[16][64], sb[16][64], sx[16][64];
   const int fl = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int f = blockIdx.x * 64 + fl;
-  float ag = 0.f, ab = 0.f;
+  float ag = 0.f, ab = 0.f, ax = 0.f;
   if (f < F) {
     int b = part;
     for (; b + 7 * 16 < B; b += 8 * 16) {  // 8 rows in flight, accumulated in row order
-      float d[8], x[8];
+      float d[8], x[8], e[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) d[k] = dy[(size_t)(b + 16 * k) * F + f], x[k] = xhat[(size_t)(b + 16 * k) * F + f];
+      for (int k = 0; k < 8; ++k) {
+        d[k] = dy[(size_t)(b + 16 * k) * F + f], x[k] = xhat[(size_t)(b + 16 * k) * F + f];
+        e[k] = dbias ? dx[(size_t)(b + 16 * k) * F + f] : 0.f;
+      }
 #pragma unroll
-      for (int k = 0; k < 8; ++k) ag += d[k] * x[k], ab += d[k];
+      for (int k = 0; k < 8; ++k) ag += d[k] * x[k], ab += d[k], ax += e[k];
     }
     for (; b < B; b += 16) {
       const float d = dy[(size_t)b * F + f];
       ag += d * xhat[(size_t)b * F + f];
       ab += d;
+      if (dbias) ax += dx[(size_t)b * F + f];
     }
   }
-  sg[part][fl] = ag, sb[part][fl] = ab;
+  sg[part][fl] = ag, sb[part][fl] = ab, sx[part][fl] = ax;
   __syncthreads();
   if (part == 0 && f < F) {
-    float g = sg[0][fl], bsum = sb[0][fl];
+    float g = sg[0][fl], bsum = sb[0][fl], xs = sx[0][fl];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) g += sg[k][fl], bsum += sb[k][fl];
+    for (int k = 1; k < 16; ++k) g += sg[k][fl], bsum += sb[k][fl], xs += sx[k][fl];
     dgamma[f] = g;
     dbeta[f] = bsum;
+    if (dbias) dbias[f] = xs;
   }
 }
 
@@ -172,6 +178,43 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const float* X, int M, int
 #pragma unroll
     for (int k = 1; k < 32; ++k) t += sm[k][c];
     out[blockIdx.y * sOut + n] = t;
+  }
+}
+
+// three column sums in one launch (the three bias gradients of an MLP backward): blockIdx.z picks the matrix
+struct Colsum3Args {
+  const float* X[3];
+  float* out[3];
+  int N[3];
+  long long sX[3];
+};
+__global__ __launch_bounds__(1024) void colsum3_kernel(Colsum3Args a, int M, long long sOut) {
+  __shared__ float sm[32][33];
+  const int z = blockIdx.z;
+  const int N = a.N[z];
+  const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + c;
+  if (blockIdx.x * 32 >= N) return;  // block-uniform
+  const float* x = a.X[z] + blockIdx.y * a.sX[z];
+  float acc = 0.f;
+  if (n < N) {
+    int m = part;
+    for (; m + 7 * 32 < M; m += 8 * 32) {  // 8 rows in flight, accumulated in row order
+      float t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = x[(size_t)(m + 32 * k) * N + n];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc += t[k];
+    }
+    for (; m < M; m += 32) acc += x[(size_t)m * N + n];
+  }
+  sm[part][c] = acc;
+  __syncthreads();
+  if (part == 0 && n < N) {
+    float t = sm[0][c];
+#pragma unroll
+    for (int k = 1; k < 32; ++k) t += sm[k][c];
+    a.out[z][blockIdx.y * sOut + n] = t;
   }
 }
 
@@ -419,7 +462,7 @@ int curla_fc_ln_fwd(const float* partial, int nsplit, long long split_stride, in
 }
 
 int curla_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int F, float* dx,
-                 float* dgamma, float* dbeta, void* stream) {
+                 float* dgamma, float* dbeta, float* dbias_in, void* stream) {
   CURLA_REQUIRE(dy && xhat && rstd && gamma && dx && B > 0 && F > 0);
   if (F > 256) return CURLA_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -432,8 +475,10 @@ int curla_ln_bwd(const float* dy, const float* xhat, const float* rstd, const fl
     default: CURLA_LN_BWD(4); break;
   }
 #undef CURLA_LN_BWD
+  CURLA_REQUIRE(!dbias_in || (dgamma && dbeta));
   if (dgamma && dbeta)
-    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((F + 63) / 64), dim3(1024), 0, st, dy, xhat, B, F, dgamma, dbeta);
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((F + 63) / 64), dim3(1024), 0, st, dy, xhat, dx, B, F, dgamma, dbeta,
+                       dbias_in);
   return curla_launch_status();
 }
 
@@ -442,6 +487,19 @@ int curla_colsum(const float* X, int M, int N, int ldx, long long strideX, float
   CURLA_REQUIRE(X && out && M > 0 && N > 0 && nbatch > 0);
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32, nbatch), dim3(1024), 0, static_cast<hipStream_t>(stream), X, M,
                      N, ldx, strideX, out, strideOut);
+  return curla_launch_status();
+}
+
+int curla_colsum3(const float* X0, int N0, const float* X1, int N1, const float* X2, int N2, int M, float* out0,
+                  float* out1, float* out2, long long strideOut, int nbatch, void* stream) {
+  CURLA_REQUIRE(X0 && X1 && X2 && out0 && out1 && out2 && M > 0 && N0 > 0 && N1 > 0 && N2 > 0 && nbatch > 0);
+  Colsum3Args a;
+  a.X[0] = X0, a.X[1] = X1, a.X[2] = X2, a.out[0] = out0, a.out[1] = out1, a.out[2] = out2;
+  a.N[0] = N0, a.N[1] = N1, a.N[2] = N2;
+  a.sX[0] = (long long)M * N0, a.sX[1] = (long long)M * N1, a.sX[2] = (long long)M * N2;
+  const int nmax = N0 > N1 ? (N0 > N2 ? N0 : N2) : (N1 > N2 ? N1 : N2);
+  hipLaunchKernelGGL(colsum3_kernel, dim3((nmax + 31) / 32, nbatch, 3), dim3(1024), 0, static_cast<hipStream_t>(stream), a, M,
+                     strideOut);
   return curla_launch_status();
 }
 

@@ -78,15 +78,13 @@ def _mlp_bwd(x, sx, P, G, nb, B, din, H, dout, h1, h2, dy, dh2, dh1, dx):
     s = P.stride
     if G is not None:
         ops.linear_dw(dy, B * dout, h2, B * H, G.W[2], s, B, dout, H, nb)
-        ops.colsum(dy, B, dout, dout, B * dout, G.b[2], s, nb)
     ops.linear_dx(dy, B * dout, P.W[2], s, dh2, B * H, B, dout, H, nb, mask=h2, smask=B * H)
     if G is not None:
         ops.linear_dw(dh2, B * H, h1, B * H, G.W[1], s, B, H, H, nb)
-        ops.colsum(dh2, B, H, H, B * H, G.b[1], s, nb)
     ops.linear_dx(dh2, B * H, P.W[1], s, dh1, B * H, B, H, H, nb, mask=h1, smask=B * H)
     if G is not None:
         ops.linear_dw(dh1, B * H, x, sx, G.W[0], s, B, H, din, nb)
-        ops.colsum(dh1, B, H, H, B * H, G.b[0], s, nb)
+        ops.colsum3(dy, dout, dh2, H, dh1, H, B, G.b[2], G.b[1], G.b[0], s, nb)  # the three bias gradients
     if dx is not None:
         ops.linear_dx(dh1, B * H, P.W[0], s, dx, B * din, B, H, din, nb)
 
@@ -496,8 +494,8 @@ class CurlSacAgent(object):
         writes .grad of enc.{ln,fc,convs}."""
         B, F, K, L = obs_ref.B, enc.feature_dim, enc.flat_dim, enc.num_layers
         acts = ws.acts_main
-        ops.ln_bwd(dz, xhat, rstd, enc.ln.weight, B, F, ws.dfc, dgamma=enc.ln.weight.grad, dbeta=enc.ln.bias.grad)
-        ops.colsum(ws.dfc, B, F, F, 0, enc.fc.bias.grad, 0)
+        ops.ln_bwd(dz, xhat, rstd, enc.ln.weight, B, F, ws.dfc, dgamma=enc.ln.weight.grad, dbeta=enc.ln.bias.grad,
+                   dbias_in=enc.fc.bias.grad)
         h = acts[-1]
         ops.linear_dw(ws.dfc, 0, h, 0, enc.fc.weight.grad, 0, B, F, K)
         if not conv_grads:
@@ -611,8 +609,7 @@ class CurlSacAgent(object):
         _mlp_bwd(ws.z_a, 0, trunk, _Mlp(self.actor.trunk, grads=True), 1, B, F, H, 2 * A, ws.a_h1, ws.a_h2, ws.a_dout,
                  ws.a_dh2, ws.a_dh1, ws.dz)
         ops.ln_bwd(ws.dz, ws.xhat_a, ws.rstd_a, aenc.ln.weight, B, F, ws.dfc, dgamma=aenc.ln.weight.grad,
-                   dbeta=aenc.ln.bias.grad)
-        ops.colsum(ws.dfc, B, F, F, 0, aenc.fc.bias.grad, 0)
+                   dbeta=aenc.ln.bias.grad, dbias_in=aenc.fc.bias.grad)
         ops.linear_dw(ws.dfc, 0, h, 0, aenc.fc.weight.grad, 0, B, F, enc.flat_dim)
 
         self._allreduce(self._actor_gflat, self.log_alpha.grad)

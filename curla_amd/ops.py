@@ -114,12 +114,19 @@ def fc_ln_fwd(partial, nsplit, split_stride, ldp, bias, gamma, beta, B, F, y, fc
          ptr(fc_out), ptr(y), ptr(xhat), ptr(rstd), tanh_out, stream())
 
 
-def ln_bwd(dy, xhat, rstd, gamma, B, F, dx, dgamma=None, dbeta=None):
-    call("curla_ln_bwd", ptr(dy), ptr(xhat), ptr(rstd), ptr(gamma), B, F, ptr(dx), ptr(dgamma), ptr(dbeta), stream())
+def ln_bwd(dy, xhat, rstd, gamma, B, F, dx, dgamma=None, dbeta=None, dbias_in=None):
+    """LayerNorm backward; ``dbias_in`` (optional) receives the column sums of dx (the fc bias gradient)."""
+    call("curla_ln_bwd", ptr(dy), ptr(xhat), ptr(rstd), ptr(gamma), B, F, ptr(dx), ptr(dgamma), ptr(dbeta),
+         ptr(dbias_in), stream())
 
 
 def colsum(X, M, N, ldx, sX, out, sOut, nb=1):
     call("curla_colsum", ptr(X), M, N, ldx, sX, ptr(out), sOut, nb, stream())
+
+
+def colsum3(X0, N0, X1, N1, X2, N2, M, out0, out1, out2, sOut, nb=1):
+    """Three column sums (dense [nb][M][N_i] inputs) in one launch."""
+    call("curla_colsum3", ptr(X0), N0, ptr(X1), N1, ptr(X2), N2, M, ptr(out0), ptr(out1), ptr(out2), sOut, nb, stream())
 
 
 def actor_head_fwd(trunk_out, noise, B, A, lo, hi, mu=None, pi=None, log_pi=None, log_std=None, tanh_ls=None):

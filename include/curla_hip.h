@@ -86,11 +86,18 @@ int curla_splitk_reduce(const float* partial, int nsplit, long long split_stride
 int curla_fc_ln_fwd(const float* partial, int nsplit, long long split_stride, int ldp, const float* bias,
                     const float* gamma, const float* beta, int B, int F, float eps, float* fc_out, float* y,
                     float* xhat, float* rstd, int tanh_out, void* stream);
+/* dx, and (when non-NULL) dgamma, dbeta; dbias_in (optional, needs dgamma/dbeta) = column sums of dx = the gradient of
+ * the fc bias feeding the LayerNorm */
 int curla_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int F, float* dx,
-                 float* dgamma, float* dbeta, void* stream);
+                 float* dgamma, float* dbeta, float* dbias_in, void* stream);
 /* out[z][n] = sum_m X[z][m][n] (bias gradients) */
 int curla_colsum(const float* X, int M, int N, int ldx, long long strideX, float* out, long long strideOut, int nbatch,
                  void* stream);
+
+/* the three bias gradients of a (batched) 3-layer MLP backward in one launch: out_i[z][n] = sum_m X_i[z][m][n],
+ * X_i dense [nbatch][M][N_i], out_i batches `strideOut` floats apart (curl_sac.py:70-74,129-133 backward) */
+int curla_colsum3(const float* X0, int N0, const float* X1, int N1, const float* X2, int N2, int M, float* out0,
+                  float* out1, float* out2, long long strideOut, int nbatch, void* stream);
 
 /* ---- squashed-Gaussian policy head (curl_sac.py:20-35, 87-108) ----
  * trunk_out [B][2A] = [mu | raw log_std]; `noise` replaces torch.randn_like

@@ -203,7 +203,9 @@ def test_gemm_splitk_and_fc_ln(ops, B, Fd, K):
     dy = rnd(B, Fd, seed=36)
     y_ref.backward(dy)
     dx, dg, db_ = torch.empty(B, Fd, device="cuda"), torch.empty(Fd, device="cuda"), torch.empty(Fd, device="cuda")
-    ops.ln_bwd(dev(dy), xhat, rstd, dev(gamma), B, Fd, dx, dgamma=dg, dbeta=db_)
+    dbin = torch.empty(Fd, device="cuda")
+    ops.ln_bwd(dev(dy), xhat, rstd, dev(gamma), B, Fd, dx, dgamma=dg, dbeta=db_, dbias_in=dbin)
+    check("fc dbias fused into the LayerNorm backward", dbin.cpu(), bl.grad)
     check("layernorm dgamma", dg.cpu(), gl.grad)
     check("layernorm dbeta", db_.cpu(), betal.grad)
     fcl = fc.detach().clone().requires_grad_(True)
@@ -422,3 +424,15 @@ def test_full_size_batch_independence(ops):
     F.conv2d(xs.cpu(), wref, None, stride=2).backward(g1[sel].permute(0, 3, 1, 2).cpu())
     check("conv1 wgrad from the ring (8 of 512)", dws.cpu(), wref.grad)
     assert torch.isfinite(dw1).all() and float(dw1.abs().max()) > 0
+
+
+def test_colsum3(ops):
+    """Three bias gradients of a batched MLP backward in one launch."""
+    M, nb = 300, 2
+    Ns = (1, 70, 33)
+    Xs = [rnd(nb, M, n, seed=50 + i) for i, n in enumerate(Ns)]
+    outs = [torch.full((nb, 128), float("nan"), device="cuda") for _ in Ns]
+    ops.colsum3(dev(Xs[0]), Ns[0], dev(Xs[1]), Ns[1], dev(Xs[2]), Ns[2], M, outs[0], outs[1], outs[2], 128, nb)
+    for i, n in enumerate(Ns):
+        check(f"colsum3[{i}] N={n}", outs[i][:, :n].cpu(), Xs[i].sum(1))
+        assert torch.isnan(outs[i][:, n:]).all()  # nothing written past N
