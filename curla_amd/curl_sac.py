@@ -438,7 +438,7 @@ class CurlSacAgent(object):
             return
         import torch.distributed as dist
         for t in buckets:
-            if self._dp_avg:
+            if self._dp_avg and t.dtype == torch.float32:  # (the float64 log_alpha scalar takes the plain sum path)
                 dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self._dp_group)
             else:
                 dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._dp_group)
