@@ -151,7 +151,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # one priming update outside everything (workspaces, split-K buffers and the Adam states are allocated on
+    # first use), so that even --warmup 0 times steady-state steps; then the W untimed warm-up steps
     step = 0
+    agent.update(rb, L, step)
+    step += 1
     for _ in range(args.warmup):
         agent.update(rb, L, step)
         step += 1
@@ -234,7 +238,7 @@ def main():
             "config": {"workload": "BASELINE.json configs[1]: CurlSacAgent.update(), per-GPU batch 512, 84x84x9 uint8 "
                                    "replay ring -> random_crop 76x76, encoder 4x32 filters feat 50, hidden 1024, "
                                    "CURL+critic+actor (actor/target every 2nd step)",
-                       "replay_capacity": cap * world, "parallelism": f"dp{world}"},
+                       "replay_capacity": cap * world, "parallelism": f"dp{world}", "priming_updates": 1},
             "transitions_per_s": updates_per_s * BATCH,
             "conv_algorithmic_gflop_per_update": per_update / 1e9,
             "conv_roofline_frac_whole_update": per_update * (args.steps / dt) / (PEAK_F32_TFLOPS * 1e12),
