@@ -10,12 +10,13 @@
 // product runs on the exact-f32 matrix pipe (v_mfma_f32_16x16x4_f32), which has
 // the same 157 TFLOP/s roof as the fp32 vector pipe but needs one operand VGPR
 // per lane instead of 2 per FMA.  GEMM view of the forward:
-//   D[cout (16 per m-tile, 2 tiles)][pixel (16 per n-tile)] += W[cout][k] * X[k][pixel],
-//   k = (tap, cin).  A 512-thread workgroup stages a band of input rows in LDS
-// (pixel stride padded 32 -> 36 floats) and its 4 waves walk the band's
-// 16-pixel tiles.  Two such workgroups share a CU (<= 80 KB LDS, <= 256 VGPRs
-// each): their load / barrier stalls are uncorrelated, so one wave per SIMD is
-// always ready to feed the matrix pipe.
+//   D[cout (16 per wave)][pixel pair (16 per tile)] += U[cout][k] * V[k][pixel pair],  k = (row tap, cin),
+// with the x direction in 1-D Winograd F(2,3) form (4 products per two outputs).  A 256-thread workgroup
+// stages a band of input rows in LDS (pixel stride padded 32 -> 36 floats); its 4 waves are 2 output-channel
+// halves x 2 tile slots.  Two such workgroups share a CU (<= 80 KB LDS, <= 256 VGPRs each): while one stages
+// or stores, the other's waves keep the matrix pipe fed.  What bounds the tile loops is VALU issue time (a VALU
+// instruction and an MFMA cannot issue in the same cycle), so everything in them is counted in instructions:
+// packed fp32 adds for the Winograd transform, division-free pixel walks, epilogues deferred into the next tile.
 #include "common.h"
 
 namespace {
