@@ -44,6 +44,8 @@ SIGNATURES = {
     "curla_color_jiggle": [vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp],
     "curla_noisy_cover": [vp, vp, vp, c_float, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp],
     "curla_gather_nhwc": [vp, vp, c_int, c_int, c_int, c_int, vp, vp],
+    "curla_color_jiggle_nchw": [vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp],
+    "curla_noisy_cover_nchw": [vp, vp, c_float, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp],
     "curla_version": [],
 }
 _RESTYPES = {"curla_conv_wgrad_workspace_floats": c_size_t, "curla_version": ctypes.c_char_p}

@@ -9,6 +9,19 @@ callers that want tensors, done by ``curla_crop_nchw``.
 import numpy as np
 
 
+def _device_batch(image_batch, input_shape):
+    """The float NCHW device tensor the augmentation kernels take; anything else is an error (no CPU path)."""
+    import torch
+    if not (torch.is_tensor(image_batch) and image_batch.dim() == 4 and image_batch.shape[1] % 3 == 0
+            and tuple(image_batch.shape[2:]) == tuple(input_shape)):
+        raise ValueError("expected a (B, 3*frame_stack, %d, %d) tensor, got %r"
+                         % (input_shape[0], input_shape[1], getattr(image_batch, "shape", type(image_batch))))
+    from . import _lib
+    if not image_batch.is_cuda and _lib._trace_hook is None:
+        raise RuntimeError("ColorJiggle / NoisyCover run on the HIP device only: curla_amd has no CPU path")
+    return image_batch.float().contiguous()
+
+
 class IdentityAugmentation:
     """augmentations.py:7-17."""
 
@@ -87,6 +100,23 @@ class ColorJiggle(IdentityAugmentation):
         order = torch.randperm(4).int()
         return torch.stack([apply, con, sat, hue], 1).contiguous(), order
 
+    def training_augmentation(self, image_batch, params=None, order=None):
+        """augmentations.py:105-136 on the reference's tensor contract: a float (B, 3k, H, W) device tensor in
+        [0,255] in, the jittered batch out -- the same kernel arithmetic ``ReplayBuffer`` applies straight from
+        the ring.  A new tensor is returned (the reference scales its argument in place by 1/255 and returns a
+        fresh tensor; callers only use the return value, utils.py:174-182).  ``params`` / ``order`` replace
+        the random draws (tests)."""
+        import torch
+        from . import ops
+        x = _device_batch(image_batch, self.input_shape)
+        B, C = x.shape[:2]
+        if params is None:
+            params, order = self.draw_params(B * (C // 3))
+        out = torch.empty_like(x)
+        ops.color_jiggle_nchw(x, params.to(x.device, torch.float32).contiguous(),
+                              torch.as_tensor(order, dtype=torch.int32).to(x.device), out)
+        return out
+
 
 class NoisyCover(IdentityAugmentation):
     """augmentations.py:138-205: rows [0, ceil(0.31 h)) and [h - ceil(0.20 h), h) of every frame are painted
@@ -103,6 +133,21 @@ class NoisyCover(IdentityAugmentation):
 
     def draw_colors(self):
         return [np.random.randint(0, 255) for _ in range(3)]
+
+    def training_augmentation(self, image_batch, colors=None, noise=None):
+        """augmentations.py:170-205 on the reference's tensor contract (float (B, 3k, H, W) device tensor in
+        [0,255]); returns a new tensor (the reference paints the cover into its argument in place and returns a
+        fresh noisy tensor).  ``colors`` / ``noise`` replace the random draws (tests)."""
+        import torch
+        from . import ops
+        x = _device_batch(image_batch, self.input_shape)
+        if colors is None:
+            colors = self.draw_colors()
+        if noise is None:
+            noise = torch.randn(x.shape, device=x.device) * self.std
+        out = torch.empty_like(x)
+        ops.noisy_cover_nchw(x, noise.to(x.device, torch.float32).contiguous(), colors, self.top, self.bottom, out)
+        return out
 
 
 def make_augmentor(name, input_shape, output_shape=None):

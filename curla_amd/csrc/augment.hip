@@ -46,6 +46,34 @@ __device__ __forceinline__ void hsv_to_rgb(float h, float s, float v, float& r, 
   }
 }
 
+// One RGB pixel in [0,1] through the jitter chain.  p = (apply, contrast, saturation, hue_radians) of the pixel's
+// frame; o0..o3 = the call's permutation of {0 brightness (factor 0: identity), 1 contrast, 2 saturation, 3 hue}.
+__device__ __forceinline__ void jiggle_rgb(float& r, float& g, float& bl, const float* p, int o0, int o1, int o2,
+                                           int o3) {
+  if (p[0] == 0.f) return;
+  const float con = p[1], sat = p[2], hue = p[3];
+#pragma unroll
+  for (int step = 0; step < 4; ++step) {
+    const int op = step == 0 ? o0 : step == 1 ? o1 : step == 2 ? o2 : o3;
+    if (op == 1) {
+      r = fminf(fmaxf(r * con, 0.f), 1.f);
+      g = fminf(fmaxf(g * con, 0.f), 1.f);
+      bl = fminf(fmaxf(bl * con, 0.f), 1.f);
+    } else if (op == 2) {
+      float h, s, v;
+      rgb_to_hsv(r, g, bl, h, s, v);
+      s = fminf(fmaxf(s * sat, 0.f), 1.f);
+      hsv_to_rgb(h, s, v, r, g, bl);
+    } else if (op == 3) {
+      float h, s, v;
+      rgb_to_hsv(r, g, bl, h, s, v);
+      h = h + hue;
+      h = h - kTwoPi * floorf(h / kTwoPi);  // fmod into [0, 2pi)
+      hsv_to_rgb(h, s, v, r, g, bl);
+    }
+  }
+}
+
 // params[img] = (apply, contrast, saturation, hue_radians); order[4] = permutation of {0 brightness(identity),
 // 1 contrast, 2 saturation, 3 hue}; one image = one RGB frame of the stack (augmentations.py:124-128).
 __global__ void color_jiggle_kernel(const uint8_t* frames, const int64_t* idx, const float* params, const int* order,
@@ -62,33 +90,30 @@ __global__ void color_jiggle_kernel(const uint8_t* frames, const int64_t* idx, c
     const size_t yx = pix - (size_t)b * H * W;
     const int64_t fi = idx ? idx[b] : b;
     const uint8_t* src = frames + ((size_t)fi * H * W + yx) * C + 3 * fr;
-    float r = src[0] * (1.f / 255.f), g = src[1] * (1.f / 255.f), bl = src[2] * (1.f / 255.f);
-    const float* p = params + ((size_t)b * k + fr) * 4;
-    if (p[0] != 0.f) {
-      const float con = p[1], sat = p[2], hue = p[3];
-#pragma unroll
-      for (int step = 0; step < 4; ++step) {
-        const int op = step == 0 ? o0 : step == 1 ? o1 : step == 2 ? o2 : o3;
-        if (op == 1) {
-          r = fminf(fmaxf(r * con, 0.f), 1.f);
-          g = fminf(fmaxf(g * con, 0.f), 1.f);
-          bl = fminf(fmaxf(bl * con, 0.f), 1.f);
-        } else if (op == 2) {
-          float h, s, v;
-          rgb_to_hsv(r, g, bl, h, s, v);
-          s = fminf(fmaxf(s * sat, 0.f), 1.f);
-          hsv_to_rgb(h, s, v, r, g, bl);
-        } else if (op == 3) {
-          float h, s, v;
-          rgb_to_hsv(r, g, bl, h, s, v);
-          h = h + hue;
-          h = h - kTwoPi * floorf(h / kTwoPi);  // fmod into [0, 2pi)
-          hsv_to_rgb(h, s, v, r, g, bl);
-        }
-      }
-    }
+    float r = src[0] / 255.f, g = src[1] / 255.f, bl = src[2] / 255.f;  // `image_batch /= 255.0`, augmentations.py:118
+    jiggle_rgb(r, g, bl, params + ((size_t)b * k + fr) * 4, o0, o1, o2, o3);
     float* dst = out + pix * C + 3 * fr;
     dst[0] = r * 255.f, dst[1] = g * 255.f, dst[2] = bl * 255.f;
+  }
+}
+
+// the same on the reference's tensor contract: float NCHW [B][C][H][W] in [0,255] in and out
+// (ColorJiggle.training_augmentation(image_batch), augmentations.py:105-136; in == out is allowed)
+__global__ void color_jiggle_nchw_kernel(const float* in, const float* params, const int* order, int B, int C, int H,
+                                         int W, float* out) {
+  const int k = C / 3;
+  const size_t plane = (size_t)H * W;
+  const size_t n = (size_t)B * k * plane;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const int o0 = order[0], o1 = order[1], o2 = order[2], o3 = order[3];
+  for (; i < n; i += stride) {
+    const size_t img = i / plane;  // b * k + frame
+    const size_t yx = i - img * plane;
+    const size_t base = img * 3 * plane + yx;
+    float r = in[base] / 255.f, g = in[base + plane] / 255.f, bl = in[base + 2 * plane] / 255.f;
+    jiggle_rgb(r, g, bl, params + img * 4, o0, o1, o2, o3);
+    out[base] = r * 255.f, out[base + plane] = g * 255.f, out[base + 2 * plane] = bl * 255.f;
   }
 }
 
@@ -107,6 +132,23 @@ __global__ void noisy_cover_kernel(const uint8_t* frames, const int64_t* idx, co
     const int y = yx / W;
     const int64_t fi = idx ? idx[b] : b;
     float v = (float)frames[((size_t)fi * H * W + yx) * C + c];
+    if (y < top || y >= H - bottom) v = (c % 3 == 0) ? c0 : (c % 3 == 1) ? c1 : c2;
+    v += noise[i];
+    out[i] = fminf(fmaxf(v, 0.f), 255.f);
+  }
+}
+
+// the same on the reference's tensor contract: float NCHW in [0,255] in, noise NCHW, out NCHW
+// (NoisyCover.training_augmentation(image_batch), augmentations.py:170-205; in == out is allowed)
+__global__ void noisy_cover_nchw_kernel(const float* in, const float* noise, float c0, float c1, float c2, int top,
+                                        int bottom, int B, int C, int H, int W, float* out) {
+  const size_t n = (size_t)B * C * H * W;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const int y = (i / W) % H;
+    const int c = (i / ((size_t)W * H)) % C;
+    float v = in[i];
     if (y < top || y >= H - bottom) v = (c % 3 == 0) ? c0 : (c % 3 == 1) ? c1 : c2;
     v += noise[i];
     out[i] = fminf(fmaxf(v, 0.f), 255.f);
@@ -147,6 +189,22 @@ int curla_noisy_cover(const uint8_t* frames, const int64_t* idx, const float* no
   CURLA_REQUIRE(frames && noise && out && B > 0 && C > 0 && H > 0 && W > 0 && top >= 0 && bottom >= 0);
   hipLaunchKernelGGL(noisy_cover_kernel, dim3(blocks_for((size_t)B * H * W * C)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), frames, idx, noise, c0, c1, c2, top, bottom, B, C, H, W, out);
+  return curla_launch_status();
+}
+
+int curla_color_jiggle_nchw(const float* in, const float* params, const int32_t* order, int B, int C, int H, int W,
+                            float* out, void* stream) {
+  CURLA_REQUIRE(in && params && order && out && B > 0 && C > 0 && C % 3 == 0 && H > 0 && W > 0);
+  hipLaunchKernelGGL(color_jiggle_nchw_kernel, dim3(blocks_for((size_t)B * H * W * (C / 3))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, params, order, B, C, H, W, out);
+  return curla_launch_status();
+}
+
+int curla_noisy_cover_nchw(const float* in, const float* noise, float c0, float c1, float c2, int top, int bottom,
+                           int B, int C, int H, int W, float* out, void* stream) {
+  CURLA_REQUIRE(in && noise && out && B > 0 && C > 0 && H > 0 && W > 0 && top >= 0 && bottom >= 0);
+  hipLaunchKernelGGL(noisy_cover_nchw_kernel, dim3(blocks_for((size_t)B * H * W * C)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), in, noise, c0, c1, c2, top, bottom, B, C, H, W, out);
   return curla_launch_status();
 }
 

@@ -1252,7 +1252,7 @@ int curla_conv1_fwd(const void* src, int src_kind, const int64_t* idx, const int
   a.dbg = ABL_HOST;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t wl = (size_t)32 * C * 9 * sizeof(float);
-  if (src_kind == 1) {
+  if (src_kind == 1 && !(ABL_HOST & 128)) {
     // uint8 ring: the band stays bytes in LDS; the tallest band that leaves room for two workgroups per CU
     const int RSb = ((Wc * C + 15) & ~15) + 16;
     int th = a.Ho;
@@ -1336,7 +1336,7 @@ int curla_conv1_wgrad(const void* src, int src_kind, const int64_t* idx, const i
   const int nw = 32 * C * 9;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int grid;
-  if (src_kind == 1) {
+  if (src_kind == 1 && !(ABL_HOST & 256)) {
     const int RSb = ((Wc * C + 15) & ~15) + 16;
     int th = a.Ho;
     while (th > 1 && (size_t)(2 * th + 1) * RSb + (size_t)th * a.Wo * kLdsPix * sizeof(float) > 76 * 1024) --th;

@@ -346,6 +346,9 @@ class CurlSacAgent(object):
         self._dp_world = 1
         self._dp_active = False
         self._dp_avg = False
+        self._dp_overlap = False
+        self._dp_check_every = 0
+        self._dp_pending = []
         self.train()
         self.critic_target.train()
 
@@ -419,12 +422,27 @@ class CurlSacAgent(object):
         return self._workspaces[B]
 
     # --------------------------------------------------------------- data parallel
-    def enable_data_parallel(self, process_group=None, single_rank_collectives=False):
+    def enable_data_parallel(self, process_group=None, single_rank_collectives=False, overlap=None, broadcast=True,
+                             check_every=None):
         """Synchronous data parallelism (one process per GPU): before every
         optimizer step the freshly written flat gradient bucket is averaged over
-        ranks with one all-reduce (RCCL over xGMI).  Ranks must hold
-        identical parameters (same seed).  RCCL averages inside the collective
+        ranks (RCCL over xGMI).  RCCL averages inside the collective
         (ncclAvg); other backends (gloo in the CPU tests) sum and divide.
+
+        ``broadcast``: rank 0's parameters, targets and log_alpha replace every
+        other rank's (three flat buffers + one scalar), so ranks need not have
+        been seeded identically.  ``check_every`` (default 1000 updates, env
+        CURLA_DP_CHECK_EVERY, 0 = never): a checksum of the replicated state is
+        compared across ranks and a mismatch raises -- replicas that drift apart
+        would otherwise train on silently.
+        ``overlap`` (default on, env CURLA_DP_OVERLAP=0 turns it off): each
+        bucket is reduced in two asynchronous pieces issued where their
+        gradients become final -- the twin-Q / fc / LayerNorm gradients (almost
+        all of the bytes) before the conv backward starts, the conv gradients
+        after it -- on the communicator's own stream; the compute stream only
+        waits for them right before ``optimizer.step()``.  Off: one blocking
+        all-reduce per bucket.  Both orders reduce the same elements with the
+        same collective, so the result does not depend on the flag.
         ``single_rank_collectives`` issues the collectives even in a world of one
         (a 1-GPU check of the exact calls an N-GPU run makes)."""
         import torch.distributed as dist
@@ -432,17 +450,67 @@ class CurlSacAgent(object):
         self._dp_world = dist.get_world_size(self._dp_group)
         self._dp_active = self._dp_world > 1 or single_rank_collectives
         self._dp_avg = dist.get_backend(self._dp_group) == "nccl"
+        if overlap is None:
+            overlap = os.environ.get("CURLA_DP_OVERLAP", "1") != "0"
+        self._dp_overlap = bool(overlap)
+        if check_every is None:
+            check_every = int(os.environ.get("CURLA_DP_CHECK_EVERY", "1000"))
+        self._dp_check_every = int(check_every)
+        self._dp_pending = []
+        if self._dp_active and broadcast:
+            src = dist.get_global_rank(self._dp_group, 0)
+            with torch.no_grad():
+                for t in (self._critic_flat, self._target_flat, self._actor_flat, self.log_alpha):
+                    dist.broadcast(t, src=src, group=self._dp_group)
 
-    def _allreduce(self, *buckets):
+    def _replica_checksum(self):
+        """float64 sums of the replicated state (deterministic: same kernel, same data => same bits)."""
+        with torch.no_grad():
+            return torch.stack([self._critic_flat.sum(dtype=torch.float64), self._target_flat.sum(dtype=torch.float64),
+                                self._actor_flat.sum(dtype=torch.float64), self.log_alpha.detach().to(torch.float64)])
+
+    def check_replicas(self):
+        """Raise if the ranks' parameters differ (costs one 64-byte all-reduce and a host sync)."""
+        if not self._dp_active:
+            return
+        import torch.distributed as dist
+        s = self._replica_checksum()
+        both = torch.stack([s, -s])  # max over ranks of (s, -s) = (max, -min)
+        dist.all_reduce(both, op=dist.ReduceOp.MAX, group=self._dp_group)
+        hi, lo = both[0], -both[1]
+        if not bool(torch.equal(hi, lo)):
+            names = ("critic", "critic_target", "actor", "log_alpha")
+            bad = [n for n, a, b in zip(names, hi.tolist(), lo.tolist()) if a != b]
+            raise RuntimeError("data-parallel replicas have diverged (%s differ across ranks): seed every rank "
+                               "identically or keep broadcast=True in enable_data_parallel" % ", ".join(bad))
+
+    def _allreduce(self, *buckets, async_op=False):
+        """Average each tensor over the ranks.  async_op: the collectives are only enqueued (they start once
+        the compute stream reaches this point); _allreduce_wait() makes the compute stream wait for them."""
         if not self._dp_active:
             return
         import torch.distributed as dist
         for t in buckets:
-            if self._dp_avg and t.dtype == torch.float32:  # (the float64 log_alpha scalar takes the plain sum path)
-                dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self._dp_group)
+            if t.numel() == 0:
+                continue
+            avg = self._dp_avg and t.dtype == torch.float32  # (the float64 log_alpha scalar takes the sum path)
+            op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+            if async_op:
+                self._dp_pending.append((dist.all_reduce(t, op=op, group=self._dp_group, async_op=True), t, not avg))
             else:
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self._dp_group)
+                dist.all_reduce(t, op=op, group=self._dp_group)
+                if not avg:
+                    t.div_(self._dp_world)
+
+    def _allreduce_wait(self):
+        for work, t, divide in self._dp_pending:
+            work.wait()
+            if divide:
                 t.div_(self._dp_world)
+        self._dp_pending = []
+
+    def _grad_offset(self, p, flat):
+        return (p.grad.data_ptr() - flat.data_ptr()) // 4
 
     # ------------------------------------------------------------------ reference API
     def train(self, training=True):
@@ -489,15 +557,18 @@ class CurlSacAgent(object):
             return pi.cpu().data.numpy().flatten()
 
     # ------------------------------------------------------------------ building blocks
-    def _encoder_backward(self, ws, obs_ref, dz, xhat, rstd, enc, conv_grads=True):
+    def _encoder_backward(self, ws, obs_ref, dz, xhat, rstd, enc, conv_grads=True, dense_done=None):
         """Backward of fc+LN and (optionally) the conv stack from d(loss)/d(z);
-        writes .grad of enc.{ln,fc,convs}."""
+        writes .grad of enc.{ln,fc,convs}.  ``dense_done()`` is called once the fc / LayerNorm gradients are
+        final, i.e. before the conv backward is enqueued (data parallel: their all-reduce starts there)."""
         B, F, K, L = obs_ref.B, enc.feature_dim, enc.flat_dim, enc.num_layers
         acts = ws.acts_main
         ops.ln_bwd(dz, xhat, rstd, enc.ln.weight, B, F, ws.dfc, dgamma=enc.ln.weight.grad, dbeta=enc.ln.bias.grad,
                    dbias_in=enc.fc.bias.grad)
         h = acts[-1]
         ops.linear_dw(ws.dfc, 0, h, 0, enc.fc.weight.grad, 0, B, F, K)
+        if dense_done is not None:
+            dense_done()
         if not conv_grads:
             return
         cur = L % 2
@@ -554,10 +625,19 @@ class CurlSacAgent(object):
         _mlp_bwd(ws.xa, 0, self.critic.twin(), self.critic.twin(grads=True), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.dq,
                  ws.q_dh2, ws.q_dh1, ws.dxa)
         ops.split_sum(ws.dxa, B * (F + A), B, F, A, dz=ws.dz)
-        self._encoder_backward(ws, o, ws.dz, ws.xhat_c, ws.rstd_c, enc, conv_grads=not self.detach_encoder)
-
+        # data parallel: the bucket is [convs | fc, ln | Q1 | Q2]; everything behind the convs is final before the
+        # conv backward starts and is reduced underneath it
         lay = self._lay
-        self._allreduce(self._critic_gflat[lay["enc"][0]:lay["total"]])
+        e0, total = lay["enc"][0], lay["total"]
+        if self._dp_active and self._dp_overlap:
+            cut = self._grad_offset(enc.fc.weight, self._critic_gflat)
+            self._encoder_backward(ws, o, ws.dz, ws.xhat_c, ws.rstd_c, enc, conv_grads=not self.detach_encoder,
+                                   dense_done=lambda: self._allreduce(self._critic_gflat[cut:total], async_op=True))
+            self._allreduce(self._critic_gflat[e0:cut], async_op=True)
+            self._allreduce_wait()
+        else:
+            self._encoder_backward(ws, o, ws.dz, ws.xhat_c, ws.rstd_c, enc, conv_grads=not self.detach_encoder)
+            self._allreduce(self._critic_gflat[e0:total])
         if self.detach_encoder:  # convs received no gradient: Adam must skip them (grad None in the reference)
             saved = [(p, p.grad) for m in enc.convs for p in (m.weight, m.bias)]
             for p, _ in saved:
@@ -608,11 +688,19 @@ class CurlSacAgent(object):
         ops.actor_head_bwd(ws.gpi, self.log_alpha, 1.0 / B, nz, ws.pi, ws.log_std, ws.tanh_ls, B, A, lo, hi, ws.a_dout)
         _mlp_bwd(ws.z_a, 0, trunk, _Mlp(self.actor.trunk, grads=True), 1, B, F, H, 2 * A, ws.a_h1, ws.a_h2, ws.a_dout,
                  ws.a_dh2, ws.a_dh1, ws.dz)
+        overlap = self._dp_active and self._dp_overlap
+        if overlap:  # bucket = [fc, ln | trunk]: the trunk gradients are final here, fc / ln follow
+            cut = self._grad_offset(self.actor.trunk[0].weight, self._actor_gflat)
+            self._allreduce(self._actor_gflat[cut:], self.log_alpha.grad, async_op=True)
         ops.ln_bwd(ws.dz, ws.xhat_a, ws.rstd_a, aenc.ln.weight, B, F, ws.dfc, dgamma=aenc.ln.weight.grad,
                    dbeta=aenc.ln.bias.grad, dbias_in=aenc.fc.bias.grad)
         ops.linear_dw(ws.dfc, 0, h, 0, aenc.fc.weight.grad, 0, B, F, enc.flat_dim)
 
-        self._allreduce(self._actor_gflat, self.log_alpha.grad)
+        if overlap:
+            self._allreduce(self._actor_gflat[:cut], async_op=True)
+            self._allreduce_wait()
+        else:
+            self._allreduce(self._actor_gflat, self.log_alpha.grad)
         self.actor_optimizer.step()
         if self.log_param_hist_imgs:
             self.actor.log(L, step)
@@ -641,10 +729,18 @@ class CurlSacAgent(object):
         ops.linear_dx(ws.dlogits, 0, ws.WzT, 0, ws.dz, 0, B, B, F)             # d z_a
         ops.linear_dw(ws.dlogits, 0, ws.z_c, 0, ws.dWzT, 0, B, B, F)           # d (W z_pos^T)^T
         ops.linear_dw(ws.dWzT, 0, ws.z_pos, 0, W.grad, 0, B, F, F)             # d W
-        self._encoder_backward(ws, oa, ws.dz, ws.xhat_c, ws.rstd_c, enc)
-
-        lay = self._lay
-        self._allreduce(self._critic_gflat[0:lay["enc"][1]])
+        # data parallel: the bucket is [W | convs | fc, ln]; the encoder gradients are reduced ONCE and consumed by
+        # both encoder_optimizer and cpc_optimizer
+        e1 = self._lay["enc"][1]
+        if self._dp_active and self._dp_overlap:
+            cut = self._grad_offset(enc.fc.weight, self._critic_gflat)
+            self._encoder_backward(ws, oa, ws.dz, ws.xhat_c, ws.rstd_c, enc,
+                                   dense_done=lambda: self._allreduce(self._critic_gflat[cut:e1], async_op=True))
+            self._allreduce(self._critic_gflat[0:cut], async_op=True)
+            self._allreduce_wait()
+        else:
+            self._encoder_backward(ws, oa, ws.dz, ws.xhat_c, ws.rstd_c, enc)
+            self._allreduce(self._critic_gflat[0:e1])
         self.encoder_optimizer.step()
         self.cpc_optimizer.step()
         if step % self.log_interval == 0:
@@ -665,6 +761,9 @@ class CurlSacAgent(object):
             obs, action, reward, next_obs, not_done, cpc_kwargs = replay_buffer.sample_cpc_refs()
         else:
             obs, action, reward, next_obs, not_done, cpc_kwargs = replay_buffer.sample_cpc()
+
+        if self._dp_active and self._dp_check_every > 0 and step % self._dp_check_every == 0:
+            self.check_replicas()
 
         if step % self.log_interval == 0:
             ws = self._ws(action.shape[0])

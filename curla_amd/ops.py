@@ -202,6 +202,17 @@ def noisy_cover(frames, idx, noise, colors, top, bottom, B, out):
          int(top), int(bottom), B, C, H, W, ptr(out), stream())
 
 
+def color_jiggle_nchw(x, params, order, out):
+    B, C, H, W = x.shape
+    call("curla_color_jiggle_nchw", ptr(_dev(x)), ptr(params), ptr(order), B, C, H, W, ptr(_dev(out)), stream())
+
+
+def noisy_cover_nchw(x, noise, colors, top, bottom, out):
+    B, C, H, W = x.shape
+    call("curla_noisy_cover_nchw", ptr(_dev(x)), ptr(_dev(noise)), float(colors[0]), float(colors[1]), float(colors[2]),
+         int(top), int(bottom), B, C, H, W, ptr(_dev(out)), stream())
+
+
 def gather_nhwc(frames, idx, B, out):
     _, H, W, C = frames.shape
     call("curla_gather_nhwc", ptr(frames), ptr(idx), B, C, H, W, ptr(out), stream())

@@ -146,6 +146,13 @@ int curla_color_jiggle(const uint8_t* frames, const int64_t* idx, const float* p
 int curla_noisy_cover(const uint8_t* frames, const int64_t* idx, const float* noise, float c0, float c1, float c2,
                       int top, int bottom, int B, int C, int H, int W, float* out, void* stream);
 int curla_gather_nhwc(const uint8_t* frames, const int64_t* idx, int B, int C, int H, int W, float* out, void* stream);
+/* The two augmentations on the reference's own tensor contract -- what ColorJiggle.training_augmentation(image_batch)
+ * and NoisyCover.training_augmentation(image_batch) take and return (augmentations.py:105-136,170-205): float NCHW
+ * [B][C][H][W] in [0,255], same arithmetic as the ring forms above; `out` may alias `in`. */
+int curla_color_jiggle_nchw(const float* in, const float* params, const int32_t* order, int B, int C, int H, int W,
+                            float* out, void* stream);
+int curla_noisy_cover_nchw(const float* in, const float* noise, float c0, float c1, float c2, int top, int bottom,
+                           int B, int C, int H, int W, float* out, void* stream);
 
 /* ---- replay ring helpers ---- */
 /* float/uint8 NCHW crops exactly as sample_cpc returns them (utils.py:151-166) */

@@ -46,10 +46,13 @@ def _worker(rank, world, port, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         import curla_amd
         from curla_amd import _lib
-        curla_amd.set_seed_everywhere(1)
+        curla_amd.set_seed_everywhere(1 + rank)  # ranks start from DIFFERENT parameters ...
         aug = curla_amd.RandomCrop((34, 40), (28, 34))
         agent = curla_amd.CurlSacAgent((9, 28, 34), (2,), "cpu", aug, hidden_dim=64, **HP)
-        agent.enable_data_parallel()
+        before = agent._replica_checksum().clone()
+        agent.enable_data_parallel()             # ... and the rank-0 broadcast makes them replicas
+        agent.check_replicas()
+        bcast = (before.numpy(), agent._replica_checksum().numpy())
         fx = [load("tiny.npz"), load("tiny_rank1.npz")]
         mine = fx[rank]
         lay = agent._lay
@@ -86,11 +89,8 @@ def _worker(rank, world, port, q):
             if name.endswith("encoder.fc.weight"):
                 g = agent.critic.encoder.fc.to_reference_layout(g)
             out["cpc/" + name] = g.clone().numpy()
-        # launch/all-reduce schedule of a whole update (nothing is computed under the trace hook)
-        n_calls = []
-        real = dist.all_reduce
-        dist.all_reduce = lambda t, **k: (n_calls.append(t.numel()), real(t, **k))[1]
-        _lib.set_trace_hook(lambda n, a: None)
+        # launch/all-reduce schedule of a whole update (nothing is computed under the trace hook), for the
+        # overlapped (two asynchronous pieces per bucket) and the blocking (one call per bucket) modes
         rb = curla_amd.ReplayBuffer((9, 34, 40), (2,), 16, 8, "cpu", aug)
         for _ in range(10):
             rb.add(np.zeros((9, 34, 40), np.uint8), [0, 0], 0.0, np.zeros((9, 34, 40), np.uint8), False)
@@ -98,12 +98,33 @@ def _worker(rank, world, port, q):
         class L:
             def log(self, *a, **k):
                 pass
-        np.random.seed(rank)
-        agent.update(rb, L(), 0)
-        agent.update(rb, L(), 1)
-        _lib.set_trace_hook(None)
-        dist.all_reduce = real
-        q.put((rank, out, n_calls, dict(lay)))
+        sched = {}
+        real = dist.all_reduce
+        for overlap in (True, False):
+            agent.enable_data_parallel(overlap=overlap, check_every=0)
+            n_calls = []
+            dist.all_reduce = lambda t, **k: (n_calls.append((t.numel(), bool(k.get("async_op")))), real(t, **k))[1]
+            _lib.set_trace_hook(lambda n, a: None)
+            np.random.seed(rank)
+            agent.update(rb, L(), 0)
+            agent.update(rb, L(), 1)
+            _lib.set_trace_hook(None)
+            dist.all_reduce = real
+            assert not agent._dp_pending
+            sched[overlap] = n_calls
+        cuts = dict(enc_fc=agent._grad_offset(agent.critic.encoder.fc.weight, agent._critic_gflat),
+                    actor_trunk=agent._grad_offset(agent.actor.trunk[0].weight, agent._actor_gflat),
+                    actor_total=agent._actor_gflat.numel())
+        # replicas that drift apart are caught: perturb one rank, the check must raise on every rank
+        with torch.no_grad():
+            if rank == 1:
+                agent.actor.trunk[2].bias[3] += 1e-3
+        try:
+            agent.check_replicas()
+            drift = "not detected"
+        except RuntimeError as e:
+            drift = str(e)
+        q.put((rank, out, (sched, cuts, bcast, drift), dict(lay)))
         dist.barrier()
         dist.destroy_process_group()
     except Exception as e:  # surface the failure in the parent
@@ -126,17 +147,29 @@ def test_two_rank_gradient_mean_matches_reference():
     for r in results:
         assert not isinstance(r[1], str), r[1]
     g0, g1 = load("tiny.npz"), load("tiny_rank1.npz")
-    for rank, out, n_calls, lay in results:
+    bc = {}
+    for rank, out, (sched, cuts, bcast, drift), lay in results:
         for key, got in out.items():
             phase, name = key.split("/", 1)
             want = 0.5 * (g0[f"{phase}/grad/{name}"].astype(np.float64) + g1[f"{phase}/grad/{name}"].astype(np.float64))
             err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
             assert err < 1e-6, (rank, key, err)
-        # even step: critic bucket, actor bucket + log_alpha, cpc bucket; odd step: critic + cpc
-        enc_q = lay["total"] - lay["enc"][0]
-        w_enc = lay["enc"][1]
-        actor_n = n_calls[1]
-        assert n_calls == [enc_q, actor_n, 1, w_enc, enc_q, w_enc], n_calls
+        e0, e1, total = lay["enc"][0], lay["enc"][1], lay["total"]
+        cut, at, an = cuts["enc_fc"], cuts["actor_trunk"], cuts["actor_total"]
+        assert e0 < cut < e1 and 0 < at < an
+        # blocking mode -- even step: critic bucket, actor bucket + log_alpha, cpc bucket; odd step: critic + cpc
+        assert sched[False] == [(total - e0, False), (an, False), (1, False), (e1, False),
+                                (total - e0, False), (e1, False)], sched[False]
+        # overlapped mode: [fc, ln | Q1 | Q2] before the conv backward then the convs; actor trunk + log_alpha then
+        # fc/ln; cpc [fc, ln] then [W | convs].  The same elements, every one exactly once.
+        crit = [(total - cut, True), (cut - e0, True)]
+        cpc = [(e1 - cut, True), (cut, True)]
+        assert sched[True] == crit + [(an - at, True), (1, True), (at, True)] + cpc + crit + cpc, sched[True]
+        assert "diverged" in drift and "actor" in drift, drift
+        bc[rank] = bcast
+    # the two ranks were seeded differently; after enable_data_parallel both hold rank 0's parameters
+    assert not np.array_equal(bc[0][0], bc[1][0])
+    assert np.array_equal(bc[0][1], bc[1][1]) and np.array_equal(bc[0][0], bc[0][1])
     # both ranks end with identical reduced gradients
     for k in results[0][1]:
         assert np.array_equal(results[0][1][k], results[1][1][k]), k

@@ -370,23 +370,8 @@ def test_other_config_geometries_vs_oracle(name, obs_shape, layers, pixel_sac, B
     agent = curla_amd.CurlSacAgent(obs_shape, (A,), torch.device("cuda"), aug, hidden_dim=hidden, pixel_sac=pixel_sac, **hp)
     oracle = O.OracleAgent(obs_shape, (A,), hidden_dim=hidden, pixel_sac=pixel_sac,
                            **{k: v for k, v in hp.items() if k != "log_interval"})
-    for dst, src in ((oracle.critic, agent.critic.state_dict()), (oracle.critic_target, agent.critic_target.state_dict()),
-                     (oracle.actor, agent.actor.state_dict())):
-        for k in dst:
-            dst[k].data.copy_(src[k].cpu())
-    # move the convs off the delta-orthogonal init (all taps live) -- same perturbation on both sides
-    g = torch.Generator().manual_seed(5)
-    with torch.no_grad():
-        for i in range(layers):
-            for nm in ("weight", "bias"):
-                k = f"encoder.convs.{i}.{nm}"
-                d = 0.05 * torch.randn(oracle.critic[k].shape, generator=g)
-                oracle.critic[k].add_(d)
-                oracle.critic_target[k].add_(0.5 * d)
-        sd = {k: v.detach().clone() for k, v in oracle.critic.items()}
-        agent.critic.load_state_dict(sd)
-        agent.critic_target.load_state_dict({k: v.detach().clone() for k, v in oracle.critic_target.items()})
-    oracle.W.data.copy_(agent.CURL.W.detach().cpu())
+    _copy_agent_into_oracle(agent, oracle)
+    _perturb_convs(agent, oracle, layers)
     rb = curla_amd.ReplayBuffer(obs_shape, (A,), 8, B, torch.device("cuda"), aug)
     rs = np.random.RandomState(2)
     n = 8
@@ -663,3 +648,145 @@ def test_kernels_are_graph_capturable(tiny):
     forward()
     torch.cuda.synchronize()
     assert torch.equal(z, replayed) and not torch.equal(z, eager)
+
+
+def _copy_agent_into_oracle(agent, oracle):
+    for dst, src in ((oracle.critic, agent.critic.state_dict()), (oracle.critic_target, agent.critic_target.state_dict()),
+                     (oracle.actor, agent.actor.state_dict())):
+        for k in dst:
+            dst[k].data.copy_(src[k].cpu())
+    oracle.W.data.copy_(agent.CURL.W.detach().cpu())
+
+
+def _perturb_convs(agent, oracle, layers, seed=5):
+    """Move the convs off the delta-orthogonal init (all nine taps live), identically on both sides."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for i in range(layers):
+            for nm in ("weight", "bias"):
+                k = f"encoder.convs.{i}.{nm}"
+                d = 0.05 * torch.randn(oracle.critic[k].shape, generator=g)
+                oracle.critic[k].add_(d)
+                oracle.critic_target[k].add_(0.5 * d)
+        agent.critic.load_state_dict({k: v.detach().clone() for k, v in oracle.critic.items()})
+        agent.critic_target.load_state_dict({k: v.detach().clone() for k, v in oracle.critic_target.items()})
+
+
+@pytest.mark.parametrize("aug_name", ["color_jiggle", "noisy_cover"])
+def test_c5_update_vs_oracle_on_identical_post_augmentation_tensors(aug_name):
+    """BASELINE configs[4] (frame_stack 4, 6 conv layers, colour jitter) with everything AFTER the augmentation
+    pinned: the augmented float tensors that ``ReplayBuffer.sample_cpc()`` returns are handed,
+    byte for byte, to the oracle agent and to update_critic / update_actor_and_alpha / update_cpc; per-phase
+    losses and every gradient that reaches Adam must agree to 1e-4.  (The jitter arithmetic itself is kornia's:
+    parity unpinned, test_gpu_augment.py checks it against this build's restatement only.)"""
+    import curla_amd
+    from oracle import curla_oracle as O
+    torch.manual_seed(21)
+    np.random.seed(21)
+    obs_shape, layers, B, A, hidden = (12, 72, 76), 6, 6, 2, 64
+    hw = obs_shape[1:]
+    aug = curla_amd.make_augmentor(aug_name, hw)
+    hp = {**HP, "num_layers": layers}
+    agent = curla_amd.CurlSacAgent(obs_shape, (A,), torch.device("cuda"), aug, hidden_dim=hidden, **hp)
+    oracle = O.OracleAgent(obs_shape, (A,), hidden_dim=hidden, **{k: v for k, v in hp.items() if k != "log_interval"})
+    _copy_agent_into_oracle(agent, oracle)
+    _perturb_convs(agent, oracle, layers)
+    rb = curla_amd.ReplayBuffer(obs_shape, (A,), 16, B, torch.device("cuda"), aug)
+    rs = np.random.RandomState(2)
+    n = 12
+    rb.add_batch(rs.randint(0, 256, (n,) + obs_shape, dtype=np.uint8), rs.uniform(-1, 1, (n, A)).astype(np.float32),
+                 rs.randn(n).astype(np.float32), rs.randint(0, 256, (n,) + obs_shape, dtype=np.uint8),
+                 (np.arange(n) % 5) == 4)
+    obs, act, rew, nxt, nd, kw = rb.sample_cpc()  # the reference's return contract: float NCHW in [0, 255]
+    pos = kw["obs_pos"]
+    assert kw["obs_anchor"] is obs and obs.shape == (B,) + obs_shape and not torch.equal(obs, pos)
+    assert float(obs.min()) >= 0.0 and float(obs.max()) <= 255.001
+    nc, na = torch.randn(B, A), torch.randn(B, A)
+    c = lambda t: t.detach().cpu().clone()  # noqa: E731
+    ref_critic = O.critic_phase(oracle.actor, oracle.critic, oracle.critic_target, oracle.log_alpha, c(obs), c(act),
+                                c(rew), c(nxt), c(nd), nc, num_layers=layers, discount=0.99, log_std_min=-10,
+                                log_std_max=2)
+    ref = oracle.update(c(obs), c(act), c(rew), c(nxt), c(nd), c(pos), nc, na, step=0)
+    L = NullLogger()
+    grads = {}
+    real = agent.critic_optimizer.step
+
+    def step():
+        grads.update(grads_of(agent.critic))
+        real()
+    agent.critic_optimizer.step = step
+    agent.update_critic(obs, act, rew, nxt, nd, L, 0, noise=nc.cuda())
+    agent.update_actor_and_alpha(obs, L, 0, noise=na.cuda())
+    agent.soft_update_targets()
+    agent.update_cpc(obs, pos, kw, L, 0)
+    tag = f"c5[{aug_name}]"
+    check(f"{tag} critic loss", L.scalars["train_critic/loss"], ref["critic_loss"])
+    check(f"{tag} actor loss", L.scalars["train_actor/loss"], ref["actor_loss"])
+    check(f"{tag} alpha loss", L.scalars["train_alpha/loss"], ref["alpha_loss"])
+    check(f"{tag} curl loss", L.scalars["train/curl_loss"], ref["curl_loss"])
+    assert len(grads) == 8 + 2 * layers + 8
+    for k, v in ref_critic["grads"].items():
+        check(f"{tag} critic grad {k}", grads[k], v)
+    sd = agent.critic.state_dict()
+    for k in ("encoder.convs.0.weight", f"encoder.convs.{layers - 1}.weight"):
+        check(f"{tag} params after update {k}", sd[k].cpu(), oracle.critic[k].detach(), 1e-3)
+
+
+def test_full_size_c5_gradients_are_the_mean_over_shards():
+    """BASELINE configs[4] at its full size -- B=1024, 168x168x12, 6 conv layers, colour-jittered float
+    observations, hidden 1024 -- through the size-independent property the data-parallel definition rests on:
+    the gradients of the 1024-minibatch are the mean of those of its two 512-halves (critic bucket, actor bucket,
+    log_alpha, cpc bucket), and the whole thing is finite and non-trivial."""
+    import curla_amd
+    from curla_amd import ops
+    hp = dict(HP, num_layers=6)
+    for k in ("alpha_lr", "actor_lr", "critic_lr", "encoder_lr"):
+        hp[k] = 0.0
+    torch.manual_seed(3)
+    H = W = 168
+    C, B = 12, 1024
+    aug = curla_amd.make_augmentor("color_jiggle", (H, W))
+    agent = curla_amd.CurlSacAgent((C, H, W), (2,), torch.device("cuda"), aug, hidden_dim=1024, **hp)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    nfr = 256
+    store = torch.randint(0, 256, (nfr * H * W * C + 32,), dtype=torch.uint8, device="cuda", generator=g)
+    ring = store[:nfr * H * W * C].view(nfr, H, W, C)
+    tens = []
+    for j in range(3):  # obs, next_obs, pos: each jittered with its own draws, as sample_cpc does
+        idx = torch.randint(0, nfr, (B,), device="cuda", generator=g)
+        params, order = aug.draw_params(B * (C // 3))
+        out = torch.empty((B, H, W, C), device="cuda")
+        ops.color_jiggle(ring, idx, params.cuda(), order.cuda(), B, out)
+        tens.append(out)
+    action = torch.rand(B, 2, device="cuda", generator=g) * 2 - 1
+    reward = torch.randn(B, 1, device="cuda", generator=g)
+    not_done = (torch.rand(B, 1, device="cuda", generator=g) > 0.02).float()
+    noise_c = torch.randn(B, 2, device="cuda", generator=g)
+    noise_a = torch.randn(B, 2, device="cuda", generator=g)
+    L = NullLogger()
+    lay = agent._lay
+
+    def grads(lo, hi):
+        sl = lambda t: t[lo:hi].contiguous()  # noqa: E731
+        obs, nxt, pos = (ops.ObsRef.from_nhwc(t[lo:hi]) for t in tens)
+        agent.update_critic(obs, sl(action), sl(reward), nxt, sl(not_done), L, 1, noise=sl(noise_c))
+        gc = agent._critic_gflat[lay["enc"][0]:lay["total"]].clone()
+        closs = L.scalars["train_critic/loss"]
+        agent.update_actor_and_alpha(obs, L, 1, noise=sl(noise_a))
+        ga, gl = agent._actor_gflat.clone(), agent.log_alpha.grad.clone()
+        agent.update_cpc(obs, pos, None, L, 1)
+        gw = agent.CURL.W.grad.clone()
+        return gc, ga, gl, closs, L.scalars["train_actor/loss"], gw, L.scalars["train/curl_loss"]
+
+    full = grads(0, B)
+    a, b = grads(0, B // 2), grads(B // 2, B)
+    check("c5 full size critic grads: 1024 = mean of 2 x 512", full[0].cpu(), (0.5 * (a[0] + b[0])).cpu(), 2e-5)
+    check("c5 full size actor grads: 1024 = mean of 2 x 512", full[1].cpu(), (0.5 * (a[1] + b[1])).cpu(), 2e-5)
+    check("c5 full size log_alpha grad", full[2].cpu().float().reshape(1), (0.5 * (a[2] + b[2])).cpu().float().reshape(1), 2e-5)
+    assert abs(full[3] - 0.5 * (a[3] + b[3])) <= 2e-5 * abs(full[3])
+    assert abs(full[4] - 0.5 * (a[4] + b[4])) <= 2e-5 * max(1.0, abs(full[4]))
+    assert float(full[0].abs().max()) > 0 and bool(torch.isfinite(full[0]).all()) and bool(torch.isfinite(full[1]).all())
+    # the InfoNCE loss couples the samples of a minibatch (B x B logits), so its gradient is NOT additive over
+    # shards: only finiteness and scale are asserted for the cpc phase at this size
+    assert bool(torch.isfinite(full[5]).all()) and float(full[5].abs().max()) > 0 and np.isfinite(full[6])
+    assert full[6] >= 0.0  # a cross-entropy

@@ -54,6 +54,58 @@ def test_noisy_cover_kernel_vs_reference_fixture():
     assert np.abs(got.numpy() - g["out"].astype(np.float32)).max() <= 0.13
 
 
+def test_augmentor_tensor_api_color_jiggle():
+    """ColorJiggle.training_augmentation(batch) -- the reference's own call (augmentations.py:105-136,
+    utils.py:174-182) -- runs the jitter kernel on a float NCHW tensor: equal to the restatement, and bit-equal
+    to what ReplayBuffer produces from the ring with the same parameters."""
+    import curla_amd
+    from curla_amd import ops
+    from oracle import curla_oracle as O
+    C, H, W, B = 12, 26, 30, 5
+    rs = np.random.RandomState(4)
+    frames = rs.randint(0, 256, (B, C, H, W), dtype=np.uint8)
+    aug = curla_amd.make_augmentor("color_jiggle", (H, W))
+    torch.manual_seed(2)
+    params, order = aug.draw_params(B * (C // 3))
+    x = torch.from_numpy(frames).float().cuda()
+    keep = x.clone()
+    got = aug.training_augmentation(x, params=params, order=order)
+    assert got.shape == x.shape and got.dtype == torch.float32 and got.is_cuda
+    assert torch.equal(x, keep)  # the argument is left alone
+    assert rel_err(got.cpu(), O.color_jiggle(frames, params, order)) <= 1e-4
+    nhwc = torch.empty((B, H, W, C), device="cuda")
+    ops.color_jiggle(_ring(frames), None, params.cuda(), order.cuda(), B, nhwc)
+    assert torch.equal(got, nhwc.permute(0, 3, 1, 2).contiguous())
+    # with its own random draws: in range, changed, frames jittered independently
+    torch.manual_seed(3)
+    rnd = aug.training_augmentation(x)
+    assert float(rnd.min()) >= 0 and float(rnd.max()) <= 255.001 and not torch.equal(rnd, x)
+    with pytest.raises(ValueError):
+        aug.training_augmentation(x[:, :, :-1])
+    with pytest.raises(RuntimeError):
+        aug.training_augmentation(x.cpu())
+
+
+def test_augmentor_tensor_api_noisy_cover():
+    """NoisyCover.training_augmentation(batch) (augmentations.py:170-205) against the reference-generated fixture."""
+    import curla_amd
+    g = load("noisy_cover.npz")
+    rs = np.random.RandomState(int(g["imgs_seed"]))
+    imgs = rs.randint(0, 256, (5, 9, 34, 40), dtype=np.uint8)
+    noise = rs.randn(5, 9, 34, 40).astype(np.float32) * 10.0
+    aug = curla_amd.make_augmentor("noisy_cover", (34, 40))
+    assert (aug.top, aug.bottom) == (int(g["top"]), int(g["bottom"]))
+    x = torch.from_numpy(imgs).float().cuda()
+    got = aug.training_augmentation(x, colors=list(g["colors"]), noise=torch.from_numpy(noise).cuda()).cpu()
+    assert abs(got.double().sum().item() - float(g["out_sum"])) <= 1e-6 * abs(float(g["out_sum"]))
+    assert np.abs(got.numpy() - g["out"].astype(np.float32)).max() <= 0.13
+    np.random.seed(0)
+    rnd = aug.training_augmentation(x)  # own draws: 3 colours from NumPy's stream, device Gaussian noise
+    np.random.seed(0)
+    cols = [np.random.randint(0, 255) for _ in range(3)]
+    assert abs(float(rnd[:, 0, :aug.top].mean()) - cols[0]) < 3.0 and float(rnd.max()) <= 255.0
+
+
 def test_gather_and_conv1_nhwc_source_matches_nchw_contract():
     from curla_amd import ops
     rs = np.random.RandomState(1)

@@ -112,7 +112,12 @@ def main():
         g = r(B, 37, 37, 32)
         dw0 = torch.empty(32, 9, 3, 3, device=dev)
         ws0 = torch.empty(ops.wgrad_workspace_floats(9), device=dev)
-        report("conv1_wgrad(+reduce) u8", timeit(lambda: ops.conv1_wgrad(obs, g, dw0, db, ws0)), fl_)
+        for fl in flags:
+            if flags != [0]:
+                lib.curla_debug_ablate(fl)
+            report(f"[abl {fl}] conv1_wgrad(+reduce) u8", timeit(lambda: ops.conv1_wgrad(obs, g, dw0, db, ws0)), fl_)
+        if flags != [0]:
+            lib.curla_debug_ablate(0)
 
     if "gemm" in args.what:
         H, F, K = 1024, 50, 30752
