@@ -1,20 +1,24 @@
 #!/usr/bin/env python3
 """Benchmark of the CURL+SAC learner hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one ``CurlSacAgent.update()`` (critic + [actor/alpha + target soft
-update on even steps] + CURL, curl_sac.py:426-451) on one per-GPU minibatch of
-512 transitions sampled from the HBM-resident replay ring (84x84x9 uint8 frames,
-random-crop to 76x76, encoder 4 layers x 32 filters, feature 50, hidden 1024) --
-BASELINE.json configs[1]; with N>1 every rank does the same on its own ring
-shard and the three gradient buckets are all-reduced over RCCL (weak scaling).
-Prints ONE JSON line on rank 0.
+update on even steps] + CURL, curl_sac.py:426-451) on one per-GPU minibatch
+sampled from the HBM-resident replay ring.  ``--config`` picks the BASELINE.json
+configuration (default c2 = configs[1], the one the metric is quoted on):
+  c2  B=512, 84x84x9 uint8 ring -> random_crop 76x76, 4 conv layers, CURL+critic+actor
+  c3  --pixel_sac: identity augmentation (84x84 un-cropped, train.py:262-264), no CURL head, B=512
+  c5  B=1024, 168x168x12 (frame_stack 4), color_jiggle, 6 conv layers (configs[4] per GPU)
+With N>1 every rank does the same on its own ring shard and the gradient buckets
+are all-reduced over RCCL (weak scaling).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,11 +29,30 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_TFLOPS = 157.3  # MI355X dense fp32 (vector == f32 MFMA), MI355X_MICROARCH.md chip table
-IN_HW, CROP_HW, FRAMES_C, BATCH, HIDDEN = (84, 84), (76, 76), 9, 512, 1024
-CAPACITY = 100_000
+HIDDEN, CAPACITY = 1024, 100_000
+
+CONFIGS = {
+    "c2": dict(baseline_index=1, obs=(9, 84, 84), crop=(76, 76), aug="random_crop", layers=4, batch=512, pixel_sac=False,
+               metric="SAC+CURL gradient updates/sec, batch=512 84x84x9",
+               workload="BASELINE.json configs[1]: CurlSacAgent.update(), per-GPU batch 512, 84x84x9 uint8 replay ring "
+                        "-> random_crop 76x76, encoder 4x32 filters feat 50, hidden 1024, CURL+critic+actor "
+                        "(actor/target every 2nd step)", cpu_batch=512, cpu_calls=4),
+    "c3": dict(baseline_index=2, obs=(9, 84, 84), crop=None, aug="identity", layers=4, batch=512, pixel_sac=True,
+               metric="SAC (--pixel_sac) gradient updates/sec, batch=512 84x84x9",
+               workload="BASELINE.json configs[2]: CurlSacAgent.update() with pixel_sac=True, per-GPU batch 512, "
+                        "84x84x9 uint8 replay ring, identity augmentation (84x84 un-cropped, train.py:262-264), encoder "
+                        "4x32 filters feat 50, hidden 1024, critic+actor only (actor/target every 2nd step)",
+               cpu_batch=512, cpu_calls=4),
+    "c5": dict(baseline_index=4, obs=(12, 168, 168), crop=None, aug="color_jiggle", layers=6, batch=1024,
+               pixel_sac=False, metric="SAC+CURL gradient updates/sec, batch=1024 168x168x12 color_jiggle L=6",
+               workload="BASELINE.json configs[4] (one GPU's share): CurlSacAgent.update(), per-GPU batch 1024, "
+                        "168x168x12 uint8 replay ring (frame_stack 4), color_jiggle augmentation, encoder 6x32 filters "
+                        "feat 50, hidden 1024, CURL+critic+actor (actor/target every 2nd step)",
+               cpu_batch=32, cpu_calls=2),
+}
 
 
-def conv_layer_flops(hw_in, num_layers=4, nf=32, cin=FRAMES_C):
+def conv_layer_flops(hw_in, num_layers, cin, nf=32):
     """Algorithmic FLOPs per sample of each conv layer (2*Ho*Wo*Cout*Cin*9), SURVEY.md 8d."""
     h, w = (hw_in[0] - 3) // 2 + 1, (hw_in[1] - 3) // 2 + 1
     out = [2.0 * h * w * nf * cin * 9]
@@ -39,6 +62,16 @@ def conv_layer_flops(hw_in, num_layers=4, nf=32, cin=FRAMES_C):
     return out
 
 
+def flops_per_update(cfg, step):
+    """CURL mode n_f=5, n_b=2 on every step; pixel_sac n_f=4 (even) / 3 (odd), n_b=1."""
+    hw = cfg["crop"] or cfg["obs"][1:]
+    f = conv_layer_flops(hw, cfg["layers"], cfg["obs"][0])
+    fc, f1 = sum(f), f[0]
+    if cfg["pixel_sac"]:
+        return cfg["batch"] * ((4 if step % 2 == 0 else 3) * fc + (2 * fc - f1))
+    return cfg["batch"] * (5 * fc + 2 * (2 * fc - f1))
+
+
 class NullLogger:
     def log(self, *a, **k):
         pass
@@ -46,51 +79,119 @@ class NullLogger:
     log_histogram = log_param = log_image = log
 
 
-def cpu_baseline(budget_s=20.0, max_calls=4):
-    """The oracle (CPU restatement pinned to the reference) on the host cores:
-    a bounded sample of the same workload (same shapes, B=512).  Thread count
-    is capped at 32: torch's CPU conv kernels get slower, not faster, beyond
-    that on a 256-thread host."""
+def _oracle_sample(cfg, batch, calls, budget_s, threads):
+    """``calls`` timed OracleAgent.update() calls at batch ``batch`` after one warm-up call (stops early when the
+    time budget is spent).  Returns (seconds per call, calls timed, had_warmup)."""
     from oracle import curla_oracle as O
-    threads = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(threads)
     rs = np.random.RandomState(0)
-    ag = O.OracleAgent((FRAMES_C,) + CROP_HW, (2,), hidden_dim=HIDDEN)
-    B = BATCH
+    shape = (cfg["obs"][0],) + tuple(cfg["crop"] or cfg["obs"][1:])
+    ag = O.OracleAgent(shape, (2,), hidden_dim=HIDDEN, num_layers=cfg["layers"], pixel_sac=cfg["pixel_sac"])
 
-    def batch():
-        f = lambda: torch.from_numpy(rs.randint(0, 256, (B, FRAMES_C) + CROP_HW, dtype=np.uint8)).float()  # noqa: E731
-        return (f(), torch.from_numpy(rs.uniform(-1, 1, (B, 2)).astype(np.float32)),
-                torch.from_numpy(rs.randn(B, 1).astype(np.float32)), f(), torch.ones(B, 1), f(),
-                torch.randn(B, 2), torch.randn(B, 2))
+    def minibatch():
+        f = lambda: torch.from_numpy(rs.randint(0, 256, (batch,) + shape, dtype=np.uint8)).float()  # noqa: E731
+        return (f(), torch.from_numpy(rs.uniform(-1, 1, (batch, 2)).astype(np.float32)),
+                torch.from_numpy(rs.randn(batch, 1).astype(np.float32)), f(), torch.ones(batch, 1), f(),
+                torch.randn(batch, 2), torch.randn(batch, 2))
     times = []
     t_start = time.perf_counter()
-    for s in range(max_calls + 1):  # call 0 is the warm-up unless it alone exhausts the budget
-        bt = batch()
+    for s in range(calls + 1):  # call 0 is the warm-up unless it alone exhausts the budget
+        bt = minibatch()
         t0 = time.perf_counter()
         ag.update(*bt, step=s)
         times.append(time.perf_counter() - t0)
         if time.perf_counter() - t_start > budget_s:
             break
     timed = times[1:] if len(times) > 1 else times
-    return {"value": len(timed) / sum(timed), "unit": "batch-512 gradient updates/s", "cores": threads,
-            "kind": "port", "sample": f"{len(timed)} OracleAgent.update() call(s) at B=512, 76x76x9, hidden 1024 "
-            f"({'after 1 warm-up call' if len(times) > 1 else 'first call, no warm-up: budget exhausted'}; "
-            f"{threads} of {os.cpu_count()} host threads), torch {torch.__version__} CPU"}
+    return sum(timed) / len(timed), len(timed), len(times) > 1
+
+
+def cpu_baseline(cfg, name):
+    """The oracle (CPU restatement pinned to the reference) on the host cores, on a bounded sample of the same
+    workload.  Thread count is capped at 32: torch's CPU conv kernels get slower, not faster, beyond that on a
+    256-thread host.  When the sample's batch is smaller than the configuration's, the rate is scaled to the
+    metric's unit (updates of the full batch per second) and the sample says so.  For c2 the reference's own
+    CPU-runnable case, BASELINE.json configs[0] (B=32), is timed as well."""
+    threads = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(threads)
+    B, b = cfg["batch"], cfg["cpu_batch"]
+    sec, n, warm = _oracle_sample(cfg, b, cfg["cpu_calls"], 25.0, threads)
+    shape = (cfg["obs"][0],) + tuple(cfg["crop"] or cfg["obs"][1:])
+    out = {"value": (1.0 / sec) * b / B, "unit": f"batch-{B} gradient updates/s", "cores": threads, "kind": "port",
+           "sample": f"{n} OracleAgent.update() call(s) at B={b}, {shape[1]}x{shape[2]}x{shape[0]}, "
+                     f"{cfg['layers']} conv layers, hidden {HIDDEN}{', pixel_sac' if cfg['pixel_sac'] else ''} "
+                     f"({'after 1 warm-up call' if warm else 'first call, no warm-up: budget exhausted'}; "
+                     f"{threads} of {os.cpu_count()} host threads), torch {torch.__version__} CPU"
+                     + ("" if b == B else f"; rate scaled by {b}/{B} to the batch-{B} unit"),
+           "transitions_per_s": b / sec}
+    if name == "c2":
+        sec0, n0, _ = _oracle_sample(cfg, 32, 200, 25.0, threads)
+        out["configs0"] = {"value": 1.0 / sec0, "unit": "batch-32 gradient updates/s", "calls": n0,
+                           "note": "BASELINE.json configs[0] shapes (B=32, 76x76 crop of 84x84x9) on the oracle; the "
+                                   "reference itself measured 9.30/s on 8 vCPUs in the build container (SURVEY.md 6)"}
+    return out
+
+
+def committed_counters(cfg_name, kernel):
+    """HBM bytes per launch and matrix-pipe busy fraction of ``kernel`` from the committed rocprofv3 PMC summaries
+    (tools/pmc_traffic.sh, tools/pmc_sq.sh: separate --pmc passes, FETCH_SIZE doubled as gfx950 needs).  They are
+    measured offline, so they are only quoted when the summary was taken from the kernel sources this library was
+    built from (the summary records their hash); otherwise null."""
+    from curla_amd import build
+    cur = build.source_hash()
+    traffic = busy = None
+    note = "no committed PMC summary for this configuration"
+    for fn, key in ((f"r02_pmc_traffic_{cfg_name}.json", "traffic"), (f"r02_pmc_sq_{cfg_name}.json", "sq")):
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as f:
+                d = json.load(f)
+        except Exception:
+            continue
+        if d.get("_source_hash") != cur:
+            note = f"profiles/{fn} was measured on other kernel sources ({d.get('_source_hash')} != {cur}): not quoted"
+            continue
+        if key == "traffic":
+            traffic = d[kernel]["traffic_bytes"]
+            note = f"profiles/{fn} (rocprofv3 --pmc, same kernel sources {cur})"
+        else:
+            c = d[kernel]
+            busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_BUSY_CU_CYCLES"])
+    return traffic, busy, note
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a child job (before anything here has
+    touched the GPU) and leave with its exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd))
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--capacity", type=int, default=CAPACITY)
+    ap.add_argument("--prefill", choices=("device", "host"), default="device")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    if args.steps is None:
+        args.steps = 200 if args.config != "c5" else 20
+    if args.warmup is None:
+        args.warmup = 20 if args.config != "c5" else 3
 
+    if "RANK" not in os.environ and args.gpus > 1:
+        respawn_under_torchrun(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # CURLA_BENCH_FORCE_DIST=1: take the RCCL code path with a single rank (1-GPU check of the N>1 branch)
     distributed = world > 1 or os.environ.get("CURLA_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
@@ -98,39 +199,56 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import curla_amd
     from curla_amd import ops
 
-    # identical parameters on every rank (same seed), rank-specific sampling streams
+    C, (H, W), B = cfg["obs"][0], cfg["obs"][1:], cfg["batch"]
     curla_amd.set_seed_everywhere(1)
-    aug = curla_amd.RandomCrop(IN_HW, CROP_HW)
+    from curla_amd import augmentations as A  # (make_augmentor prints a banner; stdout carries the JSON line only)
+    aug = {"random_crop": lambda: A.RandomCrop((H, W), cfg["crop"]), "identity": lambda: A.IdentityAugmentation((H, W)),
+           "color_jiggle": lambda: A.ColorJiggle((H, W))}[cfg["aug"]]()
     agent = curla_amd.CurlSacAgent(
-        (FRAMES_C,) + CROP_HW, (2,), dev, aug, hidden_dim=HIDDEN, discount=0.99, init_temperature=0.1, alpha_lr=1e-4,
-        alpha_beta=0.5, actor_lr=1e-3, actor_beta=0.9, critic_lr=1e-3, critic_beta=0.9, critic_tau=0.01,
-        encoder_feature_dim=50, encoder_lr=1e-3, encoder_tau=0.05, num_layers=4, num_filters=32, log_interval=10 ** 9)
+        (C,) + tuple(aug.output_shape), (2,), dev, aug, hidden_dim=HIDDEN, discount=0.99, init_temperature=0.1,
+        alpha_lr=1e-4, alpha_beta=0.5, actor_lr=1e-3, actor_beta=0.9, critic_lr=1e-3, critic_beta=0.9, critic_tau=0.01,
+        encoder_feature_dim=50, encoder_lr=1e-3, encoder_tau=0.05, num_layers=cfg["layers"], num_filters=32,
+        pixel_sac=cfg["pixel_sac"], log_interval=10 ** 9)
     if distributed:
-        agent.enable_data_parallel(single_rank_collectives=(world == 1))
-    curla_amd.set_seed_everywhere(1 + rank)
+        agent.enable_data_parallel(single_rank_collectives=(world == 1))  # rank 0's parameters are broadcast
+    curla_amd.set_seed_everywhere(1 + rank)  # rank-specific sampling / policy-noise streams
 
-    # replay ring shard, pre-filled on the device with i.i.d. uniform bytes (worst case for any compression)
+    # replay ring shard.  SURVEY.md 8d recipe: obs, next_obs i.i.d. uniform bytes (worst case for any compression),
+    # action ~ U(-1,1)^2, reward ~ N(0,1), not_done = 1 except every 50th transition.
     cap = args.capacity // world
-    rb = curla_amd.ReplayBuffer((FRAMES_C,) + IN_HW, (2,), cap, BATCH, dev, aug)
-    g = torch.Generator(device=dev).manual_seed(rank)
-    for ring in (rb._obs_store, rb._next_store):
-        for s in range(0, ring.numel(), 1 << 28):
-            e = min(ring.numel(), s + (1 << 28))
-            ring[s:e] = torch.randint(0, 256, (e - s,), dtype=torch.uint8, device=dev, generator=g)
-    rb.actions.uniform_(-1, 1, generator=g)
-    rb.rewards.normal_(generator=g)
-    rb.not_dones.fill_(1.0)
-    rb.not_dones[49::50] = 0.0
-    rb.idx, rb.full = 0, True
+    rb = curla_amd.ReplayBuffer((C, H, W), (2,), cap, B, dev, aug)
+    if args.prefill == "host":
+        # the recipe to the letter: RandomState(0) on the host, transition by transition (slow: ~1 GB/s)
+        rs = np.random.RandomState(rank)
+        for s in range(0, cap, 512):
+            n = min(512, cap - s)
+            rb.add_batch(rs.randint(0, 256, (n, C, H, W), dtype=np.uint8), rs.uniform(-1, 1, (n, 2)).astype(np.float32),
+                         rs.randn(n).astype(np.float32), rs.randint(0, 256, (n, C, H, W), dtype=np.uint8),
+                         (np.arange(s, s + n) % 50) == 49)
+        prefill = "SURVEY.md 8d recipe on the host: RandomState(rank) uniform bytes, U(-1,1) actions, N(0,1) rewards"
+    else:
+        g = torch.Generator(device=dev).manual_seed(rank)
+        for ring in (rb._obs_store, rb._next_store):
+            for s in range(0, ring.numel(), 1 << 28):
+                e = min(ring.numel(), s + (1 << 28))
+                ring[s:e] = torch.randint(0, 256, (e - s,), dtype=torch.uint8, device=dev, generator=g)
+        rb.actions.uniform_(-1, 1, generator=g)
+        rb.rewards.normal_(generator=g)
+        rb.not_dones.fill_(1.0)
+        rb.not_dones[49::50] = 0.0
+        rb.idx, rb.full = 0, True
+        prefill = ("same distributions as the SURVEY.md 8d recipe (uniform bytes, U(-1,1) actions, N(0,1) rewards, "
+                   "every 50th transition terminal) drawn by a device generator seeded with the rank instead of "
+                   "numpy RandomState(0) on the host (--prefill host follows the recipe to the letter)")
 
     L = NullLogger()
-    # HIP-event timing of the dominant kernel (stride-1 32->32 conv forward) on its own stream
-    flops = conv_layer_flops(CROP_HW)
+    # HIP-event timing of the dominant kernel (stride-1 32->32 conv forward) on the stream it is launched on
     ev_pairs = []
     real_s1 = ops.conv_s1_fwd
     recording = [False]
@@ -142,7 +260,8 @@ def main():
         e0.record()
         real_s1(x, w, b, out)
         e1.record()
-        ev_pairs.append((e0, e1, 2.0 * x.shape[0] * out.shape[1] * out.shape[2] * 32 * 32 * 9))
+        ev_pairs.append((e0, e1, 2.0 * x.shape[0] * out.shape[1] * out.shape[2] * 32 * 32 * 9,
+                         4.0 * (x.numel() + out.numel())))
     ops.conv_s1_fwd = timed_s1
 
     def barrier():
@@ -158,9 +277,9 @@ def main():
     step += 1
     # the first ~0.5 s of matrix-pipe work in a process runs ~8 % slow while the clocks ramp: burn it on scratch
     # buffers (no agent state involved) so that short runs (small K and W) also measure the steady state
-    bx = torch.zeros((BATCH, 37, 37, 32), device=dev)
+    bx = torch.zeros((512, 37, 37, 32), device=dev)
     bw, bb = torch.zeros((32, 32, 3, 3), device=dev), torch.zeros(32, device=dev)
-    bo = torch.empty((BATCH, 35, 35, 32), device=dev)
+    bo = torch.empty((512, 35, 35, 32), device=dev)
     t_burn = time.perf_counter()
     while time.perf_counter() - t_burn < 0.6:
         for _ in range(200):
@@ -171,9 +290,10 @@ def main():
         agent.update(rb, L, step)
         step += 1
     barrier()
-    # event pairs are taken on a sample of the timed steps spread over the whole region (<= 32 steps = 480
-    # launches): thousands of pending HIP events slow the runtime itself and would perturb the measurement
+    # event pairs are taken on a sample of the timed steps spread over the whole region (<= 32 steps): thousands
+    # of pending HIP events slow the runtime itself and would perturb the measurement
     rec_stride = max(4, args.steps // 32)  # (an instrumented step is ~3 % slower: at most every 4th one)
+    first_step = step
     t0 = time.perf_counter()
     for i in range(args.steps):
         recording[0] = (i % rec_stride == 0)
@@ -183,7 +303,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     # the timed updates must have produced finite numbers (a NaN run would be meaningless)
-    ws = agent._ws(BATCH)
+    ws = agent._ws(B)
     assert bool(torch.isfinite(ws.scalars).all()) and bool(torch.isfinite(agent._critic_flat).all()), "non-finite state"
 
     allreduce = None
@@ -192,12 +312,12 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        # outside the timed region: cost of the three gradient all-reduces of one update, each timed alone
+        # outside the timed region: cost of the gradient all-reduces of one update, each bucket timed alone
         # (SURVEY.md 8e reporting: all-reduce time per phase and the bus bandwidth it reaches)
         lay = agent._lay
         buckets = {"critic": agent._critic_gflat[lay["enc"][0]:lay["total"]], "actor": agent._actor_gflat,
                    "cpc": agent._critic_gflat[0:lay["enc"][1]]}
-        allreduce = {}
+        allreduce = {"overlapped_with_backward": bool(agent._dp_overlap)}
         for name, buf in buckets.items():
             scratch = torch.zeros_like(buf)
             for _ in range(3):
@@ -216,48 +336,34 @@ def main():
 
     if rank == 0:
         kflops = sum(p[2] for p in ev_pairs)
+        kbytes = sum(p[3] for p in ev_pairs)
         kms = sum(p[0].elapsed_time(p[1]) for p in ev_pairs)
         achieved = kflops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
         updates_per_s = world * args.steps / dt
-        per_update = BATCH * (5 * sum(flops) + 2 * (2 * sum(flops) - flops[0]))  # n_f=5, n_b=2
-        # HBM traffic of the dominant kernel per launch: measured offline with rocprofv3 PMC counters
-        # (tools/pmc_traffic.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled as gfx950 needs),
-        # summary committed under profiles/; null if that file is absent
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-                traffic = json.load(f)["conv_s1_kernel<0>"]["traffic_bytes"]
-        except Exception:
-            pass
-        # matrix-pipe utilisation of the same kernel from the shader-core PMC pass (tools/pmc_sq.sh), if committed
-        mfma_busy = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_sq.json")) as f:
-                c = json.load(f)["conv_s1_kernel<0>"]
-                mfma_busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_BUSY_CU_CYCLES"])
-        except Exception:
-            pass
-        avg_ms = kms / max(1, len(ev_pairs))
+        per_update = sum(flops_per_update(cfg, first_step + i) for i in range(args.steps)) / args.steps
+        kname = "conv_s1_kernel<0>"
+        traffic, mfma_busy, pmc_note = committed_counters(args.config, kname)
+        n_launch = max(1, len(ev_pairs))
+        avg_ms = kms / n_launch
         out = {
-            "metric": "SAC+CURL gradient updates/sec, batch=512 84x84x9",
+            "metric": cfg["metric"],
             "value": updates_per_s,
-            "unit": "batch-512 gradient updates/s (sum over ranks)",
+            "unit": f"batch-{B} gradient updates/s (sum over ranks)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: CurlSacAgent.update(), per-GPU batch 512, 84x84x9 uint8 "
-                                   "replay ring -> random_crop 76x76, encoder 4x32 filters feat 50, hidden 1024, "
-                                   "CURL+critic+actor (actor/target every 2nd step)",
-                       "replay_capacity": cap * world, "parallelism": f"dp{world}", "priming_updates": 1, "clock_warmup_s": 0.6},
-            "transitions_per_s": updates_per_s * BATCH,
+            "config": {"workload": cfg["workload"], "baseline_config": f"configs[{cfg['baseline_index']}]",
+                       "replay_capacity": cap * world, "prefill": prefill, "parallelism": f"dp{world}",
+                       "priming_updates": 1, "clock_warmup_s": 0.6},
+            "transitions_per_s": updates_per_s * B,
             "conv_algorithmic_gflop_per_update": per_update / 1e9,
             "conv_roofline_frac_whole_update": per_update * (args.steps / dt) / (PEAK_F32_TFLOPS * 1e12),
             "roofline": {"bound": "mfma", "kernel": "conv_s1_kernel<FWD> (3x3 s1 32->32 + bias + ReLU, f32 MFMA 16x16x4)",
                          "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_TFLOPS, "traffic": traffic,
-                         "traffic_unit": "HBM bytes per launch (rocprofv3 PMC, profiles/r01_pmc_traffic.json); "
-                                         "algorithmic in+out = 152 MB per launch (mean of the 3 layers)",
+                         "traffic_unit": "HBM bytes per launch; " + pmc_note,
+                         "algorithmic_bytes_per_launch": kbytes / n_launch,
                          "launches": len(ev_pairs), "avg_launch_ms": avg_ms,
                          "hbm_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
                          "hbm_peak_GBps": 8000.0,
@@ -266,7 +372,7 @@ def main():
         if allreduce is not None:
             out["allreduce"] = allreduce
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(cfg, args.config)
         print(json.dumps(out), flush=True)
     if distributed:
         import torch.distributed as dist

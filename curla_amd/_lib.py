@@ -68,6 +68,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise CurlaHipError(f"{LIB_PATH} is missing: build it with `python -m curla_amd.build` "
                             "(there is no CPU/PyTorch fallback for the learner path)")
+    if LIB_PATH == os.path.join(_HERE, "libcurla_hip.so"):
+        from . import build
+        if build.built_hash() != build.source_hash():
+            raise CurlaHipError(f"{LIB_PATH} was built from other sources than the ones in curla_amd/csrc "
+                                f"(stamp {build.built_hash()} != {build.source_hash()}): rebuild it with "
+                                "`python -m curla_amd.build`")
     lib = ctypes.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library drift apart

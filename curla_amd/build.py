@@ -1,4 +1,10 @@
-"""Builds curla_amd/libcurla_hip.so (the C-ABI HIP library) in-tree with hipcc."""
+"""Builds curla_amd/libcurla_hip.so (the C-ABI HIP library) in-tree with hipcc.
+
+The library is stamped with a hash of the sources it was compiled from
+(``libcurla_hip.so.srchash``, next to it): ``build_library`` recompiles when the
+stamp and the sources disagree (not on mtimes, which a checkout or a copy to the
+GPU box rewrites), and ``_lib.load`` refuses a library whose stamp is stale."""
+import hashlib
 import os
 import subprocess
 import sys
@@ -6,26 +12,43 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcurla_hip.so")
+STAMP = LIB + ".srchash"
+HEADER = os.path.join(HERE, "..", "include", "curla_hip.h")
 SOURCES = ["conv.hip", "gemm.hip", "heads.hip", "augment.hip"]
 ARCH = "gfx950"  # MI355X only
+FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC"]
 
 
-def _stale():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "curla_hip.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources, the shared header, the C-ABI header and the flags."""
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for path in sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [HEADER]:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def built_hash():
+    try:
+        with open(STAMP) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
+def is_stale():
+    return not os.path.exists(LIB) or built_hash() != source_hash()
 
 
 def build_library(force=False, verbose=False):
-    if not force and not _stale():
+    if not force and not is_stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        cmd = [hipcc, "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
@@ -34,6 +57,8 @@ def build_library(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
     return LIB
 
 

@@ -21,10 +21,11 @@ def short(name):
     return name[:90]
 
 
-def main(path, out):
+def main(path, out, what=""):
     rows = list(csv.DictReader(open(path)))
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     with open(out, "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats -- python {what}\n" if what else "")
         f.write(f"# source: {path}\n# total kernel time {tot / 1e6:.3f} ms\n")
         f.write(f"{'kernel':70s} {'calls':>7s} {'total_ms':>10s} {'avg_us':>10s} {'pct':>7s}\n")
         for r in rows:
@@ -33,4 +34,4 @@ def main(path, out):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
