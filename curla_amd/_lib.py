@@ -40,6 +40,7 @@ SIGNATURES = {
     "curla_soft_update": [vp, vp, c_size_t, c_float, c_float, vp],
     "curla_crop_nchw": [vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp, vp],
     "curla_store_frame": [vp, vp, c_ll, c_int, c_int, c_int, vp],
+    "curla_gather_stacks": [vp, vp, c_int, vp, c_int, c_int, c_int, c_int, vp, vp],
     "curla_nhwc_to_nchw": [vp, vp, c_int, c_int, c_int, c_int, vp],
     "curla_color_jiggle": [vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp],
     "curla_noisy_cover": [vp, vp, vp, c_float, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp],

@@ -322,9 +322,9 @@ __device__ __forceinline__ void conv1_stage(float* lds, const void* src, const i
     for (int i = tid; i < rows * G; i += nthreads) {
       const int r = i / G, g = i - r * G;
       const uint8_t* p = frame + ((size_t)(oh + r0 + r) * Ws + ow) * C + 4 * g;
-      const uintptr_t ad = reinterpret_cast<uintptr_t>(p);
-      const uint32_t* q = reinterpret_cast<const uint32_t*>(ad & ~(uintptr_t)3);
-      const uint32_t sh = (uint32_t)(ad & 3);
+      // (pointer arithmetic, not an integer round trip: the loads stay global_load, not flat_load)
+      const uint32_t sh = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(p - sh);
       const uint32_t d0 = q[0];
       const uint32_t d1 = sh ? q[1] : 0u;   // only touch the next dword when the run straddles it
       const uint32_t v = __builtin_amdgcn_alignbyte(d1, d0, sh);
@@ -458,9 +458,9 @@ __device__ __forceinline__ void conv1_stage_u8_issue(Conv1StageRegs<U>& rg, cons
     const int ic = ok ? i : 0;
     const int r = ic / runs, g = ic - r * runs;
     const uint8_t* p = frame + ((size_t)(oh + r0 + r) * Ws + ow) * C + 16 * g;
-    const uintptr_t ad = reinterpret_cast<uintptr_t>(p);
-    const uint32_t* q = reinterpret_cast<const uint32_t*>(ad & ~(uintptr_t)3);
-    rg.sh[k] = (uint32_t)(ad & 3);
+    // (pointer arithmetic, not an integer round trip: the loads stay global_load, not flat_load)
+    rg.sh[k] = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p - rg.sh[k]);
     rg.dst[k] = ok ? r * RSb + 16 * g : -1;
 #pragma unroll
     for (int e = 0; e < 4; ++e) rg.dw[k][e] = ok ? q[e] : 0u;

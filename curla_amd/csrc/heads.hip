@@ -417,6 +417,52 @@ __global__ void store_frame_kernel(const uint8_t* chw, uint8_t* frames, int64_t 
   }
 }
 
+// De-duplicated replay storage: every RGB frame is stored once ([F][H][W][3] uint8) and a transition keeps the k frame
+// ids of its observation stack.  out[b][y][x][3f+c] = store[fid[idx[b]][f]][y][x][c] rebuilds the [B][H][W][3k] stacks
+// of a minibatch (the layout the first conv's loader reads).  One thread moves 4 pixels: 3 aligned dwords from each
+// of the k frames, 3k aligned dwords out (FAST); any other geometry goes byte by byte.
+template <bool FAST>
+__global__ void gather_stacks_kernel(const uint8_t* store, const int32_t* fid, int fid_stride, const int64_t* idx, int B,
+                                     int K, int HW, uint8_t* out) {
+  const int groups = (HW + 3) >> 2;
+  const size_t n = (size_t)B * groups;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  const int C = 3 * K;
+  for (; i < n; i += stride) {
+    const int b = i / groups, g = i - (size_t)b * groups;
+    const int32_t* ids = fid + (size_t)(idx ? idx[b] : b) * fid_stride;
+    uint8_t* o = out + ((size_t)b * HW + 4 * (size_t)g) * C;
+    if (FAST) {
+      uint32_t ob[12];  // up to k = 4 frames: 4 pixels x 12 bytes
+#pragma unroll
+      for (int w = 0; w < 12; ++w) ob[w] = 0;
+      for (int f = 0; f < K; ++f) {
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(store + ((size_t)ids[f] * HW + 4 * (size_t)g) * 3);
+        const uint32_t s0 = src[0], s1 = src[1], s2 = src[2];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {
+            const int sb = 3 * p + c;  // byte of the 12 source bytes
+            const uint32_t v = ((sb < 4 ? s0 : sb < 8 ? s1 : s2) >> (8 * (sb & 3))) & 0xffu;
+            const int db = p * C + 3 * f + c;  // byte of the 4*C output bytes
+            ob[db >> 2] |= v << (8 * (db & 3));
+          }
+      }
+      uint32_t* o4 = reinterpret_cast<uint32_t*>(o);
+      for (int w = 0; w < C; ++w) o4[w] = ob[w];  // 4 pixels x C bytes = C dwords
+    } else {
+      const int np = min(4, HW - 4 * g);
+      for (int f = 0; f < K; ++f) {
+        const uint8_t* src = store + ((size_t)ids[f] * HW + 4 * (size_t)g) * 3;
+        for (int p = 0; p < np; ++p)
+          for (int c = 0; c < 3; ++c) o[p * C + 3 * f + c] = src[3 * p + c];
+      }
+    }
+  }
+}
+
 // NHWC float activation -> NCHW (for callers that read encoder.outputs)
 __global__ void nhwc_to_nchw_kernel(const float* in, float* out, int B, int H, int W, int C) {
   const size_t n = (size_t)B * H * W * C;
@@ -598,6 +644,23 @@ int curla_store_frame(const uint8_t* chw, uint8_t* frames, long long slot, int C
   CURLA_REQUIRE(chw && frames && slot >= 0 && C > 0 && H > 0 && W > 0);
   hipLaunchKernelGGL(store_frame_kernel, dim3(nblocks((size_t)C * H * W, 256, 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), chw, frames, (int64_t)slot, C, H, W);
+  return curla_launch_status();
+}
+
+int curla_gather_stacks(const uint8_t* store, const int32_t* fid, int fid_stride, const int64_t* idx, int B, int K,
+                        int H, int W, uint8_t* out, void* stream) {
+  CURLA_REQUIRE(store && fid && out && B > 0 && K > 0 && H > 0 && W > 0 && fid_stride >= K);
+  const int HW = H * W;
+  const size_t n = (size_t)B * ((HW + 3) / 4);
+  const bool fast = K <= 4 && HW % 4 == 0 && (reinterpret_cast<uintptr_t>(store) & 3) == 0 &&
+                    (reinterpret_cast<uintptr_t>(out) & 3) == 0;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (fast)
+    hipLaunchKernelGGL(gather_stacks_kernel<true>, dim3(nblocks(n, 256, 8192)), dim3(256), 0, st, store, fid, fid_stride,
+                       idx, B, K, HW, out);
+  else
+    hipLaunchKernelGGL(gather_stacks_kernel<false>, dim3(nblocks(n, 256, 8192)), dim3(256), 0, st, store, fid,
+                       fid_stride, idx, B, K, HW, out);
   return curla_launch_status();
 }
 

@@ -32,20 +32,23 @@ LOG_FREQ = 25_000
 
 
 def weight_init(m):
-    """Custom weight init for Conv2D and Linear layers (curl_sac.py:38-54)."""
+    """The reference's initialisation (curl_sac.py:38-54), applied with ``module.apply``: Linear weights orthogonal
+    with zero bias; Conv2d / ConvTranspose2d "delta-orthogonal" (arXiv:1806.05393) -- every tap zero except the
+    centre one, which is an orthogonal (out x in) matrix with the ReLU gain -- and zero bias.  The draws come from
+    torch's global generator in module order, so a seeded construction reproduces the reference's parameters."""
     if isinstance(m, nn.Linear):
         nn.init.orthogonal_(m.weight.data)
         if m.bias is not None:
-            m.bias.data.fill_(0.0)
-    elif isinstance(m, nn.Conv2d) or isinstance(m, nn.ConvTranspose2d):
-        # delta-orthogonal init from https://arxiv.org/pdf/1806.05393.pdf
-        assert m.weight.size(2) == m.weight.size(3)
-        m.weight.data.fill_(0.0)
+            m.bias.data.zero_()
+        return
+    if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+        kh, kw = m.weight.shape[2:]
+        assert kh == kw, "square kernels only"
+        m.weight.data.zero_()
         if m.bias is not None:
-            m.bias.data.fill_(0.0)
-        mid = m.weight.size(2) // 2
-        gain = nn.init.calculate_gain('relu')
-        nn.init.orthogonal_(m.weight.data[:, :, mid, mid], gain)
+            m.bias.data.zero_()
+        centre = kh // 2
+        nn.init.orthogonal_(m.weight.data[:, :, centre, centre], nn.init.calculate_gain('relu'))
 
 
 def _as_ref(obs):
@@ -129,18 +132,19 @@ class Actor(nn.Module):
             log_pi = torch.empty((B, 1), device=dev) if compute_log_pi else None
         ops.actor_head_fwd(out, noise if compute_pi else None, B, A, self.log_std_min, self.log_std_max, mu=mu, pi=pi,
                            log_pi=log_pi, log_std=log_std)
-        self.outputs['mu'] = mu
+        self.outputs['mu'] = out[:, :A]  # the pre-squash mean, as the reference records it (curl_sac.py:92)
         self.outputs['std'] = log_std.exp()
         return mu, pi, log_pi, log_std
 
     def log(self, L, step, log_freq=LOG_FREQ):
-        if step % log_freq != 0:
+        """Histograms of the recorded outputs and of the three trunk layers, every ``log_freq`` steps
+        (curl_sac.py:112-121; same keys)."""
+        if step % log_freq:
             return
-        for k, v in self.outputs.items():
-            L.log_histogram('train_actor/%s_hist' % k, v, step)
-        L.log_param('train_actor/fc1', self.trunk[0], step)
-        L.log_param('train_actor/fc2', self.trunk[2], step)
-        L.log_param('train_actor/fc3', self.trunk[4], step)
+        for name, value in self.outputs.items():
+            L.log_histogram('train_actor/%s_hist' % name, value, step)
+        for n, layer in enumerate((self.trunk[0], self.trunk[2], self.trunk[4]), start=1):
+            L.log_param('train_actor/fc%d' % n, layer, step)
 
 
 class QFunction(nn.Module):
@@ -189,13 +193,15 @@ class Critic(nn.Module):
         return q[0], q[1]
 
     def log(self, L, step, log_freq=LOG_FREQ):
-        if step % log_freq != 0:
+        """Histograms of the recorded Q values and of both Q trunks, every ``log_freq`` steps
+        (curl_sac.py:171-180; same keys)."""
+        if step % log_freq:
             return
-        for k, v in self.outputs.items():
-            L.log_histogram('train_critic/%s_hist' % k, v, step)
-        for i in range(3):
-            L.log_param('train_critic/q1_fc%d' % i, self.Q1.trunk[i * 2], step)
-            L.log_param('train_critic/q2_fc%d' % i, self.Q2.trunk[i * 2], step)
+        for name, value in self.outputs.items():
+            L.log_histogram('train_critic/%s_hist' % name, value, step)
+        for layer in range(3):
+            for tag, q in (('q1', self.Q1), ('q2', self.Q2)):
+                L.log_param('train_critic/%s_fc%d' % (tag, layer), q.trunk[2 * layer], step)
 
 
 class CURL(nn.Module):
@@ -242,6 +248,7 @@ class _Workspace:
         self.z_a, self.z_t, self.z_c, self.z_pos = f(B, F), f(B, F), f(B, F), f(B, F)
         self.xhat_c, self.rstd_c, self.xhat_a, self.rstd_a = f(B, F), f(B), f(B, F), f(B)
         self.dz, self.dfc = f(B, F), f(B, F)
+        self.fc_out = f(B, F)  # pre-LayerNorm features, only written on histogram-logging steps
         # actor trunk
         self.a_h1, self.a_h2, self.a_out = f(B, H), f(B, H), f(B, 2 * A)
         self.a_dh1, self.a_dh2, self.a_dout = f(B, H), f(B, H), f(B, 2 * A)
@@ -583,6 +590,11 @@ class CurlSacAgent(object):
             g = gin
         ops.conv1_wgrad(obs_ref, g, enc.convs[0].weight.grad, enc.convs[0].bias.grad, ws.wg_ws)
 
+    def _records(self, step):
+        """True on the steps whose module outputs the optional histogram / image logging reads
+        (log_param_hist_imgs, every LOG_FREQ steps: curl_sac.py:17,112-121,171-180)."""
+        return self.log_param_hist_imgs and step % LOG_FREQ == 0
+
     def _noise(self, ws, noise):
         if noise is None:
             ws.noise.normal_()
@@ -616,9 +628,13 @@ class CurlSacAgent(object):
 
         # -- current Q estimates + loss + backward (curl_sac.py:357-367)
         enc.conv_forward(o, ws.acts_main)
-        enc.head_forward(ws.acts_main[-1], ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c)
+        rec = self._records(step)
+        enc.head_forward(ws.acts_main[-1], ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c, fc_out=ws.fc_out if rec else None)
         ops.concat(ws.z_c, action, B, F, A, ws.xa)
         _mlp_fwd(ws.xa, 0, self.critic.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.q)
+        if rec:  # what critic.log() / encoder.log() histogram: the outputs of THIS forward (curl_sac.py:163-167)
+            self.critic.outputs['q1'], self.critic.outputs['q2'] = ws.q[0].clone(), ws.q[1].clone()
+            enc.record_from(o, ws.acts_main, ws.fc_out, ws.z_c)
         ops.critic_loss(ws.q, B, ws.target_q, B, ws.scalars[0:1], ws.dq)
         if step % self.log_interval == 0:
             L.log('train_critic/loss', ws.scalars[0], step)
@@ -672,6 +688,8 @@ class CurlSacAgent(object):
         lo, hi = self.actor.log_std_min, self.actor.log_std_max
         ops.actor_head_fwd(ws.a_out, nz, B, A, lo, hi, mu=ws.mu, pi=ws.pi, log_pi=ws.log_pi, log_std=ws.log_std,
                            tanh_ls=ws.tanh_ls)
+        if self._records(step):  # what actor.log() histograms (curl_sac.py:92-93): pre-squash mean and std
+            self.actor.outputs['mu'], self.actor.outputs['std'] = ws.a_out[:, :A].clone(), ws.log_std.exp()
         ops.concat(ws.z_c, ws.pi, B, F, A, ws.xa)
         _mlp_fwd(ws.xa, 0, self.critic.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.q)
         ops.actor_loss(ws.q, B, ws.log_pi, ws.log_std, A, self.log_alpha, float(self.target_entropy), B,

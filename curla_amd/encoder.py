@@ -21,10 +21,10 @@ from . import ops
 
 
 def tie_weights(src, trg):
-    """encoder.py:12-15."""
-    assert type(src) == type(trg)
-    trg.weight = src.weight
-    trg.bias = src.bias
+    """Make ``trg`` use ``src``'s Parameter objects (not copies) for weight and bias (encoder.py:12-15)."""
+    if type(src) is not type(trg):
+        raise AssertionError("tie_weights needs two layers of the same type")
+    trg.weight, trg.bias = src.weight, src.bias
 
 
 def conv_out_hw(h, w, num_layers):
@@ -185,20 +185,41 @@ class CNNEncoder(nn.Module):
         return z
 
     def copy_conv_weights_from(self, source):
-        """Tie convolutional layers (encoder.py:112-116)."""
-        for i in range(self.num_layers):
-            tie_weights(src=source.convs[i], trg=self.convs[i])
+        """Share every conv layer's Parameters with ``source`` (encoder.py:112-116); fc and ln stay separate."""
+        for mine, theirs in zip(self.convs, source.convs):
+            tie_weights(src=theirs, trg=mine)
+
+    def record_from(self, obs_ref, acts, fc_out, z):
+        """Fill ``outputs`` with the reference's entries (encoder.py:79-108) from a pass that has just run through
+        the kernels: 'obs' (the /255 input, NCHW), 'conv1'..'convL' (NCHW copies of the NHWC activations), 'fc',
+        and 'ln' (or 'tanh').  Called on histogram-logging steps only -- it copies every activation."""
+        if obs_ref.is_u8 == 1:
+            x = torch.empty((obs_ref.B, obs_ref.C, obs_ref.Hc, obs_ref.Wc), device=z.device, dtype=torch.float32)
+            ops.crop_nchw(obs_ref.src, obs_ref.idx, obs_ref.h1, obs_ref.w1, obs_ref.B, (obs_ref.Hc, obs_ref.Wc), out_f32=x)
+        elif obs_ref.is_u8 == 2:
+            x = torch.empty((obs_ref.B, obs_ref.C, obs_ref.Hc, obs_ref.Wc), device=z.device, dtype=torch.float32)
+            ops.nhwc_to_nchw(obs_ref.src, x)
+        else:
+            x = obs_ref.src.clone()
+        self.outputs['obs'] = x.div_(255.0)
+        for i, a in enumerate(acts):
+            out = torch.empty((a.shape[0], a.shape[3], a.shape[1], a.shape[2]), device=a.device, dtype=a.dtype)
+            ops.nhwc_to_nchw(a, out)
+            self.outputs['conv%s' % (i + 1)] = out
+        self.outputs['fc'] = fc_out.clone()
+        self.outputs['ln' if self.output_logits else 'tanh'] = z.clone()
 
     def log(self, L, step, log_freq):
-        """encoder.py:118-130."""
-        if step % log_freq != 0:
+        """Histograms (and, for feature maps, the first sample as an image) of the recorded outputs plus the
+        layer parameters, every ``log_freq`` steps (encoder.py:118-130; same keys)."""
+        if step % log_freq:
             return
-        for k, v in self.outputs.items():
-            L.log_histogram('train_encoder/%s_hist' % k, v, step)
-            if len(v.shape) > 2:
-                L.log_image('train_encoder/%s_img' % k, v[0], step)
-        for i in range(self.num_layers):
-            L.log_param('train_encoder/conv%s' % (i + 1), self.convs[i], step)
+        for name, value in self.outputs.items():
+            L.log_histogram('train_encoder/%s_hist' % name, value, step)
+            if value.dim() > 2:
+                L.log_image('train_encoder/%s_img' % name, value[0], step)
+        for n, conv in enumerate(self.convs, start=1):
+            L.log_param('train_encoder/conv%s' % n, conv, step)
         L.log_param('train_encoder/fc', self.fc, step)
         L.log_param('train_encoder/ln', self.ln, step)
 

@@ -25,16 +25,30 @@ class ObsRef:
     a float NCHW tensor in [0,255] (is_u8 = 0: the reference's tensor contract) or
     a float NHWC tensor (is_u8 = 2: output of the float augmentations)."""
 
-    __slots__ = ("src", "is_u8", "idx", "h1", "w1", "B", "C", "Hs", "Ws", "Hc", "Wc")
+    __slots__ = ("src", "is_u8", "idx", "h1", "w1", "B", "C", "Hs", "Ws", "Hc", "Wc", "guard")
+
+    def __init__(self):
+        self.guard = None
 
     @staticmethod
-    def from_ring(frames, idx, h1, w1, B, crop_hw):
+    def from_ring(frames, idx, h1, w1, B, crop_hw, guard=None):
+        """``guard`` = (generation list, slot, generation): the replay buffer's device index block (and assembled
+        stacks) this handle points into is recycled after a few further samples; check() raises once it has been."""
         o = ObsRef()
         _dev(frames, torch.uint8)
         o.src, o.is_u8, o.idx, o.h1, o.w1, o.B = frames, 1, idx, h1, w1, B
         _, o.Hs, o.Ws, o.C = frames.shape
         o.Hc, o.Wc = crop_hw
+        o.guard = guard
         return o
+
+    def check(self):
+        g = self.guard
+        if g is not None and g[0][g[1]] != g[2]:
+            raise _lib.CurlaHipError("stale minibatch handle: the replay buffer has drawn further samples since and "
+                                     "recycled this one's device index block (ReplayBuffer.N_SAMPLE_SLOTS handles "
+                                     "are valid at a time)")
+        return self
 
     @staticmethod
     def from_nhwc(x):
@@ -57,11 +71,13 @@ class ObsRef:
 
 
 def conv1_fwd(obs: ObsRef, w, b, out, scale=1.0 / 255.0):
+    obs.check()
     call("curla_conv1_fwd", ptr(obs.src), obs.is_u8, ptr(obs.idx), ptr(obs.h1), ptr(obs.w1), ptr(w), ptr(b), ptr(out),
          obs.B, obs.C, obs.Hs, obs.Ws, obs.Hc, obs.Wc, w.shape[0], scale, stream())
 
 
 def conv1_wgrad(obs: ObsRef, g, dw, db, ws, scale=1.0 / 255.0):
+    obs.check()
     call("curla_conv1_wgrad", ptr(obs.src), obs.is_u8, ptr(obs.idx), ptr(obs.h1), ptr(obs.w1), ptr(g), ptr(dw), ptr(db),
          ptr(ws), obs.B, obs.C, obs.Hs, obs.Ws, obs.Hc, obs.Wc, dw.shape[0], scale, stream())
 
@@ -184,6 +200,12 @@ def crop_nchw(frames, idx, h1, w1, B, crop_hw, out_f32=None, out_u8=None):
 def store_frame(chw_u8, frames, slot):
     _, H, W, C = frames.shape
     call("curla_store_frame", ptr(chw_u8), ptr(frames), int(slot), C, H, W, stream())
+
+
+def gather_stacks(store, fid, idx, B, out):
+    """store u8 [F, H, W, 3]; fid int32 [rows, k] (a view with row stride fid.stride(0)); out u8 [B, H, W, 3k]."""
+    _, H, W, _ = store.shape
+    call("curla_gather_stacks", ptr(store), ptr(fid), fid.stride(0), ptr(idx), B, fid.shape[1], H, W, ptr(out), stream())
 
 
 def nhwc_to_nchw(x, out):

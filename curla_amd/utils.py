@@ -8,7 +8,16 @@ reference's 3 x B x C x H x W float32 host->device copy per update (utils.py:161
 disappears.  Index and crop-offset draws stay on the host in NumPy's legacy
 global stream, in the reference's order, so a seeded run samples the same
 transitions and windows (bit-exact).
+
+``dedup_frames=True`` stores every RGB frame once: a frame
+stack of k frames shares k-1 of them with its successor and ``next_obs[t]`` is
+``obs[t+1]`` inside an episode (utils.py:238-268), so an environment step adds
+ONE new frame instead of 2k -- 63.5 KB -> 21 KB per transition at 84x84x9,
+339 KB -> 85 KB at 168x168x12.  Sharing is detected from the bytes handed to
+``add`` (hash, then full comparison), never assumed, so sampled pixels are the
+reference's whatever the caller does.
 """
+import collections
 import os
 import random
 
@@ -17,22 +26,31 @@ import torch
 
 from . import augmentations, ops
 
+try:  # 64-bit frame fingerprints for the de-duplicating store (~10 GB/s); zlib is the slower stand-in
+    from xxhash import xxh3_64_intdigest as _fingerprint
+except ImportError:  # pragma: no cover
+    import zlib
+
+    def _fingerprint(buf):
+        return zlib.crc32(buf) | (zlib.adler32(buf) << 32)
+
 
 class eval_mode(object):
-    """utils.py:21-34."""
+    """Context manager that puts the given models (anything with ``.training`` and ``.train(bool)``) in
+    evaluation mode and restores each one's previous mode on exit (utils.py:21-34)."""
 
     def __init__(self, *models):
         self.models = models
+        self._was_training = None
 
     def __enter__(self):
-        self.prev_states = []
-        for model in self.models:
-            self.prev_states.append(model.training)
-            model.train(False)
+        self._was_training = [m.training for m in self.models]
+        for m in self.models:
+            m.train(False)
 
-    def __exit__(self, *args):
-        for model, state in zip(self.models, self.prev_states):
-            model.train(state)
+    def __exit__(self, *exc):
+        for m, mode in zip(self.models, self._was_training):
+            m.train(mode)
         return False
 
 
@@ -53,17 +71,107 @@ def set_seed_everywhere(seed):
 
 
 def make_dir(dir_path):
-    try:
-        os.mkdir(dir_path)
-    except OSError:
-        print('Unable to create directory ' + dir_path)
+    """Create ``dir_path`` unless it exists; like the reference (utils.py:61-66) a failure is reported, not raised,
+    and the path is returned either way."""
+    if not os.path.isdir(dir_path):
+        try:
+            os.mkdir(dir_path)
+        except OSError as e:
+            print('Unable to create directory %s (%s)' % (dir_path, e.strerror))
     return dir_path
+
+
+class FrameStack(object):
+    """Observation wrapper that returns the last ``k`` frames concatenated on the channel axis (utils.py:238-268):
+    ``reset`` fills the stack with k copies of the first frame, ``step`` pushes the new frame.  Plain duck-typed
+    wrapper (``gymnasium`` is only used for the observation space when it is importable): every other attribute
+    is forwarded to the wrapped environment, as ``gym.Wrapper`` does."""
+
+    def __init__(self, env, k):
+        self.env = env
+        self._k = k
+        self._frames = collections.deque([], maxlen=k)
+        space = getattr(env, "observation_space", None)
+        shp = tuple(getattr(space, "shape", ()))
+        if shp:
+            stacked = (shp[0] * k,) + shp[1:]
+            try:
+                import gymnasium
+                self.observation_space = gymnasium.spaces.Box(low=0, high=1, shape=stacked, dtype=space.dtype)
+            except ImportError:
+                self.observation_space = type("Box", (), dict(shape=stacked, dtype=getattr(space, "dtype", np.uint8),
+                                                              low=0, high=1))()
+        self._max_episode_steps = getattr(env, "_max_episode_steps", None)
+        self.curl_driving = False
+
+    def __getattr__(self, name):  # only called for attributes not found on the wrapper itself
+        if name in ("env", "_frames"):
+            raise AttributeError(name)
+        return getattr(self.env, name)
+
+    def reset(self):
+        first = self.env.reset()
+        self.curl_driving = getattr(self.env, "curl_driving", False)
+        self._frames.extend([first] * self._k)
+        return self._get_obs()
+
+    def step(self, action):
+        frame, reward, done, info = self.env.step(action)
+        self.env.curl_driving = self.curl_driving
+        self._frames.append(frame)
+        return self._get_obs(), reward, done, info
+
+    def _get_obs(self):
+        assert len(self._frames) == self._k
+        return np.concatenate(list(self._frames), axis=0)
+
+
+class _FrameStore:
+    """Host-side bookkeeping of the de-duplicating frame store: reference counts, a free list and a small cache of
+    the most recently interned frames (hash -> (frame id, bytes)) that new frames are matched against."""
+
+    def __init__(self, n_frames, recent):
+        self.refs = np.zeros(n_frames, dtype=np.int32)
+        self.free = collections.deque(range(n_frames))
+        self.recent = collections.OrderedDict()  # fingerprint -> (fid, ndarray copy)
+        self.max_recent = recent
+
+    def lookup(self, frame):
+        """(fid or None, fingerprint) of a (3, H, W) uint8 frame among the recent ones -- byte-exact."""
+        h = _fingerprint(frame)
+        hit = self.recent.get(h)
+        if hit is not None and np.array_equal(hit[1], frame):
+            self.recent.move_to_end(h)
+            return hit[0], h
+        return None, h
+
+    def allocate(self, frame, h):
+        if not self.free:
+            raise MemoryError("frame store exhausted: the observations handed to add() share fewer frames than a "
+                              "frame-stacked episode does; raise frame_capacity or construct the ReplayBuffer with "
+                              "dedup_frames=False")
+        fid = self.free.popleft()
+        self.recent[h] = (fid, np.array(frame, copy=True))
+        while len(self.recent) > self.max_recent:
+            self.recent.popitem(last=False)
+        return fid
+
+    def release(self, fid):
+        self.refs[fid] -= 1
+        if self.refs[fid] == 0:
+            self.free.append(fid)
+            for h, (f, _) in list(self.recent.items()):
+                if f == fid:
+                    del self.recent[h]
 
 
 class ReplayBuffer(object):
     """Buffer to store environment transitions (utils.py:80-236), HBM-resident."""
 
-    def __init__(self, obs_shape, action_shape, capacity, batch_size, device, augmentor, transform=None):
+    N_SAMPLE_SLOTS = 2  # minibatches whose references may be alive at once (the current one + one drawn ahead)
+
+    def __init__(self, obs_shape, action_shape, capacity, batch_size, device, augmentor, transform=None,
+                 dedup_frames=False, frame_capacity=None):
         self.capacity = capacity
         self.batch_size = batch_size
         self.device = torch.device(device)
@@ -74,69 +182,109 @@ class ReplayBuffer(object):
         c, h, w = obs_shape
         self.obs_shape = tuple(obs_shape)
         frame = c * h * w
-        total_bytes = 2 * capacity * frame + capacity * (4 * int(np.prod(action_shape)) + 8)
+        A = int(np.prod(action_shape))
+        self.dedup_frames = bool(dedup_frames)
+        if self.dedup_frames:
+            if c % 3 != 0:
+                raise ValueError("dedup_frames needs stacked RGB frames (channels a multiple of 3)")
+            self._k = c // 3
+            if frame_capacity is None:  # one new frame per step + one extra per episode start, with headroom
+                frame_capacity = capacity + capacity // 16 + 4 * self._k + 8
+            self.frame_capacity = int(frame_capacity)
+            total_bytes = self.frame_capacity * 3 * h * w + capacity * (8 * self._k + 4 * A + 8) \
+                + self.N_SAMPLE_SLOTS * 2 * batch_size * frame
+        else:
+            total_bytes = 2 * capacity * frame + capacity * (4 * A + 8)
         if self.device.type == "cuda":
             free, _ = torch.cuda.mem_get_info(self.device)
             if total_bytes > free:
                 raise ValueError('Replay buffer size exceeds available memory')  # utils.py:112-113
-        # ring storage: NHWC uint8 frames (+32 B slack: the aligning loader reads whole 16-byte runs plus one dword)
-        self._obs_store = torch.zeros(capacity * frame + 32, dtype=torch.uint8, device=self.device)
-        self._next_store = torch.zeros(capacity * frame + 32, dtype=torch.uint8, device=self.device)
-        self.obses = self._obs_store[:capacity * frame].view(capacity, h, w, c)
-        self.next_obses = self._next_store[:capacity * frame].view(capacity, h, w, c)
+        dev = self.device
+        if self.dedup_frames:
+            # every RGB frame once: uint8 [F][H][W][3] (+32 B slack like a ring); a transition keeps 2k frame ids
+            f3 = 3 * h * w
+            self._frame_store = torch.zeros(self.frame_capacity * f3 + 32, dtype=torch.uint8, device=dev)
+            self.frames = self._frame_store[:self.frame_capacity * f3].view(self.frame_capacity, h, w, 3)
+            self._fid = torch.zeros((capacity, 2, self._k), dtype=torch.int32, device=dev)
+            self._fid_h = np.full((capacity, 2, self._k), -1, dtype=np.int32)
+            self._store = _FrameStore(self.frame_capacity, recent=2 * self._k + 2)
+            self.obses = self.next_obses = None  # stacks are assembled per minibatch (stack(i) materialises one)
+        else:
+            # ring storage: NHWC uint8 frames (+32 B slack: the aligning loader reads whole 16-byte runs plus a dword)
+            self._obs_store = torch.zeros(capacity * frame + 32, dtype=torch.uint8, device=dev)
+            self._next_store = torch.zeros(capacity * frame + 32, dtype=torch.uint8, device=dev)
+            self.obses = self._obs_store[:capacity * frame].view(capacity, h, w, c)
+            self.next_obses = self._next_store[:capacity * frame].view(capacity, h, w, c)
         # action | reward | not_done of a transition sit in one row, so add() writes them with one small copy;
         # the three reference attributes are column views of it
-        A = int(np.prod(action_shape))
         self._n_act = A
-        self._sc = torch.empty((capacity, A + 2), dtype=torch.float32, device=self.device)
+        self._sc = torch.empty((capacity, A + 2), dtype=torch.float32, device=dev)
         self.actions = self._sc[:, :A].unflatten(1, tuple(action_shape)) if len(action_shape) != 1 else self._sc[:, :A]
         self.rewards = self._sc[:, A:A + 1]
         self.not_dones = self._sc[:, A + 1:A + 2]
         self.idx = 0
         self.last_save = 0
         self.full = False
-        # staging: pinned host rows for add(), static device index buffers for sampling
+        # staging: pinned host rows for add(), device index buffers for sampling
         pin = self.device.type == "cuda"
-        # add(): one pinned block per slot = [obs frame | next_obs frame | pad | action, reward, not_done], a few
-        # slots guarded by events so that add() never waits for the GPU; one device block receives the copy
+        # add(): one pinned block per slot = [frames | pad | frame ids, action, reward, not_done], a few slots
+        # guarded by events so that add() never waits for the GPU; one device block receives the copy
         self._frame = frame
-        self._sc_off = (2 * frame + 15) & ~15
-        blk = self._sc_off + 4 * (A + 2)
+        n_stage = 2 * frame  # plain: the two stacks; dedup: up to 2k new RGB frames = the same bytes
+        self._sc_off = (n_stage + 15) & ~15
+        self._hdr = 4 * (2 * self._k) if self.dedup_frames else 0  # frame-id row in front of the scalars
+        blk = self._sc_off + self._hdr + 4 * (A + 2)
         self._n_add, self._add_slot = 4, 0
         self._h_add = torch.empty((self._n_add, blk), dtype=torch.uint8, pin_memory=pin)
         self._h_add_np = self._h_add.numpy()
         self._add_events = [None] * self._n_add
-        self._d_add = torch.empty(blk, dtype=torch.uint8, device=self.device)
+        self._d_add = torch.empty(blk, dtype=torch.uint8, device=dev)
         self._d_add_frames = self._d_add[:2 * frame].view(2, frame)
-        self._d_add_sc = self._d_add[self._sc_off:].view(torch.float32)
+        self._d_add_sc = self._d_add[self._sc_off + self._hdr:].view(torch.float32)
         B = batch_size
         # the host may run several updates ahead of the GPU: a small ring of pinned slots, each guarded by an
         # event, keeps an index upload's source intact until its async copy has executed
         self._n_slots, self._slot = 8, 0
-        self._h_index = torch.empty((self._n_slots, B * 8 + B * 4 * 6), dtype=torch.uint8, pin_memory=pin)
+        nbytes = B * 8 + B * 4 * 6
+        self._h_index = torch.empty((self._n_slots, nbytes), dtype=torch.uint8, pin_memory=pin)
         self._slot_events = [None] * self._n_slots
-        self._d_index = torch.empty(B * 8 + B * 4 * 6, dtype=torch.uint8, device=self.device)
-        self._d_idx = self._d_index[:B * 8].view(torch.int64)
-        self._d_off = self._d_index[B * 8:].view(torch.int32).view(6, B)
+        # every minibatch gets its own device index block (and, de-duplicated, its own assembled stacks), so the
+        # references of one sample stay valid while the next one is drawn (N_SAMPLE_SLOTS alive at a time)
+        self._d_index = torch.empty((self.N_SAMPLE_SLOTS, nbytes), dtype=torch.uint8, device=dev)
+        self._sample_gen = [0] * self.N_SAMPLE_SLOTS
+        self._sample_slot = -1
+        if self.dedup_frames:
+            self._mb_store = torch.zeros((self.N_SAMPLE_SLOTS, 2, B * frame + 32), dtype=torch.uint8, device=dev)
 
     # ------------------------------------------------------------------ writing
-    def add(self, obs, action, reward, next_obs, done):
-        """utils.py:120-128: store one transition at ``idx``.  The two frames and the scalars travel in one
-        pinned block and one async copy; two kernels turn CHW into the ring's HWC, one row copy stores the
-        scalars.  Nothing here waits for the GPU (a slot is reused only after its copy has executed)."""
-        i = self.idx
+    def _stage_scalars(self, row, action, reward, done):
+        A = self._n_act
+        sc = row[self._sc_off + self._hdr:].view(np.float32)
+        sc[:A] = np.asarray(action, dtype=np.float32).reshape(-1)
+        sc[A] = float(reward)
+        sc[A + 1] = float(not done)
+        return sc
+
+    def _next_add_slot(self):
         k = self._add_slot
         self._add_slot = (k + 1) % self._n_add
         if self._add_events[k] is not None:
             self._add_events[k].synchronize()
-        fr, A = self._frame, self._n_act
+        return k
+
+    def add(self, obs, action, reward, next_obs, done):
+        """utils.py:120-128: store one transition at ``idx``.  The two frames and the scalars travel in one
+        pinned block and one async copy; two kernels turn CHW into the ring's HWC, one row copy stores the
+        scalars.  Nothing here waits for the GPU (a slot is reused only after its copy has executed)."""
+        if self.dedup_frames:
+            return self._add_dedup(obs, action, reward, next_obs, done)
+        i = self.idx
+        k = self._next_add_slot()
+        fr = self._frame
         row = self._h_add_np[k]
         row[:fr] = np.asarray(obs, dtype=np.uint8).reshape(-1)
         row[fr:2 * fr] = np.asarray(next_obs, dtype=np.uint8).reshape(-1)
-        sc = row[self._sc_off:].view(np.float32)
-        sc[:A] = np.asarray(action, dtype=np.float32).reshape(-1)
-        sc[A] = float(reward)
-        sc[A + 1] = float(not done)
+        sc = self._stage_scalars(row, action, reward, done)
         if self.device.type == "cuda":
             self._d_add.copy_(self._h_add[k], non_blocking=True)
             ev = torch.cuda.Event()
@@ -151,13 +299,69 @@ class ReplayBuffer(object):
             self.obses[i] = blk[:fr].view(c, h, w).permute(1, 2, 0)
             self.next_obses[i] = blk[fr:2 * fr].view(c, h, w).permute(1, 2, 0)
             self._sc[i] = torch.from_numpy(sc.copy())
-        self.idx = (self.idx + 1) % self.capacity
-        self.full = self.full or self.idx == 0
+        self._advance(1)
+
+    def _advance(self, n):
+        new_idx = self.idx + n
+        self.full = self.full or new_idx >= self.capacity
+        self.idx = new_idx % self.capacity
+
+    def _add_dedup(self, obs, action, reward, next_obs, done):
+        """add() into the frame store: each of the 2k RGB frames of (obs, next_obs) is matched byte for byte
+        against the recently stored ones (in a frame-stacked episode 2k-1 of them are), only the new ones are
+        uploaded, and the transition records 2k frame ids."""
+        c, h, w = self.obs_shape
+        K, f3 = self._k, 3 * h * w
+        i = self.idx
+        st = self._store
+        old = self._fid_h[i].reshape(-1)
+        slot = self._next_add_slot()
+        row = self._h_add_np[slot]
+        ids, new = np.empty(2 * K, dtype=np.int32), []
+        frames = np.concatenate([np.asarray(obs, dtype=np.uint8).reshape(K, 3, h, w),
+                                 np.asarray(next_obs, dtype=np.uint8).reshape(K, 3, h, w)])
+        for j in range(2 * K):
+            fid, fp = st.lookup(frames[j])
+            if fid is None:
+                fid = st.allocate(frames[j], fp)
+                row[len(new) * f3:(len(new) + 1) * f3] = frames[j].reshape(-1)
+                new.append(fid)
+            st.refs[fid] += 1
+            ids[j] = fid
+        for fid in old:  # the transition this slot held before (ring wrap) lets go of its frames
+            if fid >= 0:
+                st.release(int(fid))
+        self._fid_h[i] = ids.reshape(2, K)
+        row[self._sc_off:self._sc_off + self._hdr].view(np.int32)[:] = ids
+        sc = self._stage_scalars(row, action, reward, done)
+        if self.device.type == "cuda":
+            n = len(new) * f3
+            if n:
+                self._d_add[:n].copy_(self._h_add[slot, :n], non_blocking=True)
+            self._d_add[self._sc_off:].copy_(self._h_add[slot, self._sc_off:], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._add_events[slot] = ev
+            for j, fid in enumerate(new):
+                ops.store_frame(self._d_add[j * f3:(j + 1) * f3], self.frames, fid)
+            self._fid[i].view(-1).copy_(self._d_add[self._sc_off:self._sc_off + self._hdr].view(torch.int32))
+            self._sc[i].copy_(self._d_add_sc)
+        else:  # host-side bookkeeping only
+            for j, fid in enumerate(new):
+                self.frames[fid] = torch.from_numpy(row[j * f3:(j + 1) * f3].reshape(3, h, w).copy()).permute(1, 2, 0)
+            self._fid[i] = torch.from_numpy(ids.reshape(2, K).copy())
+            self._sc[i] = torch.from_numpy(sc.copy())
+        self._advance(1)
 
     def add_batch(self, obses, actions, rewards, next_obses, dones):
         """Bulk fill (benchmarks / buffer load): N transitions, observations as
         (N, C, H, W) uint8 arrays.  Same ring semantics as N add() calls."""
         n = len(obses)
+        if self.dedup_frames:
+            for j in range(n):
+                self.add(obses[j], actions[j], float(np.asarray(rewards[j]).reshape(-1)[0]), next_obses[j],
+                         bool(np.asarray(dones[j]).reshape(-1)[0]))
+            return
         for s in range(0, n, 1024):
             e = min(n, s + 1024)
             m = e - s
@@ -172,9 +376,11 @@ class ReplayBuffer(object):
                                                     device=self.device)
             nd = 1.0 - np.asarray(dones[s:e], dtype=np.float32).reshape(m, 1)
             self.not_dones[slots_d] = torch.as_tensor(nd, device=self.device)
-            new_idx = self.idx + m
-            self.full = self.full or new_idx >= self.capacity
-            self.idx = new_idx % self.capacity
+            self._advance(m)
+
+    def frames_in_use(self):
+        """(dedup_frames) RGB frames currently held / the store's capacity."""
+        return self.frame_capacity - len(self._store.free), self.frame_capacity
 
     # ------------------------------------------------------------------ sampling
     def _is_crop(self):
@@ -197,8 +403,8 @@ class ReplayBuffer(object):
             raise NotImplementedError("unknown augmentation object: %r" % (self.augmentor,))
         return idxs, offs
 
-    def _float_augmented(self, ring):
-        """One augmented float NHWC minibatch [B, H, W, C] from ``ring`` at the uploaded indices
+    def _float_augmented(self, ring, idx):
+        """One augmented float NHWC minibatch [B, H, W, C] from ``ring`` rows ``idx`` (None: rows 0..B-1)
         (utils.py:168-182 branch: the torch/kornia augmentations)."""
         B = self.batch_size
         c, h, w = self.obs_shape
@@ -206,19 +412,21 @@ class ReplayBuffer(object):
         aug = self.augmentor
         if isinstance(aug, augmentations.ColorJiggle):
             params, order = aug.draw_params(B * (c // 3))
-            ops.color_jiggle(ring, self._d_idx, params.to(self.device), order.to(self.device), B, out)
+            ops.color_jiggle(ring, idx, params.to(self.device), order.to(self.device), B, out)
         elif isinstance(aug, augmentations.NoisyCover):
             colors = aug.draw_colors()
             noise = torch.randn((B, h, w, c), device=self.device) * aug.std
-            ops.noisy_cover(ring, self._d_idx, noise, colors, aug.top, aug.bottom, B, out)
+            ops.noisy_cover(ring, idx, noise, colors, aug.top, aug.bottom, B, out)
         else:
-            ops.gather_nhwc(ring, self._d_idx, B, out)
+            ops.gather_nhwc(ring, idx, B, out)
         return out
 
     def _is_float_aug(self):
         return isinstance(self.augmentor, (augmentations.ColorJiggle, augmentations.NoisyCover))
 
     def _upload_indices(self, idxs, offs):
+        """Copy a minibatch's indices and crop offsets into the next device sample slot; returns the slot's
+        (guard, idx view [B] int64, offsets view [6, B] int32)."""
         B = self.batch_size
         k = self._slot
         self._slot = (k + 1) % self._n_slots
@@ -227,41 +435,62 @@ class ReplayBuffer(object):
         host = self._h_index[k]
         host[:B * 8].view(torch.int64).copy_(torch.from_numpy(np.ascontiguousarray(idxs, dtype=np.int64)))
         host[B * 8:].view(torch.int32).view(6, B).copy_(torch.from_numpy(np.ascontiguousarray(offs, dtype=np.int32)))
-        self._d_index.copy_(host, non_blocking=True)
+        s = self._sample_slot = (self._sample_slot + 1) % self.N_SAMPLE_SLOTS
+        self._sample_gen[s] += 1
+        dst = self._d_index[s]
+        dst.copy_(host, non_blocking=True)
         if self.device.type == "cuda":
             ev = torch.cuda.Event()
             ev.record()
             self._slot_events[k] = ev
+        guard = (self._sample_gen, s, self._sample_gen[s])
+        return guard, dst[:B * 8].view(torch.int64), dst[B * 8:].view(torch.int32).view(6, B)
 
-    def _scalars(self):
-        return (self.actions.index_select(0, self._d_idx), self.rewards.index_select(0, self._d_idx),
-                self.not_dones.index_select(0, self._d_idx))
+    def _scalars(self, d_idx):
+        return (self.actions.index_select(0, d_idx), self.rewards.index_select(0, d_idx),
+                self.not_dones.index_select(0, d_idx))
 
     def _require_cuda(self):
         from . import _lib
         if self.device.type != "cuda" and _lib._trace_hook is None:
             raise RuntimeError("sampling pixels needs the HIP device: curla_amd has no CPU fallback for the learner path")
 
+    def _sources(self, d_idx):
+        """(obs ring, next_obs ring, row index tensor or None) the loaders read a minibatch from.  Plain storage:
+        the two rings, indexed by the sampled slots.  De-duplicated storage: the k frames of every sampled stack
+        are first assembled into this sample slot's [B][H][W][3k] uint8 buffers (one gather kernel per tensor)."""
+        if not self.dedup_frames:
+            return self.obses, self.next_obses, d_idx
+        B = self.batch_size
+        c, h, w = self.obs_shape
+        mb = self._mb_store[self._sample_slot]
+        views = [mb[j, :B * self._frame].view(B, h, w, c) for j in range(2)]
+        for j in range(2):
+            ops.gather_stacks(self.frames, self._fid[:, j, :], d_idx, B, views[j])
+        return views[0], views[1], None
+
     def sample_cpc_refs(self, indices=None):
         """The fused form of sample_cpc: same 6-tuple, but obs / next_obs / pos are
         ``ObsRef`` handles (ring + indices + crop offsets) consumed directly by the
-        first conv kernel.  ``indices=(idxs, offs)`` injects pre-drawn indices (tests, DP)."""
+        first conv kernel.  ``indices=(idxs, offs)`` injects pre-drawn indices (tests, DP).
+        The handles of one call stay valid until N_SAMPLE_SLOTS further samples have been drawn (using an older
+        one raises)."""
         self._require_cuda()
         idxs, offs = indices if indices is not None else self.draw_indices()
-        self._upload_indices(idxs, offs)
+        guard, d_idx, off = self._upload_indices(idxs, offs)
         B = self.batch_size
         crop = tuple(self.augmentor.output_shape)
-        off = self._d_off
+        ring_o, ring_n, rows = self._sources(d_idx)
         if self._is_float_aug():
             # obs, next_obs and pos (= a copy of obs) are augmented independently (utils.py:173-182)
-            obses = ops.ObsRef.from_nhwc(self._float_augmented(self.obses))
-            next_obses = ops.ObsRef.from_nhwc(self._float_augmented(self.next_obses))
-            pos = ops.ObsRef.from_nhwc(self._float_augmented(self.obses))
+            obses = ops.ObsRef.from_nhwc(self._float_augmented(ring_o, rows))
+            next_obses = ops.ObsRef.from_nhwc(self._float_augmented(ring_n, rows))
+            pos = ops.ObsRef.from_nhwc(self._float_augmented(ring_o, rows))
         else:
-            obses = ops.ObsRef.from_ring(self.obses, self._d_idx, off[0], off[1], B, crop)
-            next_obses = ops.ObsRef.from_ring(self.next_obses, self._d_idx, off[2], off[3], B, crop)
-            pos = ops.ObsRef.from_ring(self.obses, self._d_idx, off[4], off[5], B, crop)
-        actions, rewards, not_dones = self._scalars()
+            obses = ops.ObsRef.from_ring(ring_o, rows, off[0], off[1], B, crop, guard)
+            next_obses = ops.ObsRef.from_ring(ring_n, rows, off[2], off[3], B, crop, guard)
+            pos = ops.ObsRef.from_ring(ring_o, rows, off[4], off[5], B, crop, guard)
+        actions, rewards, not_dones = self._scalars(d_idx)
         cpc_kwargs = dict(obs_anchor=obses, obs_pos=pos, time_anchor=None, time_pos=None)
         return obses, actions, rewards, next_obses, not_dones, cpc_kwargs
 
@@ -270,57 +499,75 @@ class ReplayBuffer(object):
         in [0,255] on the device (materialised by one crop kernel per tensor)."""
         self._require_cuda()
         idxs, offs = indices if indices is not None else self.draw_indices()
-        self._upload_indices(idxs, offs)
+        _, d_idx, off = self._upload_indices(idxs, offs)
         B = self.batch_size
         c = self.obs_shape[0]
         oh, ow = self.augmentor.output_shape
-        off = self._d_off
+        ring_o, ring_n, rows = self._sources(d_idx)
         outs = []
-        for ring, j in ((self.obses, 0), (self.next_obses, 1), (self.obses, 2)):
+        for ring, j in ((ring_o, 0), (ring_n, 1), (ring_o, 2)):
             t = torch.empty((B, c, oh, ow), dtype=torch.float32, device=self.device)
             if self._is_float_aug():
-                ops.nhwc_to_nchw(self._float_augmented(ring), t)
+                ops.nhwc_to_nchw(self._float_augmented(ring, rows), t)
             else:
-                ops.crop_nchw(ring, self._d_idx, off[2 * j], off[2 * j + 1], B, (oh, ow), out_f32=t)
+                ops.crop_nchw(ring, rows, off[2 * j], off[2 * j + 1], B, (oh, ow), out_f32=t)
             outs.append(t)
         obses, next_obses, pos = outs
-        actions, rewards, not_dones = self._scalars()
+        actions, rewards, not_dones = self._scalars(d_idx)
         cpc_kwargs = dict(obs_anchor=obses, obs_pos=pos, time_anchor=None, time_pos=None)
         return obses, actions, rewards, next_obses, not_dones, cpc_kwargs
 
     # ------------------------------------------------------------------ persistence
-    def _chw(self, ring, lo, hi):
-        return ring[lo:hi].permute(0, 3, 1, 2).contiguous().cpu().numpy()
+    def stacks(self, lo, hi, which=0):
+        """Transitions [lo, hi) as the reference stores them: a (hi-lo, C, H, W) uint8 NumPy array of obs
+        (which=0) or next_obs (which=1) stacks."""
+        c, h, w = self.obs_shape
+        n = hi - lo
+        if n <= 0:
+            return np.empty((0, c, h, w), dtype=np.uint8)
+        if self.dedup_frames:
+            rows = torch.arange(lo, hi, device=self.device, dtype=torch.int64)
+            buf = torch.zeros(n * self._frame + 32, dtype=torch.uint8, device=self.device)
+            out = buf[:n * self._frame].view(n, h, w, c)
+            ops.gather_stacks(self.frames, self._fid[:, which, :], rows, n, out)
+            ring = out
+        else:
+            ring = (self.obses, self.next_obses)[which][lo:hi]
+        return ring.permute(0, 3, 1, 2).contiguous().cpu().numpy()
 
     def save(self, save_dir):
-        """utils.py:189-202: incremental chunk ``{start}_{end}.pt`` in the reference's
-        payload format (CHW uint8 NumPy arrays)."""
-        if self.idx == self.last_save:
-            return
-        path = os.path.join(save_dir, '%d_%d.pt' % (self.last_save, self.idx))
+        """utils.py:189-202: the transitions added since the last call go to one file ``{start}_{end}.pt`` whose
+        payload is the reference's (five arrays, observation stacks as CHW uint8)."""
         lo, hi = self.last_save, self.idx
-        payload = [self._chw(self.obses, lo, hi), self._chw(self.next_obses, lo, hi),
-                   self.actions[lo:hi].cpu().numpy(), self.rewards[lo:hi].cpu().numpy(),
-                   self.not_dones[lo:hi].cpu().numpy()]
-        self.last_save = self.idx
-        torch.save(payload, path)
+        if lo == hi:
+            return
+        payload = [self.stacks(lo, hi, 0), self.stacks(lo, hi, 1)]
+        payload += [t[lo:hi].cpu().numpy() for t in (self.actions, self.rewards, self.not_dones)]
+        self.last_save = hi
+        torch.save(payload, os.path.join(save_dir, '%d_%d.pt' % (lo, hi)))
 
     def load(self, save_dir):
-        """utils.py:204-216."""
-        chunks = os.listdir(save_dir)
-        chucks = sorted(chunks, key=lambda x: int(x.split('_')[0]))
-        for chunk in chucks:
-            start, end = [int(x) for x in chunk.split('.')[0].split('_')]
-            path = os.path.join(save_dir, chunk)
-            payload = torch.load(path, weights_only=False)
-            assert self.idx == start
-            dev = self.device
-            self.obses[start:end] = torch.as_tensor(payload[0]).to(dev).permute(0, 2, 3, 1)
-            self.next_obses[start:end] = torch.as_tensor(payload[1]).to(dev).permute(0, 2, 3, 1)
-            self.actions[start:end] = torch.as_tensor(payload[2]).to(dev)
-            self.rewards[start:end] = torch.as_tensor(payload[3]).to(dev)
-            self.not_dones[start:end] = torch.as_tensor(payload[4]).to(dev)
-            self.idx = end
+        """utils.py:204-216: read the ``{start}_{end}.pt`` files of ``save_dir`` back in ascending order of
+        ``start``; each file must continue where the previous one ended."""
+        def span(name):
+            lo, hi = os.path.splitext(name)[0].split('_')
+            return int(lo), int(hi)
+
+        for name in sorted(os.listdir(save_dir), key=lambda n: span(n)[0]):
+            lo, hi = span(name)
+            if lo != self.idx:
+                raise AssertionError("chunk %s does not continue the buffer at index %d" % (name, self.idx))
+            obs, nxt, act, rew, nd = torch.load(os.path.join(save_dir, name), weights_only=False)
+            if self.dedup_frames:
+                self.add_batch(obs, act, rew, nxt, 1.0 - np.asarray(nd))
+                self.idx = hi  # (the reference's load does not wrap either)
+                continue
+            to_ring = lambda a: torch.as_tensor(a).to(self.device).permute(0, 2, 3, 1)  # noqa: E731  CHW -> HWC
+            self.obses[lo:hi] = to_ring(obs)
+            self.next_obses[lo:hi] = to_ring(nxt)
+            for dst, src in ((self.actions, act), (self.rewards, rew), (self.not_dones, nd)):
+                dst[lo:hi] = torch.as_tensor(src).to(self.device)
+            self.idx = hi
 
     def __len__(self):
         return self.capacity

@@ -160,6 +160,13 @@ int curla_crop_nchw(const uint8_t* frames, const int64_t* idx, const int32_t* h1
                     int Hs, int Ws, int Hc, int Wc, float* out_f32, uint8_t* out_u8, void* stream);
 /* ReplayBuffer.add: one CHW uint8 observation into ring slot `slot` (utils.py:120-128) */
 int curla_store_frame(const uint8_t* chw, uint8_t* frames, long long slot, int C, int H, int W, void* stream);
+/* De-duplicated frame store (next_obs[t] shares k-1 of its k frames with obs[t], and equals obs[t+1]
+ * inside an episode, utils.py:238-268): `store` holds every RGB frame once, uint8 [F][H][W][3]; row idx[b] (NULL: b) of
+ * `fid` (int32, `fid_stride` entries per row) lists the K frame ids of a stack.  Writes the minibatch of stacks
+ * out[b][y][x][3f+c] = store[fid[idx[b]][f]][y][x][c] -- uint8 [B][H][W][3K], what curla_conv1_fwd reads (src_kind 1,
+ * idx NULL); `out` needs the same 32 bytes of slack as a ring. */
+int curla_gather_stacks(const uint8_t* store, const int32_t* fid, int fid_stride, const int64_t* idx, int B, int K,
+                        int H, int W, uint8_t* out, void* stream);
 int curla_nhwc_to_nchw(const float* in, float* out, int B, int H, int W, int C, void* stream);
 
 #ifdef __cplusplus

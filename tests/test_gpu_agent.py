@@ -117,7 +117,7 @@ def test_state_dict_roundtrip_reference_layout(tiny):
         assert torch.equal(sd[k].cpu(), v), k
 
 
-@pytest.mark.parametrize("path", ["tensors", "ring"])
+@pytest.mark.parametrize("path", ["tensors", "ring", "dedup"])
 def test_critic_phase_vs_reference(tiny, path):
     import curla_amd
     g = tiny
@@ -128,7 +128,10 @@ def test_critic_phase_vs_reference(tiny, path):
     if path == "tensors":
         obs, nxt = _t(g["batch/obs"]).float(), _t(g["batch/next_obs"]).float()
     else:
-        rb = curla_amd.ReplayBuffer((9, 34, 40), (2,), 16, B, torch.device("cuda"), aug)
+        # "dedup": every RGB frame stored once, stacks re-assembled per minibatch (the fixture's frames share
+        # nothing, so the store is sized for 6 frames per transition)
+        kw_store = dict(dedup_frames=True, frame_capacity=6 * 16) if path == "dedup" else {}
+        rb = curla_amd.ReplayBuffer((9, 34, 40), (2,), 16, B, torch.device("cuda"), aug, **kw_store)
         fill_ring(rb, g["batch/obs_full"], g["batch/next_obs_full"])
         offs = np.stack([g["rng/h1_obs"], g["rng/w1_obs"], g["rng/h1_next_obs"], g["rng/w1_next_obs"],
                          g["rng/h1_pos"], g["rng/w1_pos"]]).astype(np.int32)
@@ -410,7 +413,9 @@ def test_other_config_geometries_vs_oracle(name, obs_shape, layers, pixel_sac, B
     check(f"{name} critic loss", L.scalars["train_critic/loss"], ref["critic_loss"])
     check(f"{name} actor loss", L.scalars["train_actor/loss"], ref["actor_loss"])
     if not pixel_sac:
-        check(f"{name} curl loss", L.scalars["train/curl_loss"], ref["curl_loss"])
+        # feature 130 with W ~ U(0,1): logits of magnitude ~40 whose softmax is close to one-hot, so the loss is a
+        # small difference of large numbers -- 5e-4 there (the gradients below stay at 1e-4)
+        check(f"{name} curl loss", L.scalars["train/curl_loss"], ref["curl_loss"], 5e-4 if feat > 64 else RTOL)
     for k, v in ref_critic["grads"].items():
         check(f"{name} critic grad {k}", grads["critic"][k], v)
     # post-Adam conv parameters (fc.weight is left out: its entries are ~lr-sized, so one Adam step of a
@@ -790,3 +795,135 @@ def test_full_size_c5_gradients_are_the_mean_over_shards():
     # shards: only finiteness and scale are asserted for the cpc phase at this size
     assert bool(torch.isfinite(full[5]).all()) and float(full[5].abs().max()) > 0 and np.isfinite(full[6])
     assert full[6] >= 0.0  # a cross-entropy
+
+
+def test_dedup_frame_store_is_bitwise_the_plain_ring(tmp_path):
+    """dedup_frames=True (every RGB frame stored once) against the plain ring, fed the same
+    frame-stacked episodes (FrameStack, utils.py:238-268) through add() with the ring wrapping: identical sampled
+    bytes, identical training (bit for bit: the kernels read the same pixels), the reference's chunk format on
+    save, and ~1 stored frame per transition."""
+    import curla_amd
+    from tests.test_host_logic import _FakeEnv, _rollout
+    hw, k, cap, B = (34, 40), 3, 40, 8
+    dev = torch.device("cuda")
+    aug = curla_amd.RandomCrop(hw, (28, 34))
+    trans = _rollout(curla_amd.utils.FrameStack(_FakeEnv(hw, 11, 3), k), 70)
+    plain = curla_amd.ReplayBuffer((9,) + hw, (2,), cap, B, dev, aug)
+    dedup = curla_amd.ReplayBuffer((9,) + hw, (2,), cap, B, dev, aug, dedup_frames=True)
+    for t in trans[:30]:
+        plain.add(*t), dedup.add(*t)
+    d1, d2 = tmp_path / "plain", tmp_path / "dedup"
+    d1.mkdir(), d2.mkdir()
+    plain.save(str(d1)), dedup.save(str(d2))
+    a, b = torch.load(d1 / "0_30.pt", weights_only=False), torch.load(d2 / "0_30.pt", weights_only=False)
+    for x, y in zip(a, b):
+        assert x.shape == y.shape and np.array_equal(x, y)
+    assert a[0].shape == (30, 9) + hw and np.array_equal(a[1][4], trans[4][3])
+    for t in trans[30:]:
+        plain.add(*t), dedup.add(*t)  # 70 transitions into 40 slots: both rings wrap
+    assert dedup.idx == plain.idx == 30 and dedup.full
+    used, total = dedup.frames_in_use()
+    assert used <= cap + 8 and total < 2 * cap  # vs 6 RGB frames per transition in the plain ring
+    np.random.seed(4)
+    idxs, offs = plain.draw_indices()
+    sp, sd = plain.sample_cpc(indices=(idxs, offs)), dedup.sample_cpc(indices=(idxs, offs))
+    for x, y in zip(sp[:5] + (sp[5]["obs_pos"],), sd[:5] + (sd[5]["obs_pos"],)):
+        assert torch.equal(x, y)
+    # a buffer re-loaded from the chunks continues identically
+    again = curla_amd.ReplayBuffer((9,) + hw, (2,), cap, B, dev, aug, dedup_frames=True)
+    again.load(str(d2))
+    assert again.idx == 30
+    i30 = (np.arange(B) % 30, offs)
+    for x, y in zip(again.sample_cpc(indices=i30)[:4], curla_amd.ReplayBuffer.sample_cpc(_reload(plain, d1, cap, B, aug, hw), indices=i30)[:4]):
+        assert torch.equal(x, y)
+    # training from either storage is the same computation
+    flats = []
+    for rb in (plain, dedup):
+        curla_amd.set_seed_everywhere(9)
+        agent = curla_amd.CurlSacAgent((9, 28, 34), (2,), dev, aug, hidden_dim=64, **HP)
+        L = NullLogger()
+        for step in range(3):
+            agent.update(rb, L, step)
+        torch.cuda.synchronize()
+        flats.append((agent._critic_flat.clone(), agent._actor_flat.clone(), dict(L.scalars)))
+    assert torch.equal(flats[0][0], flats[1][0]) and torch.equal(flats[0][1], flats[1][1]) and flats[0][2] == flats[1][2]
+
+
+def _reload(_unused, save_dir, cap, B, aug, hw):
+    import curla_amd
+    rb = curla_amd.ReplayBuffer((9,) + hw, (2,), cap, B, torch.device("cuda"), aug)
+    rb.load(str(save_dir))
+    return rb
+
+
+def test_stale_minibatch_handle_is_refused_on_the_device():
+    import curla_amd
+    from curla_amd import _lib
+    aug = curla_amd.RandomCrop((34, 40), (28, 34))
+    rb = curla_amd.ReplayBuffer((9, 34, 40), (2,), 16, 8, torch.device("cuda"), aug)
+    rs = np.random.RandomState(0)
+    rb.add_batch(rs.randint(0, 256, (12, 9, 34, 40), dtype=np.uint8), np.zeros((12, 2), np.float32), np.zeros(12, np.float32),
+                 rs.randint(0, 256, (12, 9, 34, 40), dtype=np.uint8), np.zeros(12, bool))
+    agent, _ = make_agent((9, 28, 34), (34, 40), 64)
+    old = rb.sample_cpc_refs()
+    rb.sample_cpc_refs(), rb.sample_cpc_refs()
+    with pytest.raises(_lib.CurlaHipError):
+        agent.update_critic(old[0], old[1], old[2], old[3], old[4], NullLogger(), 0)
+
+
+def test_histogram_logging_hooks_record_the_training_forward(tiny):
+    """log_param_hist_imgs=True (curl_sac.py:17,112-121,171-180; encoder.py:79-108,118-130): on a logging step
+    critic.log() / actor.log() histogram the module outputs of the update's own forward passes -- checked
+    against the reference's recorded tensors -- and cost nothing on the other steps."""
+    import curla_amd
+    g = tiny
+    aug = curla_amd.RandomCrop((34, 40), (28, 34))
+    torch.manual_seed(0)
+    agent = curla_amd.CurlSacAgent((9, 28, 34), (2,), torch.device("cuda"), aug, hidden_dim=64, log_param_hist_imgs=True, **HP)
+    load_state(agent, sub(g, "state0/actor/"), sub(g, "state0/critic/"), sub(g, "state0/critic_target/"),
+               g["state0/W"], g["state0/log_alpha"])
+
+    class HistLogger(NullLogger):
+        def __init__(self):
+            super().__init__()
+            self.hist, self.params, self.images = {}, [], {}
+
+        def log_histogram(self, key, value, step):
+            self.hist[key] = value.detach().cpu().clone()
+
+        def log_param(self, key, module, step):
+            self.params.append(key)
+
+        def log_image(self, key, value, step):
+            self.images[key] = tuple(value.shape)
+    L = HistLogger()
+    obs, nxt = _t(g["batch/obs"]).float(), _t(g["batch/next_obs"]).float()
+    act, rew, nd = _t(g["batch/action"]), _t(g["batch/reward"]), _t(g["batch/not_done"])
+    for opt in (agent.critic_optimizer, agent.actor_optimizer, agent.log_alpha_optimizer):
+        opt.step = lambda: None
+    agent.update_critic(obs, act, rew, nxt, nd, L, 0, noise=_t(g["noise/critic"]))  # step 0: a logging step
+    check("hist q1", L.hist["train_critic/q1_hist"], g["critic/q1"])
+    check("hist q2", L.hist["train_critic/q2_hist"], g["critic/q2"])
+    assert [p for p in L.params if p.startswith("train_critic/")] == [f"train_critic/q{q}_fc{i}" for i in range(3) for q in (1, 2)]
+    enc = agent.critic.encoder
+    for i in range(4):
+        check(f"recorded conv{i + 1}", enc.outputs[f"conv{i + 1}"].cpu(), g[f"critic/enc/conv{i + 1}"])
+    check("recorded fc", enc.outputs["fc"].cpu(), g["critic/enc/fc"])
+    check("recorded ln", enc.outputs["ln"].cpu(), g["critic/enc/ln"])
+    check("recorded obs", enc.outputs["obs"].cpu(), torch.from_numpy(g["batch/obs"]).float() / 255.0, 1e-6)
+    enc.log(L, 0, 25000)
+    assert L.images["train_encoder/conv2_img"] == tuple(g["critic/enc/conv2"].shape[1:]) and "train_encoder/fc_hist" in L.hist
+    assert "train_encoder/fc_img" not in L.images and L.params[-2:] == ["train_encoder/fc", "train_encoder/ln"]
+    agent.critic.load_state_dict(sub(g, "critic_after/"))
+    agent.update_actor_and_alpha(obs, L, 0, noise=_t(g["noise/actor"]))
+    # the reference records mu BEFORE the tanh squash (curl_sac.py:92); the fixture holds the returned, squashed one
+    check("hist mu (pre-squash)", torch.tanh(L.hist["train_actor/mu_hist"]), g["actor/mu"])
+    assert float(L.hist["train_actor/mu_hist"].abs().max()) > float(np.abs(g["actor/mu"]).max())
+    check("hist std", L.hist["train_actor/std_hist"], np.exp(g["actor/log_std"]))
+    assert [p for p in L.params if p.startswith("train_actor/")] == ["train_actor/fc1", "train_actor/fc2", "train_actor/fc3"]
+    # off the logging steps nothing is recorded or logged
+    L2 = HistLogger()
+    agent.critic.outputs.clear(), agent.actor.outputs.clear(), enc.outputs.clear()
+    agent.update_critic(obs, act, rew, nxt, nd, L2, 7, noise=_t(g["noise/critic"]))
+    agent.update_actor_and_alpha(obs, L2, 8, noise=_t(g["noise/actor"]))
+    assert not L2.hist and not L2.params and not agent.critic.outputs and not enc.outputs

@@ -261,3 +261,115 @@ def test_full_checkpoint_file_layout(tmp_path):
     torch.save({"format": "x"}, tmp_path / "bad.pt")
     with pytest.raises(ValueError):
         b.load_checkpoint(str(tmp_path / "bad.pt"))
+
+
+class _FakeEnv:
+    """Minimal environment for FrameStack: random RGB frames, fixed-length episodes."""
+
+    def __init__(self, hw, episode_len, seed):
+        self.rs = np.random.RandomState(seed)
+        self.hw, self.episode_len, self.t = hw, episode_len, 0
+        self.observation_space = type("S", (), dict(shape=(3,) + hw, dtype=np.uint8))()
+        self._max_episode_steps = episode_len
+        self.curl_driving = False
+
+    def _frame(self):
+        return self.rs.randint(0, 256, (3,) + self.hw, dtype=np.uint8)
+
+    def reset(self):
+        self.t = 0
+        return self._frame()
+
+    def step(self, action):
+        self.t += 1
+        return self._frame(), 1.0, self.t >= self.episode_len, {}
+
+
+def _rollout(env, n):
+    """n transitions as train.py collects them (train.py:396-445): obs = next_obs inside an episode."""
+    out = []
+    obs = env.reset()
+    for i in range(n):
+        nxt, r, done, _ = env.step(None)
+        out.append((obs, np.array([0.01 * i, -0.02 * i], np.float32), float(i), nxt, done))
+        obs = env.reset() if done else nxt
+    return out
+
+
+def test_frame_stack_wrapper():
+    """utils.py:238-268: reset() returns k copies of the first frame, step() shifts the new frame in."""
+    env = curla_amd.utils.FrameStack(_FakeEnv((8, 10), 5, 0), 3)
+    assert env.observation_space.shape == (9, 8, 10) and env._max_episode_steps == 5
+    o0 = env.reset()
+    assert o0.shape == (9, 8, 10) and np.array_equal(o0[:3], o0[3:6]) and np.array_equal(o0[:3], o0[6:])
+    o1, r, done, info = env.step(None)
+    assert np.array_equal(o1[:6], o0[3:]) and not np.array_equal(o1[6:], o0[6:]) and r == 1.0 and not done
+    assert env.hw == (8, 10)  # other attributes are the wrapped environment's
+
+
+def test_dedup_frame_store_bookkeeping():
+    """dedup_frames=True: one new RGB frame per environment step (two at an episode start), byte-exact stacks,
+    frames released when the transition ring wraps, loud failure when the caller's observations share nothing."""
+    hw, k, cap = (8, 10), 3, 12
+    aug = curla_amd.IdentityAugmentation(hw)
+    rb = curla_amd.ReplayBuffer((3 * k,) + hw, (2,), cap, 4, "cpu", aug, dedup_frames=True)
+    trans = _rollout(curla_amd.utils.FrameStack(_FakeEnv(hw, 7, 1), k), 30)
+    new_frames = []
+    for t, (o, a, r, n, d) in enumerate(trans):
+        before = rb.frames_in_use()[0]
+        rb.add(o, a, r, n, d)
+        new_frames.append(rb.frames_in_use()[0] - before)
+        live = range(max(0, t + 1 - cap), t + 1)
+        # every live transition still reads back byte for byte
+        for u in live:
+            slot = u % cap
+            for which, want in ((0, trans[u][0]), (1, trans[u][3])):
+                ids = rb._fid_h[slot, which]
+                got = np.concatenate([rb.frames[int(f)].permute(2, 0, 1).numpy() for f in ids])
+                assert np.array_equal(got, want), (t, u, which)
+        assert float(rb.rewards[t % cap]) == r and float(rb.not_dones[t % cap]) == float(not d)
+    # first transition of an episode: 2 new frames (k copies of the first frame + the next one); otherwise 1 --
+    # minus what the wrapping ring released
+    assert new_frames[0] == 2 and new_frames[1] == 1 and new_frames[6] == 1 and new_frames[7] == 2
+    used, total = rb.frames_in_use()
+    assert used <= cap + cap // 7 + 2 * k and total == rb.frame_capacity  # ~1 frame per live transition
+    assert int((rb._store.refs > 0).sum()) == used and rb.full and rb.idx == 30 % cap
+    # observations that share nothing exhaust a store sized for stacked episodes -- loudly
+    rb2 = curla_amd.ReplayBuffer((3 * k,) + hw, (2,), 8, 4, "cpu", aug, dedup_frames=True, frame_capacity=20)
+    rs = np.random.RandomState(0)
+    with pytest.raises(MemoryError):
+        for _ in range(8):
+            rb2.add(rs.randint(0, 256, (9,) + hw, dtype=np.uint8), [0, 0], 0.0, rs.randint(0, 256, (9,) + hw, dtype=np.uint8), False)
+    with pytest.raises(ValueError):
+        curla_amd.ReplayBuffer((4,) + hw, (2,), 8, 4, "cpu", aug, dedup_frames=True)
+
+
+def test_stale_minibatch_handle_raises():
+    """Each sample gets its own device index block; a handle older than N_SAMPLE_SLOTS samples is refused
+    instead of silently reading another minibatch's pixels."""
+    aug = curla_amd.RandomCrop((34, 40), (28, 34))
+    rb = _filled_rb(aug)
+    _lib.set_trace_hook(lambda n, a: None)
+    try:
+        first = rb.sample_cpc_refs()[0]
+        second = rb.sample_cpc_refs()[0]
+        assert first.idx.data_ptr() != second.idx.data_ptr()
+        first.check(), second.check()
+        rb.sample_cpc_refs()
+        second.check()
+        with pytest.raises(_lib.CurlaHipError):
+            first.check()
+    finally:
+        _lib.set_trace_hook(None)
+
+
+def test_augmentor_tensor_api_needs_the_device():
+    """ColorJiggle / NoisyCover.training_augmentation run the HIP kernels; a CPU tensor is refused (no fallback)
+    instead of being passed through un-augmented."""
+    for name in ("color_jiggle", "noisy_cover"):
+        aug = curla_amd.make_augmentor(name, (20, 24))
+        with pytest.raises(RuntimeError):
+            aug.training_augmentation(torch.zeros(2, 9, 20, 24))
+        with pytest.raises(ValueError):
+            aug.training_augmentation(torch.zeros(2, 9, 20, 25))
+    assert curla_amd.make_augmentor("identity", (20, 24)).training_augmentation("x") == "x"

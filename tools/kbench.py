@@ -69,6 +69,27 @@ def main():
         ops.conv_s1_fwd(xw, ww, bw, ow)
     torch.cuda.synchronize()
 
+    if "c1only" in args.what:  # just the two first-layer kernels (for rocprofv3 --pmc passes)
+        store = torch.randint(0, 256, (2048 * 84 * 84 * 9 + 32,), dtype=torch.uint8, device=dev)
+        ring = store[:2048 * 84 * 84 * 9].view(2048, 84, 84, 9)
+        idx = torch.randint(0, 2048, (B,), device=dev)
+        h1 = torch.randint(0, 8, (B,), device=dev, dtype=torch.int32)
+        w1 = torch.randint(0, 8, (B,), device=dev, dtype=torch.int32)
+        obs = ops.ObsRef.from_ring(ring, idx, h1, w1, B, (76, 76))
+        w0, b = r(32, 9, 3, 3) * 0.1, r(32) * 0.1
+        out = torch.empty(B, 37, 37, 32, device=dev)
+        g = r(B, 37, 37, 32)
+        dw0, db = torch.empty(32, 9, 3, 3, device=dev), torch.empty(32, device=dev)
+        ws0 = torch.empty(ops.wgrad_workspace_floats(9), device=dev)
+        fl_ = 2.0 * B * 37 * 37 * 32 * 9 * 9
+        for fl in flags:
+            if flags != [0]:
+                lib.curla_debug_ablate(fl)
+            report(f"[abl {fl}] conv1_fwd u8", timeit(lambda: ops.conv1_fwd(obs, w0, b, out)), fl_)
+            report(f"[abl {fl}] conv1_wgrad u8", timeit(lambda: ops.conv1_wgrad(obs, g, dw0, db, ws0)), fl_)
+        if flags != [0]:
+            lib.curla_debug_ablate(0)
+
     if "conv" in args.what:
         w, b = r(32, 32, 3, 3) * 0.1, r(32) * 0.1
         for fl in flags:
