@@ -24,7 +24,13 @@ SIGNATURES = {
     "curla_gemm": [vp, c_int, c_int, c_ll, vp, c_int, c_int, c_ll, vp, c_int, c_ll, c_int, c_int, c_int, c_int, c_int,
                    c_ll, c_float, vp, c_ll, c_int, vp, c_int, c_ll, vp],
     "curla_splitk_reduce": [vp, c_int, c_ll, c_int, c_int, c_int, vp, c_int, vp, c_int, vp],
-    "curla_fc_ln_fwd": [vp, c_int, c_ll, c_int, vp, vp, vp, c_int, c_int, c_float, vp, vp, vp, vp, c_int, vp],
+    "curla_mlp_out_fwd": [vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, c_int, c_int, c_int, c_int, vp],
+    "curla_mlp_out_bwd": [vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, c_int, c_int, c_int, c_int, vp],
+    "curla_fc_ln_fwd": [vp, c_int, c_ll, c_int, vp, vp, vp, c_int, c_int, c_float, vp, vp, vp, vp, c_int, vp, vp, c_int,
+                        vp],
+    "curla_critic_td_loss": [vp, vp, c_ll, vp, vp, vp, vp, c_float, c_int, vp, vp, vp, vp],
+    "curla_soft_update2": [vp, vp, c_size_t, c_size_t, c_float, c_float, c_float, c_float, vp],
+    "curla_gather_transition_scalars": [vp, vp, c_int, c_int, vp, vp, vp, vp],
     "curla_ln_bwd": [vp, vp, vp, vp, c_int, c_int, vp, vp, vp, vp, vp],
     "curla_colsum": [vp, c_int, c_int, c_int, c_ll, vp, c_ll, c_int, vp],
     "curla_colsum3": [vp, c_int, vp, c_int, vp, c_int, c_int, vp, vp, vp, c_ll, c_int, vp],

@@ -44,6 +44,7 @@ struct ConvS1Args {
   float* out;        // [B][Ho][Wo][32]
   int B, Hs, Ws, Ho, Wo, pad, th, nbands;
   int h1;  // height of band 0 (>= th; the other bands are th rows, the last one what is left)
+  int qstep, rstep;  // 32 = qstep * PW + rstep, PW = pixel pairs per output row
   int dbg;
 };
 
@@ -207,9 +208,11 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
     auto tile = [&](f32x4 (&acc)[4], const f32x4 (&pacc)[4], int t, bool have_prev) {
       const bool pv = t * 16 + li < npairs;
       if (!pv) ty = 0, j = 0;
-      const float* base = lds + (ty * WT + 2 * j) * kLdsPix + 4 * kq;
+      // (24-bit multiplies: full-rate v_mad_u32_u24 instead of the quarter-rate 32-bit forms; every index here is
+      // far below 2^24)
+      const float* base = lds + __mul24(__mul24(ty, WT) + 2 * j, kLdsPix) + 4 * kq;
       const int x0 = 2 * j;
-      const int g = (ty * a.Wo + x0) * 32 + mt * 16 + 4 * kq;  // element offset inside the item's output band
+      const int g = (__mul24(ty, a.Wo) + x0) * 32 + mt * 16 + 4 * kq;  // element offset inside the item's output band
       const bool second = x0 + 1 < a.Wo;
       f32x4 ma = {0, 0, 0, 0}, mb = {0, 0, 0, 0};
       if (MODE == MODE_DGRAD && pv && !ABL(4)) {  // ReLU mask of the layer below: in flight for a whole tile
@@ -253,17 +256,12 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
         __builtin_amdgcn_sched_barrier(0);
       }
       pma = ma, pmb = mb, pg = g, ppv = pv, psecond = second;
-      j += 32;
-      if (PW >= 16) {  // wave-uniform: at most two row wraps per tile step, done without a divergent loop
-#pragma unroll
-        for (int rep = 0; rep < 2; ++rep) {
-          const bool wrap = j >= PW;
-          j = wrap ? j - PW : j;
-          ty = wrap ? ty + 1 : ty;
-        }
-      } else {
-        while (j >= PW) j -= PW, ++ty;
-      }
+      // the lane's pair index advances by 32 per tile step = a.qstep whole rows + a.rstep pairs (host-computed), plus
+      // at most one more wrap: five VALU instructions, no branch, whatever the row length
+      j += a.rstep, ty += a.qstep;
+      const bool wrap = j >= PW;
+      j = wrap ? j - PW : j;
+      ty = wrap ? ty + 1 : ty;
     };
     int t = tslot, done = 0;
     for (; t < ntiles; t += 4) {
@@ -543,17 +541,24 @@ __global__ __launch_bounds__(512) void conv1_fwd_u8_kernel(Conv1Args a) {
     if (!ABL(1)) conv1_stage_u8_issue<U0>(rg0, frame0, oh0, ow0, C, a.Ws, a.Wc, 2 * y0, 2 * tha + 1, RSb, 0, tid, 512);
   }
 
-  for (int i = tid; i < 32 * C * 9; i += 512) lds[i] = a.w[i];
+  // weights -> MFMA A-operand registers through a k-major LDS image [dy][rr (KR, zero padded)][cout 32], rr = dx*C + c,
+  // with the 1/255 of `obs / 255.` (encoder.py:78) folded in: the index arithmetic is paid once per weight while
+  // staging (5 per thread), and every lane then reads its 2 x NS values at compile-time offsets from ONE base
+  // (the per-register gather out of the OIHW image cost ~10 VALU for each of the 42 registers of every lane).
+  for (int i = tid; i < 3 * KR * 32; i += 512) {
+    const int co = i & 31, k = i >> 5;
+    const int dy = k / KR, rr = k - dy * KR;
+    const int dx = rr / C, c = rr - dx * C;
+    lds[i] = rr < 3 * C ? a.w[(co * C + c) * 9 + dy * 3 + dx] * a.scale : 0.f;
+  }
   __syncthreads();
   float wr[NS][2];
+  {
+    const float* wl = lds + kq * 32 + li;
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    const int dy = s / KQ, rr = 4 * (s - dy * KQ) + kq;
-    const bool ok = rr < 3 * C;
-    const int dx = ok ? rr / C : 0, c = ok ? rr - dx * C : 0;
+    for (int s = 0; s < NS; ++s)
 #pragma unroll
-    // the 1/255 of `obs / 255.` (encoder.py:78) is folded into the weights: the bytes go to the MFMA unscaled
-    for (int mt = 0; mt < 2; ++mt) wr[s][mt] = ok ? lds[((mt * 16 + li) * C + c) * 9 + dy * 3 + dx] * a.scale : 0.f;
+      for (int mt = 0; mt < 2; ++mt) wr[s][mt] = wl[((s / KQ) * KR + 4 * (s % KQ)) * 32 + mt * 16];
   }
   f32x4 bias4[2];
 #pragma unroll
@@ -571,31 +576,48 @@ __global__ __launch_bounds__(512) void conv1_fwd_u8_kernel(Conv1Args a) {
   const int npix = tha * a.Wo;
   const int ntiles = ABL(64) ? 0 : (npix + 15) >> 4;
   int ty = (wave * 16 + li) / a.Wo, x = (wave * 16 + li) - ty * a.Wo;
+  const int qstep = 128 / a.Wo, rstep = 128 - qstep * a.Wo;
   for (int t = wave; t < ntiles; t += 8) {
     const bool pv = t * 16 + li < npix;
     if (!pv) ty = 0, x = 0;
     const uint8_t* base = ldsb + 2 * ty * RSb + 2 * x * C + kq;
-    float bv[NS];
+    // all NS byte reads of the tile are issued first; each conversion is then placed one k-step ahead of the MFMA
+    // pair that consumes it (left alone, the compiler emits read -> wait -> convert -> s_nop -> 2 MFMAs chains that
+    // expose the LDS latency and a VALU->MFMA hazard stall on every k-step: tools/micro/conv1_loop.hip)
+    uint32_t raw[NS];
 #pragma unroll
-    for (int s = 0; s < NS; ++s) bv[s] = (float)base[(s / KQ) * RSb + 4 * (s % KQ)];
-    f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int s = 0; s < NS; ++s) raw[s] = base[(s / KQ) * RSb + 4 * (s % KQ)];
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[2] = {bias4[0], bias4[1]};  // bias through the accumulators' initial values
+    // (the conversions are volatile asm so that instruction selection cannot sink them next to their users; the
+    // first one carries the 2 wait states a VALU write needs before an MFMA reads it, every other one has the two
+    // MFMAs of the previous k-step between itself and its reader: tools/check_asm_hazards.py scans the ISA)
+    float cur;
+    asm volatile("v_cvt_f32_ubyte0 %0, %1\n\ts_nop 1" : "=v"(cur) : "v"(raw[0]));
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      acc[0] = mfma16(wr[s][0], bv[s], acc[0]);
-      acc[1] = mfma16(wr[s][1], bv[s], acc[1]);
+      float nxt = cur;
+      if (s + 1 < NS) asm volatile("v_cvt_f32_ubyte0 %0, %1" : "=v"(nxt) : "v"(raw[s + 1]));
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = mfma16(wr[s][0], cur, acc[0]);
+      acc[1] = mfma16(wr[s][1], cur, acc[1]);
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
     }
     if (pv && !ABL(4)) {
       const size_t g = ((size_t)(b * a.Ho + y0 + ty) * a.Wo + x) * 32 + 4 * kq;
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
-        f32x4 v = acc[mt] + bias4[mt];
+        f32x4 v = acc[mt];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + g + mt * 16));
       }
     }
-    x += 128;
-    while (x >= a.Wo) x -= a.Wo, ++ty;
+    x += rstep, ty += qstep;  // 8 waves x 16 pixels further: qstep rows + rstep columns, at most one more wrap
+    const bool wrap = x >= a.Wo;
+    x = wrap ? x - a.Wo : x;
+    ty = wrap ? ty + 1 : ty;
   }
 }
 
@@ -876,8 +898,12 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(Wgrad1Args a) {
 
 // first-layer weight gradient from the uint8 ring with the input band kept as bytes in LDS (see
 // conv1_fwd_u8_kernel); the gradient band stays float (pixel stride kLdsPix).
-template <int C>
-__global__ __launch_bounds__(512) void wgrad1_u8_kernel(Wgrad1Args a) {
+// NW waves per workgroup: 8 (two workgroups per CU) or 4 (four smaller ones: the stage -> barrier -> multiply ->
+// barrier phases of a workgroup do not overlap each other, so what covers a workgroup's staging is the number of
+// OTHER workgroups on its CU that are multiplying at that moment)
+template <int C, int NW>
+__global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
+  constexpr int NTHR = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int KR = (3 * C + 3) & ~3;
   constexpr int NT = (3 * KR + 15) / 16;
@@ -906,16 +932,16 @@ __global__ __launch_bounds__(512) void wgrad1_u8_kernel(Wgrad1Args a) {
     const int y0 = band * a.th;
     const int tha = min(a.th, a.Ho - y0);
     conv1_stage_u8(ldsb, static_cast<const uint8_t*>(a.src), a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Wc, 2 * y0,
-                   2 * tha + 1, RSb, tid, 512);
-    stage_band_f32(ldsg, a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32, tha * a.Wo * 8, tid, 512);
+                   2 * tha + 1, RSb, tid, NTHR);
+    stage_band_f32(ldsg, a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32, tha * a.Wo * 8, tid, NTHR);
     __syncthreads();
     const int npix = tha * a.Wo;
     const int nunits = ((npix + 15) >> 4) << 2;
-    // the lane's pixel p(u) = (u>>2)*16 + (u&3) + 4*kq advances by 32 per iteration: (ty, x) are kept
+    // the lane's pixel p(u) = (u>>2)*16 + (u&3) + 4*kq advances by 4*NW per iteration: (ty, x) are kept
     // incrementally (no division in the loop); the bytes are multiplied unscaled, `scale` is applied once to
     // the accumulated sums
     int ty = ((wave >> 2) * 16 + (wave & 3) + 4 * kq) / a.Wo, x = ((wave >> 2) * 16 + (wave & 3) + 4 * kq) - ty * a.Wo;
-    // fetch() runs for u = wave, wave+8, ... in order and leaves (ty, x) at the next unit's pixel
+    // fetch() runs for u = wave, wave+NW, ... in order and leaves (ty, x) at the next unit's pixel
     auto fetch = [&](int u, float (&av)[2], float (&bv)[NT]) {
       const int p = (u >> 2) * 16 + (u & 3) + 4 * kq;
       const bool pv = (u < nunits) && (p < npix);
@@ -926,8 +952,8 @@ __global__ __launch_bounds__(512) void wgrad1_u8_kernel(Wgrad1Args a) {
       const uint8_t* ip = ldsb + 2 * cy * RSb + 2 * cx * C;
 #pragma unroll
       for (int t = 0; t < NT; ++t) bv[t] = (float)ip[koff[t]];
-      x += 32;
-      if (a.Wo >= 32) {  // wave-uniform: one wrap at most
+      x += 4 * NW;
+      if (a.Wo >= 4 * NW) {  // wave-uniform: one wrap at most
         const bool wrap = x >= a.Wo;
         x = wrap ? x - a.Wo : x;
         ty = wrap ? ty + 1 : ty;
@@ -948,12 +974,12 @@ __global__ __launch_bounds__(512) void wgrad1_u8_kernel(Wgrad1Args a) {
     // MFMAs of the current one issue
     float aA[2], aB[2], bA[NT], bB[NT];
     fetch(wave, aA, bA);
-    for (int u = wave; u < nunits; u += 16) {
-      fetch(u + 8, aB, bB);
+    for (int u = wave; u < nunits; u += 2 * NW) {
+      fetch(u + NW, aB, bB);
       __builtin_amdgcn_sched_barrier(0);
       mma(aA, bA);
       __builtin_amdgcn_sched_barrier(0);
-      fetch(u + 16, aA, bA);
+      fetch(u + 2 * NW, aA, bA);
       __builtin_amdgcn_sched_barrier(0);
       mma(aB, bB);
       __builtin_amdgcn_sched_barrier(0);
@@ -970,7 +996,7 @@ __global__ __launch_bounds__(512) void wgrad1_u8_kernel(Wgrad1Args a) {
   bsum[1] += __shfl_xor(bsum[1], 16);
   bsum[1] += __shfl_xor(bsum[1], 32);
   const int nw = 32 * C * 9;
-  for (int w = 0; w < 8; ++w) {
+  for (int w = 0; w < NW; ++w) {
     if (wave == w) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
@@ -999,7 +1025,7 @@ __global__ __launch_bounds__(512) void wgrad1_u8_kernel(Wgrad1Args a) {
     __syncthreads();
   }
   float* slab = a.partial + (size_t)blockIdx.x * (nw + 32);
-  for (int i = tid; i < nw + 32; i += 512) slab[i] = lds[i];
+  for (int i = tid; i < nw + 32; i += NTHR) slab[i] = lds[i];
 }
 
 // second pass: dW = sum over workgroup slabs.  32 elements x 32 slab-groups per
@@ -1131,6 +1157,8 @@ int launch_conv_s1(int mode, const float* in, const float* w, const float* aux, 
   a.Wo = mode == MODE_FWD ? Ws - 2 : Ws + 2;
   if (a.Ho <= 0 || a.Wo <= 0 || (a.Wo + 2) * 3 > kBandPx) return CURLA_ERR_UNSUPPORTED;
   plan_bands_conv_s1(a.Ho, a.Wo, kBandPx, &a.th, &a.h1, &a.nbands);
+  const int PW = (a.Wo + 1) / 2;
+  a.qstep = 32 / PW, a.rstep = 32 - a.qstep * PW;
   a.dbg = ABL_HOST;
   size_t lds = ((size_t)(a.h1 + 2) * (a.Wo + 2) + 1) * kLdsPix * sizeof(float);  // +1 pixel: 4th window pixel of the last pair
   const size_t wl = (size_t)32 * kWStride * sizeof(float);
@@ -1260,7 +1288,8 @@ int curla_conv1_fwd(const void* src, int src_kind, const int64_t* idx, const int
     a.nbands = (a.Ho + th - 1) / th;
     a.th = (a.Ho + a.nbands - 1) / a.nbands;  // near-equal bands
     size_t lds = (size_t)(2 * a.th + 1) * RSb + 32;
-    if (lds < wl) lds = wl;
+    const size_t wl8 = (size_t)3 * ((3 * C + 3) & ~3) * 32 * sizeof(float);  // the kernel's k-major weight image
+    if (lds < wl8) lds = wl8;
     const int grid = B * a.nbands;
 #define CONV1_U8_LAUNCH(CC)                                                                                 \
   {                                                                                                         \
@@ -1286,7 +1315,7 @@ int curla_conv1_fwd(const void* src, int src_kind, const int64_t* idx, const int
 
 // workspace (floats) the weight-gradient kernels need for their per-workgroup slabs
 size_t curla_conv_wgrad_workspace_floats(int cin) {
-  return (size_t)2 * curla_cu_count() * ((size_t)32 * cin * 9 + 32);
+  return (size_t)4 * curla_cu_count() * ((size_t)32 * cin * 9 + 32);  // at most four workgroups (slabs) per CU
 }
 
 int curla_conv3x3_s1_wgrad(const float* in, const float* g, float* dw, float* db, float* workspace, int B, int Hi,
@@ -1337,19 +1366,32 @@ int curla_conv1_wgrad(const void* src, int src_kind, const int64_t* idx, const i
   hipStream_t st = static_cast<hipStream_t>(stream);
   int grid;
   if (src_kind == 1 && !(ABL_HOST & 256)) {
+    // uint8 ring, input band kept as bytes: two 512-thread workgroups per CU (<= 76 KB of LDS each).
     const int RSb = ((Wc * C + 15) & ~15) + 16;
+    auto band_bytes = [&](int th) { return (size_t)(2 * th + 1) * RSb + (size_t)th * a.Wo * kLdsPix * sizeof(float); };
+    // (measured at 84x84x9, B = 512: 71.9 us with two 512-thread workgroups per CU, 77.4 us with four 256-thread ones:
+    // the shorter bands' extra halo rows and slabs cost more than the finer interleaving buys)
+    int nwaves = 8;
+    size_t budget = 76 * 1024;
+    if ((ABL_HOST & 1024) && band_bytes(4) <= 38 * 1024) nwaves = 4, budget = 38 * 1024;
     int th = a.Ho;
-    while (th > 1 && (size_t)(2 * th + 1) * RSb + (size_t)th * a.Wo * kLdsPix * sizeof(float) > 76 * 1024) --th;
+    while (th > 1 && band_bytes(th) > budget) --th;
     a.nbands = (a.Ho + th - 1) / th;
     a.th = (a.Ho + a.nbands - 1) / a.nbands;
     size_t lds = (((size_t)(2 * a.th + 1) * RSb + 15) & ~(size_t)15) + (size_t)a.th * a.Wo * kLdsPix * sizeof(float) + 32;
     if (lds < (size_t)(nw + 32) * sizeof(float)) lds = (size_t)(nw + 32) * sizeof(float);
     const int nitems = B * a.nbands;
-    grid = nitems < 2 * curla_cu_count() ? nitems : 2 * curla_cu_count();
-#define WGRAD1_U8_LAUNCH(CC)                                                                             \
-  {                                                                                                      \
-    rc = set_lds(wgrad1_u8_kernel<CC>, lds);                                                             \
-    if (rc == CURLA_OK) hipLaunchKernelGGL((wgrad1_u8_kernel<CC>), dim3(grid), dim3(512), lds, st, a);   \
+    const int per_cu = nwaves == 4 ? 4 : 2;
+    grid = nitems < per_cu * curla_cu_count() ? nitems : per_cu * curla_cu_count();
+#define WGRAD1_U8_LAUNCH(CC)                                                                                       \
+  {                                                                                                                \
+    if (nwaves == 4) {                                                                                             \
+      rc = set_lds(wgrad1_u8_kernel<CC, 4>, lds);                                                                  \
+      if (rc == CURLA_OK) hipLaunchKernelGGL((wgrad1_u8_kernel<CC, 4>), dim3(grid), dim3(256), lds, st, a);        \
+    } else {                                                                                                       \
+      rc = set_lds(wgrad1_u8_kernel<CC, 8>, lds);                                                                  \
+      if (rc == CURLA_OK) hipLaunchKernelGGL((wgrad1_u8_kernel<CC, 8>), dim3(grid), dim3(512), lds, st, a);        \
+    }                                                                                                              \
   }
     if (C == 9) WGRAD1_U8_LAUNCH(9) else if (C == 12) WGRAD1_U8_LAUNCH(12) else if (C == 6) WGRAD1_U8_LAUNCH(6) else WGRAD1_U8_LAUNCH(3)
 #undef WGRAD1_U8_LAUNCH

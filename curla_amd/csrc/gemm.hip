@@ -125,14 +125,17 @@ __device__ __forceinline__ void frags(const float* __restrict__ S, int row, int 
 // 256 threads = 2 x 2 waves; a wave computes 32 x (TBN/2) of the 64 x TBN tile.
 // TBN = 32 doubles the workgroup count for the mid-sized GEMMs of the heads
 // (512 x 1024 x 1024 is only 128 tiles of 64 x 64 on a 256-CU chip).
+// The k loop is double-buffered in LDS (two operand tile pairs, 40 KB): while the waves multiply tile t out of one
+// buffer, tile t+1 goes from registers into the other and tile t+2 is in flight from HBM/L2 -- ONE barrier per k tile,
+// and the LDS write -> barrier -> fragment read latency of the next tile sits under the current tile's MFMAs.
 template <bool AK, bool BKM, int TBM, int TBN, bool FAST>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int MI = TBM / 32;  // 16-row fragments per wave
   constexpr int WM = TBM / 2;   // rows per wave
   constexpr int NJ = TBN / 32;
   constexpr int WN = TBN / 2;  // columns per wave
-  __shared__ __attribute__((aligned(16))) float As[BK * KSTR];
-  __shared__ __attribute__((aligned(16))) float Bs[BK * KSTR];
+  __shared__ __attribute__((aligned(16))) float As[2][BK * KSTR];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * KSTR];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
@@ -145,14 +148,32 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int kbeg = ks * g.kchunk;
   const int kend = min(g.K, kbeg + g.kchunk);
 
+  const bool epi = g.ksplit == 1;
+  const float* bias = (epi && g.bias) ? g.bias + batch * g.sBias : nullptr;
+  const float* mask = (epi && g.mask) ? g.mask + batch * g.sMask : nullptr;
+  // The MFMA is issued with the N-side operand as its row operand, so a lane holds 4 CONSECUTIVE n
+  // (rows 4kq..4kq+3 of the 16x16 tile) of ONE m (column li): C, bias and mask move as float4.
+  const bool vec_c = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                     (!mask || ((g.ldmask % 4 == 0) && ((reinterpret_cast<uintptr_t>(mask) & 15) == 0)));
+  // the ReLU mask of a data-gradient product (as large as C itself for the fc layer) is requested before the k loop
+  // and arrives under it, instead of being waited for between the last MFMA and the stores
+  f32x4 mk[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      mk[i][j] = f32x4{1.f, 1.f, 1.f, 1.f};
+      const int m = m0 + wm * WM + i * 16 + li;
+      const int n = n0 + wn * WN + j * 16 + 4 * kq;
+      if (mask && vec_c && m < g.M && n + 3 < g.N) mk[i][j] = *reinterpret_cast<const f32x4*>(mask + (size_t)m * g.ldmask + n);
+    }
+
   f32x4 acc[MI][NJ];
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-  // Two operand tiles are kept in flight in registers (prefetch distance 2): most of these GEMMs run at two
-  // workgroups per CU, where one tile (12-16 KB per workgroup) in flight does not cover the HBM/L2 latency.
   f32x4 ra0[TBM / 32], rb0[TBN / 32], ra1[TBM / 32], rb1[TBN / 32];
   auto load = [&](int k0, f32x4 (&ra)[TBM / 32], f32x4 (&rb)[TBN / 32]) {
     if (FAST) {
@@ -163,49 +184,57 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       tile_load<BKM, TBN>(B, g.ldb, g.N, n0, k0, kend, g.vecB, tid, rb);
     }
   };
-  // one k tile: registers -> LDS, refill the registers with the tile two ahead, multiply
-  auto step = [&](int k0, f32x4 (&ra)[TBM / 32], f32x4 (&rb)[TBN / 32], bool refill) {
-    tile_store<AK, TBM>(As, tid, ra);
-    tile_store<BKM, TBN>(Bs, tid, rb);
-    __syncthreads();
-    if (refill) load(k0 + 2 * BK, ra, rb);
+  auto stage = [&](int buf, const f32x4 (&ra)[TBM / 32], const f32x4 (&rb)[TBN / 32]) {
+    tile_store<AK, TBM>(As[buf], tid, ra);
+    tile_store<BKM, TBN>(Bs[buf], tid, rb);
+  };
+  auto multiply = [&](int buf) {
     float fa[MI][8], fb[NJ][8];
 #pragma unroll
-    for (int i = 0; i < MI; ++i) frags<AK>(As, wm * WM + i * 16 + li, kq, fa[i]);
+    for (int i = 0; i < MI; ++i) frags<AK>(As[buf], wm * WM + i * 16 + li, kq, fa[i]);
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) frags<BKM>(Bs, wn * WN + j * 16 + li, kq, fb[j]);
+    for (int j = 0; j < NJ; ++j) frags<BKM>(Bs[buf], wn * WN + j * 16 + li, kq, fb[j]);
 #pragma unroll
     for (int s = 0; s < BK / 4; ++s)
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(fb[j][s], fa[i][s], acc[i][j]);
-    __syncthreads();
   };
   const int ntiles = (kend - kbeg + BK - 1) / BK;
   if (ntiles > 0) {
     load(kbeg, ra0, rb0);
     load(ntiles > 1 ? kbeg + BK : kbeg, ra1, rb1);  // (a single-tile product re-reads its tile: keeps this branch-free)
+    stage(0, ra0, rb0);
+    __syncthreads();
     int k0 = kbeg, t = 0;
-    // steady state: pairs of tiles with no exit between the halves, so that the compiler's vmcnt bookkeeping
-    // keeps the younger tile's loads in flight across each LDS store
+    // steady state: tile t in buffer 0, tile t+1 in the second register set; both refills unconditional so that the
+    // compiler's vmcnt bookkeeping keeps the younger tile's loads in flight across each LDS store
     for (; t + 3 < ntiles; t += 2, k0 += 2 * BK) {
-      step(k0, ra0, rb0, true);
-      step(k0 + BK, ra1, rb1, true);
+      load(k0 + 2 * BK, ra0, rb0);
+      multiply(0);
+      stage(1, ra1, rb1);
+      __syncthreads();
+      load(k0 + 3 * BK, ra1, rb1);
+      multiply(1);
+      stage(0, ra0, rb0);
+      __syncthreads();
     }
-    const int rem = ntiles - t;  // 1..3 tiles left, the first two already in registers
-    step(k0, ra0, rb0, rem >= 3);
-    if (rem >= 2) step(k0 + BK, ra1, rb1, false);
-    if (rem >= 3) step(k0 + 2 * BK, ra0, rb0, false);
+    const int rem = ntiles - t;  // 1..3 tiles left: tile t in buffer 0, tile t+1 (if any) in the second register set
+    if (rem >= 3) load(k0 + 2 * BK, ra0, rb0);
+    multiply(0);
+    if (rem >= 2) {
+      stage(1, ra1, rb1);
+      __syncthreads();
+      multiply(1);
+    }
+    if (rem >= 3) {
+      stage(0, ra0, rb0);  // (buffer 0 was last read before the barrier above)
+      __syncthreads();
+      multiply(0);
+    }
   }
 
-  const bool epi = g.ksplit == 1;
-  const float* bias = (epi && g.bias) ? g.bias + batch * g.sBias : nullptr;
-  const float* mask = (epi && g.mask) ? g.mask + batch * g.sMask : nullptr;
-  // The MFMA is issued with the N-side operand as its row operand, so a lane holds 4 CONSECUTIVE n
-  // (rows 4kq..4kq+3 of the 16x16 tile) of ONE m (column li): C, bias and mask move as float4.
-  const bool vec_c = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
-                     (!mask || ((g.ldmask % 4 == 0) && ((reinterpret_cast<uintptr_t>(mask) & 15) == 0)));
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -224,9 +253,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
         if (mask) {
-          const f32x4 mk = *reinterpret_cast<const f32x4*>(mask + (size_t)m * g.ldmask + n);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = mk[r] > 0.f ? v[r] : 0.f;
+          for (int r = 0; r < 4; ++r) v[r] = mk[i][j][r] > 0.f ? v[r] : 0.f;
         }
         if (g.stream_c)
           __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(C + (size_t)m * g.ldc + n));
@@ -288,6 +316,10 @@ int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const f
   const long long wgs64 = (long long)((N + 63) / 64) * ((M + 63) / 64) * zb;
   const long long wgs6432 = (long long)((N + 31) / 32) * ((M + 63) / 64) * zb;
   int tbm = 64, tbn = 64;
+  // (the encoder fc forward, [512 x 30752] x [30752 x 50] split 32 ways along K, lands here with 32-wide tiles and
+  // so streams its 63 MB activation operand twice, 117 MB of HBM traffic per launch; the single-pass alternative,
+  // one 64-wide N tile with a 64-way split, was measured: 26.9 us against 25.5 us -- the product is bound by the
+  // padded MFMA work (N = 50 -> 64) and load latency, not by HBM bytes, and more, smaller workgroups hide those better)
   if (wgs64 < cu2 && N > 32) tbn = 32;
   // a single row of tiles streaming a k-major B (the fc weight gradient, M = 50): the wider tile reads 256-B
   // instead of 128-B pieces of each HBM row and is faster even at one workgroup per CU

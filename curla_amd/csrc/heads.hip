@@ -33,7 +33,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm) {
 template <int NF>
 __global__ void fc_ln_fwd_kernel(const float* P, int nsplit, long long sSplit, int ldp, const float* bias,
                                  const float* gamma, const float* beta, int B, int F, float eps, float* fc_out,
-                                 float* y, float* xhat, float* rstd, int tanh_out) {
+                                 float* y, float* xhat, float* rstd, int tanh_out, float* xa, const float* act,
+                                 int A) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= B) return;
@@ -79,8 +80,10 @@ __global__ void fc_ln_fwd_kernel(const float* P, int nsplit, long long sSplit, i
       if (fc_out) fc_out[(size_t)row * F + f] = v[j];
       y[(size_t)row * F + f] = o;
       if (xhat) xhat[(size_t)row * F + f] = xh;
+      if (xa) xa[(size_t)row * (F + A) + f] = o;  // torch.cat([z, action], 1) written in place (curl_sac.py:138)
     }
   }
+  if (xa && lane < A) xa[(size_t)row * (F + A) + F + lane] = act[(size_t)row * A + lane];
   if (lane == 0 && rstd) rstd[row] = rs;
 }
 
@@ -218,6 +221,102 @@ __global__ __launch_bounds__(1024) void colsum3_kernel(Colsum3Args a, int M, lon
   }
 }
 
+// ---- last layer of the actor / Q trunks: hidden -> N outputs with N tiny (Q: 1, actor: 2|A|) ----
+// As GEMMs these are 16-32 workgroups walking K = 1024 behind two barriers per step (15-22 us each, pure latency);
+// here the forward is one wave per row and the backward one pass over the activations that produces both the
+// data gradient (ReLU mask of the layer below fused) and the weight gradient.
+constexpr int kMaxOut = 16;
+
+// out[z][m][n] = bias[z][n] + sum_k h[z][m][k] * W[z][n][k]        (curl_sac.py:73-74,132-133 forward)
+__global__ __launch_bounds__(256) void mlp_out_fwd_kernel(const float* h, long long sH, const float* W, long long sW,
+                                                          const float* bias, long long sB, float* out, long long sOut,
+                                                          int M, int N, int K) {
+  const int z = blockIdx.y;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* hr = h + z * sH + (size_t)row * K;
+  const float* Wz = W + z * sW;
+  float acc[kMaxOut];
+#pragma unroll
+  for (int n = 0; n < kMaxOut; ++n) acc[n] = 0.f;
+  for (int k = 4 * lane; k < K; k += 256) {  // (K % 4 == 0 checked by the host)
+    const f32x4 hv = *reinterpret_cast<const f32x4*>(hr + k);
+#pragma unroll
+    for (int n = 0; n < kMaxOut; ++n)
+      if (n < N) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(Wz + (size_t)n * K + k);
+        acc[n] += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
+      }
+  }
+#pragma unroll
+  for (int n = 0; n < kMaxOut; ++n)
+    if (n < N) {
+      const float s = wave_sum(acc[n]);
+      if (lane == 0) out[z * sOut + (size_t)row * N + n] = s + (bias ? bias[z * sB + n] : 0.f);
+    }
+}
+
+// dh[z][m][k] = (h[z][m][k] > 0) * sum_n dy[z][m][n] * W[z][n][k];   dW[z][n][k] = sum_m dy[z][m][n] * h[z][m][k]
+// One block = 16 k-columns x 64 row parts (K/16 x nbatch blocks: 128 for the twin Q functions); a thread's rows are
+// all in flight at once; the 64 partial dW sums are added in part order (fixed order).
+constexpr int kOutRows = 8;  // rows per thread per pass (64 parts x 8 = 512 rows per pass)
+__global__ __launch_bounds__(1024) void mlp_out_bwd_kernel(const float* dy, long long sDy, const float* h,
+                                                           long long sH, const float* W, long long sW, float* dh,
+                                                           long long sDh, float* dW, long long sDW, int M, int N,
+                                                           int K) {
+  __shared__ float sm[64][17];
+  const int z = blockIdx.y;
+  const int kl = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int k = blockIdx.x * 16 + kl;
+  const bool kv = k < K;
+  const float* dyz = dy + z * sDy;
+  const float* hz = h + z * sH;
+  float* dhz = dh + z * sDh;
+  float wreg[kMaxOut], acc[kMaxOut];
+#pragma unroll
+  for (int n = 0; n < kMaxOut; ++n) {
+    wreg[n] = (n < N && kv) ? W[z * sW + (size_t)n * K + k] : 0.f;
+    acc[n] = 0.f;
+  }
+  for (int m0 = part; m0 < M; m0 += 64 * kOutRows) {
+    float hv[kOutRows];
+#pragma unroll
+    for (int u = 0; u < kOutRows; ++u) {
+      const int m = m0 + 64 * u;
+      hv[u] = (m < M && kv) ? hz[(size_t)m * K + k] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < kOutRows; ++u) {
+      const int m = m0 + 64 * u;
+      if (m < M) {
+        float s = 0.f;
+#pragma unroll
+        for (int n = 0; n < kMaxOut; ++n)
+          if (n < N) {
+            const float d = dyz[(size_t)m * N + n];
+            s += d * wreg[n];
+            acc[n] += d * hv[u];
+          }
+        if (kv) dhz[(size_t)m * K + k] = hv[u] > 0.f ? s : 0.f;
+      }
+    }
+  }
+  if (dW == nullptr) return;  // block-uniform
+#pragma unroll
+  for (int n = 0; n < kMaxOut; ++n)
+    if (n < N) {  // block-uniform
+      __syncthreads();
+      sm[part][kl] = acc[n];
+      __syncthreads();
+      if (part == 0 && kv) {
+        float t = sm[0][kl];
+#pragma unroll 8
+        for (int p = 1; p < 64; ++p) t += sm[p][kl];
+        dW[z * sDW + (size_t)n * K + k] = t;
+      }
+    }
+}
+
 // ---- policy head ----
 constexpr int kMaxA = 8;
 constexpr float kHalfLog2Pi = 0.9189385332046727f;
@@ -317,6 +416,29 @@ __global__ void critic_loss_kernel(const float* q, long long sTwin, const float*
   if (threadIdx.x == 0) loss[0] = s1 * inv + s2 * inv;
 }
 
+// the two kernels above in one launch (the TD target only feeds the loss): target_q is still written out
+__global__ void critic_td_loss_kernel(const float* q, const float* tq, long long sTwin, const float* log_pi,
+                                      const float* reward, const float* not_done, const double* log_alpha,
+                                      float discount, int B, float* target_q, float* loss, float* dq) {
+  __shared__ float sm[4];
+  float a1 = 0.f, a2 = 0.f;
+  const float inv = 1.f / B;
+  const float alpha = (float)exp(*log_alpha);
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float v = fminf(tq[b], tq[sTwin + b]) - alpha * log_pi[b];
+    const float t = reward[b] + not_done[b] * discount * v;
+    target_q[b] = t;
+    const float d1 = q[b] - t, d2 = q[sTwin + b] - t;
+    a1 += d1 * d1;
+    a2 += d2 * d2;
+    dq[b] = 2.f * d1 * inv;
+    dq[sTwin + b] = 2.f * d2 * inv;
+  }
+  const float s1 = block_sum_256(a1, sm);
+  const float s2 = block_sum_256(a2, sm);
+  if (threadIdx.x == 0) loss[0] = s1 * inv + s2 * inv;
+}
+
 // actor/alpha losses and their seeds                                  (curl_sac.py:378-399)
 // scalars: [0] actor_loss [1] alpha_loss [2] entropy mean [3] alpha
 __global__ void actor_loss_kernel(const float* q, long long sTwin, const float* log_pi, const float* log_std, int A,
@@ -384,7 +506,41 @@ __global__ void mean_kernel(const float* x, int n, float* out) {
 __global__ void soft_update_kernel(const float* p, float* tgt, size_t n, float tau, float omt) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) tgt[i] = tau * p[i] + omt * tgt[i];
+  // two roundings of the products and one of the sum, as `tau * p + (1 - tau) * t` evaluates in torch (no fused
+  // multiply-add), so the targets match the reference's bit for bit given the same inputs
+  for (; i < n; i += stride) {
+#pragma clang fp contract(off)
+    tgt[i] = tau * p[i] + omt * tgt[i];
+  }
+}
+
+// the same over one flat block whose first `split` elements take (tau_a, 1-tau_a) and the rest (tau_b, 1-tau_b):
+// the encoder and the Q functions of the critic are adjacent in the flat layout and have their own rates
+__global__ void soft_update2_kernel(const float* p, float* tgt, size_t n, size_t split, float tau_a, float omt_a,
+                                    float tau_b, float omt_b) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+#pragma clang fp contract(off)
+    const bool a = i < split;
+    tgt[i] = (a ? tau_a : tau_b) * p[i] + (a ? omt_a : omt_b) * tgt[i];
+  }
+}
+
+// out_act[b][:] = sc[idx[b]][0:A], out_rew[b] = sc[idx[b]][A], out_nd[b] = sc[idx[b]][A+1]: the action / reward /
+// not_done of the sampled transitions (utils.py:159-166) from the ring's [capacity][A+2] scalar rows, one launch
+__global__ void gather_transition_scalars_kernel(const float* sc, const int64_t* idx, int B, int A, float* act,
+                                                 float* rew, float* nd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * (A + 2)) return;
+  const int b = i / (A + 2), c = i - b * (A + 2);
+  const float v = sc[(size_t)idx[b] * (A + 2) + c];
+  if (c < A)
+    act[(size_t)b * A + c] = v;
+  else if (c == A)
+    rew[b] = v;
+  else
+    nd[b] = v;
 }
 
 // out[b][c][i][j] = (float) frames[idx[b]][h1[b]+i][w1[b]+j][c]          (augmentations.py:47-75 + utils.py:161)
@@ -490,13 +646,14 @@ extern "C" {
 
 int curla_fc_ln_fwd(const float* partial, int nsplit, long long split_stride, int ldp, const float* bias,
                     const float* gamma, const float* beta, int B, int F, float eps, float* fc_out, float* y,
-                    float* xhat, float* rstd, int tanh_out, void* stream) {
+                    float* xhat, float* rstd, int tanh_out, float* xa, const float* act, int A, void* stream) {
   CURLA_REQUIRE(partial && bias && gamma && beta && y && B > 0 && F > 0 && nsplit > 0);
+  CURLA_REQUIRE(!xa || (act && A > 0 && A <= 64));
   if (F > 256) return CURLA_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define CURLA_FC_LN(NF)                                                                                         \
   hipLaunchKernelGGL(fc_ln_fwd_kernel<NF>, dim3((B + 3) / 4), dim3(256), 0, st, partial, nsplit, split_stride, ldp, \
-                     bias, gamma, beta, B, F, eps, fc_out, y, xhat, rstd, tanh_out)
+                     bias, gamma, beta, B, F, eps, fc_out, y, xhat, rstd, tanh_out, xa, act, A)
   switch ((F + 63) / 64) {
     case 1: CURLA_FC_LN(1); break;
     case 2: CURLA_FC_LN(2); break;
@@ -546,6 +703,27 @@ int curla_colsum3(const float* X0, int N0, const float* X1, int N1, const float*
   const int nmax = N0 > N1 ? (N0 > N2 ? N0 : N2) : (N1 > N2 ? N1 : N2);
   hipLaunchKernelGGL(colsum3_kernel, dim3((nmax + 31) / 32, nbatch, 3), dim3(1024), 0, static_cast<hipStream_t>(stream), a, M,
                      strideOut);
+  return curla_launch_status();
+}
+
+int curla_mlp_out_fwd(const float* h, long long strideH, const float* W, long long strideW, const float* bias,
+                      long long strideBias, float* out, long long strideOut, int M, int N, int K, int nbatch,
+                      void* stream) {
+  CURLA_REQUIRE(h && W && out && M > 0 && N > 0 && K > 0 && nbatch > 0);
+  if (N > kMaxOut || K % 4 != 0 || strideH % 4 != 0 || strideW % 4 != 0) return CURLA_ERR_UNSUPPORTED;
+  CURLA_REQUIRE(aligned16(h) && aligned16(W));
+  hipLaunchKernelGGL(mlp_out_fwd_kernel, dim3((M + 3) / 4, nbatch), dim3(256), 0, static_cast<hipStream_t>(stream), h,
+                     strideH, W, strideW, bias, strideBias, out, strideOut, M, N, K);
+  return curla_launch_status();
+}
+
+int curla_mlp_out_bwd(const float* dy, long long strideDy, const float* h, long long strideH, const float* W,
+                      long long strideW, float* dh, long long strideDh, float* dW, long long strideDW, int M, int N,
+                      int K, int nbatch, void* stream) {
+  CURLA_REQUIRE(dy && h && W && dh && M > 0 && N > 0 && K > 0 && nbatch > 0);
+  if (N > kMaxOut) return CURLA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(mlp_out_bwd_kernel, dim3((K + 15) / 16, nbatch), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                     dy, strideDy, h, strideH, W, strideW, dh, strideDh, dW, strideDW, M, N, K);
   return curla_launch_status();
 }
 
@@ -602,6 +780,15 @@ int curla_critic_loss(const float* q, long long twin_stride, const float* target
   return curla_launch_status();
 }
 
+int curla_critic_td_loss(const float* q, const float* tq, long long twin_stride, const float* log_pi,
+                         const float* reward, const float* not_done, const double* log_alpha, float discount, int B,
+                         float* target_q, float* loss, float* dq, void* stream) {
+  CURLA_REQUIRE(q && tq && log_pi && reward && not_done && log_alpha && target_q && loss && dq && B > 0);
+  hipLaunchKernelGGL(critic_td_loss_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), q, tq, twin_stride,
+                     log_pi, reward, not_done, log_alpha, discount, B, target_q, loss, dq);
+  return curla_launch_status();
+}
+
 int curla_actor_loss(const float* q, long long twin_stride, const float* log_pi, const float* log_std, int A,
                      const double* log_alpha, float target_entropy, int B, float* scalars4, float* dq,
                      double* dlog_alpha, void* stream) {
@@ -612,10 +799,10 @@ int curla_actor_loss(const float* q, long long twin_stride, const float* log_pi,
 }
 
 int curla_curl_ce(const float* logits, int B, int ld, float* row_loss, float* loss, float* dlogits, void* stream) {
-  CURLA_REQUIRE(logits && row_loss && loss && B > 0 && ld >= B);
+  CURLA_REQUIRE(logits && row_loss && B > 0 && ld >= B);
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(curl_ce_kernel, dim3((B + 3) / 4), dim3(256), 0, st, logits, B, ld, row_loss, dlogits);
-  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, row_loss, B, loss);
+  if (loss) hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, row_loss, B, loss);  // only when it is logged
   return curla_launch_status();
 }
 
@@ -629,6 +816,22 @@ int curla_soft_update(const float* param, float* target, size_t n, float tau, fl
   CURLA_REQUIRE(param && target && n > 0);
   hipLaunchKernelGGL(soft_update_kernel, dim3(nblocks(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), param,
                      target, n, tau, one_minus_tau);
+  return curla_launch_status();
+}
+
+int curla_soft_update2(const float* param, float* target, size_t n, size_t split, float tau_a, float one_minus_tau_a,
+                       float tau_b, float one_minus_tau_b, void* stream) {
+  CURLA_REQUIRE(param && target && n > 0 && split <= n);
+  hipLaunchKernelGGL(soft_update2_kernel, dim3(nblocks(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), param,
+                     target, n, split, tau_a, one_minus_tau_a, tau_b, one_minus_tau_b);
+  return curla_launch_status();
+}
+
+int curla_gather_transition_scalars(const float* scalars, const int64_t* idx, int B, int A, float* action, float* reward,
+                                    float* not_done, void* stream) {
+  CURLA_REQUIRE(scalars && idx && action && reward && not_done && B > 0 && A > 0);
+  hipLaunchKernelGGL(gather_transition_scalars_kernel, dim3((B * (A + 2) + 255) / 256), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), scalars, idx, B, A, action, reward, not_done);
   return curla_launch_status();
 }
 

@@ -73,15 +73,22 @@ def _mlp_fwd(x, sx, P, nb, B, din, H, dout, h1, h2, out, relu_out=0):
     s = P.stride
     ops.linear_fwd(x, sx, P.W[0], s, P.b[0], s, h1, B * H, B, H, din, nb, relu=1)
     ops.linear_fwd(h1, B * H, P.W[1], s, P.b[1], s, h2, B * H, B, H, H, nb, relu=1)
-    ops.linear_fwd(h2, B * H, P.W[2], s, P.b[2], s, out, B * dout, B, dout, H, nb, relu=relu_out)
+    if dout <= ops.MLP_OUT_MAX and H % 4 == 0 and not relu_out:  # a handful of outputs: row dot products, not a GEMM
+        ops.mlp_out_fwd(h2, B * H, P.W[2], s, P.b[2], s, out, B * dout, B, dout, H, nb)
+    else:
+        ops.linear_fwd(h2, B * H, P.W[2], s, P.b[2], s, out, B * dout, B, dout, H, nb, relu=relu_out)
 
 
 def _mlp_bwd(x, sx, P, G, nb, B, din, H, dout, h1, h2, dy, dh2, dh1, dx):
     """Backward of _mlp_fwd.  G (parameter gradients) and dx are optional."""
     s = P.stride
-    if G is not None:
-        ops.linear_dw(dy, B * dout, h2, B * H, G.W[2], s, B, dout, H, nb)
-    ops.linear_dx(dy, B * dout, P.W[2], s, dh2, B * H, B, dout, H, nb, mask=h2, smask=B * H)
+    if dout <= ops.MLP_OUT_MAX:  # last layer: data and weight gradient in one pass over h2
+        ops.mlp_out_bwd(dy, B * dout, h2, B * H, P.W[2], s, dh2, B * H, G.W[2] if G is not None else None, s, B, dout,
+                        H, nb)
+    else:
+        if G is not None:
+            ops.linear_dw(dy, B * dout, h2, B * H, G.W[2], s, B, dout, H, nb)
+        ops.linear_dx(dy, B * dout, P.W[2], s, dh2, B * H, B, dout, H, nb, mask=h2, smask=B * H)
     if G is not None:
         ops.linear_dw(dh2, B * H, h1, B * H, G.W[1], s, B, H, H, nb)
     ops.linear_dx(dh2, B * H, P.W[1], s, dh1, B * H, B, H, H, nb, mask=h1, smask=B * H)
@@ -258,7 +265,7 @@ class _Workspace:
         # twin Q
         self.xa, self.dxa = f(B, F + A), f(2, B, F + A)
         self.q_h1, self.q_h2, self.q_dh1, self.q_dh2 = f(2, B, H), f(2, B, H), f(2, B, H), f(2, B, H)
-        self.q, self.dq, self.target_q = f(2, B, 1), f(2, B, 1), f(B, 1)
+        self.q, self.tq, self.dq, self.target_q = f(2, B, 1), f(2, B, 1), f(2, B, 1), f(B, 1)
         # scalars: [0] critic loss, [1..4] actor_loss/alpha_loss/entropy/alpha, [5] curl loss, [6] batch reward
         self.scalars = torch.zeros(8, device=dev, dtype=torch.float32)
         # CURL
@@ -621,21 +628,21 @@ class CurlSacAgent(object):
                            log_pi=ws.log_pi)
         tenc = self.critic_target.encoder
         tenc.conv_forward(no, ws.acts_tmp)
-        tenc.head_forward(ws.acts_tmp[-1], ws.z_t)
-        ops.concat(ws.z_t, ws.pi, B, F, A, ws.xa)
-        _mlp_fwd(ws.xa, 0, self.critic_target.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.q)
-        ops.td_target(ws.q, B, ws.log_pi, reward, not_done, self.log_alpha, self.discount, B, ws.target_q)
+        tenc.head_forward(ws.acts_tmp[-1], ws.z_t, xa=ws.xa, act=ws.pi)  # xa = cat([z, a'], 1)
+        _mlp_fwd(ws.xa, 0, self.critic_target.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.tq)
 
         # -- current Q estimates + loss + backward (curl_sac.py:357-367)
         enc.conv_forward(o, ws.acts_main)
         rec = self._records(step)
-        enc.head_forward(ws.acts_main[-1], ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c, fc_out=ws.fc_out if rec else None)
-        ops.concat(ws.z_c, action, B, F, A, ws.xa)
+        enc.head_forward(ws.acts_main[-1], ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c, fc_out=ws.fc_out if rec else None,
+                         xa=ws.xa, act=action)
         _mlp_fwd(ws.xa, 0, self.critic.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.q)
         if rec:  # what critic.log() / encoder.log() histogram: the outputs of THIS forward (curl_sac.py:163-167)
             self.critic.outputs['q1'], self.critic.outputs['q2'] = ws.q[0].clone(), ws.q[1].clone()
             enc.record_from(o, ws.acts_main, ws.fc_out, ws.z_c)
-        ops.critic_loss(ws.q, B, ws.target_q, B, ws.scalars[0:1], ws.dq)
+        # target_Q = r + not_done * gamma * (min Q' - alpha log pi') and the two MSE terms, one launch
+        ops.critic_td_loss(ws.q, ws.tq, B, ws.log_pi, reward, not_done, self.log_alpha, self.discount, B, ws.target_q,
+                           ws.scalars[0:1], ws.dq)
         if step % self.log_interval == 0:
             L.log('train_critic/loss', ws.scalars[0], step)
         _mlp_bwd(ws.xa, 0, self.critic.twin(), self.critic.twin(grads=True), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.dq,
@@ -679,7 +686,6 @@ class CurlSacAgent(object):
         enc.conv_forward(o, ws.acts_main)
         h = ws.acts_main[-1]
         aenc.head_forward(h, ws.z_a, xhat=ws.xhat_a, rstd=ws.rstd_a)
-        enc.head_forward(h, ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c)
         self._anchor_cache = obs
 
         trunk = _Mlp(self.actor.trunk)
@@ -690,7 +696,8 @@ class CurlSacAgent(object):
                            tanh_ls=ws.tanh_ls)
         if self._records(step):  # what actor.log() histograms (curl_sac.py:92-93): pre-squash mean and std
             self.actor.outputs['mu'], self.actor.outputs['std'] = ws.a_out[:, :A].clone(), ws.log_std.exp()
-        ops.concat(ws.z_c, ws.pi, B, F, A, ws.xa)
+        # critic features of the same conv output (kept for the CURL anchor branch), with xa = cat([z, pi], 1)
+        enc.head_forward(h, ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c, xa=ws.xa, act=ws.pi)
         _mlp_fwd(ws.xa, 0, self.critic.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.q)
         ops.actor_loss(ws.q, B, ws.log_pi, ws.log_std, A, self.log_alpha, float(self.target_entropy), B,
                        ws.scalars[1:5], ws.dq, self.log_alpha.grad)
@@ -743,7 +750,8 @@ class CurlSacAgent(object):
         W = self.CURL.W
         ops.linear_fwd(ws.z_pos, 0, W, 0, None, 0, ws.WzT, 0, B, F, F)         # (W z_pos^T)^T
         ops.linear_fwd(ws.z_c, 0, ws.WzT, 0, None, 0, ws.logits, 0, B, B, F)   # z_a (W z_pos^T)
-        ops.curl_ce(ws.logits, B, B, ws.row_loss, ws.scalars[5:6], ws.dlogits)
+        logged = step % self.log_interval == 0  # the mean of the row losses is only needed when it is logged
+        ops.curl_ce(ws.logits, B, B, ws.row_loss, ws.scalars[5:6] if logged else None, ws.dlogits)
         ops.linear_dx(ws.dlogits, 0, ws.WzT, 0, ws.dz, 0, B, B, F)             # d z_a
         ops.linear_dw(ws.dlogits, 0, ws.z_c, 0, ws.dWzT, 0, B, B, F)           # d (W z_pos^T)^T
         ops.linear_dw(ws.dWzT, 0, ws.z_pos, 0, W.grad, 0, B, F, F)             # d W
@@ -765,11 +773,11 @@ class CurlSacAgent(object):
             L.log('train/curl_loss', ws.scalars[5], step)
 
     def soft_update_targets(self):
-        """utils.soft_update_params x3 (curl_sac.py:442-445) as two flat lerps."""
+        """utils.soft_update_params x3 (curl_sac.py:442-445) as one flat lerp with two rates."""
         lay = self._lay
         (e0, e1), (q0, q1) = lay["enc"], lay["q"]
-        ops.soft_update(self._critic_flat[q0:q1], self._target_flat[q0:q1], self.critic_tau)
-        ops.soft_update(self._critic_flat[e0:e1], self._target_flat[e0:e1], self.encoder_tau)
+        assert e1 == q0  # [encoder | Q1 | Q2] are adjacent: one launch, two rates
+        ops.soft_update2(self._critic_flat[e0:q1], self._target_flat[e0:q1], e1 - e0, self.encoder_tau, self.critic_tau)
 
     def update(self, replay_buffer, L, step, only_cpc=False):
         """curl_sac.py:426-451.  A curla_amd ReplayBuffer hands over references

@@ -136,8 +136,9 @@ class CNNEncoder(nn.Module):
             ops.conv_s1_fwd(acts[i - 1], cp[i][0], cp[i][1], acts[i])
         return acts[-1]
 
-    def head_forward(self, h, z, fc_out=None, xhat=None, rstd=None):
-        """fc + LayerNorm (+tanh) on the NHWC-flattened conv output (encoder.py:98-107)."""
+    def head_forward(self, h, z, fc_out=None, xhat=None, rstd=None, xa=None, act=None):
+        """fc + LayerNorm (+tanh) on the NHWC-flattened conv output (encoder.py:98-107).  ``xa`` / ``act``: the
+        LayerNorm kernel also writes the Q functions' input rows [z | act] (torch.cat, curl_sac.py:138)."""
         B = h.shape[0]
         if self.fc.nhwc is None:
             raise RuntimeError("encoder weights are not in kernel layout; call CNNEncoder.to_kernel_layout() "
@@ -146,7 +147,7 @@ class CNNEncoder(nn.Module):
         ks, part = self.ksplit(B), self.partial(B)
         ops.gemm(h, 0, K, 0, self.fc.weight, 0, K, 0, part, F, 0, B, F, K, 1, ksplit=ks, split_stride=B * F)
         ops.fc_ln_fwd(part, ks, B * F, F, self.fc.bias, self.ln.weight, self.ln.bias, B, F, z, fc_out=fc_out, xhat=xhat,
-                      rstd=rstd, eps=self.ln.eps, tanh_out=0 if self.output_logits else 1)
+                      rstd=rstd, eps=self.ln.eps, tanh_out=0 if self.output_logits else 1, xa=xa, act=act)
         return z
 
     def to_kernel_layout(self):

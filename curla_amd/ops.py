@@ -124,10 +124,25 @@ def linear_dw(dy, sdy, x, sx, out, so, M, N, K, nb=1):
     gemm(dy, 1, N, sdy, x, 1, K, sx, out, K, so, N, K, M, nb)
 
 
+def mlp_out_fwd(h, sh, W, sW, bias, sb, out, so, M, N, K, nb=1):
+    """out[z] = h[z] @ W[z]^T + bias[z] for a last layer with N <= 16 outputs (one wave per row, no GEMM)."""
+    call("curla_mlp_out_fwd", ptr(h), sh, ptr(W), sW, ptr(bias), sb, ptr(out), so, M, N, K, nb, stream())
+
+
+def mlp_out_bwd(dy, sdy, h, sh, W, sW, dh, sdh, dW, sdW, M, N, K, nb=1):
+    """dh[z] = (dy[z] @ W[z]) masked by h[z] > 0 and (dW not None) dW[z] = dy[z]^T @ h[z], in one pass over h."""
+    call("curla_mlp_out_bwd", ptr(dy), sdy, ptr(h), sh, ptr(W), sW, ptr(dh), sdh, ptr(dW), sdW, M, N, K, nb, stream())
+
+
+MLP_OUT_MAX = 16
+
+
 def fc_ln_fwd(partial, nsplit, split_stride, ldp, bias, gamma, beta, B, F, y, fc_out=None, xhat=None, rstd=None,
-              eps=1e-5, tanh_out=0):
+              eps=1e-5, tanh_out=0, xa=None, act=None):
+    """``xa`` [B, F + A] with ``act`` [B, A]: also writes the rows [y | act] (the Q functions' input)."""
+    A = 0 if xa is None else xa.shape[1] - F
     call("curla_fc_ln_fwd", ptr(partial), nsplit, split_stride, ldp, ptr(bias), ptr(gamma), ptr(beta), B, F, eps,
-         ptr(fc_out), ptr(y), ptr(xhat), ptr(rstd), tanh_out, stream())
+         ptr(fc_out), ptr(y), ptr(xhat), ptr(rstd), tanh_out, ptr(xa), ptr(act), A, stream())
 
 
 def ln_bwd(dy, xhat, rstd, gamma, B, F, dx, dgamma=None, dbeta=None, dbias_in=None):
@@ -172,6 +187,11 @@ def critic_loss(q, twin_stride, target_q, B, loss, dq):
     call("curla_critic_loss", ptr(q), twin_stride, ptr(target_q), B, ptr(loss), ptr(dq), stream())
 
 
+def critic_td_loss(q, tq, twin_stride, log_pi, reward, not_done, log_alpha, discount, B, target_q, loss, dq):
+    call("curla_critic_td_loss", ptr(q), ptr(tq), twin_stride, ptr(log_pi), ptr(reward), ptr(not_done), ptr(log_alpha),
+         discount, B, ptr(target_q), ptr(loss), ptr(dq), stream())
+
+
 def actor_loss(q, twin_stride, log_pi, log_std, A, log_alpha, target_entropy, B, scalars4, dq, dlog_alpha):
     call("curla_actor_loss", ptr(q), twin_stride, ptr(log_pi), ptr(log_std), A, ptr(log_alpha), target_entropy, B,
          ptr(scalars4), ptr(dq), ptr(dlog_alpha), stream())
@@ -189,6 +209,16 @@ def soft_update(param_flat, target_flat, tau):
     # tau and (1 - tau) are rounded to fp32 separately, as `tau * p + (1 - tau) * t` does in torch (utils.py:39-41)
     call("curla_soft_update", ptr(param_flat), ptr(target_flat), param_flat.numel(), float(tau), float(1 - tau),
          stream())
+
+
+def soft_update2(param_flat, target_flat, split, tau_a, tau_b):
+    """One launch for a flat block whose first ``split`` elements use tau_a and the rest tau_b."""
+    call("curla_soft_update2", ptr(param_flat), ptr(target_flat), param_flat.numel(), int(split), float(tau_a),
+         float(1 - tau_a), float(tau_b), float(1 - tau_b), stream())
+
+
+def gather_transition_scalars(sc, idx, B, A, act, rew, nd):
+    call("curla_gather_transition_scalars", ptr(sc), ptr(idx), B, A, ptr(act), ptr(rew), ptr(nd), stream())
 
 
 def crop_nchw(frames, idx, h1, w1, B, crop_hw, out_f32=None, out_u8=None):

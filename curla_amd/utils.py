@@ -35,6 +35,11 @@ except ImportError:  # pragma: no cover
         return zlib.crc32(buf) | (zlib.adler32(buf) << 32)
 
 
+def _lib_tracing():
+    from . import _lib
+    return _lib._trace_hook is not None
+
+
 class eval_mode(object):
     """Context manager that puts the given models (anything with ``.training`` and ``.train(bool)``) in
     evaluation mode and restores each one's previous mode on exit (utils.py:21-34)."""
@@ -251,6 +256,7 @@ class ReplayBuffer(object):
         # every minibatch gets its own device index block (and, de-duplicated, its own assembled stacks), so the
         # references of one sample stay valid while the next one is drawn (N_SAMPLE_SLOTS alive at a time)
         self._d_index = torch.empty((self.N_SAMPLE_SLOTS, nbytes), dtype=torch.uint8, device=dev)
+        self._d_scal = torch.empty((self.N_SAMPLE_SLOTS, B * (A + 2)), dtype=torch.float32, device=dev)
         self._sample_gen = [0] * self.N_SAMPLE_SLOTS
         self._sample_slot = -1
         if self.dedup_frames:
@@ -447,8 +453,15 @@ class ReplayBuffer(object):
         return guard, dst[:B * 8].view(torch.int64), dst[B * 8:].view(torch.int32).view(6, B)
 
     def _scalars(self, d_idx):
-        return (self.actions.index_select(0, d_idx), self.rewards.index_select(0, d_idx),
-                self.not_dones.index_select(0, d_idx))
+        """actions [B, ...], rewards [B, 1], not_dones [B, 1] of the sampled transitions (utils.py:159-166): one
+        gather kernel into this sample slot's buffer (valid as long as the slot's pixel handles are)."""
+        B, A = self.batch_size, self._n_act
+        buf = self._d_scal[self._sample_slot]
+        act, rew, nd = buf[:B * A].view((B,) + tuple(self.actions.shape[1:])), buf[B * A:B * A + B].view(B, 1), \
+            buf[B * A + B:].view(B, 1)
+        if self.device.type == "cuda" or _lib_tracing():
+            ops.gather_transition_scalars(self._sc, d_idx, B, A, act, rew, nd)
+        return act, rew, nd
 
     def _require_cuda(self):
         from . import _lib
@@ -513,7 +526,7 @@ class ReplayBuffer(object):
                 ops.crop_nchw(ring, rows, off[2 * j], off[2 * j + 1], B, (oh, ow), out_f32=t)
             outs.append(t)
         obses, next_obses, pos = outs
-        actions, rewards, not_dones = self._scalars(d_idx)
+        actions, rewards, not_dones = (t.clone() for t in self._scalars(d_idx))  # fresh tensors, like the reference's
         cpc_kwargs = dict(obs_anchor=obses, obs_pos=pos, time_anchor=None, time_pos=None)
         return obses, actions, rewards, next_obses, not_dones, cpc_kwargs
 

@@ -81,11 +81,24 @@ int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const f
 int curla_splitk_reduce(const float* partial, int nsplit, long long split_stride, int M, int N, int ldp, float* C,
                         int ldc, const float* bias, int relu, void* stream);
 
+/* Last layer of the actor trunk / the Q functions (curl_sac.py:73-74, 132-133): hidden -> N outputs, N <= 16
+ * (Q: 1, actor: 2|A|), batched over `nbatch` identically laid-out networks `stride*` floats apart.
+ *   fwd: out[z][m][n] = bias[z][n] + sum_k h[z][m][k] W[z][n][k]                       (K % 4 == 0)
+ *   bwd: dh[z][m][k] = (h[z][m][k] > 0) * sum_n dy[z][m][n] W[z][n][k]   (ReLU mask of the layer below fused)
+ *        dW[z][n][k] = sum_m dy[z][m][n] h[z][m][k]                      (dW may be NULL: data gradient only) */
+int curla_mlp_out_fwd(const float* h, long long strideH, const float* W, long long strideW, const float* bias,
+                      long long strideBias, float* out, long long strideOut, int M, int N, int K, int nbatch,
+                      void* stream);
+int curla_mlp_out_bwd(const float* dy, long long strideDy, const float* h, long long strideH, const float* W,
+                      long long strideW, float* dh, long long strideDh, float* dW, long long strideDW, int M, int N,
+                      int K, int nbatch, void* stream);
+
 /* fc split-K reduce + bias + LayerNorm(eps) [+ tanh] (encoder.py:98-107).  Saves
- * xhat / rstd for the backward when non-NULL.  F <= 256. */
+ * xhat / rstd for the backward when non-NULL.  F <= 256.  `xa` (optional, with `act` [B][A]): also writes the Q
+ * functions' input rows xa[b] = [ y[b] | act[b] ], i.e. torch.cat([obs, action], dim=1) (curl_sac.py:138). */
 int curla_fc_ln_fwd(const float* partial, int nsplit, long long split_stride, int ldp, const float* bias,
                     const float* gamma, const float* beta, int B, int F, float eps, float* fc_out, float* y,
-                    float* xhat, float* rstd, int tanh_out, void* stream);
+                    float* xhat, float* rstd, int tanh_out, float* xa, const float* act, int A, void* stream);
 /* dx, and (when non-NULL) dgamma, dbeta; dbias_in (optional, needs dgamma/dbeta) = column sums of dx = the gradient of
  * the fc bias feeding the LayerNorm */
 int curla_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int F, float* dx,
@@ -123,17 +136,26 @@ int curla_td_target(const float* tq, long long twin_stride, const float* log_pi,
 /* loss = mse(q1,tQ)+mse(q2,tQ) and dq = dloss/dq (curl_sac.py:359) */
 int curla_critic_loss(const float* q, long long twin_stride, const float* target_q, int B, float* loss, float* dq,
                       void* stream);
+/* the two above in one launch: target_Q from the target critic's `tq`, then the loss and dq of the critic's `q` */
+int curla_critic_td_loss(const float* q, const float* tq, long long twin_stride, const float* log_pi,
+                         const float* reward, const float* not_done, const double* log_alpha, float discount, int B,
+                         float* target_q, float* loss, float* dq, void* stream);
 /* actor_loss, alpha_loss, entropy, alpha -> scalars4; dq = d actor_loss/dq; dlog_alpha (float64 like the
  * reference's log_alpha, curl_sac.py:292) (curl_sac.py:378-399) */
 int curla_actor_loss(const float* q, long long twin_stride, const float* log_pi, const float* log_std, int A,
                      const double* log_alpha, float target_entropy, int B, float* scalars4, float* dq,
                      double* dlog_alpha, void* stream);
-/* CrossEntropyLoss(logits, arange(B)) and d/dlogits (curl_sac.py:221,411-413) */
+/* CrossEntropyLoss(logits, arange(B)) and d/dlogits (curl_sac.py:221,411-413); `loss` (the mean of row_loss) may be
+ * NULL when the scalar is not going to be logged */
 int curla_curl_ce(const float* logits, int B, int ld, float* row_loss, float* loss, float* dlogits, void* stream);
 int curla_mean(const float* x, int n, float* out, void* stream);
 
 /* target <- tau*param + (1-tau)*target over a flat parameter block (utils.py:37-41) */
 int curla_soft_update(const float* param, float* target, size_t n, float tau, float one_minus_tau, void* stream);
+/* one flat block with two rates: elements [0, split) use tau_a, [split, n) tau_b (encoder_tau | critic_tau,
+ * curl_sac.py:442-445) */
+int curla_soft_update2(const float* param, float* target, size_t n, size_t split, float tau_a, float one_minus_tau_a,
+                       float tau_b, float one_minus_tau_b, void* stream);
 
 /* ---- augmentations that produce float observations (augmentations.py:78-205; kornia arithmetic is not
  * vendored by the reference: PARITY UNPINNED, the algorithm is this build's statement of kornia's documented
@@ -158,6 +180,10 @@ int curla_noisy_cover_nchw(const float* in, const float* noise, float c0, float 
 /* float/uint8 NCHW crops exactly as sample_cpc returns them (utils.py:151-166) */
 int curla_crop_nchw(const uint8_t* frames, const int64_t* idx, const int32_t* h1, const int32_t* w1, int B, int C,
                     int Hs, int Ws, int Hc, int Wc, float* out_f32, uint8_t* out_u8, void* stream);
+/* actions / rewards / not_dones of the sampled transitions (utils.py:159-166): rows idx[b] of the ring's
+ * [capacity][A+2] scalar block (action | reward | not_done) into three dense outputs */
+int curla_gather_transition_scalars(const float* scalars, const int64_t* idx, int B, int A, float* action, float* reward,
+                                    float* not_done, void* stream);
 /* ReplayBuffer.add: one CHW uint8 observation into ring slot `slot` (utils.py:120-128) */
 int curla_store_frame(const uint8_t* chw, uint8_t* frames, long long slot, int C, int H, int W, void* stream);
 /* De-duplicated frame store (next_obs[t] shares k-1 of its k frames with obs[t], and equals obs[t+1]

@@ -775,22 +775,36 @@ def test_full_size_c5_gradients_are_the_mean_over_shards():
         sl = lambda t: t[lo:hi].contiguous()  # noqa: E731
         obs, nxt, pos = (ops.ObsRef.from_nhwc(t[lo:hi]) for t in tens)
         agent.update_critic(obs, sl(action), sl(reward), nxt, sl(not_done), L, 1, noise=sl(noise_c))
-        gc = agent._critic_gflat[lay["enc"][0]:lay["total"]].clone()
+        gc = {n: p.grad.clone() for n, p in agent.critic.named_parameters()}
         closs = L.scalars["train_critic/loss"]
         agent.update_actor_and_alpha(obs, L, 1, noise=sl(noise_a))
-        ga, gl = agent._actor_gflat.clone(), agent.log_alpha.grad.clone()
+        ga = {n: p.grad.clone() for n, p in agent.actor.named_parameters() if ".convs." not in n}
+        gl = agent.log_alpha.grad.clone()
         agent.update_cpc(obs, pos, None, L, 1)
         gw = agent.CURL.W.grad.clone()
         return gc, ga, gl, closs, L.scalars["train_actor/loss"], gw, L.scalars["train/curl_loss"]
 
     full = grads(0, B)
     a, b = grads(0, B // 2), grads(B // 2, B)
-    check("c5 full size critic grads: 1024 = mean of 2 x 512", full[0].cpu(), (0.5 * (a[0] + b[0])).cpu(), 2e-5)
-    check("c5 full size actor grads: 1024 = mean of 2 x 512", full[1].cpu(), (0.5 * (a[1] + b[1])).cpu(), 2e-5)
+    # Per tensor, so that a small tensor cannot hide behind a large one.  A sample's own gradient contribution is the
+    # same bits in the 1024- and the 512-minibatch (the 1/B factors are powers of two), so what differs is only the
+    # ORDER in which contributions are summed: 1024 rows for the dense layers, up to 1024 x 83 x 83 = 7 M signed,
+    # largely cancelling products per conv weight -- fp32 summation noise of ~1e-4 .. 1e-3 of the tensor's scale
+    # (the sums are a few percent of the sum of the magnitudes, which amplifies the ~1e-6 differences between the
+    # two split-K orders of the fc layer accordingly).
+    bad = []
+    for tag, j in (("critic", 0), ("actor", 1)):
+        for n in full[j]:
+            e = rel_err(full[j][n].cpu(), (0.5 * (a[j][n] + b[j][n])).cpu())
+            REPORT.append((f"c5 full size {tag} grad {n}: 1024 = mean of 2 x 512", e))
+            tol = 3e-3 if ".convs." in n else 1e-3
+            if not (np.isfinite(e) and e <= tol):
+                bad.append((tag, n, e, tol))
+    assert not bad, bad
     check("c5 full size log_alpha grad", full[2].cpu().float().reshape(1), (0.5 * (a[2] + b[2])).cpu().float().reshape(1), 2e-5)
     assert abs(full[3] - 0.5 * (a[3] + b[3])) <= 2e-5 * abs(full[3])
     assert abs(full[4] - 0.5 * (a[4] + b[4])) <= 2e-5 * max(1.0, abs(full[4]))
-    assert float(full[0].abs().max()) > 0 and bool(torch.isfinite(full[0]).all()) and bool(torch.isfinite(full[1]).all())
+    assert all(float(g.abs().max()) > 0 and bool(torch.isfinite(g).all()) for g in list(full[0].values()) + list(full[1].values()))
     # the InfoNCE loss couples the samples of a minibatch (B x B logits), so its gradient is NOT additive over
     # shards: only finiteness and scale are asserted for the cpc phase at this size
     assert bool(torch.isfinite(full[5]).all()) and float(full[5].abs().max()) > 0 and np.isfinite(full[6])

@@ -197,9 +197,13 @@ def test_gemm_splitk_and_fc_ln(ops, B, Fd, K):
     y_ref = F.layer_norm(fc, (Fd,), gl, betal, 1e-5)
     y, fco, xhat = (torch.empty(B, Fd, device="cuda") for _ in range(3))
     rstd = torch.empty(B, device="cuda")
-    ops.fc_ln_fwd(part, ks, B * Fd, Fd, dev(bias), dev(gamma), dev(beta), B, Fd, y, fc_out=fco, xhat=xhat, rstd=rstd)
+    act = rnd(B, 3, seed=38)
+    xa = torch.full((B, Fd + 3), float("nan"), device="cuda")
+    ops.fc_ln_fwd(part, ks, B * Fd, Fd, dev(bias), dev(gamma), dev(beta), B, Fd, y, fc_out=fco, xhat=xhat, rstd=rstd,
+                  xa=xa, act=dev(act))
     check("fc splitk + bias", fco.cpu(), fc.detach())
     check("layernorm fwd", y.cpu(), y_ref.detach())
+    assert torch.equal(xa.cpu(), torch.cat([y.cpu(), act], 1))  # torch.cat([z, action], 1) written by the same kernel
     dy = rnd(B, Fd, seed=36)
     y_ref.backward(dy)
     dx, dg, db_ = torch.empty(B, Fd, device="cuda"), torch.empty(Fd, device="cuda"), torch.empty(Fd, device="cuda")
@@ -282,6 +286,10 @@ def test_losses(ops):
     ops.critic_loss(dev(q.detach()), B, tgt, B, loss, dq)
     check("critic_loss", loss.cpu(), loss_ref.detach().reshape(1))
     check("critic_loss dq", dq.cpu(), q.grad)
+    # the fused form used by update_critic: bit-identical to the two kernels above
+    tgt2, loss2, dq3 = torch.empty(B, 1, device="cuda"), torch.empty(1, device="cuda"), torch.empty(2, B, 1, device="cuda")
+    ops.critic_td_loss(dev(q.detach()), dev(tq), B, dev(lp), dev(r), dev(nd), d_la, 0.99, B, tgt2, loss2, dq3)
+    assert torch.equal(tgt2, tgt) and torch.equal(loss2, loss) and torch.equal(dq3, dq)
     # actor / alpha
     q2 = rnd(2, B, 1, seed=56).requires_grad_(True)
     ls = rnd(B, A, seed=57)
@@ -305,6 +313,9 @@ def test_curl_ce(ops, B):
     ref.backward()
     rl, loss, dl = torch.empty(B, device="cuda"), torch.empty(1, device="cuda"), torch.empty(B, B, device="cuda")
     ops.curl_ce(dev(logits.detach()), B, B, rl, loss, dl)
+    dl2 = torch.empty(B, B, device="cuda")
+    ops.curl_ce(dev(logits.detach()), B, B, rl, None, dl2)  # the mean is optional (only computed when logged)
+    assert torch.equal(dl, dl2)
     check(f"curl_ce loss B{B}", loss.cpu(), ref.detach().reshape(1))
     check(f"curl_ce dlogits B{B}", dl.cpu(), logits.grad)
 
@@ -324,6 +335,16 @@ def test_concat_split_softupdate_mean(ops):
     td = dev(t)
     ops.soft_update(dev(p), td, 0.05)
     check("soft_update", td.cpu(), 0.05 * p + (1 - 0.05) * t, 1e-6)
+    td2 = dev(t)
+    ops.soft_update2(dev(p), td2, 40000, 0.05, 0.01)  # two rates over one flat block
+    check("soft_update2 head", td2[:40000].cpu(), 0.05 * p[:40000] + (1 - 0.05) * t[:40000], 1e-6)
+    check("soft_update2 tail", td2[40000:].cpu(), 0.01 * p[40000:] + (1 - 0.01) * t[40000:], 1e-6)
+    assert torch.equal(td2[:40000], td[:40000])
+    sc = rnd(50, 5, seed=76)  # ring scalar rows: action(3) | reward | not_done
+    idx = torch.tensor([7, 0, 49, 7, 13], dtype=torch.int64)
+    ga, gr, gn = torch.empty(5, 3, device="cuda"), torch.empty(5, 1, device="cuda"), torch.empty(5, 1, device="cuda")
+    ops.gather_transition_scalars(dev(sc), dev(idx), 5, 3, ga, gr, gn)
+    assert torch.equal(ga.cpu(), sc[idx, :3]) and torch.equal(gr.cpu(), sc[idx, 3:4]) and torch.equal(gn.cpu(), sc[idx, 4:5])
     m = torch.empty(1, device="cuda")
     ops.mean(dev(p[:777]), 777, m)
     check("mean", m.cpu(), p[:777].mean().reshape(1), 1e-5)
@@ -436,3 +457,28 @@ def test_colsum3(ops):
     for i, n in enumerate(Ns):
         check(f"colsum3[{i}] N={n}", outs[i][:, :n].cpu(), Xs[i].sum(1))
         assert torch.isnan(outs[i][:, n:]).all()  # nothing written past N
+
+
+@pytest.mark.parametrize("M,N,K,nb", [(512, 1, 1024, 2), (512, 4, 1024, 1), (37, 3, 100, 2), (5, 16, 64, 1), (130, 6, 96, 3)])
+def test_mlp_out_layer(ops, M, N, K, nb):
+    """Last layer of the trunks (hidden -> 1 or 2|A| outputs) as row dot products / one fused backward pass,
+    batched over twin networks with a parameter stride, against plain matmuls."""
+    h = torch.relu(rnd(nb, M, K, seed=1))
+    W, b, dy = rnd(nb, N, K, seed=2, scale=0.2), rnd(nb, N, seed=3), rnd(nb, M, N, seed=4)
+    pad = 8  # twin parameter blocks are `stride` floats apart, not dense
+    Wd = torch.zeros(nb, N * K + pad, device="cuda")
+    Wd[:, :N * K] = dev(W).view(nb, -1)
+    bd = torch.zeros(nb, N + 4, device="cuda")
+    bd[:, :N] = dev(b)
+    out = torch.full((nb, M, N), float("nan"), device="cuda")
+    ops.mlp_out_fwd(dev(h), M * K, Wd, N * K + pad, bd, N + 4, out, M * N, M, N, K, nb)
+    check(f"mlp_out fwd {M}x{N}x{K} nb{nb}", out.cpu(), torch.einsum("zmk,znk->zmn", h, W) + b[:, None, :])
+    dh = torch.full((nb, M, K), float("nan"), device="cuda")
+    dWd = torch.full((nb, N * K + pad), float("nan"), device="cuda")
+    ops.mlp_out_bwd(dev(dy), M * N, dev(h), M * K, Wd, N * K + pad, dh, M * K, dWd, N * K + pad, M, N, K, nb)
+    check(f"mlp_out dh {M}x{N}x{K} nb{nb}", dh.cpu(), torch.einsum("zmn,znk->zmk", dy, W) * (h > 0))
+    check(f"mlp_out dW {M}x{N}x{K} nb{nb}", dWd[:, :N * K].view(nb, N, K).cpu(), torch.einsum("zmn,zmk->znk", dy, h))
+    assert bool(torch.isnan(dWd[:, N * K:]).all())  # nothing written between the blocks
+    dh2 = torch.full((nb, M, K), float("nan"), device="cuda")
+    ops.mlp_out_bwd(dev(dy), M * N, dev(h), M * K, Wd, N * K + pad, dh2, M * K, None, 0, M, N, K, nb)  # data gradient only
+    assert torch.equal(dh, dh2)

@@ -59,9 +59,10 @@ for nb in (2, 1):
         lambda: ops.linear_dw(o3, B * n3, x, B * H, dW3, n3 * H, B, n3, H, nb))
     rec(f"dx   out  NN 512x1024x{n3} nb{nb}", 2 * nb * B * H * n3,
         lambda: ops.linear_dx(o3, B * n3, W3, n3 * H, out, B * H, B, n3, H, nb, mask=x, smask=B * H))
-h, Wfc, part = R(B, KF), R(F, KF), R(32, B, F)
-rec("fc   fwd  NT 512x50x30752 ks32", 2 * B * F * KF,
-    lambda: ops.gemm(h, 0, KF, 0, Wfc, 0, KF, 0, part, F, 0, B, F, KF, 1, ksplit=32, split_stride=B * F))
+h, Wfc, part = R(B, KF), R(F, KF), R(64, B, F)
+for ks in (32, 64):
+    rec(f"fc   fwd  NT 512x50x30752 ks{ks}", 2 * B * F * KF,
+        lambda: ops.gemm(h, 0, KF, 0, Wfc, 0, KF, 0, part, F, 0, B, F, KF, 1, ksplit=ks, split_stride=B * F))
 dfc, g = R(B, F), R(B, KF)
 rec("fc   dx   NN 512x30752x50", 2 * B * F * KF, lambda: ops.linear_dx(dfc, 0, Wfc, 0, g, 0, B, F, KF, mask=h))
 dWfc = R(F, KF)
