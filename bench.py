@@ -178,6 +178,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--capacity", type=int, default=CAPACITY)
     ap.add_argument("--prefill", choices=("device", "host"), default="device")
+    ap.add_argument("--clock-warmup-s", type=float, default=0.6,
+                    help="seconds of scratch conv launches before the warm-up steps (0 for counter-collection runs)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     if args.steps is None:
@@ -281,7 +283,7 @@ def main():
     bw, bb = torch.zeros((32, 32, 3, 3), device=dev), torch.zeros(32, device=dev)
     bo = torch.empty((512, 35, 35, 32), device=dev)
     t_burn = time.perf_counter()
-    while time.perf_counter() - t_burn < 0.6:
+    while time.perf_counter() - t_burn < args.clock_warmup_s:
         for _ in range(200):
             real_s1(bx, bw, bb, bo)
         torch.cuda.synchronize()
@@ -355,7 +357,7 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["workload"], "baseline_config": f"configs[{cfg['baseline_index']}]",
                        "replay_capacity": cap * world, "prefill": prefill, "parallelism": f"dp{world}",
-                       "priming_updates": 1, "clock_warmup_s": 0.6},
+                       "priming_updates": 1, "clock_warmup_s": args.clock_warmup_s},
             "transitions_per_s": updates_per_s * B,
             "conv_algorithmic_gflop_per_update": per_update / 1e9,
             "conv_roofline_frac_whole_update": per_update * (args.steps / dt) / (PEAK_F32_TFLOPS * 1e12),

@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcurla_hip.so")
 
 c_int, c_ll, c_float, c_size_t, vp = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+c_double = ctypes.c_double
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/curla_hip.h
 SIGNATURES = {
@@ -30,6 +31,7 @@ SIGNATURES = {
                         vp],
     "curla_critic_td_loss": [vp, vp, c_ll, vp, vp, vp, vp, c_float, c_int, vp, vp, vp, vp],
     "curla_soft_update2": [vp, vp, c_size_t, c_size_t, c_float, c_float, c_float, c_float, vp],
+    "curla_adam_step": [vp, vp, vp, vp, c_size_t, c_double, c_double, c_double, c_double, c_ll, vp],
     "curla_gather_transition_scalars": [vp, vp, c_int, c_int, vp, vp, vp, vp],
     "curla_ln_bwd": [vp, vp, vp, vp, c_int, c_int, vp, vp, vp, vp, vp],
     "curla_colsum": [vp, c_int, c_int, c_int, c_ll, vp, c_ll, c_int, vp],

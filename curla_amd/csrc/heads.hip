@@ -527,6 +527,45 @@ __global__ void soft_update2_kernel(const float* p, float* tgt, size_t n, size_t
   }
 }
 
+// One Adam step over a flat run of parameters (torch.optim.Adam, weight_decay 0, no amsgrad; curl_sac.py:299-313):
+//   m += (1-b1)(g-m);  v = b2 v + (1-b2) g g;  p -= step_size * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// with step_size = lr/(1-b1^t) and the two bias corrections evaluated on the host in double, as torch's
+// single-tensor Adam does.  Seven fp32 streams (4 read, 3 written), 16-byte accesses when the run is 16-byte
+// aligned: HBM-bound (28 B per parameter).
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float w1, float b2, float w2,
+                                         float step_size, float bc2_sqrt, float eps) {
+  m = (w1 < 0.5f) ? m + w1 * (g - m) : g - (g - m) * (1.0f - w1);
+  v = v * b2 + (w2 * g) * g;
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  p = p - (step_size * m) / denom;
+}
+
+__global__ void __launch_bounds__(256) adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                        int vec, float w1, float b2, float w2, float step_size,
+                                                        float bc2_sqrt, float eps) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  size_t done = 0;
+  if (vec) {
+    const size_t n4 = n >> 2;
+    for (size_t i = tid; i < n4; i += stride) {
+      f32x4 pp = reinterpret_cast<f32x4*>(p)[i], mm = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
+      const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float pe = pp[e], me = mm[e], ve = vv[e];
+        adam_one(pe, gg[e], me, ve, w1, b2, w2, step_size, bc2_sqrt, eps);
+        pp[e] = pe, mm[e] = me, vv[e] = ve;
+      }
+      reinterpret_cast<f32x4*>(p)[i] = pp;
+      reinterpret_cast<f32x4*>(m)[i] = mm;
+      reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+    done = n4 << 2;
+  }
+  for (size_t i = done + tid; i < n; i += stride) adam_one(p[i], g[i], m[i], v[i], w1, b2, w2, step_size, bc2_sqrt, eps);
+}
+
 // out_act[b][:] = sc[idx[b]][0:A], out_rew[b] = sc[idx[b]][A], out_nd[b] = sc[idx[b]][A+1]: the action / reward /
 // not_done of the sampled transitions (utils.py:159-166) from the ring's [capacity][A+2] scalar rows, one launch
 __global__ void gather_transition_scalars_kernel(const float* sc, const int64_t* idx, int B, int A, float* act,
@@ -824,6 +863,19 @@ int curla_soft_update2(const float* param, float* target, size_t n, size_t split
   CURLA_REQUIRE(param && target && n > 0 && split <= n);
   hipLaunchKernelGGL(soft_update2_kernel, dim3(nblocks(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), param,
                      target, n, split, tau_a, one_minus_tau_a, tau_b, one_minus_tau_b);
+  return curla_launch_status();
+}
+
+int curla_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
+                    double beta1, double beta2, double eps, long long step, void* stream) {
+  CURLA_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1 && beta1 >= 0. && beta1 < 1. &&
+                beta2 >= 0. && beta2 < 1.);
+  const double b1 = beta1, b2 = beta2;
+  const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
+  const int vec = aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq);
+  hipLaunchKernelGGL(adam_step_kernel, dim3(nblocks((n + 3) / 4, 256, 8192)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), param, grad, exp_avg, exp_avg_sq, n, vec, (float)(1.0 - b1),
+                     (float)b2, (float)(1.0 - b2), (float)(lr / bc1), (float)sqrt(bc2), (float)eps);
   return curla_launch_status();
 }
 

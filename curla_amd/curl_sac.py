@@ -2,8 +2,9 @@
 CurlSacAgent with the reference's API (curl_sac.py:57-465).
 
 Host code is Python on PyTorch-ROCm: parameters are ``nn.Parameter`` views into
-flat HBM buffers, the five optimizers are ``torch.optim.Adam`` -- exactly the
-reference's division of labour.  Everything between "minibatch indices" and
+flat HBM buffers, the five optimizers are ``torch.optim.Adam`` objects (four of
+them ``FlatAdam``: the same optimizer with its step as one flat HIP launch) --
+the reference's division of labour.  Everything between "minibatch indices" and
 ".grad is filled in" runs as hand-written HIP kernels through the C ABI
 (include/curla_hip.h); there is no autograd graph and no PyTorch fallback.
 
@@ -27,6 +28,7 @@ import torch.nn as nn
 from . import ops
 from .encoder import CNNEncoder
 from .ops import ObsRef
+from .optim import FlatAdam
 
 LOG_FREQ = 25_000
 
@@ -342,17 +344,28 @@ class CurlSacAgent(object):
 
         self._to_flat_device_layout()
 
-        cuda = self.device.type == "cuda"
-        kw = dict(fused=True) if cuda else {}
         actor_own = [p for n, p in self.actor.named_parameters() if ".convs." not in n]
         enc_params = list(self.critic.encoder.parameters())
         # Optimizers (curl_sac.py:299-313).  The reference hands Adam the tied convs (actor) and the target
         # encoder (cpc) as well; their .grad is always None at step time there, so Adam never touches them.
-        self.actor_optimizer = torch.optim.Adam(actor_own, lr=actor_lr, betas=(actor_beta, 0.999), **kw)
-        self.critic_optimizer = torch.optim.Adam(self.critic.parameters(), lr=critic_lr, betas=(critic_beta, 0.999), **kw)
-        self.log_alpha_optimizer = torch.optim.Adam([self.log_alpha], lr=alpha_lr, betas=(alpha_beta, 0.999), **kw)
-        self.encoder_optimizer = torch.optim.Adam(enc_params, lr=encoder_lr, **kw)
-        self.cpc_optimizer = torch.optim.Adam([self.CURL.W] + enc_params, lr=encoder_lr, **kw)
+        # FlatAdam is torch.optim.Adam with its step() as one HIP launch over the flat buffer (optim.py);
+        # CURLA_TORCH_ADAM=1 keeps torch's own fused multi-tensor step (same state_dict either way).
+        if self.device.type == "cuda" and os.environ.get("CURLA_TORCH_ADAM", "0") == "1":
+            def adam(params, flat, gflat, **kw):
+                return torch.optim.Adam(params, fused=True, **kw)
+        elif self.device.type == "cuda":
+            def adam(params, flat, gflat, **kw):
+                return FlatAdam(params, flat, gflat, **kw)
+        else:
+            def adam(params, flat, gflat, **kw):
+                return torch.optim.Adam(params, **kw)
+        cf, cg = self._critic_flat, self._critic_gflat
+        self.actor_optimizer = adam(actor_own, self._actor_flat, self._actor_gflat, lr=actor_lr, betas=(actor_beta, 0.999))
+        self.critic_optimizer = adam(list(self.critic.parameters()), cf, cg, lr=critic_lr, betas=(critic_beta, 0.999))
+        self.log_alpha_optimizer = torch.optim.Adam([self.log_alpha], lr=alpha_lr, betas=(alpha_beta, 0.999),
+                                                    **(dict(fused=True) if self.device.type == "cuda" else {}))
+        self.encoder_optimizer = adam(enc_params, cf, cg, lr=encoder_lr)
+        self.cpc_optimizer = adam([self.CURL.W] + enc_params, cf, cg, lr=encoder_lr)
 
         self._workspaces = {}
         self._anchor_cache = None

@@ -1,0 +1,130 @@
+"""Adam over the learner's flat parameter buffers.
+
+``FlatAdam`` IS a ``torch.optim.Adam`` (same constructor hyper-parameters,
+``param_groups``, ``state`` keys, ``state_dict()`` / ``load_state_dict()``
+format -- curl_sac.py:299-313 builds five of them), but its ``step()`` is one
+HIP launch per contiguous run of live parameters in the flat buffer
+(``curla_adam_step``) instead of torch's multi-tensor launches, which put ~70
+workgroups on a 256-CU chip (45 us for 6 MB of parameters; the flat kernel
+streams the same 7 arrays at HBM rate).  The moments live in two flat mirror
+buffers; ``state[p]['exp_avg']`` / ``['exp_avg_sq']`` are views into them, so a
+checkpoint written from ``state_dict()`` is what torch's Adam would write.
+"""
+import torch
+
+from ._lib import call, stream
+
+
+class FlatAdam(torch.optim.Adam):
+    def __init__(self, params, flat, gflat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        """``params``: Parameters whose ``.data`` are views into ``flat`` and whose ``.grad`` (when not None) are the
+        views at the same offsets of ``gflat``."""
+        super().__init__(params, lr=lr, betas=betas, eps=eps)
+        self._flat, self._gflat = flat, gflat
+        self._plist = [p for g in self.param_groups for p in g["params"]]
+        base = flat.data_ptr()
+        self._span = []
+        for p in self._plist:
+            off = (p.data_ptr() - base) // 4
+            if p.dtype != torch.float32 or off < 0 or off + p.numel() > flat.numel() or not p.is_contiguous():
+                raise ValueError("FlatAdam: every parameter must be a contiguous float32 view into the flat buffer")
+            self._span.append((off, off + p.numel()))
+        self._lo = min(a for a, _ in self._span)
+        self._hi = max(b for _, b in self._span)
+        self._m = torch.zeros(self._hi - self._lo, device=flat.device, dtype=torch.float32)
+        self._v = torch.zeros_like(self._m)
+        self._steps = [0] * len(self._plist)
+        self._plans = {}
+
+    # -- state kept in torch's format ------------------------------------------------------------------------
+    def _views(self, i):
+        a, b = self._span[i]
+        shape = self._plist[i].shape
+        return self._m[a - self._lo:b - self._lo].view(shape), self._v[a - self._lo:b - self._lo].view(shape)
+
+    def _ensure_state(self, i):
+        p = self._plist[i]
+        st = self.state[p]
+        if len(st) == 0:
+            m, v = self._views(i)
+            st["step"] = torch.tensor(0.0, dtype=torch.float32)
+            st["exp_avg"], st["exp_avg_sq"] = m, v
+        return st
+
+    def state_dict(self):
+        for i, p in enumerate(self._plist):
+            if p in self.state and len(self.state[p]):
+                self.state[p]["step"] = torch.tensor(float(self._steps[i]), dtype=torch.float32)
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)  # deep-copies the tensors: move them back into the flat mirrors
+        with torch.no_grad():
+            for i, p in enumerate(self._plist):
+                st = self.state.get(p)
+                if not st:
+                    self._steps[i] = 0
+                    continue
+                m, v = self._views(i)
+                m.copy_(st["exp_avg"])
+                v.copy_(st["exp_avg_sq"])
+                st["exp_avg"], st["exp_avg_sq"] = m, v
+                self._steps[i] = int(round(float(st["step"])))
+                st["step"] = torch.tensor(float(self._steps[i]), dtype=torch.float32)
+
+    # -- the step --------------------------------------------------------------------------------------------
+    def _plan(self, gi, group, live):
+        """Contiguous runs [a, b) of the flat buffer covered by this group's live parameters (alignment padding
+        between two adjacent parameters -- at most 3 floats, always zero gradient -- is bridged), each with the
+        indices of its parameters."""
+        idx0 = sum(len(g["params"]) for g in self.param_groups[:gi])
+        items = sorted((self._span[idx0 + j] + (idx0 + j,) for j in range(len(group["params"])) if live[idx0 + j]))
+        runs = []
+        for a, b, i in items:
+            if runs and a - runs[-1][1] <= 3 and a >= runs[-1][1]:
+                runs[-1][1] = b
+                runs[-1][2].append(i)
+            else:
+                runs.append([a, b, [i]])
+        return runs
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        live = tuple(p.grad is not None for p in self._plist)
+        plans = self._plans.get(live)
+        if plans is None:
+            base = self._gflat.data_ptr()
+            for i, p in enumerate(self._plist):
+                if live[i] and (p.grad.data_ptr() - base) // 4 != self._span[i][0]:
+                    raise ValueError("FlatAdam: a gradient is not the flat gradient buffer's view of its parameter")
+            plans = self._plans[live] = [self._plan(gi, g, live) for gi, g in enumerate(self.param_groups)]
+        s = stream()
+        for group, runs in zip(self.param_groups, plans):
+            if group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or group.get("maximize", False):
+                raise NotImplementedError("FlatAdam implements the options the learner uses: plain Adam")
+            lr, (b1, b2), eps = group["lr"], group["betas"], group["eps"]
+            for a, b, members in runs:
+                # parameters of one run normally share their step count; split the run where they do not
+                k = 0
+                while k < len(members):
+                    t = self._steps[members[k]]
+                    e = k
+                    while e + 1 < len(members) and self._steps[members[e + 1]] == t:
+                        e += 1
+                    lo = a if k == 0 else self._span[members[k]][0]
+                    hi = b if e == len(members) - 1 else self._span[members[e]][1]
+                    for i in members[k:e + 1]:
+                        self._ensure_state(i)
+                        self._steps[i] = t + 1
+                    call("curla_adam_step", self._flat.data_ptr() + 4 * lo, self._gflat.data_ptr() + 4 * lo,
+                         self._m.data_ptr() + 4 * (lo - self._lo), self._v.data_ptr() + 4 * (lo - self._lo), hi - lo,
+                         float(lr), float(b1), float(b2), float(eps), t + 1, s)
+                    k = e + 1
+        return loss
+
+
+__all__ = ["FlatAdam"]

@@ -157,6 +157,14 @@ int curla_soft_update(const float* param, float* target, size_t n, float tau, fl
 int curla_soft_update2(const float* param, float* target, size_t n, size_t split, float tau_a, float one_minus_tau_a,
                        float tau_b, float one_minus_tau_b, void* stream);
 
+/* One torch.optim.Adam step (weight_decay 0, amsgrad off; the reference's five optimizers, curl_sac.py:299-313) over a
+ * flat run of n fp32 parameters with their gradient and moment runs: replaces torch's multi-tensor Adam launches
+ * (~70 workgroups on a 256-CU chip).  `step` is the 1-based count of this step; the hyper-parameters are doubles as in the
+ * optimizer's param_group (the bias corrections and lr/(1-beta1^step) are evaluated in double on the host, like
+ * torch's single-tensor Adam, and rounded to float once). */
+int curla_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
+                    double beta1, double beta2, double eps, long long step, void* stream);
+
 /* ---- augmentations that produce float observations (augmentations.py:78-205; kornia arithmetic is not
  * vendored by the reference: PARITY UNPINNED, the algorithm is this build's statement of kornia's documented
  * behaviour, see oracle/curla_oracle.py color_jiggle / noisy_cover).  Output: float NHWC [B][H][W][C] in [0,255].

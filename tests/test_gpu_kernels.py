@@ -482,3 +482,71 @@ def test_mlp_out_layer(ops, M, N, K, nb):
     dh2 = torch.full((nb, M, K), float("nan"), device="cuda")
     ops.mlp_out_bwd(dev(dy), M * N, dev(h), M * K, Wd, N * K + pad, dh2, M * K, None, 0, M, N, K, nb)  # data gradient only
     assert torch.equal(dh, dh2)
+
+
+def _flat_params(sizes, device, seed=0):
+    """Parameters laid out like the agent's flat buffers: 4-float aligned slots, .grad views of a mirror buffer."""
+    offs, off = [], 0
+    for n in sizes:
+        offs.append(off)
+        off += (int(np.prod(n)) + 3) & ~3
+    g = torch.Generator().manual_seed(seed)
+    flat = torch.zeros(off, device=device)
+    gflat = torch.zeros(off, device=device)
+    params = []
+    for n, o in zip(sizes, offs):
+        cnt = int(np.prod(n))
+        flat[o:o + cnt] = torch.randn(cnt, generator=g).to(device)
+        p = torch.nn.Parameter(flat[o:o + cnt].view(n))
+        p.grad = gflat[o:o + cnt].view(n)
+        params.append(p)
+    return flat, gflat, params
+
+
+@pytest.mark.parametrize("betas", [(0.9, 0.999), (0.5, 0.999)])
+def test_flat_adam_matches_torch_adam(betas):
+    """curla_adam_step (optim.FlatAdam) against torch.optim.Adam on the CPU (the reference's optimizer,
+    curl_sac.py:299-313) over 6 steps; one parameter loses its gradient for two steps in the middle (the
+    detach_encoder case: Adam must skip it and keep its own step count) and state_dict() round-trips into a fresh
+    optimizer."""
+    from curla_amd.optim import FlatAdam
+    sizes = [(32, 9, 3, 3), (32,), (50, 1203), (50,), (1,), (1024, 57), (7,)]
+    flat, gflat, params = _flat_params(sizes, "cuda")
+    ref_params = [torch.nn.Parameter(p.detach().cpu().clone()) for p in params]
+    opt = FlatAdam(params, flat, gflat, lr=1e-3, betas=betas)
+    ref = torch.optim.Adam(ref_params, lr=1e-3, betas=betas)
+    gen = torch.Generator().manual_seed(5)
+    saved = params[2].grad
+    for step in range(6):
+        skip = step in (2, 3)
+        for i, (p, r) in enumerate(zip(params, ref_params)):
+            gr = torch.randn(p.shape, generator=gen) * (10.0 ** (i % 3 - 2))
+            if i == 2:
+                p.grad = None if skip else saved
+                r.grad = None if skip else gr
+                if skip:
+                    continue
+            else:
+                r.grad = gr
+            p.grad.copy_(gr.cuda())
+        opt.step()
+        ref.step()
+        if step == 3:  # a resumed optimizer continues identically
+            sd = opt.state_dict()
+            opt = FlatAdam(params, flat, gflat, lr=1e-3, betas=betas)
+            opt.load_state_dict(sd)
+    torch.cuda.synchronize()
+    for i, (p, r) in enumerate(zip(params, ref_params)):
+        check(f"flat_adam{betas} param{i}", p.detach(), r.detach(), 2e-6)
+        st, rst = opt.state[p], ref.state[r]
+        check(f"flat_adam{betas} exp_avg{i}", st["exp_avg"], rst["exp_avg"], 2e-6)
+        check(f"flat_adam{betas} exp_avg_sq{i}", st["exp_avg_sq"], rst["exp_avg_sq"], 2e-6)
+    sd, rsd = opt.state_dict(), ref.state_dict()
+    assert sd["param_groups"][0]["betas"] == rsd["param_groups"][0]["betas"]
+    assert set(sd["state"]) == set(rsd["state"])
+    for k in sd["state"]:
+        assert set(sd["state"][k]) == set(rsd["state"][k])
+        assert float(sd["state"][k]["step"]) == float(rsd["state"][k]["step"])
+    # padding between the slots never moves
+    pad = 32 * 81 + 32 + 50 * 1203  # the (50, 1203) slot is 60150 floats + 2 of padding
+    assert float(flat[pad:pad + 2].abs().sum()) == 0.0

@@ -379,3 +379,53 @@ def test_augmentor_tensor_api_needs_the_device():
         with pytest.raises(ValueError):
             aug.training_augmentation(torch.zeros(2, 9, 20, 25))
     assert curla_amd.make_augmentor("identity", (20, 24)).training_augmentation("x") == "x"
+
+
+def test_flat_adam_plan_and_state_format():
+    """FlatAdam (curla_amd/optim.py) keeps torch.optim.Adam's param_groups / state_dict format and turns a step into
+    one launch per contiguous run of live parameters (checked through the launch trace: nothing computes here)."""
+    from curla_amd import _lib
+    from curla_amd.optim import FlatAdam
+    sizes, offs, off = [(8, 5), (8,), (3,), (16, 4), (1,)], [], 0
+    for n in sizes:
+        offs.append(off)
+        off += (int(np.prod(n)) + 3) & ~3
+    flat, gflat = torch.zeros(off), torch.zeros(off)
+    params = []
+    for n, o in zip(sizes, offs):
+        p = torch.nn.Parameter(flat[o:o + int(np.prod(n))].view(n))
+        p.grad = gflat[o:o + int(np.prod(n))].view(n)
+        params.append(p)
+    opt = FlatAdam(params, flat, gflat, lr=3e-4, betas=(0.5, 0.999))
+    assert isinstance(opt, torch.optim.Adam) and opt.param_groups[0]["lr"] == 3e-4
+    calls = []
+    _lib.set_trace_hook(lambda name, args: calls.append((name, args)))
+    try:
+        opt.step()
+        assert [c[0] for c in calls] == ["curla_adam_step"]
+        assert calls[0][1][4] == off - 3 and calls[0][1][9] == 1  # one run over everything (last slot: 1 + 3 padding)
+        calls.clear()
+        g2 = params[2].grad
+        params[2].grad = None   # a hole in the middle: two runs, and the skipped parameter keeps step 1
+        opt.step()
+        assert [(c[1][4], c[1][9]) for c in calls] == [(48, 2), (65, 2)]
+        calls.clear()
+        params[2].grad = g2     # back: its step count differs from its neighbours', so the run is split in three
+        opt.step()
+        assert [(c[1][4], c[1][9]) for c in calls] == [(48, 3), (3, 2), (65, 3)]
+    finally:
+        _lib.set_trace_hook(None)
+    sd = opt.state_dict()
+    ref = torch.optim.Adam([torch.nn.Parameter(torch.zeros(n)) for n in sizes], lr=3e-4, betas=(0.5, 0.999))
+    for p in ref.param_groups[0]["params"]:
+        p.grad = torch.zeros_like(p)
+    ref.step()
+    rsd = ref.state_dict()
+    assert set(sd["state"]) == set(rsd["state"]) and set(sd["state"][0]) == set(rsd["state"][0])
+    assert {k: v for k, v in sd["param_groups"][0].items() if k not in ("params",)}.keys() == \
+        {k: v for k, v in rsd["param_groups"][0].items() if k not in ("params",)}.keys()
+    assert [float(sd["state"][i]["step"]) for i in range(5)] == [3, 3, 2, 3, 3]
+    opt2 = FlatAdam(params, flat, gflat, lr=3e-4, betas=(0.5, 0.999))
+    opt2.load_state_dict(sd)
+    assert opt2._steps == [3, 3, 2, 3, 3]
+    assert opt2.state[params[0]]["exp_avg"].data_ptr() == opt2._m.data_ptr()  # moments are views of the flat mirror

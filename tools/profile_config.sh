@@ -23,12 +23,16 @@ if [[ $WHAT == *stats* ]]; then
   F=$(find $O/prof_${TAG}_${CFG} -name "*kernel_stats.csv" | head -1)
   python tools/summarize_rocprof.py "$F" $O/${TAG}_kernel_stats_${CFG}.txt "bench.py --config $CFG --steps $STEPS --warmup $WARM (sources $HASH)"
   head -14 $O/${TAG}_kernel_stats_${CFG}.txt
+  # raw traces are large (gpurun copies back at most 64 MiB): keep the per-dispatch trace only when asked to
+  if [ -n "$KEEP_TRACE" ]; then cp "$(find $O/prof_${TAG}_${CFG} -name "*kernel_trace.csv" | head -1)" $O/${TAG}_kernel_trace_${CFG}.csv; fi
+  rm -rf $O/prof_${TAG}_${CFG}
 fi
 if [[ $WHAT == *traffic* ]]; then
   P=$O/pmc_traffic_${TAG}_${CFG}; rm -rf $P
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/fetch -- python bench.py --config $CFG --steps $PSTEPS --warmup $PWARM --no-cpu-baseline > $P.fetch.log 2>&1 || true
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/write -- python bench.py --config $CFG --steps $PSTEPS --warmup $PWARM --no-cpu-baseline > $P.write.log 2>&1 || true
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/fetch -- python bench.py --config $CFG --steps $PSTEPS --warmup $PWARM --no-cpu-baseline --clock-warmup-s 0 > $P.fetch.log 2>&1 || true
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/write -- python bench.py --config $CFG --steps $PSTEPS --warmup $PWARM --no-cpu-baseline --clock-warmup-s 0 > $P.write.log 2>&1 || true
   python tools/pmc_summarize.py traffic $P $O/${TAG}_pmc_traffic_${CFG}.json $HASH | head -10
+  rm -rf $P
 fi
 if [[ $WHAT == *sq* ]]; then
   P=$O/pmc_sq_${TAG}_${CFG}; rm -rf $P
@@ -38,7 +42,8 @@ if [[ $WHAT == *sq* ]]; then
              "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" \
              "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_INSTS_LDS SQ_CYCLES"; do
     i=$((i+1))
-    rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $P/g$i -- python bench.py --config $CFG --steps $PSTEPS --warmup $PWARM --no-cpu-baseline > $P.g$i.log 2>&1 || echo "group $i failed"
+    rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $P/g$i -- python bench.py --config $CFG --steps $PSTEPS --warmup $PWARM --no-cpu-baseline --clock-warmup-s 0 > $P.g$i.log 2>&1 || echo "group $i failed"
   done
   python tools/pmc_summarize.py sq $P $O/${TAG}_pmc_sq_${CFG}.json $HASH | tee $O/${TAG}_pmc_sq_${CFG}.txt | head -14
+  rm -rf $P
 fi
