@@ -278,14 +278,16 @@ def main():
     agent.update(rb, L, step)
     step += 1
     # the first ~0.5 s of matrix-pipe work in a process runs ~8 % slow while the clocks ramp: burn it on scratch
-    # buffers (no agent state involved) so that short runs (small K and W) also measure the steady state
-    bx = torch.zeros((512, 37, 37, 32), device=dev)
-    bw, bb = torch.zeros((32, 32, 3, 3), device=dev), torch.zeros(32, device=dev)
-    bo = torch.empty((512, 35, 35, 32), device=dev)
+    # buffers (no agent state involved) so that short runs (small K and W) also measure the steady state.  The burn
+    # uses a kernel instance no configuration launches (first-layer conv from a float NCHW tensor with C = 3), so the
+    # rocprofv3 per-kernel averages of this command contain the updates' launches only.
+    bx = ops.ObsRef.from_tensor(torch.zeros((512, 3, 84, 84), device=dev))
+    bw, bb = torch.zeros((32, 3, 3, 3), device=dev), torch.zeros(32, device=dev)
+    bo = torch.empty((512, 41, 41, 32), device=dev)
     t_burn = time.perf_counter()
     while time.perf_counter() - t_burn < args.clock_warmup_s:
         for _ in range(200):
-            real_s1(bx, bw, bb, bo)
+            ops.conv1_fwd(bx, bw, bb, bo)
         torch.cuda.synchronize()
     del bx, bw, bb, bo
     for _ in range(args.warmup):
