@@ -87,10 +87,12 @@ __global__ void fc_ln_fwd_kernel(const float* P, int nsplit, long long sSplit, i
   if (lane == 0 && rstd) rstd[row] = rs;
 }
 
-// dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat))
+// dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat)).  The incoming gradient is dy[b*ld + f]
+// (+ dy2[b*ld + f] when dy2 is given: the two halves of the twin-Q input gradient, torch.cat's backward at
+// curl_sac.py:138, summed here instead of in a pass of their own)
 template <int NF>
-__global__ void ln_bwd_kernel(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int F,
-                              float* dx) {
+__global__ void ln_bwd_kernel(const float* dy, const float* dy2, int ld, const float* xhat, const float* rstd,
+                              const float* gamma, int B, int F, float* dx) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= B) return;
@@ -100,7 +102,9 @@ __global__ void ln_bwd_kernel(const float* dy, const float* xhat, const float* r
     const int f = lane + 64 * j;
     g[j] = 0.f, xh[j] = 0.f;
     if (f < F) {
-      g[j] = dy[(size_t)row * F + f] * gamma[f];
+      float d = dy[(size_t)row * ld + f];
+      if (dy2) d += dy2[(size_t)row * ld + f];
+      g[j] = d * gamma[f];
       xh[j] = xhat[(size_t)row * F + f];
     }
     s1 += g[j];
@@ -118,8 +122,9 @@ __global__ void ln_bwd_kernel(const float* dy, const float* xhat, const float* r
 
 // dgamma[f] = sum_b dy*xhat ; dbeta[f] = sum_b dy ; optionally dbias[f] = sum_b dx (the gradient of the fc bias
 // that feeds the LayerNorm: the same walk over the rows)   (one block of 1024 per 64 features)
-__global__ __launch_bounds__(1024) void ln_param_grad_kernel(const float* dy, const float* xhat, const float* dx, int B,
-                                                             int F, float* dgamma, float* dbeta, float* dbias) {
+__global__ __launch_bounds__(1024) void ln_param_grad_kernel(const float* dy, const float* dy2, int ld, const float* xhat,
+                                                             const float* dx, int B, int F, float* dgamma,
+                                                             float* dbeta, float* dbias) {
   __shared__ float sg[16][64], sb[16][64], sx[16][64];
   const int fl = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int f = blockIdx.x * 64 + fl;
@@ -130,14 +135,16 @@ __global__ __launch_bounds__(1024) void ln_param_grad_kernel(const float* dy, co
       float d[8], x[8], e[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        d[k] = dy[(size_t)(b + 16 * k) * F + f], x[k] = xhat[(size_t)(b + 16 * k) * F + f];
+        d[k] = dy[(size_t)(b + 16 * k) * ld + f], x[k] = xhat[(size_t)(b + 16 * k) * F + f];
+        if (dy2) d[k] += dy2[(size_t)(b + 16 * k) * ld + f];
         e[k] = dbias ? dx[(size_t)(b + 16 * k) * F + f] : 0.f;
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) ag += d[k] * x[k], ab += d[k], ax += e[k];
     }
     for (; b < B; b += 16) {
-      const float d = dy[(size_t)b * F + f];
+      float d = dy[(size_t)b * ld + f];
+      if (dy2) d += dy2[(size_t)b * ld + f];
       ag += d * xhat[(size_t)b * F + f];
       ab += d;
       if (dbias) ax += dx[(size_t)b * F + f];
@@ -345,9 +352,12 @@ __global__ void actor_head_fwd_kernel(const float* out2a, const float* noise, in
 }
 
 // gradient of (sum_a gpi[a]*pi[a] + glp*log_pi) wrt the trunk output [mu | raw_log_std]
-__global__ void actor_head_bwd_kernel(const float* gpi, const float* glp_scalar, const double* log_alpha, float glp_scale,
-                                      const float* noise, const float* pi_t, const float* log_std,
-                                      const float* tanh_ls, int B, int A, float lo, float hi, float* dout2a) {
+// gpi[b][a] = gpi[b*gpi_ld + a] (+ gpi2[b*gpi_ld + a]): the action columns of the twin-Q input gradient can be read in
+// place, summed over the twin (curl_sac.py:138), instead of through a `split_sum` pass
+__global__ void actor_head_bwd_kernel(const float* gpi, const float* gpi2, int gpi_ld, const float* glp_scalar,
+                                      const double* log_alpha, float glp_scale, const float* noise, const float* pi_t,
+                                      const float* log_std, const float* tanh_ls, int B, int A, float lo, float hi,
+                                      float* dout2a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   // d loss / d log_pi is the same for every row: alpha/B (actor loss) unless given explicitly
@@ -355,7 +365,8 @@ __global__ void actor_head_bwd_kernel(const float* gpi, const float* glp_scalar,
   for (int a = 0; a < A; ++a) {
     const float p = pi_t[(size_t)b * A + a];
     const float om = 1.f - p * p;
-    float gp = gpi[(size_t)b * A + a];
+    float gp = gpi[(size_t)b * gpi_ld + a];
+    if (gpi2) gp += gpi2[(size_t)b * gpi_ld + a];
     if (om > 0.f) gp += glp * (2.f * p / (om + 1e-6f));
     const float gu = gp * om;
     const float ls = log_std[(size_t)b * A + a];
@@ -703,13 +714,14 @@ int curla_fc_ln_fwd(const float* partial, int nsplit, long long split_stride, in
   return curla_launch_status();
 }
 
-int curla_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int F, float* dx,
-                 float* dgamma, float* dbeta, float* dbias_in, void* stream) {
-  CURLA_REQUIRE(dy && xhat && rstd && gamma && dx && B > 0 && F > 0);
+int curla_ln_bwd_twin(const float* dy, const float* dy2, int ld_dy, const float* xhat, const float* rstd,
+                      const float* gamma, int B, int F, float* dx, float* dgamma, float* dbeta, float* dbias_in,
+                      void* stream) {
+  CURLA_REQUIRE(dy && xhat && rstd && gamma && dx && B > 0 && F > 0 && ld_dy >= F);
   if (F > 256) return CURLA_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
-#define CURLA_LN_BWD(NF) \
-  hipLaunchKernelGGL(ln_bwd_kernel<NF>, dim3((B + 3) / 4), dim3(256), 0, st, dy, xhat, rstd, gamma, B, F, dx)
+#define CURLA_LN_BWD(NF)                                                                                               \
+  hipLaunchKernelGGL(ln_bwd_kernel<NF>, dim3((B + 3) / 4), dim3(256), 0, st, dy, dy2, ld_dy, xhat, rstd, gamma, B, F, dx)
   switch ((F + 63) / 64) {
     case 1: CURLA_LN_BWD(1); break;
     case 2: CURLA_LN_BWD(2); break;
@@ -719,9 +731,14 @@ int curla_ln_bwd(const float* dy, const float* xhat, const float* rstd, const fl
 #undef CURLA_LN_BWD
   CURLA_REQUIRE(!dbias_in || (dgamma && dbeta));
   if (dgamma && dbeta)
-    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((F + 63) / 64), dim3(1024), 0, st, dy, xhat, dx, B, F, dgamma, dbeta,
-                       dbias_in);
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((F + 63) / 64), dim3(1024), 0, st, dy, dy2, ld_dy, xhat, dx, B, F,
+                       dgamma, dbeta, dbias_in);
   return curla_launch_status();
+}
+
+int curla_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int F, float* dx,
+                 float* dgamma, float* dbeta, float* dbias_in, void* stream) {
+  return curla_ln_bwd_twin(dy, nullptr, F, xhat, rstd, gamma, B, F, dx, dgamma, dbeta, dbias_in, stream);
 }
 
 int curla_colsum(const float* X, int M, int N, int ldx, long long strideX, float* out, long long strideOut, int nbatch,
@@ -776,14 +793,15 @@ int curla_actor_head_fwd(const float* trunk_out, const float* noise, int B, int 
   return curla_launch_status();
 }
 
-int curla_actor_head_bwd(const float* gpi, const float* glp_rows, const double* log_alpha, float glp_scale,
-                         const float* noise, const float* pi, const float* log_std, const float* tanh_ls, int B,
-                         int A, float log_std_min, float log_std_max, float* dtrunk_out, void* stream) {
-  CURLA_REQUIRE(gpi && noise && pi && log_std && tanh_ls && dtrunk_out && B > 0 && A > 0 && A <= kMaxA);
+int curla_actor_head_bwd(const float* gpi, const float* gpi2, int gpi_ld, const float* glp_rows, const double* log_alpha,
+                         float glp_scale, const float* noise, const float* pi, const float* log_std,
+                         const float* tanh_ls, int B, int A, float log_std_min, float log_std_max, float* dtrunk_out,
+                         void* stream) {
+  CURLA_REQUIRE(gpi && noise && pi && log_std && tanh_ls && dtrunk_out && B > 0 && A > 0 && A <= kMaxA && gpi_ld >= A);
   CURLA_REQUIRE(glp_rows || log_alpha);
   hipLaunchKernelGGL(actor_head_bwd_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), gpi,
-                     glp_rows, log_alpha, glp_scale, noise, pi, log_std, tanh_ls, B, A, log_std_min, log_std_max,
-                     dtrunk_out);
+                     gpi2, gpi_ld, glp_rows, log_alpha, glp_scale, noise, pi, log_std, tanh_ls, B, A, log_std_min,
+                     log_std_max, dtrunk_out);
   return curla_launch_status();
 }
 

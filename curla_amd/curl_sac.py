@@ -584,14 +584,17 @@ class CurlSacAgent(object):
             return pi.cpu().data.numpy().flatten()
 
     # ------------------------------------------------------------------ building blocks
-    def _encoder_backward(self, ws, obs_ref, dz, xhat, rstd, enc, conv_grads=True, dense_done=None):
+    def _encoder_backward(self, ws, obs_ref, dz, xhat, rstd, enc, conv_grads=True, dense_done=None, twin_ld=None):
         """Backward of fc+LN and (optionally) the conv stack from d(loss)/d(z);
         writes .grad of enc.{ln,fc,convs}.  ``dense_done()`` is called once the fc / LayerNorm gradients are
-        final, i.e. before the conv backward is enqueued (data parallel: their all-reduce starts there)."""
+        final, i.e. before the conv backward is enqueued (data parallel: their all-reduce starts there).
+        ``twin_ld``: ``dz`` is the twin-Q input gradient [2, B, twin_ld]; d(loss)/d(z) is the sum over the twin of
+        its first F columns, read in place by the LayerNorm backward."""
         B, F, K, L = obs_ref.B, enc.feature_dim, enc.flat_dim, enc.num_layers
         acts = ws.acts_main
-        ops.ln_bwd(dz, xhat, rstd, enc.ln.weight, B, F, ws.dfc, dgamma=enc.ln.weight.grad, dbeta=enc.ln.bias.grad,
-                   dbias_in=enc.fc.bias.grad)
+        dy, dy2 = (dz, None) if twin_ld is None else (dz[0], dz[1])
+        ops.ln_bwd(dy, xhat, rstd, enc.ln.weight, B, F, ws.dfc, dgamma=enc.ln.weight.grad, dbeta=enc.ln.bias.grad,
+                   dbias_in=enc.fc.bias.grad, dy2=dy2, ld=twin_ld)
         h = acts[-1]
         ops.linear_dw(ws.dfc, 0, h, 0, enc.fc.weight.grad, 0, B, F, K)
         if dense_done is not None:
@@ -660,19 +663,21 @@ class CurlSacAgent(object):
             L.log('train_critic/loss', ws.scalars[0], step)
         _mlp_bwd(ws.xa, 0, self.critic.twin(), self.critic.twin(grads=True), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.dq,
                  ws.q_dh2, ws.q_dh1, ws.dxa)
-        ops.split_sum(ws.dxa, B * (F + A), B, F, A, dz=ws.dz)
+        # (d(loss)/d(z) = dxa[0][:, :F] + dxa[1][:, :F], torch.cat's backward: summed inside the LayerNorm backward)
         # data parallel: the bucket is [convs | fc, ln | Q1 | Q2]; everything behind the convs is final before the
         # conv backward starts and is reduced underneath it
         lay = self._lay
         e0, total = lay["enc"][0], lay["total"]
         if self._dp_active and self._dp_overlap:
             cut = self._grad_offset(enc.fc.weight, self._critic_gflat)
-            self._encoder_backward(ws, o, ws.dz, ws.xhat_c, ws.rstd_c, enc, conv_grads=not self.detach_encoder,
-                                   dense_done=lambda: self._allreduce(self._critic_gflat[cut:total], async_op=True))
+            self._encoder_backward(ws, o, ws.dxa, ws.xhat_c, ws.rstd_c, enc, conv_grads=not self.detach_encoder,
+                                   dense_done=lambda: self._allreduce(self._critic_gflat[cut:total], async_op=True),
+                                   twin_ld=F + A)
             self._allreduce(self._critic_gflat[e0:cut], async_op=True)
             self._allreduce_wait()
         else:
-            self._encoder_backward(ws, o, ws.dz, ws.xhat_c, ws.rstd_c, enc, conv_grads=not self.detach_encoder)
+            self._encoder_backward(ws, o, ws.dxa, ws.xhat_c, ws.rstd_c, enc, conv_grads=not self.detach_encoder,
+                                   twin_ld=F + A)
             self._allreduce(self._critic_gflat[e0:total])
         if self.detach_encoder:  # convs received no gradient: Adam must skip them (grad None in the reference)
             saved = [(p, p.grad) for m in enc.convs for p in (m.weight, m.bias)]
@@ -722,8 +727,9 @@ class CurlSacAgent(object):
         # backward: Q -> pi -> trunk -> LN -> fc (encoder detached, curl_sac.py:375-376)
         _mlp_bwd(ws.xa, 0, self.critic.twin(), None, 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.dq, ws.q_dh2, ws.q_dh1,
                  ws.dxa)
-        ops.split_sum(ws.dxa, B * (F + A), B, F, A, dact=ws.gpi)
-        ops.actor_head_bwd(ws.gpi, self.log_alpha, 1.0 / B, nz, ws.pi, ws.log_std, ws.tanh_ls, B, A, lo, hi, ws.a_dout)
+        # d(loss)/d(pi) = the action columns of dxa summed over the twin, read in place
+        ops.actor_head_bwd(None, self.log_alpha, 1.0 / B, nz, ws.pi, ws.log_std, ws.tanh_ls, B, A, lo, hi, ws.a_dout,
+                           twin_dxa=ws.dxa, F=F)
         _mlp_bwd(ws.z_a, 0, trunk, _Mlp(self.actor.trunk, grads=True), 1, B, F, H, 2 * A, ws.a_h1, ws.a_h2, ws.a_dout,
                  ws.a_dh2, ws.a_dh1, ws.dz)
         overlap = self._dp_active and self._dp_overlap

@@ -145,10 +145,16 @@ def fc_ln_fwd(partial, nsplit, split_stride, ldp, bias, gamma, beta, B, F, y, fc
          ptr(fc_out), ptr(y), ptr(xhat), ptr(rstd), tanh_out, ptr(xa), ptr(act), A, stream())
 
 
-def ln_bwd(dy, xhat, rstd, gamma, B, F, dx, dgamma=None, dbeta=None, dbias_in=None):
-    """LayerNorm backward; ``dbias_in`` (optional) receives the column sums of dx (the fc bias gradient)."""
-    call("curla_ln_bwd", ptr(dy), ptr(xhat), ptr(rstd), ptr(gamma), B, F, ptr(dx), ptr(dgamma), ptr(dbeta),
-         ptr(dbias_in), stream())
+def ln_bwd(dy, xhat, rstd, gamma, B, F, dx, dgamma=None, dbeta=None, dbias_in=None, dy2=None, ld=None):
+    """LayerNorm backward; ``dbias_in`` (optional) receives the column sums of dx (the fc bias gradient).
+    The incoming gradient may be ``dy[:, :F] + dy2[:, :F]`` of two row blocks with row stride ``ld`` (the twin halves
+    of d(loss)/d[z | a], read in place)."""
+    if dy2 is None and ld in (None, F):
+        call("curla_ln_bwd", ptr(dy), ptr(xhat), ptr(rstd), ptr(gamma), B, F, ptr(dx), ptr(dgamma), ptr(dbeta),
+             ptr(dbias_in), stream())
+    else:
+        call("curla_ln_bwd_twin", ptr(dy), ptr(dy2), F if ld is None else ld, ptr(xhat), ptr(rstd), ptr(gamma), B, F,
+             ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dbias_in), stream())
 
 
 def colsum(X, M, N, ldx, sX, out, sOut, nb=1):
@@ -165,9 +171,17 @@ def actor_head_fwd(trunk_out, noise, B, A, lo, hi, mu=None, pi=None, log_pi=None
          ptr(tanh_ls), stream())
 
 
-def actor_head_bwd(gpi, log_alpha, glp_scale, noise, pi, log_std, tanh_ls, B, A, lo, hi, dtrunk_out, glp_rows=None):
-    call("curla_actor_head_bwd", ptr(gpi), ptr(glp_rows), ptr(log_alpha), glp_scale, ptr(noise), ptr(pi), ptr(log_std),
-         ptr(tanh_ls), B, A, lo, hi, ptr(dtrunk_out), stream())
+def actor_head_bwd(gpi, log_alpha, glp_scale, noise, pi, log_std, tanh_ls, B, A, lo, hi, dtrunk_out, glp_rows=None,
+                   twin_dxa=None, F=0):
+    """``twin_dxa`` [2, B, F + A] (instead of ``gpi``): d(loss)/d(action) is read in place as the sum over the twin
+    of the action columns of the Q-input gradient (torch.cat's backward, curl_sac.py:138)."""
+    if twin_dxa is not None:
+        base = ptr(twin_dxa) + 4 * F
+        g1, g2, ld = base, base + 4 * B * (F + A), F + A
+    else:
+        g1, g2, ld = ptr(gpi), None, A
+    call("curla_actor_head_bwd", g1, g2, ld, ptr(glp_rows), ptr(log_alpha), glp_scale, ptr(noise), ptr(pi),
+         ptr(log_std), ptr(tanh_ls), B, A, lo, hi, ptr(dtrunk_out), stream())
 
 
 def concat(z, act, B, F, A, xa):

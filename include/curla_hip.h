@@ -103,6 +103,12 @@ int curla_fc_ln_fwd(const float* partial, int nsplit, long long split_stride, in
  * the fc bias feeding the LayerNorm */
 int curla_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int F, float* dx,
                  float* dgamma, float* dbeta, float* dbias_in, void* stream);
+/* The same with the incoming gradient the sum of two strided row blocks dy[b*ld_dy + f] + dy2[b*ld_dy + f] (dy2 may
+ * be NULL): the two halves of the twin-Q input gradient [2][B][F + A], torch.cat's backward (curl_sac.py:138), read in
+ * place. */
+int curla_ln_bwd_twin(const float* dy, const float* dy2, int ld_dy, const float* xhat, const float* rstd,
+                      const float* gamma, int B, int F, float* dx, float* dgamma, float* dbeta, float* dbias_in,
+                      void* stream);
 /* out[z][n] = sum_m X[z][m][n] (bias gradients) */
 int curla_colsum(const float* X, int M, int N, int ldx, long long strideX, float* out, long long strideOut, int nbatch,
                  void* stream);
@@ -118,10 +124,13 @@ int curla_colsum3(const float* X0, int N0, const float* X1, int N1, const float*
 int curla_actor_head_fwd(const float* trunk_out, const float* noise, int B, int A, float log_std_min,
                          float log_std_max, float* mu, float* pi, float* log_pi, float* log_std, float* tanh_ls,
                          void* stream);
-/* gradient w.r.t. trunk_out of sum(gpi*pi) + glp*log_pi; glp = glp_rows[b] or glp_scale*exp(*log_alpha) */
-int curla_actor_head_bwd(const float* gpi, const float* glp_rows, const double* log_alpha, float glp_scale,
-                         const float* noise, const float* pi, const float* log_std, const float* tanh_ls, int B,
-                         int A, float log_std_min, float log_std_max, float* dtrunk_out, void* stream);
+/* gradient w.r.t. trunk_out of sum(gpi*pi) + glp*log_pi; glp = glp_rows[b] or glp_scale*exp(*log_alpha);
+ * gpi[b][a] is read at gpi[b*gpi_ld + a] (+ gpi2[b*gpi_ld + a] when gpi2 is not NULL: the action columns of the twin-Q
+ * input gradient summed over the twin in place) */
+int curla_actor_head_bwd(const float* gpi, const float* gpi2, int gpi_ld, const float* glp_rows, const double* log_alpha,
+                         float glp_scale, const float* noise, const float* pi, const float* log_std,
+                         const float* tanh_ls, int B, int A, float log_std_min, float log_std_max, float* dtrunk_out,
+                         void* stream);
 
 /* torch.cat([z, action], 1) (curl_sac.py:138) and its backward summed over the twin */
 int curla_concat(const float* z, const float* act, int B, int F, int A, float* xa, void* stream);

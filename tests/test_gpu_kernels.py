@@ -183,7 +183,7 @@ def test_gemm(ops, M, N, K, ak, bk, nb):
     check(f"gemm mask {M}x{N}x{K} ak{ak} bk{bk} nb{nb}", C2.cpu(), ref_plain * (mask > 0))
 
 
-@pytest.mark.parametrize("B,Fd,K", [(24, 50, 3456), (9, 130, 800), (5, 64, 288), (3, 256, 512)])
+@pytest.mark.parametrize("B,Fd,K", [(24, 50, 3456), (9, 130, 800), (5, 64, 288), (3, 256, 512), (515, 50, 64)])
 def test_gemm_splitk_and_fc_ln(ops, B, Fd, K):
     h, W, bias = rnd(B, K, seed=31), rnd(Fd, K, seed=32, scale=0.05), rnd(Fd, seed=33)
     gamma, beta = 1 + 0.1 * rnd(Fd, seed=34), 0.1 * rnd(Fd, seed=35)
@@ -215,6 +215,17 @@ def test_gemm_splitk_and_fc_ln(ops, B, Fd, K):
     fcl = fc.detach().clone().requires_grad_(True)
     (F.layer_norm(fcl, (Fd,), gamma, beta, 1e-5) * dy).sum().backward()
     check("layernorm dx", dx.cpu(), fcl.grad)
+    # the incoming gradient as the sum of two strided row blocks (the twin halves of the Q-input gradient
+    # [2][B][Fd + 3], torch.cat's backward, read in place)
+    half = rnd(2, B, Fd + 3, seed=39)
+    half[1, :, :Fd] = dy - half[0, :, :Fd]
+    twin = dev(half)
+    dx2, dg2, db2, dbin2 = (torch.full_like(t, float("nan")) for t in (dx, dg, db_, dbin))
+    ops.ln_bwd(twin[0], xhat, rstd, dev(gamma), B, Fd, dx2, dgamma=dg2, dbeta=db2, dbias_in=dbin2, dy2=twin[1], ld=Fd + 3)
+    check("twin ln_bwd dx", dx2.cpu(), fcl.grad, 2e-5)
+    check("twin ln_bwd dgamma", dg2.cpu(), gl.grad, 2e-5)
+    check("twin ln_bwd dbeta", db2.cpu(), betal.grad, 2e-5)
+    check("twin ln_bwd fc dbias", dbin2.cpu(), bl.grad, 2e-5)
     # fc backward through the helpers used by the agent
     dW = torch.empty(Fd, K, device="cuda")
     ops.linear_dw(dx, 0, dev(h), 0, dW, 0, B, Fd, K)
@@ -262,6 +273,14 @@ def test_actor_head(ops, B, A):
     dout = torch.empty(B, 2 * A, device="cuda")
     ops.actor_head_bwd(dev(gpi), dev(log_alpha), 1.0 / B, dev(noise), pi, ls, tl, B, A, lo, hi, dout)
     check(f"actor_head_bwd B{B}", dout.cpu(), out.grad)
+    # d(loss)/d(pi) read in place from the twin-Q input gradient [2][B][F + A] (action columns summed over the twin)
+    Fz = 5
+    dxa = rnd(2, B, Fz + A, seed=44)
+    dxa[1, :, Fz:] = gpi - dxa[0, :, Fz:]
+    dout2 = torch.full_like(dout, float("nan"))
+    ops.actor_head_bwd(None, dev(log_alpha), 1.0 / B, dev(noise), pi, ls, tl, B, A, lo, hi, dout2, twin_dxa=dev(dxa),
+                       F=Fz)
+    check(f"actor_head_bwd twin B{B}", dout2.cpu(), out.grad, 2e-5)
     # select_action form: no noise
     mu2 = torch.empty(B, A, device="cuda")
     ops.actor_head_fwd(dev(out.detach()), None, B, A, lo, hi, mu=mu2)
