@@ -897,7 +897,11 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(Wgrad1Args a) {
 }
 
 // first-layer weight gradient from the uint8 ring with the input band kept as bytes in LDS (see
-// conv1_fwd_u8_kernel); the gradient band stays float (pixel stride kLdsPix).
+// conv1_fwd_u8_kernel).  The gradient operand never enters LDS: lane (li, kq) of a k-step needs channels li and
+// 16 + li of ONE pixel, every pixel is needed by exactly one wave, and the 16 lanes of a group read 64 contiguous
+// bytes -- so each wave loads its own operand values from HBM/L2 one k-step ahead (the other three waves of the SIMD
+// cover the latency).  That removes three quarters of the staging volume (53 KB of gradients per 16 KB of bytes at
+// 84x84x9) and lets a workgroup take a whole crop as bytes.
 // NW waves per workgroup: 8 (two workgroups per CU) or 4 (four smaller ones: the stage -> barrier -> multiply ->
 // barrier phases of a workgroup do not overlap each other, so what covers a workgroup's staging is the number of
 // OTHER workgroups on its CU that are multiplying at that moment)
@@ -924,17 +928,15 @@ __global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
     koff[t] = (dy < 3) ? dy * RSb + rr : 0;
   }
   const int nitems = a.B * a.nbands;
-  const int in_bytes = ((2 * a.th + 1) * RSb + 15) & ~15;  // LDS byte offset of the gradient band
   uint8_t* ldsb = reinterpret_cast<uint8_t*>(lds);
-  float* ldsg = reinterpret_cast<float*>(ldsb + in_bytes);
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int band = item / a.B, b = item - band * a.B;
     const int y0 = band * a.th;
     const int tha = min(a.th, a.Ho - y0);
     conv1_stage_u8(ldsb, static_cast<const uint8_t*>(a.src), a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Wc, 2 * y0,
                    2 * tha + 1, RSb, tid, NTHR);
-    stage_band_f32(ldsg, a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32, tha * a.Wo * 8, tid, NTHR);
     __syncthreads();
+    const float* const gband = a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32 + li;  // the band's pixels are contiguous
     const int npix = tha * a.Wo;
     const int nunits = ((npix + 15) >> 4) << 2;
     // the lane's pixel p(u) = (u>>2)*16 + (u&3) + 4*kq advances by 4*NW per iteration: (ty, x) are kept
@@ -946,9 +948,10 @@ __global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
       const int p = (u >> 2) * 16 + (u & 3) + 4 * kq;
       const bool pv = (u < nunits) && (p < npix);
       const int cy = pv ? ty : 0, cx = pv ? x : 0;
-      const float* gp = ldsg + (cy * a.Wo + cx) * kLdsPix + li;
-      av[0] = pv ? gp[0] : 0.f;
-      av[1] = pv ? gp[16] : 0.f;
+      const float* gp = gband + (pv ? p : 0) * 32;
+      const float g0 = gp[0], g1 = gp[16];
+      av[0] = pv ? g0 : 0.f;
+      av[1] = pv ? g1 : 0.f;
       const uint8_t* ip = ldsb + 2 * cy * RSb + 2 * cx * C;
 #pragma unroll
       for (int t = 0; t < NT; ++t) bv[t] = (float)ip[koff[t]];
@@ -1368,7 +1371,7 @@ int curla_conv1_wgrad(const void* src, int src_kind, const int64_t* idx, const i
   if (src_kind == 1 && !(ABL_HOST & 256)) {
     // uint8 ring, input band kept as bytes: two 512-thread workgroups per CU (<= 76 KB of LDS each).
     const int RSb = ((Wc * C + 15) & ~15) + 16;
-    auto band_bytes = [&](int th) { return (size_t)(2 * th + 1) * RSb + (size_t)th * a.Wo * kLdsPix * sizeof(float); };
+    auto band_bytes = [&](int th) { return (size_t)(2 * th + 1) * RSb; };
     // (measured at 84x84x9, B = 512: 71.9 us with two 512-thread workgroups per CU, 77.4 us with four 256-thread ones:
     // the shorter bands' extra halo rows and slabs cost more than the finer interleaving buys)
     int nwaves = 8;
@@ -1378,7 +1381,7 @@ int curla_conv1_wgrad(const void* src, int src_kind, const int64_t* idx, const i
     while (th > 1 && band_bytes(th) > budget) --th;
     a.nbands = (a.Ho + th - 1) / th;
     a.th = (a.Ho + a.nbands - 1) / a.nbands;
-    size_t lds = (((size_t)(2 * a.th + 1) * RSb + 15) & ~(size_t)15) + (size_t)a.th * a.Wo * kLdsPix * sizeof(float) + 32;
+    size_t lds = (((size_t)(2 * a.th + 1) * RSb + 15) & ~(size_t)15) + 32;
     if (lds < (size_t)(nw + 32) * sizeof(float)) lds = (size_t)(nw + 32) * sizeof(float);
     const int nitems = B * a.nbands;
     const int per_cu = nwaves == 4 ? 4 : 2;
