@@ -27,6 +27,10 @@ constexpr int kMaxPf = 18;    // float4 staging registers per thread (band <= 25
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 
+// 128 bytes of zeros in HBM: where a lane with nothing to multiply points its operand load (a select on the loaded
+// VALUE would make the wave wait for the load right behind it instead of one or more k-steps later)
+__device__ float g_zero_px[32];
+
 // Timing-only ablations for tools/kbench.py (results are wrong when set); compiled out of the product library.
 #ifdef CURLA_ABLATE
 int g_ablate = 0;
@@ -656,49 +660,67 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) {
   f32x2 wt = {0, 0};  // winograd_bt_pk's temporary, live for the whole kernel (see common.h)
 
   const int PW = (a.Wo + 1) >> 1;  // pixel pairs per gradient row
+  const int qstep = 8 / PW, rstep = 8 - qstep * PW;
   const int nitems = a.B * a.nbands;
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int band = item / a.B, b = item - band * a.B;  // band-major: every workgroup sees every band size
     const int y0 = band * a.th;
     const int tha = min(a.th, a.Ho - y0);
-    // band = (tha+2) input rows followed by tha gradient rows, both contiguous in HBM
-    const int nin = (tha + 2) * a.Wi * 8, ng = tha * a.Wo * 8;
+    // band = (tha+2) input rows, contiguous in HBM.  The gradient rows are NOT staged: a lane's gradient operand is
+    // channel mt*16+li of the two pixels of its pair, every value is needed by exactly one wave, and the 16 lanes
+    // of a group read 64 contiguous bytes -- each wave loads them from HBM/L2 itself, three k-steps ahead.  The
+    // LDS then holds input rows only: bands of 13 rows instead of 6 at 37x37 (half the items, 12 % less halo).
+    const int nin = (tha + 2) * a.Wi * 8;
     {
       const float* pin = a.in + ((size_t)(b * a.Hi + y0) * a.Wi) * 32;
-      const float* pg = a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
       f32x4 pf[kMaxPf];
 #pragma unroll
       for (int u = 0; u < kMaxPf; ++u) {
         const int f = tid + u * 256;
         f32x4 v = {0, 0, 0, 0};
-        if (f < nin)
-          v = *reinterpret_cast<const f32x4*>(pin + (size_t)f * 4);
-        else if (f < nin + ng)
-          v = *reinterpret_cast<const f32x4*>(pg + (size_t)(f - nin) * 4);
+        if (f < nin) v = *reinterpret_cast<const f32x4*>(pin + (size_t)f * 4);
         pf[u] = v;
       }
 #pragma unroll
       for (int u = 0; u < kMaxPf; ++u) {
         const int f = tid + u * 256;
-        if (f < nin + ng) *reinterpret_cast<f32x4*>(lds + (f >> 3) * kLdsPix + (f & 7) * 4) = pf[u];
+        if (f < nin) *reinterpret_cast<f32x4*>(lds + (f >> 3) * kLdsPix + (f & 7) * 4) = pf[u];
       }
+      // the pixel behind the band: with an odd row length the last pair's window reaches one pixel past the last
+      // row; its product has a zero gradient factor, but 0 x (whatever LDS held) must not be NaN
+      if (tid < kLdsPix / 4) *reinterpret_cast<f32x4*>(lds + (tha + 2) * a.Wi * kLdsPix + tid * 4) = f32x4{0, 0, 0, 0};
     }
     __syncthreads();
 
     const int npairs = tha * PW;
-    const float* ldsg = lds + (tha + 2) * a.Wi * kLdsPix;
+    const float* const gband = a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32 + mt * 16 + li;
     const int nunits = ((npairs + 7) >> 3) << 1;  // 4 pairs per MFMA k-step, 2 k-steps per group of 8 pairs
-    // fetch() runs for u = uslot, uslot+2, ... in order; the lane's pair q(u) = (u>>1)*8 + (u&1) + 2*kq
-    // (pairs of a k-step are 2 apart = 4 pixels: the two lane groups of an LDS half hit disjoint banks)
-    // advances by 8 pairs per call, so (fy, fj) are kept incrementally
-    int fy = ((uslot & 1) + 2 * kq) / PW, fj = ((uslot & 1) + 2 * kq) - fy * PW;
-    auto fetch = [&](int u, float (&gv)[2], f32x2 (&dv)[3][4]) {
+    // This wave's k-steps are units u = uslot, uslot+2, ...; the lane's pair of unit u is q(u) = (u>>1)*8 + (u&1) + 2*kq
+    // (pairs of a k-step are 2 apart = 4 pixels: the two lane groups of an LDS half hit disjoint banks).  Both
+    // fetchers are called for consecutive k-steps in order and keep their pair's (row, column) incrementally
+    // (+8 pairs per call), each with its own copy because the gradient fetch runs ahead of the window fetch.
+    int gy = ((uslot & 1) + 2 * kq) / PW, gj = ((uslot & 1) + 2 * kq) - gy * PW;
+    int fy = gy, fj = gj;
+    auto advance = [&](int& y, int& j) {  // 8 pairs further = qstep rows + rstep pairs, at most one more wrap
+      j += rstep, y += qstep;
+      const bool wrap = j >= PW;
+      j = wrap ? j - PW : j;
+      y = wrap ? y + 1 : y;
+    };
+    auto gfetch = [&](int u, float (&gv)[2]) {
+      const int q = (u >> 1) * 8 + (u & 1) + 2 * kq;
+      const bool pv = (u < nunits) && (q < npairs);
+      const int x0 = 2 * gj;
+      const float* gp = gband + (gy * a.Wo + x0) * 32;
+      const bool second = pv && x0 + 1 < a.Wo;
+      gv[0] = *(pv ? gp : g_zero_px + li);  // (lanes past the band load a zero: no select on the loaded value)
+      gv[1] = *(second ? gp + 32 : g_zero_px + li);
+      advance(gy, gj);
+    };
+    auto dfetch = [&](int u, f32x2 (&dv)[3][4]) {
       const int q = (u >> 1) * 8 + (u & 1) + 2 * kq;
       const bool pv = (u < nunits) && (q < npairs);
       const int ty = pv ? fy : 0, x0 = pv ? 2 * fj : 0;
-      const float* gp = ldsg + (ty * a.Wo + x0) * kLdsPix + mt * 16 + li;
-      gv[0] = pv ? gp[0] : 0.f;
-      gv[1] = (pv && x0 + 1 < a.Wo) ? gp[kLdsPix] : 0.f;
       const float* ip = lds + (ty * a.Wi + x0) * kLdsPix + li;
 #pragma unroll
       for (int dy = 0; dy < 3; ++dy)
@@ -707,14 +729,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) {
           const float* qd = ip + (dy * a.Wi + c) * kLdsPix;
           dv[dy][c] = f32x2{qd[0], qd[16]};  // the two cin tiles of one window pixel (one ds_read2_b32)
         }
-      fj += 8;
-      if (PW >= 8) {  // wave-uniform: at most one row wrap per step, done without a divergent loop
-        const bool wrap = fj >= PW;
-        fj = wrap ? fj - PW : fj;
-        fy = wrap ? fy + 1 : fy;
-      } else {
-        while (fj >= PW) fj -= PW, ++fy;
-      }
+      advance(fy, fj);
     };
     auto mma = [&](const float (&gv)[2], f32x2 (&dv)[3][4]) {
       bsum += gv[0] + gv[1];
@@ -732,19 +747,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) {
         }
       }
     };
-    // software pipeline over this wave's k-steps (two register sets, no copies): the LDS reads of the
-    // next step are in flight while the 24 MFMAs of the current one issue
-    float gA[2], gB[2];
+    // software pipeline over this wave's k-steps: window reads (LDS) one step ahead in two register sets, gradient
+    // values (HBM/L2) three steps ahead in four; a k-step past the band multiplies zeros and is skipped
+    float g0[2], g1[2], g2[2], g3[2];
     f32x2 dA[3][4], dB[3][4];
-    fetch(uslot, gA, dA);
-    for (int u = uslot; u < nunits; u += 4) {
-      fetch(u + 2, gB, dB);
+    gfetch(uslot, g0), gfetch(uslot + 2, g1), gfetch(uslot + 4, g2);
+    dfetch(uslot, dA);
+    for (int u = uslot; u < nunits; u += 8) {
+      gfetch(u + 6, g3);
+      dfetch(u + 2, dB);
       __builtin_amdgcn_sched_barrier(0);
-      mma(gA, dA);
+      mma(g0, dA);
       __builtin_amdgcn_sched_barrier(0);
-      fetch(u + 4, gA, dA);
+      gfetch(u + 8, g0);
+      dfetch(u + 4, dA);
       __builtin_amdgcn_sched_barrier(0);
-      mma(gB, dB);
+      if (u + 2 < nunits) mma(g1, dB);
+      __builtin_amdgcn_sched_barrier(0);
+      gfetch(u + 10, g1);
+      dfetch(u + 6, dB);
+      __builtin_amdgcn_sched_barrier(0);
+      if (u + 4 < nunits) mma(g2, dA);
+      __builtin_amdgcn_sched_barrier(0);
+      gfetch(u + 12, g2);
+      dfetch(u + 8, dA);
+      __builtin_amdgcn_sched_barrier(0);
+      if (u + 6 < nunits) mma(g3, dB);
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
@@ -948,10 +976,9 @@ __global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
       const int p = (u >> 2) * 16 + (u & 3) + 4 * kq;
       const bool pv = (u < nunits) && (p < npix);
       const int cy = pv ? ty : 0, cx = pv ? x : 0;
-      const float* gp = gband + (pv ? p : 0) * 32;
-      const float g0 = gp[0], g1 = gp[16];
-      av[0] = pv ? g0 : 0.f;
-      av[1] = pv ? g1 : 0.f;
+      const float* gp = pv ? gband + p * 32 : g_zero_px;  // (a zero is loaded, not selected: see g_zero_px)
+      av[0] = gp[0];
+      av[1] = gp[16];
       const uint8_t* ip = ldsb + 2 * cy * RSb + 2 * cx * C;
 #pragma unroll
       for (int t = 0; t < NT; ++t) bv[t] = (float)ip[koff[t]];
@@ -1329,10 +1356,10 @@ int curla_conv3x3_s1_wgrad(const float* in, const float* g, float* dw, float* db
   WgradS1Args a;
   a.in = in, a.g = g, a.partial = workspace;
   a.B = B, a.Hi = Hi, a.Wi = Wi, a.Ho = Hi - 2, a.Wo = Wi - 2;
-  if ((a.Wo + 2) * 3 + a.Wo > kBandPx) return CURLA_ERR_UNSUPPORTED;
-  a.th = plan_band_s1(a.Ho, a.Wo, a.Wo, kBandPx, 8, 1, /*pairs=*/true);
+  if ((a.Wo + 2) * 3 > kBandPx) return CURLA_ERR_UNSUPPORTED;
+  a.th = plan_band_s1(a.Ho, a.Wo, 0, kBandPx, 8, 1, /*pairs=*/true);
   a.nbands = (a.Ho + a.th - 1) / a.th;
-  size_t lds = (size_t)((a.th + 2) * Wi + a.th * a.Wo) * kLdsPix * sizeof(float);
+  size_t lds = (size_t)((a.th + 2) * Wi + 1) * kLdsPix * sizeof(float);  // +1 pixel: 4th window pixel of the last pair
   if (lds < kPartialS1 * sizeof(float)) lds = kPartialS1 * sizeof(float);
   const int nitems = B * a.nbands;
   const int grid = nitems < 2 * curla_cu_count() ? nitems : 2 * curla_cu_count();
