@@ -10,6 +10,8 @@
 //   epilogue: + bias[n], ReLU, zero where mask[m][n] <= 0 (ReLU backward).
 // grid.z enumerates batch x split-K; a split writes its partial product to
 // C + split * split_stride and the caller reduces (deterministic order).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -273,6 +275,177 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// Backward of the encoder fc layer (encoder.py:98, z = fc(h), h = the NHWC-flattened conv output, K = 30752 columns at
+// 84x84): both products have ONE tiny dimension (F <= 64 features) and stream a [B][K] matrix of tens of MB once.
+// The generic kernel cuts them into 64 x 64 tiles of 2 k-tiles each -- thousands of short workgroups whose time is
+// prologue and epilogue.  Here a workgroup owns 64 columns for its whole life and nothing is staged in LDS: the big
+// operand is read with one float4 per lane whose four components are the column operands of four MFMA tiles
+// (column j of tile c is n0 + 4j + c), so that the four accumulators of a lane hold 4 CONSECUTIVE columns and every
+// wave store / mask load is 256 contiguous bytes per matrix row.
+//   fc_dx:  G[b][n] = (mask[b][n] > 0) * sum_f dz[b][f] W[f][n]     (ReLU mask of the last conv layer fused)
+//   fc_dw:  dW[f][n] = sum_b dz[b][f] x[b][n]
+// ---------------------------------------------------------------------------
+__device__ float g_zero16[16];  // where lanes past a reduction range point their operand load (see conv.hip g_zero_px)
+
+constexpr int kFcMaxSteps = 16;  // F <= 64
+
+struct FcBwdArgs {
+  const float* dz;    // [B][F]
+  const float* W;     // fc_dx: weight [F][K];  fc_dw: x [B][K]
+  const float* mask;  // fc_dx: [B][K] (may be NULL)
+  float* out;         // fc_dx: G [B][K];  fc_dw: dW [F][K]
+  int B, F, K;
+};
+
+template <int KS>  // KS = ceil(F / 4) k-steps
+__global__ __launch_bounds__(256, 2) void fc_dx_kernel(FcBwdArgs g) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * 64;
+  const int ncol = n0 + 4 * li;            // this lane's 4 columns (float4)
+  const bool cvalid = ncol + 3 < g.K;      // K % 4 == 0: a float4 is inside or outside as a whole
+  const int nc = cvalid ? ncol : n0;       // (columns past the edge re-read the first ones; their results are not stored)
+  // column operand: W[f = 4s + kq][nc .. nc+3] for every k-step, kept for the workgroup's whole life
+  f32x4 wv[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int f = 4 * s + kq;
+    wv[s] = *reinterpret_cast<const f32x4*>(g.W + (size_t)min(f, g.F - 1) * g.K + nc);
+  }
+  const int ntiles = (g.B + 15) >> 4;
+  // row operand of b-tile t: dz[16t + li][4s + kq]; features past F multiply a zero (loaded from the zero page)
+  auto load_dz = [&](int t, float (&dv)[KS]) {
+    const int b = min(16 * t + li, g.B - 1);
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int f = 4 * s + kq;
+      dv[s] = *(f < g.F ? g.dz + (size_t)b * g.F + f : g_zero16);
+    }
+  };
+  auto load_mask = [&](int t, f32x4 (&mk)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = min(16 * t + 4 * kq + r, g.B - 1);
+      mk[r] = g.mask ? *reinterpret_cast<const f32x4*>(g.mask + (size_t)b * g.K + nc) : f32x4{1.f, 1.f, 1.f, 1.f};
+    }
+  };
+  auto compute = [&](int t, const float (&dv)[KS], const f32x4 (&mk)[4]) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = mfma16(dv[s], wv[s][c], acc[c]);
+    // lane (li, kq): rows b = 16t + 4kq + r, columns nc + c
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = 16 * t + 4 * kq + r;
+      f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = mk[r][c] > 0.f ? v[c] : 0.f;
+      if (cvalid && b < g.B) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(g.out + (size_t)b * g.K + ncol));
+    }
+  };
+  // this wave's b-tiles: wave, wave + 4, ...; operands (and the mask) of the next tile are requested before the current
+  // one's MFMAs (a third register set in flight measured no faster: 39.4 against 37.5 us at B = 512, K = 30752)
+  float dA[KS], dB[KS];
+  f32x4 mA[4], mB[4];
+  int t = wave;
+  if (t < ntiles) {
+    load_dz(t, dA);
+    load_mask(t, mA);
+  }
+  for (; t < ntiles; t += 8) {
+    const int t1 = min(t + 4, ntiles - 1), t2 = min(t + 8, ntiles - 1);  // (past the end: re-read the last tile)
+    load_dz(t1, dB);
+    load_mask(t1, mB);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(t, dA, mA);
+    __builtin_amdgcn_sched_barrier(0);
+    load_dz(t2, dA);
+    load_mask(t2, mA);
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + 4 < ntiles) compute(t + 4, dB, mB);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int NT>  // NT = ceil(F / 16) feature tiles
+__global__ __launch_bounds__(256, 2) void fc_dw_kernel(FcBwdArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NT][4][64 lanes] float4
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * 64;
+  const int ncol = n0 + 4 * li;
+  const bool cvalid = ncol + 3 < g.K;
+  const int nc = cvalid ? ncol : n0;
+  const int nsteps = (g.B + 3) >> 2;  // k-steps of 4 rows b
+  const int s0 = (int)((long long)wave * nsteps / 4), s1 = (int)((long long)(wave + 1) * nsteps / 4);
+  f32x4 acc[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[t][c] = f32x4{0, 0, 0, 0};
+  // step s: rows b = 4s + kq.  Column operand: x[b][nc..nc+3]; row operand of feature tile t: dz[b][16t + li]
+  // (features past F: re-read feature F-1, those output rows are not stored; rows past B: zeros from the zero page)
+  auto fetch = [&](int s, f32x4& xv, float (&dv)[NT]) {
+    const int b = 4 * min(s, s1 - 1) + kq;
+    const bool bv = b < g.B;
+    xv = *reinterpret_cast<const f32x4*>(g.W + (size_t)min(b, g.B - 1) * g.K + nc);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      dv[t] = *(bv ? g.dz + (size_t)b * g.F + min(16 * t + li, g.F - 1) : g_zero16);
+  };
+  auto multiply = [&](const f32x4& xv, const float (&dv)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[t][c] = mfma16(dv[t], xv[c], acc[t][c]);
+  };
+  if (s1 > s0) {
+    // eight register sets: a k-step is 16 MFMAs (~0.4 us with the SIMD shared), an HBM round trip several times that
+    constexpr int D = 8;
+    f32x4 xr[D];
+    float dr[D][NT];
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) fetch(s0 + d, xr[d], dr[d]);
+    for (int s = s0; s < s1; s += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        fetch(s + d + D - 1, xr[(d + D - 1) % D], dr[(d + D - 1) % D]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + d < s1) multiply(xr[d], dr[d]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+  // sum over the four waves (b ranges) in wave order, then wave w writes feature tile(s) w, w+4, ...
+  f32x4* r4 = reinterpret_cast<f32x4*>(red);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r4[((wave * NT + t) * 4 + c) * 64 + lane] = acc[t][c];
+  __syncthreads();
+  for (int t = wave; t < NT; t += 4) {
+    f32x4 v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      v[c] = r4[((0 * NT + t) * 4 + c) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) v[c] += r4[((w * NT + t) * 4 + c) * 64 + lane];
+    }
+    // lane (li, kq): rows f = 16t + 4kq + r, columns nc + c
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 16 * t + 4 * kq + r;
+      const f32x4 o = {v[0][r], v[1][r], v[2][r], v[3][r]};
+      if (cvalid && f < g.F) *reinterpret_cast<f32x4*>(g.out + (size_t)f * g.K + ncol) = o;
+    }
+  }
+}
+
 // sum split-K partials: C[m][n] = sum_s P[s][m][n] (+bias, ReLU)
 __global__ void splitk_reduce_kernel(const float* P, int nsplit, long long sSplit, int M, int N, int ldp, float* C,
                                      int ldc, const float* bias, int relu) {
@@ -325,6 +498,15 @@ int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const f
   // instead of 128-B pieces of each HBM row and is faster even at one workgroup per CU
   if (tbn == 32 && M <= 64 && a_kmajor && b_kmajor && 2 * wgs64 >= cu2) tbn = 64;
   if (tbn == 32 && wgs6432 < cu2 && M > 32) tbm = 32;
+  {  // tuning aid (tools/gemm_shapes.py): CURLA_GEMM_TILE=6464|6432|3232 forces a tile shape
+    static const char* force = getenv("CURLA_GEMM_TILE");
+    if (force) {
+      const int v = atoi(force);
+      if (v == 6464) tbm = 64, tbn = 64;
+      if (v == 6432) tbm = 64, tbn = 32;
+      if (v == 3232) tbm = 32, tbn = 32;
+    }
+  }
   // interior + aligned everywhere: the k loop runs without bounds / alignment tests
   // (a k-major operand still needs whole tiles: its float4 runs along the rows)
   const bool fast = g.vecA && g.vecB && (K % BK == 0) && (g.kchunk % BK == 0) && (!a_kmajor || M % tbm == 0) &&
@@ -359,6 +541,58 @@ int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const f
 #undef CURLA_GEMM_LAUNCH3
 #undef CURLA_GEMM_LAUNCH2
 #undef CURLA_GEMM_LAUNCH
+  return curla_launch_status();
+}
+
+static int fc_bwd_check(const float* dz, const float* big, const float* out, int B, int F, int K) {
+  CURLA_REQUIRE(dz && big && out && B > 0 && F > 0 && K > 0);
+  if (F > 4 * kFcMaxSteps || (K % 4) != 0 || !aligned16(big) || !aligned16(out)) return CURLA_ERR_UNSUPPORTED;
+  return CURLA_OK;
+}
+
+int curla_fc_dx(const float* dz, const float* W, const float* mask, float* dx, int B, int F, int K, void* stream) {
+  int rc = fc_bwd_check(dz, W, dx, B, F, K);
+  if (rc != CURLA_OK) return rc;
+  if (mask && !aligned16(mask)) return CURLA_ERR_UNSUPPORTED;
+  FcBwdArgs g;
+  g.dz = dz, g.W = W, g.mask = mask, g.out = dx, g.B = B, g.F = F, g.K = K;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((K + 63) / 64);
+#define CURLA_FC_DX(KS) hipLaunchKernelGGL(fc_dx_kernel<KS>, grid, dim3(256), 0, st, g)
+  const int ks = (F + 3) / 4;
+  if (ks <= 4) CURLA_FC_DX(4);
+  else if (ks <= 8) CURLA_FC_DX(8);
+  else if (ks <= 13) CURLA_FC_DX(13);
+  else CURLA_FC_DX(16);
+#undef CURLA_FC_DX
+  return curla_launch_status();
+}
+
+int curla_fc_dw(const float* dz, const float* x, float* dW, int B, int F, int K, void* stream) {
+  int rc = fc_bwd_check(dz, x, dW, B, F, K);
+  if (rc != CURLA_OK) return rc;
+  FcBwdArgs g;
+  g.dz = dz, g.W = x, g.mask = nullptr, g.out = dW, g.B = B, g.F = F, g.K = K;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const dim3 grid((K + 63) / 64);
+  const int nt = (F + 15) / 16;
+  const size_t lds = (size_t)4 * nt * 4 * 64 * sizeof(f32x4);  // 16 KB per feature tile
+#define CURLA_FC_DW(NT)                                                                                               \
+  do {                                                                                                                \
+    static bool attr = false;                                                                                         \
+    if (!attr) {                                                                                                      \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(fc_dw_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)((size_t)4 * NT * 4 * 64 * sizeof(f32x4))) != hipSuccess)                           \
+        return CURLA_ERR_LAUNCH;                                                                                      \
+      attr = true;                                                                                                    \
+    }                                                                                                                 \
+    hipLaunchKernelGGL(fc_dw_kernel<NT>, grid, dim3(256), lds, st, g);                                                \
+  } while (0)
+  if (nt == 1) CURLA_FC_DW(1);
+  else if (nt == 2) CURLA_FC_DW(2);
+  else if (nt == 3) CURLA_FC_DW(3);
+  else CURLA_FC_DW(4);
+#undef CURLA_FC_DW
   return curla_launch_status();
 }
 

@@ -596,14 +596,20 @@ class CurlSacAgent(object):
         ops.ln_bwd(dy, xhat, rstd, enc.ln.weight, B, F, ws.dfc, dgamma=enc.ln.weight.grad, dbeta=enc.ln.bias.grad,
                    dbias_in=enc.fc.bias.grad, dy2=dy2, ld=twin_ld)
         h = acts[-1]
-        ops.linear_dw(ws.dfc, 0, h, 0, enc.fc.weight.grad, 0, B, F, K)
+        if ops.fc_bwd_streams(F, K):
+            ops.fc_dw(ws.dfc, h, enc.fc.weight.grad, B, F, K)
+        else:
+            ops.linear_dw(ws.dfc, 0, h, 0, enc.fc.weight.grad, 0, B, F, K)
         if dense_done is not None:
             dense_done()
         if not conv_grads:
             return
         cur = L % 2
         g = ws.gviews[cur][L - 1]
-        ops.linear_dx(ws.dfc, 0, enc.fc.weight, 0, g, 0, B, F, K, mask=h)
+        if ops.fc_bwd_streams(F, K):
+            ops.fc_dx(ws.dfc, enc.fc.weight, g, B, F, K, mask=h)
+        else:
+            ops.linear_dx(ws.dfc, 0, enc.fc.weight, 0, g, 0, B, F, K, mask=h)
         for layer in range(L, 1, -1):  # layer l: input acts[l-2], output acts[l-1]
             conv = enc.convs[layer - 1]
             ops.conv_s1_wgrad(acts[layer - 2], g, conv.weight.grad, conv.bias.grad, ws.wg_ws)
@@ -738,7 +744,10 @@ class CurlSacAgent(object):
             self._allreduce(self._actor_gflat[cut:], self.log_alpha.grad, async_op=True)
         ops.ln_bwd(ws.dz, ws.xhat_a, ws.rstd_a, aenc.ln.weight, B, F, ws.dfc, dgamma=aenc.ln.weight.grad,
                    dbeta=aenc.ln.bias.grad, dbias_in=aenc.fc.bias.grad)
-        ops.linear_dw(ws.dfc, 0, h, 0, aenc.fc.weight.grad, 0, B, F, enc.flat_dim)
+        if ops.fc_bwd_streams(F, enc.flat_dim):
+            ops.fc_dw(ws.dfc, h, aenc.fc.weight.grad, B, F, enc.flat_dim)
+        else:
+            ops.linear_dw(ws.dfc, 0, h, 0, aenc.fc.weight.grad, 0, B, F, enc.flat_dim)
 
         if overlap:
             self._allreduce(self._actor_gflat[:cut], async_op=True)

@@ -124,6 +124,21 @@ def linear_dw(dy, sdy, x, sx, out, so, M, N, K, nb=1):
     gemm(dy, 1, N, sdy, x, 1, K, sx, out, K, so, N, K, M, nb)
 
 
+def fc_bwd_streams(F_, K):
+    """True when the encoder-fc backward products take the streaming kernels (curla_fc_dx / curla_fc_dw)."""
+    return F_ <= 64 and K % 4 == 0
+
+
+def fc_dx(dz, W, out, B, F_, K, mask=None):
+    """out = (dz @ W) masked by ``mask`` > 0;  dz [B,F], W [F,K] (the encoder fc weight), out/mask [B,K]."""
+    call("curla_fc_dx", ptr(dz), ptr(W), ptr(mask), ptr(out), B, F_, K, stream())
+
+
+def fc_dw(dz, x, out, B, F_, K):
+    """out = dz^T @ x;  dz [B,F], x [B,K] -> out [F,K] (the encoder fc weight gradient)."""
+    call("curla_fc_dw", ptr(dz), ptr(x), ptr(out), B, F_, K, stream())
+
+
 def mlp_out_fwd(h, sh, W, sW, bias, sb, out, so, M, N, K, nb=1):
     """out[z] = h[z] @ W[z]^T + bias[z] for a last layer with N <= 16 outputs (one wave per row, no GEMM)."""
     call("curla_mlp_out_fwd", ptr(h), sh, ptr(W), sW, ptr(bias), sb, ptr(out), so, M, N, K, nb, stream())

@@ -80,6 +80,14 @@ int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const f
                const float* mask, int ldmask, long long strideMask, void* stream);
 int curla_splitk_reduce(const float* partial, int nsplit, long long split_stride, int M, int N, int ldp, float* C,
                         int ldc, const float* bias, int relu, void* stream);
+/* Backward of the encoder fc layer z = fc(h) (encoder.py:98; autograd of the reference's nn.Linear), F <= 64 features,
+ * K % 4 == 0 columns, 16-byte aligned matrices; CURLA_ERR_UNSUPPORTED otherwise (use curla_gemm):
+ *   curla_fc_dx: dx[b][n] = (mask == NULL || mask[b][n] > 0) * sum_f dz[b][f] W[f][n]   (W [F][K] as stored by
+ *                nn.Linear; mask = h, the ReLU output of the last conv layer: its backward fused in)
+ *   curla_fc_dw: dW[f][n] = sum_b dz[b][f] x[b][n]
+ * One workgroup per 64 columns, operands streamed from HBM/L2 straight into MFMA registers, 256-byte row pieces. */
+int curla_fc_dx(const float* dz, const float* W, const float* mask, float* dx, int B, int F, int K, void* stream);
+int curla_fc_dw(const float* dz, const float* x, float* dW, int B, int F, int K, void* stream);
 
 /* Last layer of the actor trunk / the Q functions (curl_sac.py:73-74, 132-133): hidden -> N outputs, N <= 16
  * (Q: 1, actor: 2|A|), batched over `nbatch` identically laid-out networks `stride*` floats apart.

@@ -569,3 +569,27 @@ def test_flat_adam_matches_torch_adam(betas):
     # padding between the slots never moves
     pad = 32 * 81 + 32 + 50 * 1203  # the (50, 1203) slot is 60150 floats + 2 of padding
     assert float(flat[pad:pad + 2].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("B,Fd,K", [(24, 50, 3456), (5, 50, 288), (3, 64, 512), (9, 13, 100), (515, 50, 196), (64, 7, 64),
+                                    (130, 33, 1028)])
+def test_fc_backward_streaming(ops, B, Fd, K):
+    """curla_fc_dx / curla_fc_dw (the encoder fc layer's backward products, streamed straight into MFMA registers)
+    against PyTorch: ragged batch, feature counts that are not multiples of 4 or 16, a last 64-column block that is
+    only partly there, with and without the ReLU mask."""
+    assert ops.fc_bwd_streams(Fd, K)
+    dz, W, x = rnd(B, Fd, seed=51), rnd(Fd, K, seed=52, scale=0.1), rnd(B, K, seed=53)
+    ref_dx = dz @ W
+    out = torch.full((B, K), float("nan"), device="cuda")
+    ops.fc_dx(dev(dz), dev(W), out, B, Fd, K, mask=dev(x))
+    check(f"fc_dx masked {B}x{Fd}x{K}", out.cpu(), ref_dx * (x > 0))
+    out2 = torch.full((B, K), float("nan"), device="cuda")
+    ops.fc_dx(dev(dz), dev(W), out2, B, Fd, K)
+    check(f"fc_dx {B}x{Fd}x{K}", out2.cpu(), ref_dx)
+    dW = torch.full((Fd, K), float("nan"), device="cuda")
+    ops.fc_dw(dev(dz), dev(x), dW, B, Fd, K)
+    check(f"fc_dw {B}x{Fd}x{K}", dW.cpu(), dz.t() @ x)
+    # the generic GEMM route gives the same numbers to rounding
+    dW2 = torch.empty(Fd, K, device="cuda")
+    ops.linear_dw(dev(dz), 0, dev(x), 0, dW2, 0, B, Fd, K)
+    check(f"fc_dw vs gemm {B}x{Fd}x{K}", dW.cpu(), dW2.cpu(), 2e-5)

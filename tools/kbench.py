@@ -155,6 +155,9 @@ def main():
                    timeit(lambda: ops.gemm(h, 0, K, 0, Wf, 0, K, 0, part, F, 0, B, F, K, 1, ksplit=ks, split_stride=B * F)), 2.0 * B * F * K)
         dz, dW, dh = r(B, F), torch.empty(F, K, device=dev), torch.empty(B, K, device=dev)
         report("fc dW (TN)", timeit(lambda: ops.linear_dw(dz, 0, h, 0, dW, 0, B, F, K)), 2.0 * B * F * K)
+        report("fc dW streaming", timeit(lambda: ops.fc_dw(dz, h, dW, B, F, K)), 2.0 * B * F * K)
+        WT = r(F, K)
+        report("fc dh streaming (+ mask)", timeit(lambda: ops.fc_dx(dz, WT, dh, B, F, K, mask=h)), 2.0 * B * F * K)
         report("fc dh (NN + mask)", timeit(lambda: ops.linear_dx(dz, 0, Wf, 0, dh, 0, B, F, K, mask=h)), 2.0 * B * F * K)
 
     if "misc" in args.what:
