@@ -247,7 +247,10 @@ class _Workspace:
         F, A, H, L = enc.feature_dim, agent.action_dim, agent.hidden_dim, enc.num_layers
         f = lambda *shape: torch.empty(shape, device=dev, dtype=torch.float32)  # noqa: E731
         shapes = [(B, h, w, enc.num_filters) for (h, w) in enc.layer_hw[1:]]
-        self.acts_main = [f(*s) for s in shapes]  # activations kept for a backward pass
+        # [obs | next_obs] activations of the critic phase's pass through the online convs (one launch per layer for
+        # both); the obs half doubles as the activations kept for a backward pass
+        self.acts_pair = [f(2 * s[0], *s[1:]) for s in shapes]
+        self.acts_main = [a[:B] for a in self.acts_pair]
         self.acts_tmp = [f(*s) for s in shapes]   # no-grad passes
         gmax = max(int(np.prod(s)) for s in shapes)
         self.gbuf = [f(gmax), f(gmax)]
@@ -642,8 +645,17 @@ class CurlSacAgent(object):
         action, reward, not_done = action.contiguous(), reward.contiguous(), not_done.contiguous()
 
         # -- target (no_grad block, curl_sac.py:350-355)
-        enc.conv_forward(no, ws.acts_tmp)                       # tied convs, online weights
-        self.actor.encoder.head_forward(ws.acts_tmp[-1], ws.z_a)
+        # obs and next_obs both go through the online convs (the actor's are tied to the critic's): when the buffer
+        # handed them over as one [obs | next_obs] handle they take ONE launch per layer (2B samples)
+        pair = getattr(o, "pair", None)
+        merged = pair is not None and pair[1] is no and pair[0].B == 2 * B
+        if merged:
+            enc.conv_forward(pair[0], ws.acts_pair)
+            h_next = ws.acts_pair[-1][B:]
+        else:
+            enc.conv_forward(no, ws.acts_tmp)                   # tied convs, online weights
+            h_next = ws.acts_tmp[-1]
+        self.actor.encoder.head_forward(h_next, ws.z_a)
         _mlp_fwd(ws.z_a, 0, _Mlp(self.actor.trunk), 1, B, F, H, 2 * A, ws.a_h1, ws.a_h2, ws.a_out)
         nz = self._noise(ws, noise)
         ops.actor_head_fwd(ws.a_out, nz, B, A, self.actor.log_std_min, self.actor.log_std_max, pi=ws.pi,
@@ -654,7 +666,8 @@ class CurlSacAgent(object):
         _mlp_fwd(ws.xa, 0, self.critic_target.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.tq)
 
         # -- current Q estimates + loss + backward (curl_sac.py:357-367)
-        enc.conv_forward(o, ws.acts_main)
+        if not merged:
+            enc.conv_forward(o, ws.acts_main)
         rec = self._records(step)
         enc.head_forward(ws.acts_main[-1], ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c, fc_out=ws.fc_out if rec else None,
                          xa=ws.xa, act=action)

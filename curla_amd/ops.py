@@ -25,10 +25,13 @@ class ObsRef:
     a float NCHW tensor in [0,255] (is_u8 = 0: the reference's tensor contract) or
     a float NHWC tensor (is_u8 = 2: output of the float augmentations)."""
 
-    __slots__ = ("src", "is_u8", "idx", "h1", "w1", "B", "C", "Hs", "Ws", "Hc", "Wc", "guard")
+    __slots__ = ("src", "is_u8", "idx", "h1", "w1", "B", "C", "Hs", "Ws", "Hc", "Wc", "guard", "pair")
 
     def __init__(self):
         self.guard = None
+        # (merged handle, second handle): this minibatch followed by ``second``'s as ONE handle of 2B observations
+        # (set by ReplayBuffer.sample_cpc_refs on obs for (obs | next_obs))
+        self.pair = None
 
     @staticmethod
     def from_ring(frames, idx, h1, w1, B, crop_hw, guard=None):

@@ -215,11 +215,24 @@ class ReplayBuffer(object):
             self._store = _FrameStore(self.frame_capacity, recent=2 * self._k + 2)
             self.obses = self.next_obses = None  # stacks are assembled per minibatch (stack(i) materialises one)
         else:
-            # ring storage: NHWC uint8 frames (+32 B slack: the aligning loader reads whole 16-byte runs plus a dword)
-            self._obs_store = torch.zeros(capacity * frame + 32, dtype=torch.uint8, device=dev)
-            self._next_store = torch.zeros(capacity * frame + 32, dtype=torch.uint8, device=dev)
-            self.obses = self._obs_store[:capacity * frame].view(capacity, h, w, c)
-            self.next_obses = self._next_store[:capacity * frame].view(capacity, h, w, c)
+            # ring storage: NHWC uint8 frames (+32 B slack: the aligning loader reads whole 16-byte runs plus a dword).
+            # Both rings live in ONE allocation, next_obs behind obs, so that slot i of next_obs is also frame
+            # capacity + i of a single [2 * capacity] ring: a minibatch's obs and next_obs can then be read by one
+            # first-layer launch (ObsRef.pair) -- both go through the same online conv weights in the critic phase.
+            # (only when the second half then starts on a dword, which the first-layer loader needs of a ring base)
+            self._both = None
+            if (capacity * frame) % 4 == 0:
+                self._ring_store = torch.zeros(2 * capacity * frame + 32, dtype=torch.uint8, device=dev)
+                self._obs_store = self._ring_store[:capacity * frame]
+                self._next_store = self._ring_store[capacity * frame:2 * capacity * frame]
+                self._both = self._ring_store[:2 * capacity * frame].view(2 * capacity, h, w, c)
+                self.obses = self._both[:capacity]
+                self.next_obses = self._both[capacity:]
+            else:
+                self._obs_store = torch.zeros(capacity * frame + 32, dtype=torch.uint8, device=dev)
+                self._next_store = torch.zeros(capacity * frame + 32, dtype=torch.uint8, device=dev)
+                self.obses = self._obs_store[:capacity * frame].view(capacity, h, w, c)
+                self.next_obses = self._next_store[:capacity * frame].view(capacity, h, w, c)
         # action | reward | not_done of a transition sit in one row, so add() writes them with one small copy;
         # the three reference attributes are column views of it
         self._n_act = A
@@ -250,7 +263,7 @@ class ReplayBuffer(object):
         # the host may run several updates ahead of the GPU: a small ring of pinned slots, each guarded by an
         # event, keeps an index upload's source intact until its async copy has executed
         self._n_slots, self._slot = 8, 0
-        nbytes = B * 8 + B * 4 * 6
+        nbytes = 2 * B * 8 + B * 4 * 6  # frame indices (obs | next_obs) + the six crop-offset rows
         self._h_index = torch.empty((self._n_slots, nbytes), dtype=torch.uint8, pin_memory=pin)
         self._slot_events = [None] * self._n_slots
         # every minibatch gets its own device index block (and, de-duplicated, its own assembled stacks), so the
@@ -260,7 +273,8 @@ class ReplayBuffer(object):
         self._sample_gen = [0] * self.N_SAMPLE_SLOTS
         self._sample_slot = -1
         if self.dedup_frames:
-            self._mb_store = torch.zeros((self.N_SAMPLE_SLOTS, 2, B * frame + 32), dtype=torch.uint8, device=dev)
+            # (obs stacks | next_obs stacks) of a minibatch, contiguous: also one [2B] ring for ObsRef.pair
+            self._mb_store = torch.zeros((self.N_SAMPLE_SLOTS, 2 * B * frame + 32), dtype=torch.uint8, device=dev)
 
     # ------------------------------------------------------------------ writing
     def _stage_scalars(self, row, action, reward, done):
@@ -409,12 +423,13 @@ class ReplayBuffer(object):
             raise NotImplementedError("unknown augmentation object: %r" % (self.augmentor,))
         return idxs, offs
 
-    def _float_augmented(self, ring, idx):
+    def _float_augmented(self, ring, idx, out=None):
         """One augmented float NHWC minibatch [B, H, W, C] from ``ring`` rows ``idx`` (None: rows 0..B-1)
         (utils.py:168-182 branch: the torch/kornia augmentations)."""
         B = self.batch_size
         c, h, w = self.obs_shape
-        out = torch.empty((B, h, w, c), dtype=torch.float32, device=self.device)
+        if out is None:
+            out = torch.empty((B, h, w, c), dtype=torch.float32, device=self.device)
         aug = self.augmentor
         if isinstance(aug, augmentations.ColorJiggle):
             params, order = aug.draw_params(B * (c // 3))
@@ -439,8 +454,15 @@ class ReplayBuffer(object):
         if self._slot_events[k] is not None:
             self._slot_events[k].synchronize()
         host = self._h_index[k]
-        host[:B * 8].view(torch.int64).copy_(torch.from_numpy(np.ascontiguousarray(idxs, dtype=np.int64)))
-        host[B * 8:].view(torch.int32).view(6, B).copy_(torch.from_numpy(np.ascontiguousarray(offs, dtype=np.int32)))
+        # device layout: idx [B] | idx + capacity [B] (the same transitions in the next_obs half of the double ring)
+        # | h1 of obs, next_obs, pos | w1 of obs, next_obs, pos -- so that (obs, next_obs) is ONE run of 2B frame
+        # indices, 2B row offsets and 2B column offsets
+        i64 = host[:2 * B * 8].view(torch.int64)
+        i64[:B].copy_(torch.from_numpy(np.ascontiguousarray(idxs, dtype=np.int64)))
+        i64[B:].copy_(i64[:B] + self.capacity)
+        o32 = host[2 * B * 8:].view(torch.int32).view(6, B)
+        offs = np.ascontiguousarray(offs, dtype=np.int32)
+        o32.copy_(torch.from_numpy(np.ascontiguousarray(offs[[0, 2, 4, 1, 3, 5]])))
         s = self._sample_slot = (self._sample_slot + 1) % self.N_SAMPLE_SLOTS
         self._sample_gen[s] += 1
         dst = self._d_index[s]
@@ -450,7 +472,12 @@ class ReplayBuffer(object):
             ev.record()
             self._slot_events[k] = ev
         guard = (self._sample_gen, s, self._sample_gen[s])
-        return guard, dst[:B * 8].view(torch.int64), dst[B * 8:].view(torch.int32).view(6, B)
+        d64 = dst[:2 * B * 8].view(torch.int64)
+        d32 = dst[2 * B * 8:].view(torch.int32)
+        # off[2j] / off[2j+1] = h1 / w1 of tensor j (obs, next_obs, pos) as before; pair = the 2B-long views
+        off = [d32[(j // 2 + 3 * (j % 2)) * B:(j // 2 + 3 * (j % 2) + 1) * B] for j in range(6)]
+        self._pair_views = (d64, d32[:2 * B], d32[3 * B:5 * B])
+        return guard, d64[:B], off
 
     def _scalars(self, d_idx):
         """actions [B, ...], rewards [B, 1], not_dones [B, 1] of the sampled transitions (utils.py:159-166): one
@@ -477,9 +504,11 @@ class ReplayBuffer(object):
         B = self.batch_size
         c, h, w = self.obs_shape
         mb = self._mb_store[self._sample_slot]
-        views = [mb[j, :B * self._frame].view(B, h, w, c) for j in range(2)]
+        both = mb[:2 * B * self._frame].view(2 * B, h, w, c)
+        views = [both[:B], both[B:]]
         for j in range(2):
             ops.gather_stacks(self.frames, self._fid[:, j, :], d_idx, B, views[j])
+        self._mb_both = both
         return views[0], views[1], None
 
     def sample_cpc_refs(self, indices=None):
@@ -495,14 +524,25 @@ class ReplayBuffer(object):
         crop = tuple(self.augmentor.output_shape)
         ring_o, ring_n, rows = self._sources(d_idx)
         if self._is_float_aug():
-            # obs, next_obs and pos (= a copy of obs) are augmented independently (utils.py:173-182)
-            obses = ops.ObsRef.from_nhwc(self._float_augmented(ring_o, rows))
-            next_obses = ops.ObsRef.from_nhwc(self._float_augmented(ring_n, rows))
+            # obs, next_obs and pos (= a copy of obs) are augmented independently (utils.py:173-182); obs and
+            # next_obs are written into the two halves of one [2B] tensor (ObsRef.pair, see below)
+            c, h, w = self.obs_shape
+            both = torch.empty((2 * B, h, w, c), dtype=torch.float32, device=self.device)
+            obses = ops.ObsRef.from_nhwc(self._float_augmented(ring_o, rows, out=both[:B]))
+            next_obses = ops.ObsRef.from_nhwc(self._float_augmented(ring_n, rows, out=both[B:]))
             pos = ops.ObsRef.from_nhwc(self._float_augmented(ring_o, rows))
+            obses.pair = (ops.ObsRef.from_nhwc(both), next_obses)
         else:
             obses = ops.ObsRef.from_ring(ring_o, rows, off[0], off[1], B, crop, guard)
             next_obses = ops.ObsRef.from_ring(ring_n, rows, off[2], off[3], B, crop, guard)
             pos = ops.ObsRef.from_ring(ring_o, rows, off[4], off[5], B, crop, guard)
+            # (obs | next_obs) as ONE minibatch of 2B frames: the critic phase runs both through the online convs,
+            # one launch per layer instead of two (curl_sac.py:350-358)
+            idx2, h2, w2 = self._pair_views
+            if self.dedup_frames:
+                obses.pair = (ops.ObsRef.from_ring(self._mb_both, None, h2, w2, 2 * B, crop, guard), next_obses)
+            elif self._both is not None:
+                obses.pair = (ops.ObsRef.from_ring(self._both, idx2, h2, w2, 2 * B, crop, guard), next_obses)
         actions, rewards, not_dones = self._scalars(d_idx)
         cpc_kwargs = dict(obs_anchor=obses, obs_pos=pos, time_anchor=None, time_pos=None)
         return obses, actions, rewards, next_obses, not_dones, cpc_kwargs

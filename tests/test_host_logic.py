@@ -198,11 +198,12 @@ def _filled_rb(aug, hw=(34, 40)):
 
 def test_update_schedule_launch_counts():
     """curl_sac.py:426-451 schedule, with the conv passes the build shares:
-    5 conv-stack forwards + 2 backwards on every step."""
+    5 conv-stack forwards + 2 backwards on every step -- the critic phase's obs and next_obs passes
+    through the online convs as ONE launch per layer over 2B samples (ObsRef.pair), i.e. 4 launch sequences."""
     agent, aug = tiny_agent()
     even, odd = _trace_updates(agent, _filled_rb(aug), [0, 1])
     for c in (even, odd):
-        assert c["curla_conv1_fwd"] == 5 and c["curla_conv3x3_s1_fwd"] == 15
+        assert c["curla_conv1_fwd"] == 4 and c["curla_conv3x3_s1_fwd"] == 12
         assert c["curla_conv1_wgrad"] == 2 and c["curla_conv3x3_s1_wgrad"] == 6 and c["curla_conv3x3_s1_dgrad"] == 6
         assert c["curla_curl_ce"] == 1 and c["curla_critic_td_loss"] == 1
     assert even["curla_actor_loss"] == 1 and odd["curla_actor_loss"] == 0       # actor_update_freq = 2
@@ -226,7 +227,7 @@ def test_update_schedule_pixel_sac():
     curla_amd.set_seed_everywhere(1)
     agent = curla_amd.CurlSacAgent((9, 34, 40), (2,), "cpu", aug, hidden_dim=64, pixel_sac=True, **HP)
     even, odd = _trace_updates(agent, _filled_rb(aug), [0, 1])
-    assert even["curla_conv1_fwd"] == 4 and odd["curla_conv1_fwd"] == 3
+    assert even["curla_conv1_fwd"] == 3 and odd["curla_conv1_fwd"] == 2  # (obs | next_obs) is one launch of 2B samples
     assert even["curla_conv1_wgrad"] == 1 and odd["curla_conv1_wgrad"] == 1
     assert even["curla_curl_ce"] == 0
 
