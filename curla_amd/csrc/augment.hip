@@ -11,11 +11,16 @@ namespace {
 
 constexpr float kTwoPi = 6.283185307179586f;
 
+// The colour-space round trips are the whole cost of the jitter kernel (VALU-bound: ~300 instructions per RGB pixel
+// with IEEE divisions and integer modulos), so divisions are reciprocal multiplies (v_rcp_f32, 1 ulp) and the sector
+// index uses the range the hue is known to be in; the differences to exact division are ~1e-7 relative.
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+
 __device__ __forceinline__ void rgb_to_hsv(float r, float g, float b, float& h, float& s, float& v) {
   const float mx = fmaxf(r, fmaxf(g, b)), mn = fminf(r, fminf(g, b));
   v = mx;
   float d = mx - mn;
-  s = d / (mx + 1e-8f);
+  s = fminf(d * rcp_fast(mx + 1e-8f), 1.f);  // (the reciprocal's last-bit error must not push s past 1: v(1-s) >= 0)
   if (d == 0.f) d = 1.f;
   const float rc = mx - r, gc = mx - g, bc = mx - b;
   float hh;
@@ -25,25 +30,21 @@ __device__ __forceinline__ void rgb_to_hsv(float r, float g, float b, float& h, 
     hh = (rc - bc) + 2.f * d;
   else
     hh = (gc - rc) + 4.f * d;
-  hh = hh / d / 6.f;
+  hh = hh * rcp_fast(d) * (1.f / 6.f);
   hh = hh - floorf(hh);  // python-style % 1
   h = kTwoPi * hh;
 }
 
+// h in [0, 2 pi] (what rgb_to_hsv and the hue shift below produce)
 __device__ __forceinline__ void hsv_to_rgb(float h, float s, float v, float& r, float& g, float& b) {
-  const float h6 = h / kTwoPi * 6.f;
-  const float fl = floorf(h6);
-  const int hi = ((int)fl % 6 + 6) % 6;
-  const float f = (h6 - 6.f * floorf(h6 / 6.f)) - (float)hi;
+  const float h6 = h * (6.f / kTwoPi);
+  // sector floor(h6) % 6; h6 == 6 (hue rounded up to 2 pi) is sector 5 with f = 1, the same colour as sector 0, f = 0
+  const int hi = min(max((int)h6, 0), 5);
+  const float f = h6 - (float)hi;
   const float p = v * (1.f - s), q = v * (1.f - f * s), t = v * (1.f - (1.f - f) * s);
-  switch (hi) {
-    case 0: r = v, g = t, b = p; break;
-    case 1: r = q, g = v, b = p; break;
-    case 2: r = p, g = v, b = t; break;
-    case 3: r = p, g = q, b = v; break;
-    case 4: r = t, g = p, b = v; break;
-    default: r = v, g = p, b = q; break;
-  }
+  r = (hi == 0 || hi == 5) ? v : (hi == 1) ? q : (hi == 4) ? t : p;
+  g = (hi == 1 || hi == 2) ? v : (hi == 0) ? t : (hi == 3) ? q : p;
+  b = (hi == 3 || hi == 4) ? v : (hi == 2) ? t : (hi == 5) ? q : p;
 }
 
 // One RGB pixel in [0,1] through the jitter chain.  p = (apply, contrast, saturation, hue_radians) of the pixel's
@@ -68,7 +69,8 @@ __device__ __forceinline__ void jiggle_rgb(float& r, float& g, float& bl, const 
       float h, s, v;
       rgb_to_hsv(r, g, bl, h, s, v);
       h = h + hue;
-      h = h - kTwoPi * floorf(h / kTwoPi);  // fmod into [0, 2pi)
+      h = h - kTwoPi * floorf(h * (1.f / kTwoPi));  // fmod into [0, 2pi)
+      h = fminf(fmaxf(h, 0.f), kTwoPi);
       hsv_to_rgb(h, s, v, r, g, bl);
     }
   }
@@ -90,7 +92,8 @@ __global__ void color_jiggle_kernel(const uint8_t* frames, const int64_t* idx, c
     const size_t yx = pix - (size_t)b * H * W;
     const int64_t fi = idx ? idx[b] : b;
     const uint8_t* src = frames + ((size_t)fi * H * W + yx) * C + 3 * fr;
-    float r = src[0] / 255.f, g = src[1] / 255.f, bl = src[2] / 255.f;  // `image_batch /= 255.0`, augmentations.py:118
+    constexpr float k255 = 1.f / 255.f;
+    float r = src[0] * k255, g = src[1] * k255, bl = src[2] * k255;  // `image_batch /= 255.0`, augmentations.py:118
     jiggle_rgb(r, g, bl, params + ((size_t)b * k + fr) * 4, o0, o1, o2, o3);
     float* dst = out + pix * C + 3 * fr;
     dst[0] = r * 255.f, dst[1] = g * 255.f, dst[2] = bl * 255.f;
@@ -111,7 +114,8 @@ __global__ void color_jiggle_nchw_kernel(const float* in, const float* params, c
     const size_t img = i / plane;  // b * k + frame
     const size_t yx = i - img * plane;
     const size_t base = img * 3 * plane + yx;
-    float r = in[base] / 255.f, g = in[base + plane] / 255.f, bl = in[base + 2 * plane] / 255.f;
+    constexpr float k255 = 1.f / 255.f;
+    float r = in[base] * k255, g = in[base + plane] * k255, bl = in[base + 2 * plane] * k255;
     jiggle_rgb(r, g, bl, params + img * 4, o0, o1, o2, o3);
     out[base] = r * 255.f, out[base + plane] = g * 255.f, out[base + 2 * plane] = bl * 255.f;
   }

@@ -732,9 +732,16 @@ def test_c5_update_vs_oracle_on_identical_post_augmentation_tensors(aug_name):
     assert len(grads) == 8 + 2 * layers + 8
     for k, v in ref_critic["grads"].items():
         check(f"{tag} critic grad {k}", grads[k], v)
+    # parameters after the three Adam steps a conv weight takes in one update (critic, encoder, cpc).  A first Adam
+    # step moves every element by lr * g / |g|, so an element whose gradient is zero to rounding may go the other
+    # way on the two sides (a 2 lr difference whatever the gradient's size): allow that on a handful of elements,
+    # nothing larger anywhere, and agreement to 1e-5 everywhere else
     sd = agent.critic.state_dict()
     for k in ("encoder.convs.0.weight", f"encoder.convs.{layers - 1}.weight"):
-        check(f"{tag} params after update {k}", sd[k].cpu(), oracle.critic[k].detach(), 1e-3)
+        d = (sd[k].cpu() - oracle.critic[k].detach()).abs()
+        REPORT.append((f"{tag} params after update {k} (max abs diff)", float(d.max())))
+        assert float(d.max()) <= 3 * 2 * 1e-3 + 1e-6, (k, float(d.max()))
+        assert float((d > 1e-5).float().mean()) <= 2e-3, (k, float((d > 1e-5).float().mean()))
 
 
 def test_full_size_c5_gradients_are_the_mean_over_shards():
