@@ -160,9 +160,8 @@ class CNNEncoder(nn.Module):
         return self
 
     # -- reference API ---------------------------------------------------------
-    def forward_conv(self, obs):
-        """Reference returns the NCHW-flattened features (encoder.py:77-90); this
-        returns the NHWC-flattened ones ([B, H*W*C]) that ``fc`` is laid out for."""
+    def _forward_conv_nhwc(self, obs):
+        """The conv stack on the kernels; returns (ObsRef, last activation [B, H, W, C])."""
         ref = obs if isinstance(obs, ops.ObsRef) else ops.ObsRef.from_tensor(obs.contiguous().float())
         ws = self.workspace(ref.B)
         self.conv_forward(ref, ws.acts)
@@ -171,12 +170,22 @@ class CNNEncoder(nn.Module):
                 out = torch.empty((a.shape[0], a.shape[3], a.shape[1], a.shape[2]), device=a.device, dtype=a.dtype)
                 ops.nhwc_to_nchw(a, out)
                 self.outputs["conv%s" % (i + 1)] = out
-        return ws.acts[-1].view(ref.B, -1)
+        return ref, ws.acts[-1]
+
+    def forward_conv(self, obs):
+        """encoder.py:77-90: the flattened conv features, in the reference's order -- ``conv.view(B, -1)`` of an NCHW
+        tensor, i.e. (c, y, x).  (The kernels keep activations NHWC; this public method transposes a copy.  The
+        learner never calls it: ``forward`` feeds ``fc``, whose columns are stored in (y, x, c) order, directly.)"""
+        ref, h = self._forward_conv_nhwc(obs)
+        out = torch.empty((h.shape[0], h.shape[3], h.shape[1], h.shape[2]), device=h.device, dtype=h.dtype)
+        ops.nhwc_to_nchw(h, out)
+        return out.view(ref.B, -1)
 
     def forward(self, obs, detach=False):
         """Inference forward (no autograd graph: training gradients are produced
         by CurlSacAgent's explicit backward kernels).  obs: float NCHW in [0,255]."""
-        h = self.forward_conv(obs)
+        ref, h = self._forward_conv_nhwc(obs)
+        h = h.view(ref.B, -1)
         z = torch.empty((h.shape[0], self.feature_dim), device=h.device, dtype=torch.float32)
         fc_out = torch.empty_like(z) if self.record_outputs else None
         self.head_forward(h, z, fc_out=fc_out)

@@ -224,6 +224,18 @@ def test_acting_path_vs_reference(tiny):
     x = _t(aug.evaluation_augmentation(g["act/obs"]).copy()).float()[None]
     z = agent.actor.encoder(x)
     assert z.shape == (1, 50)
+    # forward_conv keeps the reference's contract (encoder.py:77-90): conv.view(B, -1) of the NCHW tensor, and the
+    # reference-layout fc weight (state_dict order (c, y, x)) applied to it reproduces the features
+    enc = agent.actor.encoder
+    h = enc.forward_conv(x)
+    sd = enc.state_dict()
+    ref_conv = torch.relu(torch.nn.functional.conv2d(x.cpu() / 255.0, sd["convs.0.weight"].cpu(), sd["convs.0.bias"].cpu(), stride=2))
+    for i in range(1, enc.num_layers):
+        ref_conv = torch.relu(torch.nn.functional.conv2d(ref_conv, sd[f"convs.{i}.weight"].cpu(), sd[f"convs.{i}.bias"].cpu()))
+    check("forward_conv (reference flatten order)", h.cpu(), ref_conv.reshape(1, -1))
+    fc = torch.nn.functional.linear(h.cpu(), sd["fc.weight"].cpu(), sd["fc.bias"].cpu())
+    z_ref = torch.nn.functional.layer_norm(fc, (50,), sd["ln.weight"].cpu(), sd["ln.bias"].cpu())
+    check("encoder forward from forward_conv + reference-layout fc", z.cpu(), z_ref)
     q1, q2 = agent.critic(x, _t(np.zeros((1, 2), np.float32)))
     assert q1.shape == (1, 1) and q2.shape == (1, 1)
 
