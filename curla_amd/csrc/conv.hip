@@ -1092,6 +1092,52 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* partial
   }
 }
 
+// the same for up to kMaxReduceJobs weight gradients in ONE launch: the backward pass of an encoder leaves one slab set
+// per conv layer and nothing reads dW before the pass is over, so the per-layer reductions need not be launches of
+// their own (each would cost the 4.8 us launch floor for ~1 us of work)
+constexpr int kMaxReduceJobs = 8;
+struct ReduceJobs {
+  const float* partial[kMaxReduceJobs];
+  float* dw[kMaxReduceJobs];
+  float* db[kMaxReduceJobs];
+  int nslabs[kMaxReduceJobs], nw[kMaxReduceJobs], first_block[kMaxReduceJobs + 1];
+  int njobs;
+};
+
+__global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(ReduceJobs J) {
+  __shared__ float sm[32][33];
+  int j = 0;
+  while (j + 1 < J.njobs && (int)blockIdx.x >= J.first_block[j + 1]) ++j;
+  const float* partial = J.partial[j];
+  const int nslabs = J.nslabs[j], nw = J.nw[j];
+  const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int i = ((int)blockIdx.x - J.first_block[j]) * 32 + c;
+  const int n = nw + 32;
+  float s = 0.f;
+  if (i < n) {
+    int k = part;
+    for (; k + 7 * 32 < nslabs; k += 8 * 32) {  // 8 slabs in flight, added in slab order
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = partial[(size_t)(k + 32 * u) * n + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += t[u];
+    }
+    for (; k < nslabs; k += 32) s += partial[(size_t)k * n + i];
+  }
+  sm[part][c] = s;
+  __syncthreads();
+  if (part == 0 && i < n) {
+    float t = sm[0][c];
+#pragma unroll
+    for (int k = 1; k < 32; ++k) t += sm[k][c];
+    if (i < nw)
+      J.dw[j][i] = t;
+    else
+      J.db[j][i - nw] = t;
+  }
+}
+
 // ------------------------------ host-side planning ------------------------------
 constexpr int kMaxLds = 160 * 1024;
 constexpr int kBandPx = 567;  // pixels a band may hold: (567 + 1 slack) * 144 B = 79.9 KB of LDS -> 2 workgroups per CU
@@ -1348,9 +1394,9 @@ size_t curla_conv_wgrad_workspace_floats(int cin) {
   return (size_t)4 * curla_cu_count() * ((size_t)32 * cin * 9 + 32);  // at most four workgroups (slabs) per CU
 }
 
-int curla_conv3x3_s1_wgrad(const float* in, const float* g, float* dw, float* db, float* workspace, int B, int Hi,
-                           int Wi, int channels, void* stream) {
-  CURLA_REQUIRE(in && g && dw && db && workspace && B > 0 && Hi >= 3 && Wi >= 3);
+static int launch_wgrad_s1(const float* in, const float* g, float* workspace, int B, int Hi, int Wi, int channels,
+                           hipStream_t st, int* nslabs) {
+  CURLA_REQUIRE(in && g && workspace && B > 0 && Hi >= 3 && Wi >= 3);
   if (channels != 32) return CURLA_ERR_UNSUPPORTED;
   CURLA_REQUIRE(aligned16(in) && aligned16(g));
   WgradS1Args a;
@@ -1365,11 +1411,43 @@ int curla_conv3x3_s1_wgrad(const float* in, const float* g, float* dw, float* db
   const int grid = nitems < 2 * curla_cu_count() ? nitems : 2 * curla_cu_count();
   int rc = set_lds(wgrad_s1_kernel, lds);
   if (rc != CURLA_OK) return rc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(wgrad_s1_kernel, dim3(grid), dim3(256), lds, st, a);
-  if ((rc = curla_launch_status()) != CURLA_OK) return rc;
+  *nslabs = grid;
+  return curla_launch_status();
+}
+
+int curla_conv3x3_s1_wgrad(const float* in, const float* g, float* dw, float* db, float* workspace, int B, int Hi,
+                           int Wi, int channels, void* stream) {
+  CURLA_REQUIRE(dw && db);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int grid = 0;
+  int rc = launch_wgrad_s1(in, g, workspace, B, Hi, Wi, channels, st, &grid);
+  if (rc != CURLA_OK) return rc;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kPartialS1 + 31) / 32), dim3(1024), 0, st, workspace, grid, 32 * 288,
                      dw, db);
+  return curla_launch_status();
+}
+
+int curla_conv3x3_s1_wgrad_slabs(const float* in, const float* g, float* workspace, int B, int Hi, int Wi, int channels,
+                                 int* nslabs, void* stream) {
+  CURLA_REQUIRE(nslabs);
+  return launch_wgrad_s1(in, g, workspace, B, Hi, Wi, channels, static_cast<hipStream_t>(stream), nslabs);
+}
+
+int curla_wgrad_reduce_multi(int njobs, const float* const* slabs, const int* nslabs, const int* nw, float* const* dw,
+                             float* const* db, void* stream) {
+  CURLA_REQUIRE(njobs > 0 && njobs <= kMaxReduceJobs && slabs && nslabs && nw && dw && db);
+  ReduceJobs J;
+  int blocks = 0;
+  for (int j = 0; j < njobs; ++j) {
+    CURLA_REQUIRE(slabs[j] && dw[j] && db[j] && nslabs[j] > 0 && nw[j] > 0);
+    J.partial[j] = slabs[j], J.dw[j] = dw[j], J.db[j] = db[j], J.nslabs[j] = nslabs[j], J.nw[j] = nw[j];
+    J.first_block[j] = blocks;
+    blocks += (nw[j] + 32 + 31) / 32;
+  }
+  J.first_block[njobs] = blocks;
+  J.njobs = njobs;
+  hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(1024), 0, static_cast<hipStream_t>(stream), J);
   return curla_launch_status();
 }
 
@@ -1379,10 +1457,10 @@ int curla_conv3x3_s1_wgrad(const float* in, const float* g, float* dw, float* db
     if (rc == CURLA_OK) hipLaunchKernelGGL((wgrad1_kernel<SRC, CC>), dim3(grid), dim3(512), lds, st, a); \
   }
 
-int curla_conv1_wgrad(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1,
-                      const float* g, float* dw, float* db, float* workspace, int B, int C, int Hs, int Ws, int Hc,
-                      int Wc, int channels, float scale, void* stream) {
-  CURLA_REQUIRE(g && dw && db && workspace);
+static int launch_wgrad1(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1,
+                         const float* g, float* workspace, int B, int C, int Hs, int Ws, int Hc, int Wc, int channels,
+                         float scale, void* stream, int* nslabs) {
+  CURLA_REQUIRE(g && workspace);
   if (channels != 32) return CURLA_ERR_UNSUPPORTED;
   int rc = conv1_common_check(src, src_kind, B, C, Hs, Ws, Hc, Wc, h1, w1);
   if (rc != CURLA_OK) return rc;
@@ -1436,9 +1514,30 @@ int curla_conv1_wgrad(const void* src, int src_kind, const int64_t* idx, const i
     CURLA_DISPATCH_C(C, src_kind, WGRAD1_LAUNCH, grid, lds, st, a);
   }
   if (rc != CURLA_OK) return rc;
-  if ((rc = curla_launch_status()) != CURLA_OK) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nw + 32 + 31) / 32), dim3(1024), 0, st, workspace, grid, nw, dw, db);
+  *nslabs = grid;
   return curla_launch_status();
 }
+
+int curla_conv1_wgrad(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1,
+                      const float* g, float* dw, float* db, float* workspace, int B, int C, int Hs, int Ws, int Hc,
+                      int Wc, int channels, float scale, void* stream) {
+  CURLA_REQUIRE(dw && db);
+  int grid = 0;
+  int rc = launch_wgrad1(src, src_kind, idx, h1, w1, g, workspace, B, C, Hs, Ws, Hc, Wc, channels, scale, stream, &grid);
+  if (rc != CURLA_OK) return rc;
+  const int nw = 32 * C * 9;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nw + 32 + 31) / 32), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                     workspace, grid, nw, dw, db);
+  return curla_launch_status();
+}
+
+int curla_conv1_wgrad_slabs(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1,
+                            const float* g, float* workspace, int B, int C, int Hs, int Ws, int Hc, int Wc, int channels,
+                            float scale, int* nslabs, void* stream) {
+  CURLA_REQUIRE(nslabs);
+  return launch_wgrad1(src, src_kind, idx, h1, w1, g, workspace, B, C, Hs, Ws, Hc, Wc, channels, scale, stream, nslabs);
+}
+
+
 
 }  // extern "C"

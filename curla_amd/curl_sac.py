@@ -255,7 +255,9 @@ class _Workspace:
         gmax = max(int(np.prod(s)) for s in shapes)
         self.gbuf = [f(gmax), f(gmax)]
         self.gviews = [[g[:int(np.prod(s))].view(s) for s in shapes] for g in self.gbuf]
-        self.wg_ws = f(max(ops.wgrad_workspace_floats(32), ops.wgrad_workspace_floats(enc.obs_shape[0])))
+        # one slab workspace per conv layer: the layers' weight-gradient reductions run as ONE launch at the end of a
+        # backward pass (ops.wgrad_reduce_multi)
+        self.wg_ws = [f(ops.wgrad_workspace_floats(enc.obs_shape[0] if i == 0 else 32)) for i in range(L)]
         # features
         self.z_a, self.z_t, self.z_c, self.z_pos = f(B, F), f(B, F), f(B, F), f(B, F)
         self.xhat_c, self.rstd_c, self.xhat_a, self.rstd_a = f(B, F), f(B), f(B, F), f(B)
@@ -613,14 +615,19 @@ class CurlSacAgent(object):
             ops.fc_dx(ws.dfc, enc.fc.weight, g, B, F, K, mask=h)
         else:
             ops.linear_dx(ws.dfc, 0, enc.fc.weight, 0, g, 0, B, F, K, mask=h)
+        jobs = []
         for layer in range(L, 1, -1):  # layer l: input acts[l-2], output acts[l-1]
             conv = enc.convs[layer - 1]
-            ops.conv_s1_wgrad(acts[layer - 2], g, conv.weight.grad, conv.bias.grad, ws.wg_ws)
+            n = ops.conv_s1_wgrad_slabs(acts[layer - 2], g, ws.wg_ws[layer - 1])
+            jobs.append((ws.wg_ws[layer - 1], n, conv.weight.grad, conv.bias.grad))
             cur ^= 1
             gin = ws.gviews[cur][layer - 2]
             ops.conv_s1_dgrad(g, conv.weight, acts[layer - 2], gin)
             g = gin
-        ops.conv1_wgrad(obs_ref, g, enc.convs[0].weight.grad, enc.convs[0].bias.grad, ws.wg_ws)
+        n = ops.conv1_wgrad_slabs(obs_ref, g, ws.wg_ws[0], enc.num_filters)
+        jobs.append((ws.wg_ws[0], n, enc.convs[0].weight.grad, enc.convs[0].bias.grad))
+        for i in range(0, len(jobs), 8):
+            ops.wgrad_reduce_multi(jobs[i:i + 8])
 
     def _records(self, step):
         """True on the steps whose module outputs the optional histogram / image logging reads

@@ -100,6 +100,38 @@ def conv_s1_wgrad(x, g, dw, db, ws):
     call("curla_conv3x3_s1_wgrad", ptr(x), ptr(g), ptr(dw), ptr(db), ptr(ws), B, H, W, C, stream())
 
 
+def conv_s1_wgrad_slabs(x, g, ws):
+    """The weight-gradient kernel only: per-workgroup partial sums into ``ws``; returns the slab count."""
+    import ctypes
+    B, H, W, C = x.shape
+    n = ctypes.c_int(1)
+    call("curla_conv3x3_s1_wgrad_slabs", ptr(x), ptr(g), ptr(ws), B, H, W, C, ctypes.addressof(n), stream())
+    return n.value
+
+
+def conv1_wgrad_slabs(obs: ObsRef, g, ws, channels, scale=1.0 / 255.0):
+    import ctypes
+    obs.check()
+    n = ctypes.c_int(1)
+    call("curla_conv1_wgrad_slabs", ptr(obs.src), obs.is_u8, ptr(obs.idx), ptr(obs.h1), ptr(obs.w1), ptr(g), ptr(ws),
+         obs.B, obs.C, obs.Hs, obs.Ws, obs.Hc, obs.Wc, channels, scale, ctypes.addressof(n), stream())
+    return n.value
+
+
+def wgrad_reduce_multi(jobs):
+    """jobs: [(slabs workspace, slab count, dw, db), ...] (<= 8): every layer's slabs summed into dW / db in ONE launch."""
+    import ctypes
+    n = len(jobs)
+    P, I = ctypes.c_void_p * n, ctypes.c_int * n
+    slabs = P(*[ptr(j[0]) for j in jobs])
+    ns = I(*[int(j[1]) for j in jobs])
+    nw = I(*[int(j[2].numel()) for j in jobs])
+    dw = P(*[ptr(j[2]) for j in jobs])
+    db = P(*[ptr(j[3]) for j in jobs])
+    call("curla_wgrad_reduce_multi", n, ctypes.addressof(slabs), ctypes.addressof(ns), ctypes.addressof(nw),
+         ctypes.addressof(dw), ctypes.addressof(db), stream())
+
+
 def wgrad_workspace_floats(cin):
     if _lib._trace_hook is not None:
         return 512 * (32 * cin * 9 + 32)

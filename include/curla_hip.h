@@ -65,6 +65,18 @@ int curla_conv3x3_s1_wgrad(const float* in, const float* g, float* dw, float* db
 int curla_conv1_wgrad(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1,
                       const float* g, float* dw, float* db, float* workspace, int B, int C, int Hs, int Ws, int Hc,
                       int Wc, int channels, float scale, void* stream);
+/* The weight-gradient kernels alone: every workgroup leaves its partial sums as one slab in `workspace` (*nslabs of
+ * them, each 32*cin*9 + 32 floats) and nothing is reduced yet.  A backward pass runs one of these per conv layer, each
+ * into its own workspace, and ONE curla_wgrad_reduce_multi at the end sums all layers' slabs (fixed order) into their
+ * dW / db -- the per-layer reductions of curla_conv3x3_s1_wgrad / curla_conv1_wgrad would each be a launch of their
+ * own.  njobs <= 8; nw[j] = 32*cin*9 of job j. */
+int curla_conv3x3_s1_wgrad_slabs(const float* in, const float* g, float* workspace, int B, int Hi, int Wi, int channels,
+                                 int* nslabs, void* stream);
+int curla_conv1_wgrad_slabs(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1,
+                            const float* g, float* workspace, int B, int C, int Hs, int Ws, int Hc, int Wc, int channels,
+                            float scale, int* nslabs, void* stream);
+int curla_wgrad_reduce_multi(int njobs, const float* const* slabs, const int* nslabs, const int* nw, float* const* dw,
+                             float* const* db, void* stream);
 /* floats of `workspace` the two wgrad entry points need (per-workgroup partial slabs) */
 size_t curla_conv_wgrad_workspace_floats(int cin);
 

@@ -204,7 +204,8 @@ def test_update_schedule_launch_counts():
     even, odd = _trace_updates(agent, _filled_rb(aug), [0, 1])
     for c in (even, odd):
         assert c["curla_conv1_fwd"] == 4 and c["curla_conv3x3_s1_fwd"] == 12
-        assert c["curla_conv1_wgrad"] == 2 and c["curla_conv3x3_s1_wgrad"] == 6 and c["curla_conv3x3_s1_dgrad"] == 6
+        assert c["curla_conv1_wgrad_slabs"] == 2 and c["curla_conv3x3_s1_wgrad_slabs"] == 6
+        assert c["curla_conv3x3_s1_dgrad"] == 6 and c["curla_wgrad_reduce_multi"] == 2  # one reduction per backward pass
         assert c["curla_curl_ce"] == 1 and c["curla_critic_td_loss"] == 1
     assert even["curla_actor_loss"] == 1 and odd["curla_actor_loss"] == 0       # actor_update_freq = 2
     assert even["curla_soft_update2"] == 1 and odd["curla_soft_update2"] == 0   # critic_target_update_freq = 2
@@ -212,13 +213,13 @@ def test_update_schedule_launch_counts():
     # head, losses, bias-gradient sums, the scalar gather, the target lerp -- kept to about twenty per even update
     dense = ("curla_conv", "curla_gemm", "curla_mlp_out", "curla_fc_d")
     small = {k: v for k, v in even.items() if not k.startswith(dense)}
-    assert sum(small.values()) <= 20, small
+    assert sum(small.values()) <= 22, small
     assert even["curla_fc_dx"] == 2 and even["curla_fc_dw"] == 3 and even["curla_split_sum"] == 0
     assert even["curla_gemm"] <= 40 and even["curla_concat"] == 0 and even["curla_td_target"] == 0
     # only_cpc (train.py:425): no SAC phases
     (c,) = _trace_updates(agent, _filled_rb(aug), [2], only_cpc=True)
     assert c["curla_critic_td_loss"] == 0 and c["curla_actor_loss"] == 0 and c["curla_curl_ce"] == 1
-    assert c["curla_conv1_fwd"] == 2 and c["curla_conv1_wgrad"] == 1
+    assert c["curla_conv1_fwd"] == 2 and c["curla_conv1_wgrad_slabs"] == 1
 
 
 def test_update_schedule_pixel_sac():
@@ -228,7 +229,7 @@ def test_update_schedule_pixel_sac():
     agent = curla_amd.CurlSacAgent((9, 34, 40), (2,), "cpu", aug, hidden_dim=64, pixel_sac=True, **HP)
     even, odd = _trace_updates(agent, _filled_rb(aug), [0, 1])
     assert even["curla_conv1_fwd"] == 3 and odd["curla_conv1_fwd"] == 2  # (obs | next_obs) is one launch of 2B samples
-    assert even["curla_conv1_wgrad"] == 1 and odd["curla_conv1_wgrad"] == 1
+    assert even["curla_conv1_wgrad_slabs"] == 1 and odd["curla_conv1_wgrad_slabs"] == 1
     assert even["curla_curl_ce"] == 0
 
 

@@ -17,8 +17,8 @@ def short(n):
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 nlast = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-# an update starts at the index upload (__amd_rocclr_copyBuffer with a 1024-thread grid)
-starts = [i for i, r in enumerate(rows) if "copyBuffer" in r["Kernel_Name"] and r.get("Grid_Size_X") == "1024"]
+# an update starts at the gather of the sampled transitions' scalars (one launch per ReplayBuffer sample)
+starts = [i for i, r in enumerate(rows) if "gather_transition_scalars" in r["Kernel_Name"]]
 starts = starts[-(nlast + 1):]
 tot_busy = tot_gap = 0.0
 gap_by = collections.Counter()
