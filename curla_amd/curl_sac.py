@@ -467,14 +467,18 @@ class CurlSacAgent(object):
         CURLA_DP_CHECK_EVERY, 0 = never): a checksum of the replicated state is
         compared across ranks and a mismatch raises -- replicas that drift apart
         would otherwise train on silently.
-        ``overlap`` (default on, env CURLA_DP_OVERLAP=0 turns it off): each
+        ``overlap`` (default off, env CURLA_DP_OVERLAP=1 turns it on): each
         bucket is reduced in two asynchronous pieces issued where their
         gradients become final -- the twin-Q / fc / LayerNorm gradients (almost
         all of the bytes) before the conv backward starts, the conv gradients
         after it -- on the communicator's own stream; the compute stream only
         waits for them right before ``optimizer.step()``.  Off: one blocking
         all-reduce per bucket.  Both orders reduce the same elements with the
-        same collective, so the result does not depend on the flag.
+        same collective, so the result does not depend on the flag.  The default
+        follows the only measurement available so far (one GPU, one-rank RCCL
+        group): the asynchronous schedule costs 0.12 ms per update more than the
+        blocking one, like everything else that runs next to the persistent conv
+        grids (DESIGN.md sections 6, 7); flip it once an N-GPU run says otherwise.
         ``single_rank_collectives`` issues the collectives even in a world of one
         (a 1-GPU check of the exact calls an N-GPU run makes)."""
         import torch.distributed as dist
@@ -483,7 +487,7 @@ class CurlSacAgent(object):
         self._dp_active = self._dp_world > 1 or single_rank_collectives
         self._dp_avg = dist.get_backend(self._dp_group) == "nccl"
         if overlap is None:
-            overlap = os.environ.get("CURLA_DP_OVERLAP", "1") != "0"
+            overlap = os.environ.get("CURLA_DP_OVERLAP", "0") == "1"
         self._dp_overlap = bool(overlap)
         if check_every is None:
             check_every = int(os.environ.get("CURLA_DP_CHECK_EVERY", "1000"))
