@@ -36,13 +36,17 @@ static inline int curla_launch_status() {
   return e == hipSuccess ? CURLA_OK : CURLA_ERR_LAUNCH;
 }
 
+// compute units of the CURRENT device (cached per device id: a process may drive several GPUs)
 static inline int curla_cu_count() {
-  static int n = 0;
+  static int cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int n = cached[dev];
   if (n == 0) {
-    int dev = 0;
     hipDeviceProp_t p;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
     if (n <= 0) n = 256;
+    cached[dev] = n;
   }
   return n;
 }
