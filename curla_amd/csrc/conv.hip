@@ -395,39 +395,44 @@ __global__ __launch_bounds__(512) void conv1_fwd_kernel(Conv1Args a) {
   for (int mt = 0; mt < 2; ++mt) bias4[mt] = *reinterpret_cast<const f32x4*>(a.bias + mt * 16 + 4 * kq);
   __syncthreads();
 
-  const int item = blockIdx.x;
-  const int band = item / a.B, b = item - band * a.B;  // band-major: every workgroup sees every band size
-  const int y0 = band * a.th;
-  const int tha = min(a.th, a.Ho - y0);
-  conv1_stage<SRC>(lds, a.src, a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Hc, a.Wc, 2 * y0, 2 * tha + 1, RS, a.scale, tid,
-                   512);
-  __syncthreads();
+  // persistent: the weight registers above are built once per workgroup, not once per band (a band is ~2 us of
+  // tile work at 168x168x12 -- the per-band weight phase was a quarter of the kernel)
+  const int nitems = a.B * a.nbands;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int band = item / a.B, b = item - band * a.B;  // band-major: every workgroup sees every band size
+    const int y0 = band * a.th;
+    const int tha = min(a.th, a.Ho - y0);
+    conv1_stage<SRC>(lds, a.src, a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Hc, a.Wc, 2 * y0, 2 * tha + 1, RS, a.scale, tid,
+                     512);
+    __syncthreads();
 
-  const int npix = tha * a.Wo;
-  const int ntiles = (npix + 15) >> 4;
-  for (int t = wave; t < ntiles; t += 8) {
-    const int p = t * 16 + li;
-    const bool pv = p < npix;
-    const int pc = pv ? p : 0;
-    const int ty = pc / a.Wo, x = pc - ty * a.Wo;
-    const float* base = lds + 2 * ty * RS + 2 * x * C;
-    f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    const int npix = tha * a.Wo;
+    const int ntiles = (npix + 15) >> 4;
+    for (int t = wave; t < ntiles; t += 8) {
+      const int p = t * 16 + li;
+      const bool pv = p < npix;
+      const int pc = pv ? p : 0;
+      const int ty = pc / a.Wo, x = pc - ty * a.Wo;
+      const float* base = lds + 2 * ty * RS + 2 * x * C;
+      f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      const float bv = base[koff[s]];
-      acc[0] = mfma16(wr[s][0], bv, acc[0]);
-      acc[1] = mfma16(wr[s][1], bv, acc[1]);
-    }
-    if (pv) {
-      const size_t g = ((size_t)(b * a.Ho + y0 + ty) * a.Wo + x) * 32 + 4 * kq;
+      for (int s = 0; s < NS; ++s) {
+        const float bv = base[koff[s]];
+        acc[0] = mfma16(wr[s][0], bv, acc[0]);
+        acc[1] = mfma16(wr[s][1], bv, acc[1]);
+      }
+      if (pv) {
+        const size_t g = ((size_t)(b * a.Ho + y0 + ty) * a.Wo + x) * 32 + 4 * kq;
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        f32x4 v = acc[mt] + bias4[mt];
+        for (int mt = 0; mt < 2; ++mt) {
+          f32x4 v = acc[mt] + bias4[mt];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + g + mt * 16));
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + g + mt * 16));
+        }
       }
     }
+    __syncthreads();  // every wave is done with the band before the next one is staged over it
   }
 }
 
@@ -852,21 +857,16 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(Wgrad1Args a) {
   }
 
   const int nitems = a.B * a.nbands;
-  const int in_floats = (2 * a.th + 1) * RS;  // LDS offset of the gradient band
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int band = item / a.B, b = item - band * a.B;  // band-major: every workgroup sees every band size
     const int y0 = band * a.th;
     const int tha = min(a.th, a.Ho - y0);
     conv1_stage<SRC>(lds, a.src, a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Hc, a.Wc, 2 * y0, 2 * tha + 1, RS, a.scale,
                      tid, 512);
-    {
-      const float* pg = a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
-      const int ng = tha * a.Wo * 8;
-      for (int f = tid; f < ng; f += 512)
-        *reinterpret_cast<f32x4*>(lds + in_floats + (f >> 3) * kLdsPix + (f & 7) * 4) =
-            *reinterpret_cast<const f32x4*>(pg + (size_t)f * 4);
-    }
     __syncthreads();
+    // (the gradient operand is loaded from HBM/L2 straight into MFMA registers, as in wgrad1_u8_kernel: every pixel
+    // is needed by exactly one wave, and lanes with nothing to multiply read a zero page)
+    const float* const gband = a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32 + li;
     const int npix = tha * a.Wo;
     const int nunits = ((npix + 15) >> 4) << 2;
     for (int u = wave; u < nunits; u += 8) {
@@ -874,8 +874,8 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(Wgrad1Args a) {
       const bool pv = p < npix;
       const int pc = pv ? p : 0;
       const int ty = pc / a.Wo, x = pc - ty * a.Wo;
-      const float* gp = lds + in_floats + (ty * a.Wo + x) * kLdsPix + li;
-      const float a0 = pv ? gp[0] : 0.f, a1 = pv ? gp[16] : 0.f;
+      const float* gp = pv ? gband + p * 32 : g_zero_px;
+      const float a0 = gp[0], a1 = gp[16];
       bsum[0] += a0;
       bsum[1] += a1;
       const float* ip = lds + 2 * ty * RS + 2 * x * C;
@@ -1396,7 +1396,8 @@ int curla_conv1_fwd(const void* src, int src_kind, const int64_t* idx, const int
   const int RS = ((Wc * C + 3) & ~3) + 4;
   size_t lds = ((size_t)(2 * a.th + 1) * RS + 8) * sizeof(float);
   if (lds < wl) lds = wl;
-  const int grid = B * a.nbands;
+  const int nitems = B * a.nbands;
+  const int grid = nitems < 2 * curla_cu_count() ? nitems : 2 * curla_cu_count();
   CURLA_DISPATCH_C(C, src_kind, CONV1_FWD_LAUNCH, grid, lds, st, a);
   if (rc != CURLA_OK) return rc;
   return curla_launch_status();
@@ -1517,10 +1518,10 @@ static int launch_wgrad1(const void* src, int src_kind, const int64_t* idx, cons
     if (C == 9) WGRAD1_U8_LAUNCH(9) else if (C == 12) WGRAD1_U8_LAUNCH(12) else if (C == 6) WGRAD1_U8_LAUNCH(6) else WGRAD1_U8_LAUNCH(3)
 #undef WGRAD1_U8_LAUNCH
   } else {
-    a.th = plan_band_conv1(a.Ho, a.Wo, Wc, C, a.Wo, 150 * 1024);
+    a.th = plan_band_conv1(a.Ho, a.Wo, Wc, C, 0, 150 * 1024);  // input rows only, one workgroup per CU
     a.nbands = (a.Ho + a.th - 1) / a.th;
     const int RS = ((Wc * C + 3) & ~3) + 4;
-    size_t lds = ((size_t)(2 * a.th + 1) * RS + (size_t)a.th * a.Wo * kLdsPix + 8) * sizeof(float);
+    size_t lds = ((size_t)(2 * a.th + 1) * RS + 8) * sizeof(float);
     if (lds < (size_t)(nw + 32) * sizeof(float)) lds = (size_t)(nw + 32) * sizeof(float);
     const int nitems = B * a.nbands;
     grid = nitems < curla_cu_count() ? nitems : curla_cu_count();
