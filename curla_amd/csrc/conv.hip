@@ -52,6 +52,13 @@ struct ConvS1Args {
   int h1;  // height of band 0 (>= th; the other bands are th rows, the last one what is left)
   int qstep, rstep;  // 32 = qstep * PW + rstep, PW = pixel pairs per output row
   int dbg;
+  // forward only: a second problem of the same geometry with its own weights (B2 samples; 0 = none).  Its items
+  // follow the first problem's, so a workgroup re-builds its weight registers at most once.
+  const float* in2;
+  const float* w2;
+  const float* aux2;
+  float* out2;
+  int B2;
 };
 
 // ---------------------------------------------------------------------------
@@ -73,49 +80,56 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
   // wave pairs (2p, 2p+1) share pixel tiles.  k-step (q,e) of tap t covers
   // cin = 16q + 4kq' + e over the four lane groups kq'.
   const int mt = wave & 1, tslot = wave >> 1;
-  {
-    // 9216 weights = 2304 float4, 9 per thread, all in flight at once (OIHW rows are 288 floats = 72 float4)
-    f32x4 wv[9];
-#pragma unroll
-    for (int u = 0; u < 9; ++u) wv[u] = reinterpret_cast<const f32x4*>(a.w)[tid + u * 256];
-#pragma unroll
-    for (int u = 0; u < 9; ++u) {
-      const int i4 = tid + u * 256;
-      const int r = i4 / 72, c = (i4 - r * 72) * 4;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) lds[r * kWStride + c + e] = wv[u][e];
-    }
-  }
-  __syncthreads();
-  // 1-D Winograd F(2,3) along x: two adjacent outputs share one 4-pixel window and need 4 products
-  // per (row tap, cin) instead of 6.  Filter transform per row tap dy (g0,g1,g2 = the three x taps):
-  //   U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2
   float wu[3][4][8];
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int co = mt * 16 + li;
-      const int ci = 16 * (s >> 2) + 4 * kq + (s & 3);
-      float gx[3];
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const int t = dy * 3 + dx;
-        gx[dx] = (MODE == MODE_FWD) ? lds[co * kWStride + ci * 9 + t] : lds[ci * kWStride + co * 9 + (8 - t)];
-      }
-      wu[dy][0][s] = gx[0];
-      wu[dy][1][s] = 0.5f * (gx[0] + gx[1] + gx[2]);
-      wu[dy][2][s] = 0.5f * (gx[0] - gx[1] + gx[2]);
-      wu[dy][3][s] = gx[2];
-    }
   f32x4 bias4 = {0, 0, 0, 0};
-  if (MODE == MODE_FWD) bias4 = *reinterpret_cast<const f32x4*>(a.aux + mt * 16 + 4 * kq);
-  __syncthreads();
+  auto load_weights = [&](const float* wsrc, const float* aux) {
+    {
+      // 9216 weights = 2304 float4, 9 per thread, all in flight at once (OIHW rows are 288 floats = 72 float4)
+      f32x4 wv[9];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) wv[u] = reinterpret_cast<const f32x4*>(wsrc)[tid + u * 256];
+#pragma unroll
+      for (int u = 0; u < 9; ++u) {
+        const int i4 = tid + u * 256;
+        const int r = i4 / 72, c = (i4 - r * 72) * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) lds[r * kWStride + c + e] = wv[u][e];
+      }
+    }
+    __syncthreads();
+    // 1-D Winograd F(2,3) along x: two adjacent outputs share one 4-pixel window and need 4 products
+    // per (row tap, cin) instead of 6.  Filter transform per row tap dy (g0,g1,g2 = the three x taps):
+    //   U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int co = mt * 16 + li;
+        const int ci = 16 * (s >> 2) + 4 * kq + (s & 3);
+        float gx[3];
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const int t = dy * 3 + dx;
+          gx[dx] = (MODE == MODE_FWD) ? lds[co * kWStride + ci * 9 + t] : lds[ci * kWStride + co * 9 + (8 - t)];
+        }
+        wu[dy][0][s] = gx[0];
+        wu[dy][1][s] = 0.5f * (gx[0] + gx[1] + gx[2]);
+        wu[dy][2][s] = 0.5f * (gx[0] - gx[1] + gx[2]);
+        wu[dy][3][s] = gx[2];
+      }
+    if (MODE == MODE_FWD) bias4 = *reinterpret_cast<const f32x4*>(aux + mt * 16 + 4 * kq);
+    __syncthreads();
+  };
+  load_weights(a.w, a.aux);
 
   f32x2 wt = {0, 0};  // winograd_bt_pk's temporary, live for the whole kernel (see common.h)
-  const int nitems = a.B * a.nbands;
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const int band = item / a.B, b = item - band * a.B;  // band-major: every workgroup sees every band size
+  // The items of one problem, as a lambda so that the forward's optional second problem (its own weights) is a second
+  // loop after a weight reload, not a branch inside the loop (which costs the forward kernel 34 spilled registers).
+  auto run = [&](const float* in_base, const float* aux_base, float* out_base, int Bc, int item, int item_end,
+                 int item0) {
+  for (; item < item_end; item += gridDim.x) {
+    const int local = item - item0;
+    const int band = local / Bc, b = local - band * Bc;  // band-major: every workgroup sees every band size
     const int y0 = band == 0 ? 0 : a.h1 + (band - 1) * a.th;
     const int tha = band == 0 ? a.h1 : min(a.th, a.Ho - y0);
     // ---- stage the band: all loads in flight at once, then the LDS writes.  The
@@ -126,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
       f32x4 pf[kMaxPf];
       if (MODE == MODE_FWD) {
         // the band (tha+2 full rows) is one contiguous run of HBM: no index arithmetic
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.in + ((size_t)(b * a.Hs + y0) * a.Ws) * 32);
+        const f32x4* src = reinterpret_cast<const f32x4*>(in_base + ((size_t)(b * a.Hs + y0) * a.Ws) * 32);
 #pragma unroll
         for (int u = 0; u < kMaxPf; ++u) {
           const int f = tid + u * 256;
@@ -144,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
           f32x4 v = {0, 0, 0, 0};
           const int sy = y0 + r - a.pad, sx = c - a.pad;
           if (f < n4 && sy >= 0 && sy < a.Hs && sx >= 0 && sx < a.Ws && !(ABL(1) && item != (int)blockIdx.x))
-            v = *reinterpret_cast<const f32x4*>(a.in + ((size_t)(b * a.Hs + sy) * a.Ws + sx) * 32 + ch * 4);
+            v = *reinterpret_cast<const f32x4*>(in_base + ((size_t)(b * a.Hs + sy) * a.Ws + sx) * 32 + ch * 4);
           pf[u] = v;
           c += 32;
           if (WT >= 32) {  // wave-uniform: at most one row wrap per 32-pixel step
@@ -177,8 +191,8 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
     // MFMA of the current tile writes (a copy would wait for the pipe all the same).
     f32x4 accA[4], accB[4], pma = {0, 0, 0, 0}, pmb = {0, 0, 0, 0};
     // per-item (wave-uniform) base pointers: a tile only adds a 32-bit element offset
-    float* const out_item = a.out + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
-    const float* const aux_item = a.aux + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
+    float* const out_item = out_base + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
+    const float* const aux_item = aux_base + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
     int pg = 0;
     bool ppv = false, psecond = false;
     auto epilogue = [&](const f32x4 (&pacc)[4]) {
@@ -284,6 +298,16 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
       epilogue(accB);
     __syncthreads();
   }
+  };
+  const int nitems1 = a.B * a.nbands;
+  run(a.in, a.aux, a.out, a.B, blockIdx.x, nitems1, 0);
+  if (MODE == MODE_FWD && a.B2 > 0) {
+    // this workgroup's walk k, k+G, k+2G, ... over the concatenated item list continues in the second problem
+    const int G = gridDim.x;
+    const int first2 = blockIdx.x + G * ((nitems1 - (int)blockIdx.x + G - 1) / G);
+    load_weights(a.w2, a.aux2);
+    run(a.in2, a.aux2, a.out2, a.B2, first2, nitems1 + a.B2 * a.nbands, nitems1);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -304,6 +328,15 @@ struct Conv1Args {
   int B, C, Hs, Ws, Hc, Wc, Ho, Wo, th, nbands;
   float scale;
   int dbg;
+  // uint8 forward only: a second minibatch from the same ring with its own weights (B2 samples; 0 = none), whose
+  // workgroups follow the first one's in the same launch
+  const int64_t* idx2;
+  const int32_t* h1_2;
+  const int32_t* w1_2;
+  const float* w2;
+  const float* bias2;
+  float* out2;
+  int B2;
 };
 
 enum { SRC_U8 = 0, SRC_F32 = 1, SRC_NHWC = 2 };  // u8 ring / float NCHW tensor / float NHWC tensor
@@ -535,8 +568,13 @@ __global__ __launch_bounds__(512) void conv1_fwd_u8_kernel(Conv1Args a) {
   const int li = lane & 15, kq = lane >> 4;
   const int RSb = conv1_row_bytes(a.Wc, C);
 
-  const int item = blockIdx.x;
-  const int band = item / a.B, b = item - band * a.B;
+  // (two problems in one launch: the workgroups of the second minibatch follow the first's and take its weights)
+  const int nitems1 = a.B * a.nbands;
+  const bool second = (int)blockIdx.x >= nitems1;
+  const int item = second ? blockIdx.x - nitems1 : blockIdx.x;
+  const int Bc = second ? a.B2 : a.B;
+  if (second) a.idx = a.idx2, a.h1 = a.h1_2, a.w1 = a.w1_2, a.w = a.w2, a.bias = a.bias2, a.out = a.out2;
+  const int band = item / Bc, b = item - band * Bc;
   const int y0 = band * a.th;
   const int tha = min(a.th, a.Ho - y0);
   // the first staging pass (7 x 512 runs: a whole 76x76x9 crop) is issued before the weight phase, whose two
@@ -1237,9 +1275,11 @@ int set_lds(K kernel, size_t bytes) {
 }
 
 int launch_conv_s1(int mode, const float* in, const float* w, const float* aux, float* out, int B, int Hs, int Ws,
-                   hipStream_t st) {
+                   hipStream_t st, const float* in2 = nullptr, const float* w2 = nullptr, const float* aux2 = nullptr,
+                   float* out2 = nullptr, int B2 = 0) {
   ConvS1Args a;
   a.in = in, a.w = w, a.aux = aux, a.out = out;
+  a.in2 = in2, a.w2 = w2, a.aux2 = aux2, a.out2 = out2, a.B2 = B2;
   a.B = B, a.Hs = Hs, a.Ws = Ws;
   a.pad = mode == MODE_FWD ? 0 : 2;
   a.Ho = mode == MODE_FWD ? Hs - 2 : Hs + 2;
@@ -1252,7 +1292,7 @@ int launch_conv_s1(int mode, const float* in, const float* w, const float* aux, 
   size_t lds = ((size_t)(a.h1 + 2) * (a.Wo + 2) + 1) * kLdsPix * sizeof(float);  // +1 pixel: 4th window pixel of the last pair
   const size_t wl = (size_t)32 * kWStride * sizeof(float);
   if (lds < wl) lds = wl;
-  const int nitems = B * a.nbands;
+  const int nitems = (B + B2) * a.nbands;
   const int grid = nitems < 2 * curla_cu_count() ? nitems : 2 * curla_cu_count();
   int rc;
   if (mode == MODE_FWD) {
@@ -1301,6 +1341,16 @@ int curla_conv3x3_s1_fwd(const float* in, const float* w, const float* bias, flo
   if (channels != 32) return CURLA_ERR_UNSUPPORTED;
   CURLA_REQUIRE(aligned16(in) && aligned16(out) && aligned16(bias) && aligned16(w));
   return launch_conv_s1(MODE_FWD, in, w, bias, out, B, Hi, Wi, static_cast<hipStream_t>(stream));
+}
+
+int curla_conv3x3_s1_fwd2(const float* in, const float* w, const float* bias, float* out, int B, const float* in2,
+                          const float* w2, const float* bias2, float* out2, int B2, int Hi, int Wi, int channels,
+                          void* stream) {
+  CURLA_REQUIRE(in && w && bias && out && B > 0 && in2 && w2 && bias2 && out2 && B2 > 0 && Hi >= 3 && Wi >= 3);
+  if (channels != 32) return CURLA_ERR_UNSUPPORTED;
+  CURLA_REQUIRE(aligned16(in) && aligned16(out) && aligned16(bias) && aligned16(w));
+  CURLA_REQUIRE(aligned16(in2) && aligned16(out2) && aligned16(bias2) && aligned16(w2));
+  return launch_conv_s1(MODE_FWD, in, w, bias, out, B, Hi, Wi, static_cast<hipStream_t>(stream), in2, w2, bias2, out2, B2);
 }
 
 int curla_conv3x3_s1_dgrad(const float* g, const float* w, const float* act_below, float* gin, int B, int Ho, int Wo,
@@ -1354,9 +1404,19 @@ static int conv1_common_check(const void* src, int src_is_u8, int B, int C, int 
     if (rc == CURLA_OK) hipLaunchKernelGGL((conv1_fwd_kernel<SRC, CC>), dim3(grid), dim3(512), lds, st, a); \
   }
 
-int curla_conv1_fwd(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1,
-                    const float* w, const float* bias, float* out, int B, int C, int Hs, int Ws, int Hc, int Wc,
-                    int channels, float scale, void* stream) {
+struct Conv1Second {
+  const int64_t* idx;
+  const int32_t* h1;
+  const int32_t* w1;
+  const float* w;
+  const float* bias;
+  float* out;
+  int B;
+};
+
+static int conv1_fwd_impl(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1,
+                          const float* w, const float* bias, float* out, int B, int C, int Hs, int Ws, int Hc, int Wc,
+                          int channels, float scale, void* stream, const Conv1Second* second) {
   CURLA_REQUIRE(w && bias && out);
   if (channels != 32) return CURLA_ERR_UNSUPPORTED;
   int rc = conv1_common_check(src, src_kind, B, C, Hs, Ws, Hc, Wc, h1, w1);
@@ -1367,8 +1427,12 @@ int curla_conv1_fwd(const void* src, int src_kind, const int64_t* idx, const int
   a.Ho = (Hc - 3) / 2 + 1, a.Wo = (Wc - 3) / 2 + 1;
   a.scale = scale;
   a.dbg = ABL_HOST;
+  a.idx2 = second ? second->idx : nullptr, a.h1_2 = second ? second->h1 : nullptr, a.w1_2 = second ? second->w1 : nullptr;
+  a.w2 = second ? second->w : nullptr, a.bias2 = second ? second->bias : nullptr, a.out2 = second ? second->out : nullptr;
+  a.B2 = second ? second->B : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t wl = (size_t)32 * C * 9 * sizeof(float);
+  if (second && src_kind != 1) return CURLA_ERR_UNSUPPORTED;
   if (src_kind == 1 && !(ABL_HOST & 128)) {
     // uint8 ring: the band stays bytes in LDS; the tallest band that leaves room for two workgroups per CU
     const int RSb = ((Wc * C + 15) & ~15) + 16;
@@ -1379,7 +1443,7 @@ int curla_conv1_fwd(const void* src, int src_kind, const int64_t* idx, const int
     size_t lds = (size_t)(2 * a.th + 1) * RSb + 32;
     const size_t wl8 = (size_t)3 * ((3 * C + 3) & ~3) * 32 * sizeof(float);  // the kernel's k-major weight image
     if (lds < wl8) lds = wl8;
-    const int grid = B * a.nbands;
+    const int grid = (B + a.B2) * a.nbands;
 #define CONV1_U8_LAUNCH(CC)                                                                                 \
   {                                                                                                         \
     rc = set_lds(conv1_fwd_u8_kernel<CC>, lds);                                                             \
@@ -1401,6 +1465,21 @@ int curla_conv1_fwd(const void* src, int src_kind, const int64_t* idx, const int
   CURLA_DISPATCH_C(C, src_kind, CONV1_FWD_LAUNCH, grid, lds, st, a);
   if (rc != CURLA_OK) return rc;
   return curla_launch_status();
+}
+
+int curla_conv1_fwd(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1,
+                    const float* w, const float* bias, float* out, int B, int C, int Hs, int Ws, int Hc, int Wc,
+                    int channels, float scale, void* stream) {
+  return conv1_fwd_impl(src, src_kind, idx, h1, w1, w, bias, out, B, C, Hs, Ws, Hc, Wc, channels, scale, stream, nullptr);
+}
+
+int curla_conv1_fwd2(const uint8_t* ring, const int64_t* idx, const int32_t* h1, const int32_t* w1, const float* w,
+                     const float* bias, float* out, int B, const int64_t* idx2, const int32_t* h1_2,
+                     const int32_t* w1_2, const float* w2, const float* bias2, float* out2, int B2, int C, int Hs, int Ws,
+                     int Hc, int Wc, int channels, float scale, void* stream) {
+  CURLA_REQUIRE(w2 && bias2 && out2 && B2 > 0);
+  Conv1Second sec{idx2, h1_2, w1_2, w2, bias2, out2, B2};
+  return conv1_fwd_impl(ring, 1, idx, h1, w1, w, bias, out, B, C, Hs, Ws, Hc, Wc, channels, scale, stream, &sec);
 }
 
 // workspace (floats) the weight-gradient kernels need for their per-workgroup slabs

@@ -374,6 +374,8 @@ class CurlSacAgent(object):
 
         self._workspaces = {}
         self._anchor_cache = None
+        self._pos_cache = None   # the obs_pos handle whose target-encoder activations sit in the workspace
+        self._pos_hint = None    # set by update(): the positives the actor phase may encode along the way
         self._dp_group = None
         self._dp_world = 1
         self._dp_active = False
@@ -652,7 +654,7 @@ class CurlSacAgent(object):
         B, A, H = o.B, self.action_dim, self.hidden_dim
         enc, F = self.critic.encoder, self.critic.encoder.feature_dim
         ws = self._ws(B)
-        self._anchor_cache = None
+        self._anchor_cache = self._pos_cache = None
         action, reward, not_done = action.contiguous(), reward.contiguous(), not_done.contiguous()
 
         # -- target (no_grad block, curl_sac.py:350-355)
@@ -660,8 +662,10 @@ class CurlSacAgent(object):
         # handed them over as one [obs | next_obs] handle they take ONE launch per layer (2B samples)
         pair = getattr(o, "pair", None)
         merged = pair is not None and pair[1] is no and pair[0].B == 2 * B
+        tenc = self.critic_target.encoder
         if merged:
-            enc.conv_forward(pair[0], ws.acts_pair)
+            # ... and the target encoder's pass over next_obs rides in the same launches (second problem, own weights)
+            enc.conv_forward2(pair[0], ws.acts_pair, tenc, no, ws.acts_tmp)
             h_next = ws.acts_pair[-1][B:]
         else:
             enc.conv_forward(no, ws.acts_tmp)                   # tied convs, online weights
@@ -671,8 +675,8 @@ class CurlSacAgent(object):
         nz = self._noise(ws, noise)
         ops.actor_head_fwd(ws.a_out, nz, B, A, self.actor.log_std_min, self.actor.log_std_max, pi=ws.pi,
                            log_pi=ws.log_pi)
-        tenc = self.critic_target.encoder
-        tenc.conv_forward(no, ws.acts_tmp)
+        if not merged:
+            tenc.conv_forward(no, ws.acts_tmp)
         tenc.head_forward(ws.acts_tmp[-1], ws.z_t, xa=ws.xa, act=ws.pi)  # xa = cat([z, a'], 1)
         _mlp_fwd(ws.xa, 0, self.critic_target.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.tq)
 
@@ -730,8 +734,16 @@ class CurlSacAgent(object):
         enc, aenc, F = self.critic.encoder, self.actor.encoder, self.critic.encoder.feature_dim
         ws = self._ws(B)
 
-        # one conv pass feeds actor.fc, critic.fc and (even steps) the CURL anchor branch
-        enc.conv_forward(o, ws.acts_main)
+        # one conv pass feeds actor.fc, critic.fc and (even steps) the CURL anchor branch; when update() knows that the
+        # CURL phase follows with unchanged target weights, the target encoder's pass over the positives rides in the
+        # same launches (second problem) and update_cpc finds its activations ready
+        pos = self._pos_hint
+        self._pos_hint = None
+        if pos is not None:
+            enc.conv_forward2(o, ws.acts_main, self.critic_target.encoder, pos, ws.acts_tmp)
+            self._pos_cache = pos
+        else:
+            enc.conv_forward(o, ws.acts_main)
         h = ws.acts_main[-1]
         aenc.head_forward(h, ws.z_a, xhat=ws.xhat_a, rstd=ws.rstd_a)
         self._anchor_cache = obs
@@ -792,11 +804,17 @@ class CurlSacAgent(object):
         B = oa.B
         enc, tenc, F = self.critic.encoder, self.critic_target.encoder, self.critic.encoder.feature_dim
         ws = self._ws(B)
-        if self._anchor_cache is None or self._anchor_cache is not obs_anchor:
+        need_anchor = self._anchor_cache is None or self._anchor_cache is not obs_anchor
+        need_pos = self._pos_cache is None or self._pos_cache is not obs_pos
+        self._anchor_cache = self._pos_cache = None
+        if need_anchor and need_pos:   # (odd steps) both passes in one launch per layer, own weights each
+            enc.conv_forward2(oa, ws.acts_main, tenc, op_, ws.acts_tmp)
+        elif need_anchor:
             enc.conv_forward(oa, ws.acts_main)
+        elif need_pos:
+            tenc.conv_forward(op_, ws.acts_tmp)
+        if need_anchor:
             enc.head_forward(ws.acts_main[-1], ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c)
-        self._anchor_cache = None
-        tenc.conv_forward(op_, ws.acts_tmp)
         tenc.head_forward(ws.acts_tmp[-1], ws.z_pos)
 
         W = self.CURL.W
@@ -848,17 +866,24 @@ class CurlSacAgent(object):
             ops.mean(reward.contiguous(), reward.numel(), ws.scalars[6:7])
             L.log('train/batch_reward', ws.scalars[6], step)
 
+        do_cpc = (not self.pixel_sac) and step % self.cpc_update_freq == 0
         if not only_cpc:
             self.update_critic(obs, action, reward, next_obs, not_done, L, step)
-            if step % self.actor_update_freq == 0:
-                self.update_actor_and_alpha(obs, L, step)
+            # The target soft update reads the critic's parameters, which the actor phase does not touch (it steps the
+            # actor's own tensors and log_alpha): applied BEFORE the actor phase it gives the same numbers as after
+            # it (curl_sac.py:437-445), and the target encoder is then final when the actor phase encodes obs -- so
+            # the positives' target pass can share those launches.
             if step % self.critic_target_update_freq == 0:
                 self.soft_update_targets()
+            if step % self.actor_update_freq == 0:
+                if do_cpc and isinstance(cpc_kwargs.get("obs_pos"), ObsRef):
+                    self._pos_hint = cpc_kwargs["obs_pos"]
+                self.update_actor_and_alpha(obs, L, step)
+                self._pos_hint = None
 
-        if not self.pixel_sac:
-            if step % self.cpc_update_freq == 0:
-                obs_anchor, obs_pos = cpc_kwargs["obs_anchor"], cpc_kwargs["obs_pos"]
-                self.update_cpc(obs_anchor, obs_pos, cpc_kwargs, L, step)
+        if do_cpc:
+            obs_anchor, obs_pos = cpc_kwargs["obs_anchor"], cpc_kwargs["obs_pos"]
+            self.update_cpc(obs_anchor, obs_pos, cpc_kwargs, L, step)
 
     def save(self, model_dir, augmentation, step):
         """curl_sac.py:453-456 (same three files, reference tensor layouts)."""

@@ -136,6 +136,24 @@ class CNNEncoder(nn.Module):
             ops.conv_s1_fwd(acts[i - 1], cp[i][0], cp[i][1], acts[i])
         return acts[-1]
 
+    def conv_forward2(self, obs_ref, acts, other, other_ref, other_acts):
+        """This encoder's conv stack on ``obs_ref`` and ``other``'s (another CNNEncoder of the same geometry, its own
+        weights) on ``other_ref``, one launch per layer for both when the kernels can (uint8 handles into one ring);
+        otherwise one after the other."""
+        cp, cp2 = self.conv_params(), other.conv_params()
+        if self.num_layers != other.num_layers or acts[0].shape[1:] != other_acts[0].shape[1:]:
+            self.conv_forward(obs_ref, acts)
+            other.conv_forward(other_ref, other_acts)
+            return
+        if ops.conv1_pairable(obs_ref, other_ref):
+            ops.conv1_fwd2(obs_ref, cp[0][0], cp[0][1], acts[0], other_ref, cp2[0][0], cp2[0][1], other_acts[0])
+        else:  # (float sources, or handles into different rings: the first layer runs twice)
+            ops.conv1_fwd(obs_ref, cp[0][0], cp[0][1], acts[0])
+            ops.conv1_fwd(other_ref, cp2[0][0], cp2[0][1], other_acts[0])
+        for i in range(1, self.num_layers):
+            ops.conv_s1_fwd2(acts[i - 1], cp[i][0], cp[i][1], acts[i], other_acts[i - 1], cp2[i][0], cp2[i][1],
+                             other_acts[i])
+
     def head_forward(self, h, z, fc_out=None, xhat=None, rstd=None, xa=None, act=None):
         """fc + LayerNorm (+tanh) on the NHWC-flattened conv output (encoder.py:98-107).  ``xa`` / ``act``: the
         LayerNorm kernel also writes the Q functions' input rows [z | act] (torch.cat, curl_sac.py:138)."""

@@ -90,6 +90,27 @@ def conv_s1_fwd(x, w, b, out):
     call("curla_conv3x3_s1_fwd", ptr(x), ptr(w), ptr(b), ptr(out), B, H, W, C, stream())
 
 
+def conv_s1_fwd2(x, w, b, out, x2, w2, b2, out2):
+    """Two forwards of the same geometry (own weights each) in one launch."""
+    B, H, W, C = x.shape
+    assert x2.shape[1:] == x.shape[1:]
+    call("curla_conv3x3_s1_fwd2", ptr(x), ptr(w), ptr(b), ptr(out), B, ptr(x2), ptr(w2), ptr(b2), ptr(out2), x2.shape[0],
+         H, W, C, stream())
+
+
+def conv1_pairable(o1: "ObsRef", o2: "ObsRef"):
+    """Can the first-layer forwards of two handles share a launch?  Both uint8, from the same ring, same crop."""
+    return (o1.is_u8 == 1 and o2.is_u8 == 1 and o1.src.data_ptr() == o2.src.data_ptr() and o1.src.shape == o2.src.shape
+            and (o1.Hc, o1.Wc) == (o2.Hc, o2.Wc))
+
+
+def conv1_fwd2(o1: "ObsRef", w, b, out, o2: "ObsRef", w2, b2, out2, scale=1.0 / 255.0):
+    o1.check(), o2.check()
+    call("curla_conv1_fwd2", ptr(o1.src), ptr(o1.idx), ptr(o1.h1), ptr(o1.w1), ptr(w), ptr(b), ptr(out), o1.B, ptr(o2.idx),
+         ptr(o2.h1), ptr(o2.w1), ptr(w2), ptr(b2), ptr(out2), o2.B, o1.C, o1.Hs, o1.Ws, o1.Hc, o1.Wc, w.shape[0], scale,
+         stream())
+
+
 def conv_s1_dgrad(g, w, act_below, gin):
     B, H, W, C = g.shape
     call("curla_conv3x3_s1_dgrad", ptr(g), ptr(w), ptr(act_below), ptr(gin), B, H, W, C, stream())

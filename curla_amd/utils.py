@@ -533,16 +533,25 @@ class ReplayBuffer(object):
             pos = ops.ObsRef.from_nhwc(self._float_augmented(ring_o, rows))
             obses.pair = (ops.ObsRef.from_nhwc(both), next_obses)
         else:
-            obses = ops.ObsRef.from_ring(ring_o, rows, off[0], off[1], B, crop, guard)
-            next_obses = ops.ObsRef.from_ring(ring_n, rows, off[2], off[3], B, crop, guard)
-            pos = ops.ObsRef.from_ring(ring_o, rows, off[4], off[5], B, crop, guard)
-            # (obs | next_obs) as ONE minibatch of 2B frames: the critic phase runs both through the online convs,
-            # one launch per layer instead of two (curl_sac.py:350-358)
             idx2, h2, w2 = self._pair_views
-            if self.dedup_frames:
-                obses.pair = (ops.ObsRef.from_ring(self._mb_both, None, h2, w2, 2 * B, crop, guard), next_obses)
-            elif self._both is not None:
-                obses.pair = (ops.ObsRef.from_ring(self._both, idx2, h2, w2, 2 * B, crop, guard), next_obses)
+            both = self._mb_both if self.dedup_frames else self._both
+            if both is None:  # (rings in two allocations: second half would not start on a dword)
+                obses = ops.ObsRef.from_ring(ring_o, rows, off[0], off[1], B, crop, guard)
+                next_obses = ops.ObsRef.from_ring(ring_n, rows, off[2], off[3], B, crop, guard)
+                pos = ops.ObsRef.from_ring(ring_o, rows, off[4], off[5], B, crop, guard)
+            else:
+                # every handle indexes the ONE ring that holds obs frames then next_obs frames, so that any two of
+                # them can share a first-layer launch (ops.conv1_fwd2), and (obs | next_obs) is itself a handle of
+                # 2B frames: the critic phase runs both through the online convs in one launch per layer
+                # (curl_sac.py:350-358)
+                if self.dedup_frames:
+                    if getattr(self, "_ar2", None) is None:
+                        self._ar2 = torch.arange(2 * B, device=self.device, dtype=torch.int64)
+                    idx2 = self._ar2
+                obses = ops.ObsRef.from_ring(both, idx2[:B], off[0], off[1], B, crop, guard)
+                next_obses = ops.ObsRef.from_ring(both, idx2[B:], off[2], off[3], B, crop, guard)
+                pos = ops.ObsRef.from_ring(both, idx2[:B], off[4], off[5], B, crop, guard)
+                obses.pair = (ops.ObsRef.from_ring(both, idx2, h2, w2, 2 * B, crop, guard), next_obses)
         actions, rewards, not_dones = self._scalars(d_idx)
         cpc_kwargs = dict(obs_anchor=obses, obs_pos=pos, time_anchor=None, time_pos=None)
         return obses, actions, rewards, next_obses, not_dones, cpc_kwargs

@@ -49,10 +49,22 @@ const char* curla_version(void);
 int curla_conv1_fwd(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1,
                     const float* w, const float* bias, float* out, int B, int C, int Hs, int Ws, int Hc, int Wc,
                     int channels, float scale, void* stream);
+/* The same for the first layer, both minibatches gathered from one uint8 ring (src_kind 1 of curla_conv1_fwd). */
+int curla_conv1_fwd2(const uint8_t* ring, const int64_t* idx, const int32_t* h1, const int32_t* w1, const float* w,
+                     const float* bias, float* out, int B, const int64_t* idx2, const int32_t* h1_2,
+                     const int32_t* w1_2, const float* w2, const float* bias2, float* out2, int B2, int C, int Hs, int Ws,
+                     int Hc, int Wc, int channels, float scale, void* stream);
 
 /* Layers 2..L: 3x3 stride 1, 32 -> 32, + bias + ReLU (encoder.py:59-63,84-87). */
 int curla_conv3x3_s1_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Hi, int Wi,
                          int channels, void* stream);
+/* Two forwards of the same geometry in ONE launch, each with its own weights (e.g. a minibatch through the online
+ * encoder and another through the target encoder, curl_sac.py:350-358, 408-409): the second problem's items follow the
+ * first's in the persistent grid and a workgroup re-builds its weight registers once.  A launch carries 4-9 us of
+ * fixed cost at these sizes, so two 512-sample launches are slower than one of 1024. */
+int curla_conv3x3_s1_fwd2(const float* in, const float* w, const float* bias, float* out, int B, const float* in2,
+                          const float* w2, const float* bias2, float* out2, int B2, int Hi, int Wi, int channels,
+                          void* stream);
 
 /* Autograd of the above (what critic_loss.backward() / loss.backward() run,
  * curl_sac.py:366,417).  `g` is the gradient w.r.t. the layer's pre-activation

@@ -593,3 +593,42 @@ def test_fc_backward_streaming(ops, B, Fd, K):
     dW2 = torch.empty(Fd, K, device="cuda")
     ops.linear_dw(dev(dz), 0, dev(x), 0, dW2, 0, B, Fd, K)
     check(f"fc_dw vs gemm {B}x{Fd}x{K}", dW.cpu(), dW2.cpu(), 2e-5)
+
+
+@pytest.mark.parametrize("B1,B2,H,W", [(5, 3, 13, 16), (2, 7, 37, 37), (600, 300, 9, 9), (1, 1, 35, 35)])
+def test_conv_s1_fwd_two_problems(ops, B1, B2, H, W):
+    """curla_conv3x3_s1_fwd2: two minibatches, each with its own weights, in one launch -- bit-identical to the two
+    single launches (a workgroup walks into the second problem and re-builds its weight registers there)."""
+    x1, x2 = rnd(B1, H, W, 32, seed=61).cuda(), rnd(B2, H, W, 32, seed=62).cuda()
+    w1, w2 = (rnd(32, 32, 3, 3, seed=63) * 0.1).cuda(), (rnd(32, 32, 3, 3, seed=64) * 0.1).cuda()
+    b1, b2 = (rnd(32, seed=65) * 0.1).cuda(), (rnd(32, seed=66) * 0.1).cuda()
+    r1, r2 = torch.empty(B1, H - 2, W - 2, 32, device="cuda"), torch.empty(B2, H - 2, W - 2, 32, device="cuda")
+    ops.conv_s1_fwd(x1, w1, b1, r1)
+    ops.conv_s1_fwd(x2, w2, b2, r2)
+    o1, o2 = torch.full_like(r1, float("nan")), torch.full_like(r2, float("nan"))
+    ops.conv_s1_fwd2(x1, w1, b1, o1, x2, w2, b2, o2)
+    assert torch.equal(o1, r1) and torch.equal(o2, r2)
+
+
+@pytest.mark.parametrize("B1,B2,C", [(6, 3, 9), (3, 5, 12)])
+def test_conv1_fwd_two_problems(ops, B1, B2, C):
+    """curla_conv1_fwd2: two gathers from one uint8 ring with their own indices, crop offsets and weights."""
+    Hs, Ws, Hc, Wc = 30, 34, 26, 28
+    g = torch.Generator().manual_seed(71)
+    n = 11
+    store = torch.randint(0, 256, (n * Hs * Ws * C + 32,), dtype=torch.uint8, generator=g).cuda()
+    ring = store[:n * Hs * Ws * C].view(n, Hs, Ws, C)
+    refs, ws, bs, outs = [], [], [], []
+    for k, B in enumerate((B1, B2)):
+        idx = torch.randint(0, n, (B,), generator=g).cuda()
+        h1 = torch.randint(0, Hs - Hc + 1, (B,), generator=g, dtype=torch.int32).cuda()
+        w1 = torch.randint(0, Ws - Wc + 1, (B,), generator=g, dtype=torch.int32).cuda()
+        refs.append(ops.ObsRef.from_ring(ring, idx, h1, w1, B, (Hc, Wc)))
+        ws.append((rnd(32, C, 3, 3, seed=72 + k) * 0.1).cuda())
+        bs.append((rnd(32, seed=74 + k) * 0.1).cuda())
+        outs.append(torch.empty(B, (Hc - 3) // 2 + 1, (Wc - 3) // 2 + 1, 32, device="cuda"))
+        ops.conv1_fwd(refs[k], ws[k], bs[k], outs[k])
+    assert ops.conv1_pairable(refs[0], refs[1])
+    o1, o2 = torch.full_like(outs[0], float("nan")), torch.full_like(outs[1], float("nan"))
+    ops.conv1_fwd2(refs[0], ws[0], bs[0], o1, refs[1], ws[1], bs[1], o2)
+    assert torch.equal(o1, outs[0]) and torch.equal(o2, outs[1])

@@ -198,12 +198,15 @@ def _filled_rb(aug, hw=(34, 40)):
 
 def test_update_schedule_launch_counts():
     """curl_sac.py:426-451 schedule, with the conv passes the build shares:
-    5 conv-stack forwards + 2 backwards on every step -- the critic phase's obs and next_obs passes
-    through the online convs as ONE launch per layer over 2B samples (ObsRef.pair), i.e. 4 launch sequences."""
+    5 conv-stack forwards + 2 backwards on every step, as TWO launch sequences: the critic phase's
+    [obs | next_obs] through the online convs (one minibatch of 2B, ObsRef.pair) together with next_obs through the
+    target convs (second problem of the same launches), and obs through the stepped convs together with the positives
+    through the target convs (actor phase on even steps, CURL phase on odd ones)."""
     agent, aug = tiny_agent()
     even, odd = _trace_updates(agent, _filled_rb(aug), [0, 1])
     for c in (even, odd):
-        assert c["curla_conv1_fwd"] == 4 and c["curla_conv3x3_s1_fwd"] == 12
+        assert c["curla_conv1_fwd2"] == 2 and c["curla_conv3x3_s1_fwd2"] == 6
+        assert c["curla_conv1_fwd"] == 0 and c["curla_conv3x3_s1_fwd"] == 0
         assert c["curla_conv1_wgrad_slabs"] == 2 and c["curla_conv3x3_s1_wgrad_slabs"] == 6
         assert c["curla_conv3x3_s1_dgrad"] == 6 and c["curla_wgrad_reduce_multi"] == 2  # one reduction per backward pass
         assert c["curla_curl_ce"] == 1 and c["curla_critic_td_loss"] == 1
@@ -219,7 +222,7 @@ def test_update_schedule_launch_counts():
     # only_cpc (train.py:425): no SAC phases
     (c,) = _trace_updates(agent, _filled_rb(aug), [2], only_cpc=True)
     assert c["curla_critic_td_loss"] == 0 and c["curla_actor_loss"] == 0 and c["curla_curl_ce"] == 1
-    assert c["curla_conv1_fwd"] == 2 and c["curla_conv1_wgrad_slabs"] == 1
+    assert c["curla_conv1_fwd2"] == 1 and c["curla_conv1_fwd"] == 0 and c["curla_conv1_wgrad_slabs"] == 1
 
 
 def test_update_schedule_pixel_sac():
@@ -228,7 +231,9 @@ def test_update_schedule_pixel_sac():
     curla_amd.set_seed_everywhere(1)
     agent = curla_amd.CurlSacAgent((9, 34, 40), (2,), "cpu", aug, hidden_dim=64, pixel_sac=True, **HP)
     even, odd = _trace_updates(agent, _filled_rb(aug), [0, 1])
-    assert even["curla_conv1_fwd"] == 3 and odd["curla_conv1_fwd"] == 2  # (obs | next_obs) is one launch of 2B samples
+    # critic phase: one two-problem launch ([obs | next_obs] online, next_obs target); actor phase (even): obs alone
+    assert even["curla_conv1_fwd2"] == 1 and even["curla_conv1_fwd"] == 1
+    assert odd["curla_conv1_fwd2"] == 1 and odd["curla_conv1_fwd"] == 0
     assert even["curla_conv1_wgrad_slabs"] == 1 and odd["curla_conv1_wgrad_slabs"] == 1
     assert even["curla_curl_ce"] == 0
 
