@@ -32,6 +32,12 @@ struct GemmArgs {
   float alpha;
   int relu, vecA, vecB;
   int stream_c;  // output far larger than the L2s (fc data gradient): streaming stores
+  // nptr > 0: the batch items are unrelated problems of one shape, given by pointer (A = Ap[batch] ...) instead of by
+  // stride -- e.g. the fc products of three encoders on three activation tensors in one launch
+  int nptr;
+  const float* Ap[4];
+  const float* Bp[4];
+  float* Cp[4];
 };
 
 // load one BK x ROWS operand tile into registers (ROWS/32 float4 per thread)
@@ -144,9 +150,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int z = blockIdx.z;
   const int batch = z / g.ksplit, ks = z - batch * g.ksplit;
   const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
-  const float* A = g.A + batch * g.sA;
-  const float* B = g.B + batch * g.sB;
-  float* C = g.C + batch * g.sC + ks * g.sSplit;
+  const float* A = g.nptr ? g.Ap[batch] : g.A + batch * g.sA;
+  const float* B = g.nptr ? g.Bp[batch] : g.B + batch * g.sB;
+  float* C = (g.nptr ? g.Cp[batch] : g.C + batch * g.sC) + ks * g.sSplit;
   const int kbeg = ks * g.kchunk;
   const int kend = min(g.K, kbeg + g.kchunk);
 
@@ -463,25 +469,12 @@ __global__ void splitk_reduce_kernel(const float* P, int nsplit, long long sSpli
 
 extern "C" {
 
-int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const float* B, int b_kmajor, int ldb,
-               long long strideB, float* C, int ldc, long long strideC, int M, int N, int K, int nbatch, int ksplit,
-               long long split_stride, float alpha, const float* bias, long long strideBias, int relu,
-               const float* mask, int ldmask, long long strideMask, void* stream) {
-  CURLA_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nbatch > 0 && ksplit > 0);
-  CURLA_REQUIRE(ksplit == 1 || (!bias && !mask && !relu));
-  GemmArgs g;
-  g.A = A, g.B = B, g.C = C, g.bias = bias, g.mask = mask;
-  g.M = M, g.N = N, g.K = K, g.lda = lda, g.ldb = ldb, g.ldc = ldc, g.ldmask = ldmask;
-  g.sA = strideA, g.sB = strideB, g.sC = strideC, g.sBias = strideBias, g.sMask = strideMask, g.sSplit = split_stride;
-  g.nbatch = nbatch, g.ksplit = ksplit;
+static int gemm_launch(GemmArgs& g, int a_kmajor, int b_kmajor, hipStream_t st) {
+  const int M = g.M, N = g.N, K = g.K, nbatch = g.nbatch, ksplit = g.ksplit;
   int kc = (K + ksplit - 1) / ksplit;
   kc = (kc + BK - 1) / BK * BK;  // chunk boundaries stay float4-aligned
   g.kchunk = kc;
-  g.alpha = alpha, g.relu = relu;
   g.stream_c = (long long)M * N * nbatch * (long long)sizeof(float) >= (32LL << 20);
-  g.vecA = (lda % 4 == 0) && (strideA % 4 == 0) && aligned16(A);
-  g.vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && aligned16(B);
-  hipStream_t st = static_cast<hipStream_t>(stream);
   // tile shape: 64x64 when that already fills the chip twice, else 64x32, else 32x32 (more, smaller
   // workgroups: at one workgroup per CU nothing hides the L2 latency of the single-buffered k loop)
   const long long cu2 = 2LL * curla_cu_count();
@@ -542,6 +535,45 @@ int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const f
 #undef CURLA_GEMM_LAUNCH2
 #undef CURLA_GEMM_LAUNCH
   return curla_launch_status();
+}
+
+int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const float* B, int b_kmajor, int ldb,
+               long long strideB, float* C, int ldc, long long strideC, int M, int N, int K, int nbatch, int ksplit,
+               long long split_stride, float alpha, const float* bias, long long strideBias, int relu,
+               const float* mask, int ldmask, long long strideMask, void* stream) {
+  CURLA_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nbatch > 0 && ksplit > 0);
+  CURLA_REQUIRE(ksplit == 1 || (!bias && !mask && !relu));
+  GemmArgs g;
+  g.A = A, g.B = B, g.C = C, g.bias = bias, g.mask = mask;
+  g.M = M, g.N = N, g.K = K, g.lda = lda, g.ldb = ldb, g.ldc = ldc, g.ldmask = ldmask;
+  g.sA = strideA, g.sB = strideB, g.sC = strideC, g.sBias = strideBias, g.sMask = strideMask, g.sSplit = split_stride;
+  g.nbatch = nbatch, g.ksplit = ksplit;
+  g.alpha = alpha, g.relu = relu;
+  g.vecA = (lda % 4 == 0) && (strideA % 4 == 0) && aligned16(A);
+  g.vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && aligned16(B);
+  g.nptr = 0;
+  return gemm_launch(g, a_kmajor, b_kmajor, static_cast<hipStream_t>(stream));
+}
+
+int curla_gemm_multi(int nprob, const float* const* A, const float* const* B, float* const* C, int lda, int ldb, int ldc,
+                     int M, int N, int K, int ksplit, long long split_stride, void* stream) {
+  CURLA_REQUIRE(nprob > 0 && nprob <= 4 && A && B && C && M > 0 && N > 0 && K > 0 && ksplit > 0);
+  GemmArgs g;
+  g.A = g.B = nullptr, g.C = nullptr, g.bias = nullptr, g.mask = nullptr;
+  g.M = M, g.N = N, g.K = K, g.lda = lda, g.ldb = ldb, g.ldc = ldc, g.ldmask = 0;
+  g.sA = g.sB = g.sC = g.sBias = g.sMask = 0, g.sSplit = split_stride;
+  g.nbatch = nprob, g.ksplit = ksplit;
+  g.alpha = 1.f, g.relu = 0;
+  g.vecA = (lda % 4 == 0), g.vecB = (ldb % 4 == 0);
+  g.nptr = nprob;
+  for (int i = 0; i < nprob; ++i) {
+    CURLA_REQUIRE(A[i] && B[i] && C[i]);
+    g.Ap[i] = A[i], g.Bp[i] = B[i], g.Cp[i] = C[i];
+    g.vecA = g.vecA && aligned16(A[i]);
+    g.vecB = g.vecB && aligned16(B[i]);
+  }
+  for (int i = nprob; i < 4; ++i) g.Ap[i] = g.Bp[i] = nullptr, g.Cp[i] = nullptr;
+  return gemm_launch(g, 0, 0, static_cast<hipStream_t>(stream));
 }
 
 static int fc_bwd_check(const float* dz, const float* big, const float* out, int B, int F, int K) {

@@ -670,22 +670,28 @@ class CurlSacAgent(object):
         else:
             enc.conv_forward(no, ws.acts_tmp)                   # tied convs, online weights
             h_next = ws.acts_tmp[-1]
-        self.actor.encoder.head_forward(h_next, ws.z_a)
+        if merged:  # all three activation tensors are there: the three fc products in one launch
+            CNNEncoder.fc_partial_multi([(self.actor.encoder, h_next), (tenc, ws.acts_tmp[-1]), (enc, ws.acts_main[-1])])
+        else:
+            self.actor.encoder.fc_partial(h_next)
+        self.actor.encoder.ln_from_partial(B, ws.z_a)
         _mlp_fwd(ws.z_a, 0, _Mlp(self.actor.trunk), 1, B, F, H, 2 * A, ws.a_h1, ws.a_h2, ws.a_out)
         nz = self._noise(ws, noise)
         ops.actor_head_fwd(ws.a_out, nz, B, A, self.actor.log_std_min, self.actor.log_std_max, pi=ws.pi,
                            log_pi=ws.log_pi)
         if not merged:
             tenc.conv_forward(no, ws.acts_tmp)
-        tenc.head_forward(ws.acts_tmp[-1], ws.z_t, xa=ws.xa, act=ws.pi)  # xa = cat([z, a'], 1)
+            tenc.fc_partial(ws.acts_tmp[-1])
+        tenc.ln_from_partial(B, ws.z_t, xa=ws.xa, act=ws.pi)  # xa = cat([z, a'], 1)
         _mlp_fwd(ws.xa, 0, self.critic_target.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.tq)
 
         # -- current Q estimates + loss + backward (curl_sac.py:357-367)
         if not merged:
             enc.conv_forward(o, ws.acts_main)
+            enc.fc_partial(ws.acts_main[-1])
         rec = self._records(step)
-        enc.head_forward(ws.acts_main[-1], ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c, fc_out=ws.fc_out if rec else None,
-                         xa=ws.xa, act=action)
+        enc.ln_from_partial(B, ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c, fc_out=ws.fc_out if rec else None, xa=ws.xa,
+                            act=action)
         _mlp_fwd(ws.xa, 0, self.critic.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.q)
         if rec:  # what critic.log() / encoder.log() histogram: the outputs of THIS forward (curl_sac.py:163-167)
             self.critic.outputs['q1'], self.critic.outputs['q2'] = ws.q[0].clone(), ws.q[1].clone()
@@ -745,7 +751,8 @@ class CurlSacAgent(object):
         else:
             enc.conv_forward(o, ws.acts_main)
         h = ws.acts_main[-1]
-        aenc.head_forward(h, ws.z_a, xhat=ws.xhat_a, rstd=ws.rstd_a)
+        CNNEncoder.fc_partial_multi([(aenc, h), (enc, h)])  # actor.fc and critic.fc read the same conv output
+        aenc.ln_from_partial(B, ws.z_a, xhat=ws.xhat_a, rstd=ws.rstd_a)
         self._anchor_cache = obs
 
         trunk = _Mlp(self.actor.trunk)
@@ -757,7 +764,7 @@ class CurlSacAgent(object):
         if self._records(step):  # what actor.log() histograms (curl_sac.py:92-93): pre-squash mean and std
             self.actor.outputs['mu'], self.actor.outputs['std'] = ws.a_out[:, :A].clone(), ws.log_std.exp()
         # critic features of the same conv output (kept for the CURL anchor branch), with xa = cat([z, pi], 1)
-        enc.head_forward(h, ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c, xa=ws.xa, act=ws.pi)
+        enc.ln_from_partial(B, ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c, xa=ws.xa, act=ws.pi)
         _mlp_fwd(ws.xa, 0, self.critic.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.q)
         ops.actor_loss(ws.q, B, ws.log_pi, ws.log_std, A, self.log_alpha, float(self.target_entropy), B,
                        ws.scalars[1:5], ws.dq, self.log_alpha.grad)
@@ -814,8 +821,11 @@ class CurlSacAgent(object):
         elif need_pos:
             tenc.conv_forward(op_, ws.acts_tmp)
         if need_anchor:
-            enc.head_forward(ws.acts_main[-1], ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c)
-        tenc.head_forward(ws.acts_tmp[-1], ws.z_pos)
+            CNNEncoder.fc_partial_multi([(enc, ws.acts_main[-1]), (tenc, ws.acts_tmp[-1])])
+            enc.ln_from_partial(B, ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c)
+        else:
+            tenc.fc_partial(ws.acts_tmp[-1])
+        tenc.ln_from_partial(B, ws.z_pos)
 
         W = self.CURL.W
         ops.linear_fwd(ws.z_pos, 0, W, 0, None, 0, ws.WzT, 0, B, F, F)         # (W z_pos^T)^T

@@ -157,15 +157,39 @@ class CNNEncoder(nn.Module):
     def head_forward(self, h, z, fc_out=None, xhat=None, rstd=None, xa=None, act=None):
         """fc + LayerNorm (+tanh) on the NHWC-flattened conv output (encoder.py:98-107).  ``xa`` / ``act``: the
         LayerNorm kernel also writes the Q functions' input rows [z | act] (torch.cat, curl_sac.py:138)."""
+        self.fc_partial(h)
+        return self.ln_from_partial(h.shape[0], z, fc_out=fc_out, xhat=xhat, rstd=rstd, xa=xa, act=act)
+
+    def fc_partial(self, h):
+        """The fc product as split-K partial sums into this encoder's partial buffer (first half of head_forward)."""
         B = h.shape[0]
         if self.fc.nhwc is None:
             raise RuntimeError("encoder weights are not in kernel layout; call CNNEncoder.to_kernel_layout() "
                                "(CurlSacAgent does) before running the HIP path")
         F, K = self.feature_dim, self.flat_dim
-        ks, part = self.ksplit(B), self.partial(B)
-        ops.gemm(h, 0, K, 0, self.fc.weight, 0, K, 0, part, F, 0, B, F, K, 1, ksplit=ks, split_stride=B * F)
-        ops.fc_ln_fwd(part, ks, B * F, F, self.fc.bias, self.ln.weight, self.ln.bias, B, F, z, fc_out=fc_out, xhat=xhat,
-                      rstd=rstd, eps=self.ln.eps, tanh_out=0 if self.output_logits else 1, xa=xa, act=act)
+        ops.gemm(h, 0, K, 0, self.fc.weight, 0, K, 0, self.partial(B), F, 0, B, F, K, 1, ksplit=self.ksplit(B),
+                 split_stride=B * F)
+
+    @staticmethod
+    def fc_partial_multi(pairs):
+        """``fc_partial`` of several (encoder, h) pairs of one shape in ONE launch (<= 4): e.g. the three fc layers of
+        the critic phase, whose inputs are all ready once the conv launches are through."""
+        enc0, h0 = pairs[0]
+        B, F, K = h0.shape[0], enc0.feature_dim, enc0.flat_dim
+        same = all(e.feature_dim == F and e.flat_dim == K and h.shape[0] == B and e.fc.nhwc is not None for e, h in pairs)
+        if not same or len(pairs) > 4 or len(pairs) < 2:
+            for e, h in pairs:
+                e.fc_partial(h)
+            return
+        ops.gemm_multi([h for _, h in pairs], [e.fc.weight for e, _ in pairs], [e.partial(B) for e, _ in pairs], B, F, K,
+                       ksplit=enc0.ksplit(B), split_stride=B * F)
+
+    def ln_from_partial(self, B, z, fc_out=None, xhat=None, rstd=None, xa=None, act=None):
+        """Split-K reduction + bias + LayerNorm (+tanh) of the partial sums left by ``fc_partial``."""
+        F = self.feature_dim
+        ops.fc_ln_fwd(self.partial(B), self.ksplit(B), B * F, F, self.fc.bias, self.ln.weight, self.ln.bias, B, F, z,
+                      fc_out=fc_out, xhat=xhat, rstd=rstd, eps=self.ln.eps, tanh_out=0 if self.output_logits else 1,
+                      xa=xa, act=act)
         return z
 
     def to_kernel_layout(self):

@@ -165,6 +165,17 @@ def gemm(A, a_kmajor, lda, sA, Bm, b_kmajor, ldb, sB, C, ldc, sC, M, N, K, nbatc
          split_stride, alpha, ptr(bias), sBias, relu, ptr(mask), ldmask, sMask, stream())
 
 
+def gemm_multi(As, Bs, Cs, M, N, K, ksplit=1, split_stride=0):
+    """Up to 4 products C_i = A_i [M,K] @ B_i [N,K]^T of one shape (split-K partials at C_i + s * split_stride) in one
+    launch."""
+    import ctypes
+    n = len(As)
+    P = ctypes.c_void_p * n
+    a, b, c = P(*[ptr(t) for t in As]), P(*[ptr(t) for t in Bs]), P(*[ptr(t) for t in Cs])
+    call("curla_gemm_multi", n, ctypes.addressof(a), ctypes.addressof(b), ctypes.addressof(c), K, K, N, M, N, K, ksplit,
+         split_stride, stream())
+
+
 def linear_fwd(x, sx, W, sW, bias, sb, out, so, M, N, K, nb=1, relu=0):
     """out[z] = act(x[z] @ W[z]^T + bias[z]);  x [M,K], W [N,K] (nn.Linear layout)."""
     gemm(x, 0, K, sx, W, 0, K, sW, out, N, so, M, N, K, nb, bias=bias, sBias=sb, relu=relu)

@@ -102,6 +102,11 @@ int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const f
                long long strideB, float* C, int ldc, long long strideC, int M, int N, int K, int nbatch, int ksplit,
                long long split_stride, float alpha, const float* bias, long long strideBias, int relu,
                const float* mask, int ldmask, long long strideMask, void* stream);
+/* nprob <= 4 unrelated products of ONE shape in one launch, operands by pointer: C_i (+ split partials) =
+ * A_i [M][K] * B_i [N][K]^T, no epilogue -- the fc layers of several encoders on several activation tensors (the
+ * critic phase has three, curl_sac.py:350-358).  Each launch less is ~5 us. */
+int curla_gemm_multi(int nprob, const float* const* A, const float* const* B, float* const* C, int lda, int ldb, int ldc,
+                     int M, int N, int K, int ksplit, long long split_stride, void* stream);
 int curla_splitk_reduce(const float* partial, int nsplit, long long split_stride, int M, int N, int ldp, float* C,
                         int ldc, const float* bias, int relu, void* stream);
 /* Backward of the encoder fc layer z = fc(h) (encoder.py:98; autograd of the reference's nn.Linear), F <= 64 features,

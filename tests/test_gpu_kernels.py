@@ -632,3 +632,19 @@ def test_conv1_fwd_two_problems(ops, B1, B2, C):
     o1, o2 = torch.full_like(outs[0], float("nan")), torch.full_like(outs[1], float("nan"))
     ops.conv1_fwd2(refs[0], ws[0], bs[0], o1, refs[1], ws[1], bs[1], o2)
     assert torch.equal(o1, outs[0]) and torch.equal(o2, outs[1])
+
+
+def test_gemm_multi_matches_single_launches(ops):
+    """curla_gemm_multi: three unrelated split-K products of one shape, operands by pointer, in one launch --
+    bit-identical to three curla_gemm launches."""
+    B, Fd, K, ks = 24, 50, 3456, 6
+    hs = [rnd(B, K, seed=81 + i).cuda() for i in range(3)]
+    Ws = [(rnd(Fd, K, seed=84 + i) * 0.05).cuda() for i in range(3)]
+    refs = [torch.empty(ks, B, Fd, device="cuda") for _ in range(3)]
+    for h, W, r in zip(hs, Ws, refs):
+        ops.gemm(h, 0, K, 0, W, 0, K, 0, r, Fd, 0, B, Fd, K, 1, ksplit=ks, split_stride=B * Fd)
+    outs = [torch.full((ks, B, Fd), float("nan"), device="cuda") for _ in range(3)]
+    ops.gemm_multi(hs, Ws, outs, B, Fd, K, ksplit=ks, split_stride=B * Fd)
+    for o, r in zip(outs, refs):
+        assert torch.equal(o, r)
+    check("gemm_multi vs torch", outs[1].sum(0).cpu(), hs[1].cpu() @ Ws[1].cpu().t())
