@@ -68,8 +68,10 @@ struct ConvS1Args {
 // transform is 4 vector adds on the LDS window right before the MFMAs, the output transform 4 adds
 // per pair; the y direction and the channel sums are the plain accumulation.
 // ---------------------------------------------------------------------------
+// (the kernel body as a device function of (block id, block count): conv_s1_kernel runs it over the whole grid,
+// bwd_s1_kernel over the second part of a grid whose first part is the weight-gradient kernel's)
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
+__device__ __forceinline__ void conv_s1_body(const ConvS1Args& a, const int bid, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
   // loop after a weight reload, not a branch inside the loop (which costs the forward kernel 34 spilled registers).
   auto run = [&](const float* in_base, const float* aux_base, float* out_base, int Bc, int item, int item_end,
                  int item0) {
-  for (; item < item_end; item += gridDim.x) {
+  for (; item < item_end; item += nblk) {
     const int local = item - item0;
     const int band = local / Bc, b = local - band * Bc;  // band-major: every workgroup sees every band size
     const int y0 = band == 0 ? 0 : a.h1 + (band - 1) * a.th;
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
         for (int u = 0; u < kMaxPf; ++u) {
           const int f = tid + u * 256;
           f32x4 v = {0, 0, 0, 0};
-          if (f < n4 && !(ABL(1) && item != (int)blockIdx.x)) v = src[f];
+          if (f < n4 && !(ABL(1) && item != bid)) v = src[f];
           pf[u] = v;
         }
       } else {
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
           const int f = tid + u * 256;
           f32x4 v = {0, 0, 0, 0};
           const int sy = y0 + r - a.pad, sx = c - a.pad;
-          if (f < n4 && sy >= 0 && sy < a.Hs && sx >= 0 && sx < a.Ws && !(ABL(1) && item != (int)blockIdx.x))
+          if (f < n4 && sy >= 0 && sy < a.Hs && sx >= 0 && sx < a.Ws && !(ABL(1) && item != bid))
             v = *reinterpret_cast<const f32x4*>(in_base + ((size_t)(b * a.Hs + sy) * a.Ws + sx) * 32 + ch * 4);
           pf[u] = v;
           c += 32;
@@ -173,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
 #pragma unroll
       for (int u = 0; u < kMaxPf; ++u) {
         const int f = tid + u * 256;
-        if (f < n4 && !(ABL(2) && item != (int)blockIdx.x))
+        if (f < n4 && !(ABL(2) && item != bid))
           *reinterpret_cast<f32x4*>(lds + (f >> 3) * kLdsPix + (f & 7) * 4) = pf[u];
       }
     }
@@ -300,14 +302,19 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
   }
   };
   const int nitems1 = a.B * a.nbands;
-  run(a.in, a.aux, a.out, a.B, blockIdx.x, nitems1, 0);
+  run(a.in, a.aux, a.out, a.B, bid, nitems1, 0);
   if (MODE == MODE_FWD && a.B2 > 0) {
     // this workgroup's walk k, k+G, k+2G, ... over the concatenated item list continues in the second problem
-    const int G = gridDim.x;
-    const int first2 = blockIdx.x + G * ((nitems1 - (int)blockIdx.x + G - 1) / G);
+    const int G = nblk;
+    const int first2 = bid + G * ((nitems1 - bid + G - 1) / G);
     load_weights(a.w2, a.aux2);
     run(a.in2, a.aux2, a.out2, a.B2, first2, nitems1 + a.B2 * a.nbands, nitems1);
   }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
+  conv_s1_body<MODE>(a, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -684,7 +691,7 @@ struct WgradS1Args {
 };
 constexpr int kPartialS1 = 32 * 288 + 32;
 
-__global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) {
+__device__ __forceinline__ void wgrad_s1_body(const WgradS1Args& a, const int bid, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
@@ -707,7 +714,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) {
   const int PW = (a.Wo + 1) >> 1;  // pixel pairs per gradient row
   const int qstep = 8 / PW, rstep = 8 - qstep * PW;
   const int nitems = a.B * a.nbands;
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+  for (int item = bid; item < nitems; item += nblk) {
     const int band = item / a.B, b = item - band * a.B;  // band-major: every workgroup sees every band size
     const int y0 = band * a.th;
     const int tha = min(a.th, a.Ho - y0);
@@ -852,8 +859,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) {
     }
     __syncthreads();
   }
-  float* slab = a.partial + (size_t)blockIdx.x * kPartialS1;
+  float* slab = a.partial + (size_t)bid * kPartialS1;
   for (int i = tid; i < kPartialS1; i += 256) slab[i] = lds[i];
+}
+
+__global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) { wgrad_s1_body(a, blockIdx.x, gridDim.x); }
+
+// Weight gradient and data gradient of one layer in ONE launch: both only read the layer's output gradient, so they
+// need not wait for each other.  The first nw workgroups run the weight-gradient body, the rest the data-gradient
+// body; the hardware starts the second set as the first one's workgroups retire, so the tail of one kernel and the
+// ramp of the next overlap instead of being separated by a kernel boundary (4-9 us per launch at these sizes).
+__global__ __launch_bounds__(256, 2) void bwd_s1_kernel(WgradS1Args wa, ConvS1Args da, int nw) {
+  if ((int)blockIdx.x < nw)
+    wgrad_s1_body(wa, blockIdx.x, nw);
+  else
+    conv_s1_body<MODE_DGRAD>(da, (int)blockIdx.x - nw, (int)gridDim.x - nw);
 }
 
 // ---------------------------------------------------------------------------
@@ -1525,6 +1545,47 @@ int curla_conv3x3_s1_wgrad_slabs(const float* in, const float* g, float* workspa
                                  int* nslabs, void* stream) {
   CURLA_REQUIRE(nslabs);
   return launch_wgrad_s1(in, g, workspace, B, Hi, Wi, channels, static_cast<hipStream_t>(stream), nslabs);
+}
+
+int curla_conv3x3_s1_bwd_slabs(const float* in, const float* g, const float* w, float* gin, float* workspace, int B, int Hi,
+                               int Wi, int channels, int* nslabs, void* stream) {
+  CURLA_REQUIRE(in && g && w && gin && workspace && nslabs && B > 0 && Hi >= 3 && Wi >= 3);
+  if (channels != 32) return CURLA_ERR_UNSUPPORTED;
+  CURLA_REQUIRE(aligned16(in) && aligned16(g) && aligned16(w) && aligned16(gin));
+  const int Ho = Hi - 2, Wo = Wi - 2;
+  // weight-gradient part (as launch_wgrad_s1)
+  WgradS1Args wa;
+  wa.in = in, wa.g = g, wa.partial = workspace;
+  wa.B = B, wa.Hi = Hi, wa.Wi = Wi, wa.Ho = Ho, wa.Wo = Wo;
+  if ((Wo + 2) * 3 > kBandPx) return CURLA_ERR_UNSUPPORTED;
+  wa.th = plan_band_s1(Ho, Wo, 0, kBandPx, 8, 1, /*pairs=*/true);
+  wa.nbands = (Ho + wa.th - 1) / wa.th;
+  size_t lds_w = (size_t)((wa.th + 2) * Wi + 1) * kLdsPix * sizeof(float);
+  if (lds_w < kPartialS1 * sizeof(float)) lds_w = kPartialS1 * sizeof(float);
+  const int cap = 2 * curla_cu_count();
+  const int items_w = B * wa.nbands;
+  const int nw = items_w < cap ? items_w : cap;
+  // data-gradient part (as launch_conv_s1 in MODE_DGRAD: input = the output gradient [B][Ho][Wo], output [B][Hi][Wi])
+  ConvS1Args da;
+  da.in = g, da.w = w, da.aux = in, da.out = gin;
+  da.in2 = nullptr, da.w2 = nullptr, da.aux2 = nullptr, da.out2 = nullptr, da.B2 = 0;
+  da.B = B, da.Hs = Ho, da.Ws = Wo, da.pad = 2, da.Ho = Hi, da.Wo = Wi;
+  if ((da.Wo + 2) * 3 > kBandPx) return CURLA_ERR_UNSUPPORTED;
+  plan_bands_conv_s1(da.Ho, da.Wo, kBandPx, &da.th, &da.h1, &da.nbands);
+  const int PW = (da.Wo + 1) / 2;
+  da.qstep = 32 / PW, da.rstep = 32 - da.qstep * PW;
+  da.dbg = 0;
+  size_t lds_d = ((size_t)(da.h1 + 2) * (da.Wo + 2) + 1) * kLdsPix * sizeof(float);
+  const size_t wl = (size_t)32 * kWStride * sizeof(float);
+  if (lds_d < wl) lds_d = wl;
+  const int items_d = B * da.nbands;
+  const int nd = items_d < cap ? items_d : cap;
+  const size_t lds = lds_w > lds_d ? lds_w : lds_d;
+  int rc = set_lds(bwd_s1_kernel, lds);
+  if (rc != CURLA_OK) return rc;
+  hipLaunchKernelGGL(bwd_s1_kernel, dim3(nw + nd), dim3(256), lds, static_cast<hipStream_t>(stream), wa, da, nw);
+  *nslabs = nw;
+  return curla_launch_status();
 }
 
 int curla_wgrad_reduce_multi(int njobs, const float* const* slabs, const int* nslabs, const int* nw, float* const* dw,

@@ -624,11 +624,11 @@ class CurlSacAgent(object):
         jobs = []
         for layer in range(L, 1, -1):  # layer l: input acts[l-2], output acts[l-1]
             conv = enc.convs[layer - 1]
-            n = ops.conv_s1_wgrad_slabs(acts[layer - 2], g, ws.wg_ws[layer - 1])
-            jobs.append((ws.wg_ws[layer - 1], n, conv.weight.grad, conv.bias.grad))
             cur ^= 1
             gin = ws.gviews[cur][layer - 2]
-            ops.conv_s1_dgrad(g, conv.weight, acts[layer - 2], gin)
+            # weight gradient (slabs) and data gradient of the layer: both only read g, one launch for both
+            n = ops.conv_s1_bwd_slabs(acts[layer - 2], g, conv.weight, gin, ws.wg_ws[layer - 1])
+            jobs.append((ws.wg_ws[layer - 1], n, conv.weight.grad, conv.bias.grad))
             g = gin
         n = ops.conv1_wgrad_slabs(obs_ref, g, ws.wg_ws[0], enc.num_filters)
         jobs.append((ws.wg_ws[0], n, enc.convs[0].weight.grad, enc.convs[0].bias.grad))

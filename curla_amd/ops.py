@@ -130,6 +130,17 @@ def conv_s1_wgrad_slabs(x, g, ws):
     return n.value
 
 
+def conv_s1_bwd_slabs(x, g, w, gin, ws):
+    """Weight-gradient slabs (into ``ws``) and the data gradient ``gin`` (masked by x > 0) of one stride-1 layer with
+    input ``x`` and output gradient ``g``, in one launch; returns the slab count."""
+    import ctypes
+    B, H, W, C = x.shape
+    n = ctypes.c_int(1)
+    call("curla_conv3x3_s1_bwd_slabs", ptr(x), ptr(g), ptr(w), ptr(gin), ptr(ws), B, H, W, C, ctypes.addressof(n),
+         stream())
+    return n.value
+
+
 def conv1_wgrad_slabs(obs: ObsRef, g, ws, channels, scale=1.0 / 255.0):
     import ctypes
     obs.check()

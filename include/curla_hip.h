@@ -87,6 +87,10 @@ int curla_conv3x3_s1_wgrad_slabs(const float* in, const float* g, float* workspa
 int curla_conv1_wgrad_slabs(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1,
                             const float* g, float* workspace, int B, int C, int Hs, int Ws, int Hc, int Wc, int channels,
                             float scale, int* nslabs, void* stream);
+/* Weight gradient (slabs, as curla_conv3x3_s1_wgrad_slabs) AND data gradient (as curla_conv3x3_s1_dgrad, ReLU mask =
+ * the layer's input `in`) of one stride-1 layer in ONE launch: both only read the output gradient g. */
+int curla_conv3x3_s1_bwd_slabs(const float* in, const float* g, const float* w, float* gin, float* workspace, int B, int Hi,
+                               int Wi, int channels, int* nslabs, void* stream);
 int curla_wgrad_reduce_multi(int njobs, const float* const* slabs, const int* nslabs, const int* nw, float* const* dw,
                              float* const* db, void* stream);
 /* floats of `workspace` the two wgrad entry points need (per-workgroup partial slabs) */

@@ -648,3 +648,23 @@ def test_gemm_multi_matches_single_launches(ops):
     for o, r in zip(outs, refs):
         assert torch.equal(o, r)
     check("gemm_multi vs torch", outs[1].sum(0).cpu(), hs[1].cpu() @ Ws[1].cpu().t())
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 13, 16), (2, 37, 37), (300, 9, 9), (5, 17, 15)])
+def test_conv_s1_backward_one_launch(ops, B, H, W):
+    """curla_conv3x3_s1_bwd_slabs: weight-gradient slabs and data gradient of a layer in one launch -- bit-identical to
+    the two separate kernels."""
+    x = torch.relu(rnd(B, H, W, 32, seed=91)).cuda()
+    g = rnd(B, H - 2, W - 2, 32, seed=92).cuda()
+    w = (rnd(32, 32, 3, 3, seed=93) * 0.1).cuda()
+    ws1 = torch.zeros(ops.wgrad_workspace_floats(32), device="cuda")
+    ws2 = torch.zeros_like(ws1)
+    gin1, gin2 = torch.empty_like(x), torch.full_like(x, float("nan"))
+    n1 = ops.conv_s1_wgrad_slabs(x, g, ws1)
+    ops.conv_s1_dgrad(g, w, x, gin1)
+    n2 = ops.conv_s1_bwd_slabs(x, g, w, gin2, ws2)
+    assert n1 == n2 and torch.equal(gin1, gin2)
+    dw1, db1, dw2, db2 = (torch.empty(s, device="cuda") for s in ((32, 32, 3, 3), (32,), (32, 32, 3, 3), (32,)))
+    ops.wgrad_reduce_multi([(ws1, n1, dw1, db1)])
+    ops.wgrad_reduce_multi([(ws2, n2, dw2, db2)])
+    assert torch.equal(dw1, dw2) and torch.equal(db1, db2)

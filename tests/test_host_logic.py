@@ -207,8 +207,10 @@ def test_update_schedule_launch_counts():
     for c in (even, odd):
         assert c["curla_conv1_fwd2"] == 2 and c["curla_conv3x3_s1_fwd2"] == 6
         assert c["curla_conv1_fwd"] == 0 and c["curla_conv3x3_s1_fwd"] == 0
-        assert c["curla_conv1_wgrad_slabs"] == 2 and c["curla_conv3x3_s1_wgrad_slabs"] == 6
-        assert c["curla_conv3x3_s1_dgrad"] == 6 and c["curla_wgrad_reduce_multi"] == 2  # one reduction per backward pass
+        # per backward pass: one launch per stride-1 layer (weight + data gradient together), the first layer's weight
+        # gradient, and one slab reduction for all layers
+        assert c["curla_conv1_wgrad_slabs"] == 2 and c["curla_conv3x3_s1_bwd_slabs"] == 6
+        assert c["curla_conv3x3_s1_dgrad"] == 0 and c["curla_wgrad_reduce_multi"] == 2
         assert c["curla_curl_ce"] == 1 and c["curla_critic_td_loss"] == 1
     assert even["curla_actor_loss"] == 1 and odd["curla_actor_loss"] == 0       # actor_update_freq = 2
     assert even["curla_soft_update2"] == 1 and odd["curla_soft_update2"] == 0   # critic_target_update_freq = 2
