@@ -34,6 +34,7 @@ SIGNATURES = {
                    c_ll, c_float, vp, c_ll, c_int, vp, c_int, c_ll, vp],
     "curla_fc_dx": [vp, vp, vp, vp, c_int, c_int, c_int, vp],
     "curla_fc_dw": [vp, vp, vp, c_int, c_int, c_int, vp],
+    "curla_fc_bwd": [vp, vp, vp, vp, vp, c_int, c_int, c_int, vp],
     "curla_gemm_multi": [c_int, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_ll, vp],
     "curla_splitk_reduce": [vp, c_int, c_ll, c_int, c_int, c_int, vp, c_int, vp, c_int, vp],
     "curla_mlp_out_fwd": [vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, c_int, c_int, c_int, c_int, vp],

@@ -305,10 +305,10 @@ struct FcBwdArgs {
 };
 
 template <int KS>  // KS = ceil(F / 4) k-steps
-__global__ __launch_bounds__(256, 2) void fc_dx_kernel(FcBwdArgs g) {
+__device__ __forceinline__ void fc_dx_body(const FcBwdArgs& g, const int bid) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
-  const int n0 = blockIdx.x * 64;
+  const int n0 = bid * 64;
   const int ncol = n0 + 4 * li;            // this lane's 4 columns (float4)
   const bool cvalid = ncol + 3 < g.K;      // K % 4 == 0: a float4 is inside or outside as a whole
   const int nc = cvalid ? ncol : n0;       // (columns past the edge re-read the first ones; their results are not stored)
@@ -378,12 +378,17 @@ __global__ __launch_bounds__(256, 2) void fc_dx_kernel(FcBwdArgs g) {
   }
 }
 
+template <int KS>
+__global__ __launch_bounds__(256, 2) void fc_dx_kernel(FcBwdArgs g) {
+  fc_dx_body<KS>(g, blockIdx.x);
+}
+
 template <int NT>  // NT = ceil(F / 16) feature tiles
-__global__ __launch_bounds__(256, 2) void fc_dw_kernel(FcBwdArgs g) {
+__device__ __forceinline__ void fc_dw_body(const FcBwdArgs& g, const int bid) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NT][4][64 lanes] float4
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
-  const int n0 = blockIdx.x * 64;
+  const int n0 = bid * 64;
   const int ncol = n0 + 4 * li;
   const bool cvalid = ncol + 3 < g.K;
   const int nc = cvalid ? ncol : n0;
@@ -450,6 +455,21 @@ __global__ __launch_bounds__(256, 2) void fc_dw_kernel(FcBwdArgs g) {
       if (cvalid && f < g.F) *reinterpret_cast<f32x4*>(g.out + (size_t)f * g.K + ncol) = o;
     }
   }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void fc_dw_kernel(FcBwdArgs g) {
+  fc_dw_body<NT>(g, blockIdx.x);
+}
+
+// both products of the fc backward in ONE launch (they only share their input dz): the first nblk workgroups compute
+// the data gradient (the conv backward waits for it), the rest the weight gradient
+template <int KS, int NT>
+__global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs gx, FcBwdArgs gw, int nblk) {
+  if ((int)blockIdx.x < nblk)
+    fc_dx_body<KS>(gx, blockIdx.x);
+  else
+    fc_dw_body<NT>(gw, (int)blockIdx.x - nblk);
 }
 
 // sum split-K partials: C[m][n] = sum_s P[s][m][n] (+bias, ReLU)
@@ -625,6 +645,33 @@ int curla_fc_dw(const float* dz, const float* x, float* dW, int B, int F, int K,
   else if (nt == 3) CURLA_FC_DW(3);
   else CURLA_FC_DW(4);
 #undef CURLA_FC_DW
+  return curla_launch_status();
+}
+
+int curla_fc_bwd(const float* dz, const float* W, const float* x, float* dx, float* dW, int B, int F, int K,
+                 void* stream) {
+  int rc = fc_bwd_check(dz, W, dx, B, F, K);
+  if (rc != CURLA_OK) return rc;
+  if ((rc = fc_bwd_check(dz, x, dW, B, F, K)) != CURLA_OK) return rc;
+  FcBwdArgs gx, gw;
+  gx.dz = dz, gx.W = W, gx.mask = x, gx.out = dx, gx.B = B, gx.F = F, gx.K = K;
+  gw.dz = dz, gw.W = x, gw.mask = nullptr, gw.out = dW, gw.B = B, gw.F = F, gw.K = K;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nblk = (K + 63) / 64;
+  const int ks = (F + 3) / 4, nt = (F + 15) / 16;
+  if (ks > 13 || ks <= 8 || nt != 4) {  // only the 49..52-feature shape is instantiated as one launch
+    if ((rc = curla_fc_dx(dz, W, x, dx, B, F, K, stream)) != CURLA_OK) return rc;
+    return curla_fc_dw(dz, x, dW, B, F, K, stream);
+  }
+  const size_t lds = (size_t)4 * 4 * 4 * 64 * sizeof(f32x4);
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fc_bwd_kernel<13, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return CURLA_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL((fc_bwd_kernel<13, 4>), dim3(2 * nblk), dim3(256), lds, st, gx, gw, nblk);
   return curla_launch_status();
 }
 

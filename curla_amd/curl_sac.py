@@ -607,7 +607,14 @@ class CurlSacAgent(object):
         ops.ln_bwd(dy, xhat, rstd, enc.ln.weight, B, F, ws.dfc, dgamma=enc.ln.weight.grad, dbeta=enc.ln.bias.grad,
                    dbias_in=enc.fc.bias.grad, dy2=dy2, ld=twin_ld)
         h = acts[-1]
-        if ops.fc_bwd_streams(F, K):
+        streams = ops.fc_bwd_streams(F, K)
+        cur = L % 2
+        g = ws.gviews[cur][L - 1]
+        if streams and conv_grads:
+            # fc weight gradient and the data gradient into the conv stack (ReLU mask of the last conv layer fused)
+            # in one launch: both only read dfc
+            ops.fc_bwd(ws.dfc, enc.fc.weight, h, g, enc.fc.weight.grad, B, F, K)
+        elif streams:
             ops.fc_dw(ws.dfc, h, enc.fc.weight.grad, B, F, K)
         else:
             ops.linear_dw(ws.dfc, 0, h, 0, enc.fc.weight.grad, 0, B, F, K)
@@ -615,11 +622,7 @@ class CurlSacAgent(object):
             dense_done()
         if not conv_grads:
             return
-        cur = L % 2
-        g = ws.gviews[cur][L - 1]
-        if ops.fc_bwd_streams(F, K):
-            ops.fc_dx(ws.dfc, enc.fc.weight, g, B, F, K, mask=h)
-        else:
+        if not streams:
             ops.linear_dx(ws.dfc, 0, enc.fc.weight, 0, g, 0, B, F, K, mask=h)
         jobs = []
         for layer in range(L, 1, -1):  # layer l: input acts[l-2], output acts[l-1]

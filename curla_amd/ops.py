@@ -217,6 +217,11 @@ def fc_dw(dz, x, out, B, F_, K):
     call("curla_fc_dw", ptr(dz), ptr(x), ptr(out), B, F_, K, stream())
 
 
+def fc_bwd(dz, W, x, dx, dW, B, F_, K):
+    """dx = (dz @ W) masked by x > 0 and dW = dz^T @ x in one launch (x = the fc layer's input, a ReLU output)."""
+    call("curla_fc_bwd", ptr(dz), ptr(W), ptr(x), ptr(dx), ptr(dW), B, F_, K, stream())
+
+
 def mlp_out_fwd(h, sh, W, sW, bias, sb, out, so, M, N, K, nb=1):
     """out[z] = h[z] @ W[z]^T + bias[z] for a last layer with N <= 16 outputs (one wave per row, no GEMM)."""
     call("curla_mlp_out_fwd", ptr(h), sh, ptr(W), sW, ptr(bias), sb, ptr(out), so, M, N, K, nb, stream())

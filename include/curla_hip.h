@@ -121,6 +121,10 @@ int curla_splitk_reduce(const float* partial, int nsplit, long long split_stride
  * One workgroup per 64 columns, operands streamed from HBM/L2 straight into MFMA registers, 256-byte row pieces. */
 int curla_fc_dx(const float* dz, const float* W, const float* mask, float* dx, int B, int F, int K, void* stream);
 int curla_fc_dw(const float* dz, const float* x, float* dW, int B, int F, int K, void* stream);
+/* Both at once (x doubles as the ReLU mask of dx: h = relu(conv) is the fc layer's input): one launch whose first
+ * workgroups compute dx and whose rest compute dW. */
+int curla_fc_bwd(const float* dz, const float* W, const float* x, float* dx, float* dW, int B, int F, int K,
+                 void* stream);
 
 /* Last layer of the actor trunk / the Q functions (curl_sac.py:73-74, 132-133): hidden -> N outputs, N <= 16
  * (Q: 1, actor: 2|A|), batched over `nbatch` identically laid-out networks `stride*` floats apart.

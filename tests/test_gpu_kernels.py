@@ -668,3 +668,17 @@ def test_conv_s1_backward_one_launch(ops, B, H, W):
     ops.wgrad_reduce_multi([(ws1, n1, dw1, db1)])
     ops.wgrad_reduce_multi([(ws2, n2, dw2, db2)])
     assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+
+
+def test_fc_backward_one_launch(ops):
+    """curla_fc_bwd (data + weight gradient of the encoder fc layer in one launch) is bit-identical to curla_fc_dx +
+    curla_fc_dw; shapes outside the instantiated one fall back to the two launches."""
+    for B, Fd, K in ((24, 50, 3456), (515, 50, 196), (9, 13, 100)):
+        dz, W = rnd(B, Fd, seed=95).cuda(), (rnd(Fd, K, seed=96) * 0.1).cuda()
+        x = torch.relu(rnd(B, K, seed=97)).cuda()
+        dx1, dw1 = torch.empty(B, K, device="cuda"), torch.empty(Fd, K, device="cuda")
+        ops.fc_dx(dz, W, dx1, B, Fd, K, mask=x)
+        ops.fc_dw(dz, x, dw1, B, Fd, K)
+        dx2, dw2 = torch.full_like(dx1, float("nan")), torch.full_like(dw1, float("nan"))
+        ops.fc_bwd(dz, W, x, dx2, dw2, B, Fd, K)
+        assert torch.equal(dx1, dx2) and torch.equal(dw1, dw2)
