@@ -44,6 +44,8 @@ SIGNATURES = {
     "curla_critic_td_loss": [vp, vp, c_ll, vp, vp, vp, vp, c_float, c_int, vp, vp, vp, vp],
     "curla_soft_update2": [vp, vp, c_size_t, c_size_t, c_float, c_float, c_float, c_float, vp],
     "curla_adam_step": [vp, vp, vp, vp, c_size_t, c_double, c_double, c_double, c_double, c_ll, vp],
+    "curla_adam_step2": [vp, vp, vp, vp, vp, vp, c_size_t, c_size_t, c_double, c_double, c_double, c_double, c_ll, c_double,
+                         c_double, c_double, c_double, c_ll, vp],
     "curla_gather_transition_scalars": [vp, vp, c_int, c_int, vp, vp, vp, vp],
     "curla_ln_bwd": [vp, vp, vp, vp, c_int, c_int, vp, vp, vp, vp, vp],
     "curla_ln_bwd_twin": [vp, vp, c_int, vp, vp, vp, c_int, c_int, vp, vp, vp, vp, vp],

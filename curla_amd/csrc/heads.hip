@@ -545,6 +545,9 @@ __global__ void soft_update2_kernel(const float* p, float* tgt, size_t n, size_t
 // aligned: HBM-bound (28 B per parameter).
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float w1, float b2, float w2,
                                          float step_size, float bc2_sqrt, float eps) {
+  // (no fused multiply-adds: every product and sum rounds on its own, as torch's element-wise Adam does, and the
+  // one-step and two-step kernels then agree bit for bit whatever the compiler would have contracted in each)
+#pragma clang fp contract(off)
   m = (w1 < 0.5f) ? m + w1 * (g - m) : g - (g - m) * (1.0f - w1);
   v = v * b2 + (w2 * g) * g;
   const float denom = sqrtf(v) / bc2_sqrt + eps;
@@ -575,6 +578,64 @@ __global__ void __launch_bounds__(256) adam_step_kernel(float* __restrict__ p, c
     done = n4 << 2;
   }
   for (size_t i = done + tid; i < n; i += stride) adam_one(p[i], g[i], m[i], v[i], w1, b2, w2, step_size, bc2_sqrt, eps);
+}
+
+// Two Adam steps of two optimizers on the SAME parameters with the same gradient, back to back, in one pass (the
+// reference steps the encoder with encoder_optimizer and then again with cpc_optimizer, curl_sac.py:418-423): elements
+// [0, n_pre) belong to the second optimizer only (CURL.W in front of the encoder in the flat buffer), the rest take
+// step 1 then step 2 exactly as the two launches would (the same per-element operation order).
+struct AdamHyper {
+  float w1, b2, w2, step_size, bc2_sqrt, eps;
+};
+
+__global__ void __launch_bounds__(256) adam_step2_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                         float* __restrict__ m1, float* __restrict__ v1,
+                                                         float* __restrict__ m2, float* __restrict__ v2, size_t n,
+                                                         size_t n_pre, int vec, AdamHyper h1, AdamHyper h2) {
+  const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  size_t done = 0;
+  if (vec) {  // everything 16-byte aligned and n_pre a multiple of 4: a float4 lies on one side of n_pre
+    const size_t n4 = n >> 2, pre4 = n_pre >> 2;
+    for (size_t i = tid; i < n4; i += stride) {
+      f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
+      const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+      if (i >= pre4) {
+        f32x4 mm = reinterpret_cast<f32x4*>(m1)[i - pre4], vv = reinterpret_cast<f32x4*>(v1)[i - pre4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float pe = pp[e], me = mm[e], ve = vv[e];
+          adam_one(pe, gg[e], me, ve, h1.w1, h1.b2, h1.w2, h1.step_size, h1.bc2_sqrt, h1.eps);
+          pp[e] = pe, mm[e] = me, vv[e] = ve;
+        }
+        reinterpret_cast<f32x4*>(m1)[i - pre4] = mm;
+        reinterpret_cast<f32x4*>(v1)[i - pre4] = vv;
+      }
+      f32x4 mm = reinterpret_cast<f32x4*>(m2)[i], vv = reinterpret_cast<f32x4*>(v2)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float pe = pp[e], me = mm[e], ve = vv[e];
+        adam_one(pe, gg[e], me, ve, h2.w1, h2.b2, h2.w2, h2.step_size, h2.bc2_sqrt, h2.eps);
+        pp[e] = pe, mm[e] = me, vv[e] = ve;
+      }
+      reinterpret_cast<f32x4*>(m2)[i] = mm;
+      reinterpret_cast<f32x4*>(v2)[i] = vv;
+      reinterpret_cast<f32x4*>(p)[i] = pp;
+    }
+    done = n4 << 2;
+  }
+  for (size_t i = done + tid; i < n; i += stride) {
+    float pi = p[i];
+    const float gi = g[i];
+    if (i >= n_pre) {
+      float m = m1[i - n_pre], v = v1[i - n_pre];
+      adam_one(pi, gi, m, v, h1.w1, h1.b2, h1.w2, h1.step_size, h1.bc2_sqrt, h1.eps);
+      m1[i - n_pre] = m, v1[i - n_pre] = v;
+    }
+    float m = m2[i], v = v2[i];
+    adam_one(pi, gi, m, v, h2.w1, h2.b2, h2.w2, h2.step_size, h2.bc2_sqrt, h2.eps);
+    m2[i] = m, v2[i] = v;
+    p[i] = pi;
+  }
 }
 
 // out_act[b][:] = sc[idx[b]][0:A], out_rew[b] = sc[idx[b]][A], out_nd[b] = sc[idx[b]][A+1]: the action / reward /
@@ -894,6 +955,30 @@ int curla_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
   hipLaunchKernelGGL(adam_step_kernel, dim3(nblocks((n + 3) / 4, 256, 8192)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), param, grad, exp_avg, exp_avg_sq, n, vec, (float)(1.0 - b1),
                      (float)b2, (float)(1.0 - b2), (float)(lr / bc1), (float)sqrt(bc2), (float)eps);
+  return curla_launch_status();
+}
+
+static AdamHyper adam_hyper(double lr, double beta1, double beta2, double eps, long long step) {
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  AdamHyper h;
+  h.w1 = (float)(1.0 - beta1), h.b2 = (float)beta2, h.w2 = (float)(1.0 - beta2);
+  h.step_size = (float)(lr / bc1), h.bc2_sqrt = (float)sqrt(bc2), h.eps = (float)eps;
+  return h;
+}
+
+int curla_adam_step2(float* param, const float* grad, float* exp_avg1, float* exp_avg_sq1, float* exp_avg2,
+                     float* exp_avg_sq2, size_t n, size_t n_pre, double lr1, double beta1_1, double beta2_1, double eps1,
+                     long long step1, double lr2, double beta1_2, double beta2_2, double eps2, long long step2,
+                     void* stream) {
+  CURLA_REQUIRE(param && grad && exp_avg1 && exp_avg_sq1 && exp_avg2 && exp_avg_sq2 && n > 0 && n_pre <= n &&
+                step1 >= 1 && step2 >= 1);
+  CURLA_REQUIRE(beta1_1 >= 0. && beta1_1 < 1. && beta2_1 >= 0. && beta2_1 < 1. && beta1_2 >= 0. && beta1_2 < 1. &&
+                beta2_2 >= 0. && beta2_2 < 1.);
+  const int vec = (n_pre % 4 == 0) && aligned16(param) && aligned16(grad) && aligned16(exp_avg1) &&
+                  aligned16(exp_avg_sq1) && aligned16(exp_avg2) && aligned16(exp_avg_sq2);
+  hipLaunchKernelGGL(adam_step2_kernel, dim3(nblocks((n + 3) / 4, 256, 8192)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), param, grad, exp_avg1, exp_avg_sq1, exp_avg2, exp_avg_sq2, n, n_pre, vec,
+                     adam_hyper(lr1, beta1_1, beta2_1, eps1, step1), adam_hyper(lr2, beta1_2, beta2_2, eps2, step2));
   return curla_launch_status();
 }
 

@@ -850,8 +850,11 @@ class CurlSacAgent(object):
         else:
             self._encoder_backward(ws, oa, ws.dz, ws.xhat_c, ws.rstd_c, enc)
             self._allreduce(self._critic_gflat[0:e1])
-        self.encoder_optimizer.step()
-        self.cpc_optimizer.step()
+        if isinstance(self.encoder_optimizer, FlatAdam):
+            FlatAdam.step_pair(self.encoder_optimizer, self.cpc_optimizer)  # both steps in one pass over the encoder
+        else:
+            self.encoder_optimizer.step()
+            self.cpc_optimizer.step()
         if step % self.log_interval == 0:
             L.log('train/curl_loss', ws.scalars[5], step)
 

@@ -127,4 +127,49 @@ class FlatAdam(torch.optim.Adam):
         return loss
 
 
+    # -- two optimizers, one pass ------------------------------------------------------------------------------
+    def _single_run(self):
+        """(lo, hi, step, group) when every parameter is live, they form ONE run of the flat buffer and share their
+        step count; else None."""
+        if len(self.param_groups) != 1 or any(p.grad is None for p in self._plist):
+            return None
+        live = (True,) * len(self._plist)
+        plans = self._plans.get(live)
+        if plans is None:
+            plans = self._plans[live] = [self._plan(0, self.param_groups[0], live)]
+        runs = plans[0]
+        if len(runs) != 1 or len(set(self._steps)) != 1:
+            return None
+        g = self.param_groups[0]
+        if g.get("weight_decay", 0) != 0 or g.get("amsgrad", False) or g.get("maximize", False):
+            return None
+        return runs[0][0], runs[0][1], self._steps[0], g
+
+    @staticmethod
+    @torch.no_grad()
+    def step_pair(first, second):
+        """``first.step(); second.step()`` for two FlatAdams over the same flat buffer where first's parameters are the
+        tail of second's (the encoder inside [CURL.W | encoder]): one launch that applies both steps per element in
+        that order.  Anything else (partial gradients, unequal step counts, other layouts) takes the two steps."""
+        plain = isinstance(first, FlatAdam) and isinstance(second, FlatAdam) and first._flat is second._flat and \
+            first._gflat is second._gflat and "step" not in vars(first) and "step" not in vars(second)  # (a step
+        # replaced on the instance -- tests do that to look at gradients before they are consumed -- is respected)
+        ra, rb = (first._single_run(), second._single_run()) if plain else (None, None)
+        if ra is None or rb is None or ra[1] != rb[1] or ra[0] < rb[0]:
+            first.step()
+            second.step()
+            return
+        (a0, a1, ta, ga), (b0, b1, tb, gb) = ra, rb
+        for opt in (first, second):
+            for i in range(len(opt._plist)):
+                opt._ensure_state(i)
+                opt._steps[i] += 1
+        flat, gflat = first._flat, first._gflat
+        call("curla_adam_step2", flat.data_ptr() + 4 * b0, gflat.data_ptr() + 4 * b0,
+             first._m.data_ptr() + 4 * (a0 - first._lo), first._v.data_ptr() + 4 * (a0 - first._lo),
+             second._m.data_ptr() + 4 * (b0 - second._lo), second._v.data_ptr() + 4 * (b0 - second._lo), b1 - b0, a0 - b0,
+             float(ga["lr"]), float(ga["betas"][0]), float(ga["betas"][1]), float(ga["eps"]), ta + 1,
+             float(gb["lr"]), float(gb["betas"][0]), float(gb["betas"][1]), float(gb["eps"]), tb + 1, stream())
+
+
 __all__ = ["FlatAdam"]

@@ -218,6 +218,13 @@ int curla_soft_update2(const float* param, float* target, size_t n, size_t split
  * torch's single-tensor Adam, and rounded to float once). */
 int curla_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
                     double beta1, double beta2, double eps, long long step, void* stream);
+/* Two such steps of two optimizers on the same parameters with the same gradient, one after the other, in one pass
+ * (encoder_optimizer.step(); cpc_optimizer.step(), curl_sac.py:418-423).  exp_avg2 / exp_avg_sq2 cover n elements, the
+ * first n_pre of which (CURL.W) take the second step only; exp_avg1 / exp_avg_sq1 cover the remaining n - n_pre. */
+int curla_adam_step2(float* param, const float* grad, float* exp_avg1, float* exp_avg_sq1, float* exp_avg2,
+                     float* exp_avg_sq2, size_t n, size_t n_pre, double lr1, double beta1_1, double beta2_1, double eps1,
+                     long long step1, double lr2, double beta1_2, double beta2_2, double eps2, long long step2,
+                     void* stream);
 
 /* ---- augmentations that produce float observations (augmentations.py:78-205; kornia arithmetic is not
  * vendored by the reference: PARITY UNPINNED, the algorithm is this build's statement of kornia's documented

@@ -682,3 +682,29 @@ def test_fc_backward_one_launch(ops):
         dx2, dw2 = torch.full_like(dx1, float("nan")), torch.full_like(dw1, float("nan"))
         ops.fc_bwd(dz, W, x, dx2, dw2, B, Fd, K)
         assert torch.equal(dx1, dx2) and torch.equal(dw1, dw2)
+
+
+def test_flat_adam_step_pair_is_two_steps():
+    """FlatAdam.step_pair(first, second) (the encoder stepped by encoder_optimizer and then by cpc_optimizer,
+    curl_sac.py:418-423, in one pass) leaves exactly the parameters and moments of first.step(); second.step()."""
+    from curla_amd.optim import FlatAdam
+    sizes = [(50, 50), (32, 9, 3, 3), (32,), (50, 1203), (50,)]
+    res = []
+    for fused in (False, True):
+        flat, gflat, params = _flat_params(sizes, "cuda", seed=3)
+        enc = FlatAdam(params[1:], flat, gflat, lr=1e-3)
+        cpc = FlatAdam(params, flat, gflat, lr=2e-3, betas=(0.8, 0.99))
+        gen = torch.Generator().manual_seed(9)
+        for _ in range(3):
+            gflat.copy_(torch.randn(gflat.shape, generator=gen).cuda() * 0.01)
+            if fused:
+                FlatAdam.step_pair(enc, cpc)
+            else:
+                enc.step()
+                cpc.step()
+        torch.cuda.synchronize()
+        res.append((flat.clone(), enc._m.clone(), enc._v.clone(), cpc._m.clone(), cpc._v.clone(), list(enc._steps),
+                    list(cpc._steps)))
+    for a, b in zip(res[0][:5], res[1][:5]):
+        assert torch.equal(a, b)
+    assert res[0][5:] == res[1][5:] == ([3] * 4, [3] * 5)
