@@ -376,6 +376,7 @@ class CurlSacAgent(object):
         self._anchor_cache = None
         self._pos_cache = None   # the obs_pos handle whose target-encoder activations sit in the workspace
         self._pos_hint = None    # set by update(): the positives the actor phase may encode along the way
+        self._pos_fc_done = False  # ... and whose fc product it then leaves in the target encoder's partial buffer
         self._dp_group = None
         self._dp_world = 1
         self._dp_active = False
@@ -658,6 +659,7 @@ class CurlSacAgent(object):
         enc, F = self.critic.encoder, self.critic.encoder.feature_dim
         ws = self._ws(B)
         self._anchor_cache = self._pos_cache = None
+        self._pos_fc_done = False
         action, reward, not_done = action.contiguous(), reward.contiguous(), not_done.contiguous()
 
         # -- target (no_grad block, curl_sac.py:350-355)
@@ -754,7 +756,11 @@ class CurlSacAgent(object):
         else:
             enc.conv_forward(o, ws.acts_main)
         h = ws.acts_main[-1]
-        CNNEncoder.fc_partial_multi([(aenc, h), (enc, h)])  # actor.fc and critic.fc read the same conv output
+        fcs = [(aenc, h), (enc, h)]  # actor.fc and critic.fc read the same conv output
+        if pos is not None:  # ... and the positives' target features are ready too: third problem of the launch
+            fcs.append((self.critic_target.encoder, ws.acts_tmp[-1]))
+            self._pos_fc_done = True
+        CNNEncoder.fc_partial_multi(fcs)
         aenc.ln_from_partial(B, ws.z_a, xhat=ws.xhat_a, rstd=ws.rstd_a)
         self._anchor_cache = obs
 
@@ -816,7 +822,9 @@ class CurlSacAgent(object):
         ws = self._ws(B)
         need_anchor = self._anchor_cache is None or self._anchor_cache is not obs_anchor
         need_pos = self._pos_cache is None or self._pos_cache is not obs_pos
+        pos_fc_done = self._pos_fc_done and not need_pos
         self._anchor_cache = self._pos_cache = None
+        self._pos_fc_done = False
         if need_anchor and need_pos:   # (odd steps) both passes in one launch per layer, own weights each
             enc.conv_forward2(oa, ws.acts_main, tenc, op_, ws.acts_tmp)
         elif need_anchor:
@@ -826,7 +834,7 @@ class CurlSacAgent(object):
         if need_anchor:
             CNNEncoder.fc_partial_multi([(enc, ws.acts_main[-1]), (tenc, ws.acts_tmp[-1])])
             enc.ln_from_partial(B, ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c)
-        else:
+        elif not pos_fc_done:
             tenc.fc_partial(ws.acts_tmp[-1])
         tenc.ln_from_partial(B, ws.z_pos)
 
