@@ -317,6 +317,45 @@ __global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
   conv_s1_body<MODE>(a, blockIdx.x, gridDim.x);
 }
 
+// The whole stack of stride-1 layers (layers 2..L of the encoder) of up to two minibatches in ONE launch.  With the
+// batch sizes multiples of the grid size, workgroup k of the persistent grid processes samples k, k+G, ... of every
+// layer (the item walk is band-major over `item % B`), i.e. it OWNS its samples: layer l+1 only reads what the same
+// workgroup wrote for layer l, so no other workgroup has to be waited for -- a workgroup-scope fence and a barrier
+// between layers make its own stores visible to its own loads, which then come out of the L2 instead of HBM.  Each
+// launch saved is 4-9 us at these sizes.
+constexpr int kMaxStack = 6;
+struct ConvS1StackArgs {
+  int nlayers, B, B2, Hs0, Ws0;
+  const float* in0;
+  const float* in0_2;
+  const float* w[kMaxStack];
+  const float* bias[kMaxStack];
+  float* out[kMaxStack];
+  const float* w2[kMaxStack];
+  const float* bias2[kMaxStack];
+  float* out2[kMaxStack];
+  int th[kMaxStack], h1[kMaxStack], nbands[kMaxStack];
+};
+
+__global__ __launch_bounds__(256, 2) void conv_s1_stack_kernel(ConvS1StackArgs S) {
+  for (int l = 0; l < S.nlayers; ++l) {
+    ConvS1Args a;
+    a.in = l == 0 ? S.in0 : S.out[l - 1], a.w = S.w[l], a.aux = S.bias[l], a.out = S.out[l];
+    a.in2 = l == 0 ? S.in0_2 : S.out2[l - 1], a.w2 = S.w2[l], a.aux2 = S.bias2[l], a.out2 = S.out2[l];
+    a.B = S.B, a.B2 = S.B2;
+    a.Hs = S.Hs0 - 2 * l, a.Ws = S.Ws0 - 2 * l, a.pad = 0, a.Ho = a.Hs - 2, a.Wo = a.Ws - 2;
+    a.th = S.th[l], a.h1 = S.h1[l], a.nbands = S.nbands[l];
+    const int PW = (a.Wo + 1) >> 1;
+    a.qstep = 32 / PW, a.rstep = 32 - a.qstep * PW;
+    a.dbg = 0;
+    conv_s1_body<MODE_FWD>(a, blockIdx.x, gridDim.x);
+    // this workgroup's outputs of layer l are (only) its own inputs of layer l + 1
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  }
+}
+
 // ---------------------------------------------------------------------------
 // first layer: Cin = C (9 or 12 ...), stride 2, input either the uint8 replay
 // frames (gather by index + random-crop offsets + /255 fused into the load) or
@@ -1371,6 +1410,41 @@ int curla_conv3x3_s1_fwd2(const float* in, const float* w, const float* bias, fl
   CURLA_REQUIRE(aligned16(in) && aligned16(out) && aligned16(bias) && aligned16(w));
   CURLA_REQUIRE(aligned16(in2) && aligned16(out2) && aligned16(bias2) && aligned16(w2));
   return launch_conv_s1(MODE_FWD, in, w, bias, out, B, Hi, Wi, static_cast<hipStream_t>(stream), in2, w2, bias2, out2, B2);
+}
+
+int curla_conv3x3_s1_fwd_stack(int nlayers, const float* in, const float* const* w, const float* const* bias,
+                               float* const* out, int B, const float* in2, const float* const* w2,
+                               const float* const* bias2, float* const* out2, int B2, int Hi, int Wi, int channels,
+                               void* stream) {
+  CURLA_REQUIRE(nlayers > 0 && nlayers <= kMaxStack && in && w && bias && out && B > 0 && Hi >= 3 && Wi >= 3);
+  CURLA_REQUIRE(B2 == 0 || (in2 && w2 && bias2 && out2));
+  if (channels != 32) return CURLA_ERR_UNSUPPORTED;
+  const int G = 2 * curla_cu_count();
+  // ownership of samples by workgroups needs whole rounds of the grid over each minibatch
+  if (B % G != 0 || B2 % G != 0) return CURLA_ERR_UNSUPPORTED;
+  ConvS1StackArgs S;
+  S.nlayers = nlayers, S.B = B, S.B2 = B2, S.Hs0 = Hi, S.Ws0 = Wi;
+  S.in0 = in, S.in0_2 = in2;
+  CURLA_REQUIRE(aligned16(in) && (!B2 || aligned16(in2)));
+  size_t lds = (size_t)32 * kWStride * sizeof(float);
+  for (int l = 0; l < kMaxStack; ++l) {
+    const bool on = l < nlayers;
+    S.w[l] = on ? w[l] : nullptr, S.bias[l] = on ? bias[l] : nullptr, S.out[l] = on ? out[l] : nullptr;
+    S.w2[l] = on && B2 ? w2[l] : nullptr, S.bias2[l] = on && B2 ? bias2[l] : nullptr, S.out2[l] = on && B2 ? out2[l] : nullptr;
+    S.th[l] = S.h1[l] = S.nbands[l] = 1;
+    if (!on) continue;
+    CURLA_REQUIRE(S.w[l] && S.bias[l] && S.out[l] && aligned16(S.w[l]) && aligned16(S.bias[l]) && aligned16(S.out[l]));
+    CURLA_REQUIRE(!B2 || (S.w2[l] && S.bias2[l] && S.out2[l] && aligned16(S.w2[l]) && aligned16(S.bias2[l]) && aligned16(S.out2[l])));
+    const int Ho = Hi - 2 * l - 2, Wo = Wi - 2 * l - 2;
+    if (Ho <= 0 || Wo <= 0 || (Wo + 2) * 3 > kBandPx) return CURLA_ERR_UNSUPPORTED;
+    plan_bands_conv_s1(Ho, Wo, kBandPx, &S.th[l], &S.h1[l], &S.nbands[l]);
+    const size_t need = ((size_t)(S.h1[l] + 2) * (Wo + 2) + 1) * kLdsPix * sizeof(float);
+    if (need > lds) lds = need;
+  }
+  int rc = set_lds(conv_s1_stack_kernel, lds);
+  if (rc != CURLA_OK) return rc;
+  hipLaunchKernelGGL(conv_s1_stack_kernel, dim3(G), dim3(256), lds, static_cast<hipStream_t>(stream), S);
+  return curla_launch_status();
 }
 
 int curla_conv3x3_s1_dgrad(const float* g, const float* w, const float* act_below, float* gin, int B, int Ho, int Wo,

@@ -150,7 +150,12 @@ class CNNEncoder(nn.Module):
         else:  # (float sources, or handles into different rings: the first layer runs twice)
             ops.conv1_fwd(obs_ref, cp[0][0], cp[0][1], acts[0])
             ops.conv1_fwd(other_ref, cp2[0][0], cp2[0][1], other_acts[0])
-        for i in range(1, self.num_layers):
+        L = self.num_layers
+        if L > 1 and ops.conv_s1_fwd_stack(acts[0], [cp[i][0] for i in range(1, L)], [cp[i][1] for i in range(1, L)],
+                                           acts[1:L], other_acts[0], [cp2[i][0] for i in range(1, L)],
+                                           [cp2[i][1] for i in range(1, L)], other_acts[1:L]):
+            return  # (all stride-1 layers of both minibatches in one launch)
+        for i in range(1, L):
             ops.conv_s1_fwd2(acts[i - 1], cp[i][0], cp[i][1], acts[i], other_acts[i - 1], cp2[i][0], cp2[i][1],
                              other_acts[i])
 

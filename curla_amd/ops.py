@@ -98,6 +98,42 @@ def conv_s1_fwd2(x, w, b, out, x2, w2, b2, out2):
          H, W, C, stream())
 
 
+def conv_s1_fwd_stack(x, ws, bs, outs, x2=None, ws2=None, bs2=None, outs2=None):
+    """All stride-1 layers of one or two minibatches in ONE launch (x -> outs[0] -> outs[1] ...); returns False when
+    the kernels cannot (batch sizes not multiples of the persistent grid: use one conv_s1_fwd2 per layer)."""
+    import ctypes
+    B, H, W, C = x.shape
+    n = len(ws)
+    B2 = 0 if x2 is None else x2.shape[0]
+    G = 2 * cu_count()
+    if n > 6 or B % G or B2 % G:
+        return False
+    P = ctypes.c_void_p * n
+    arr = lambda ts: P(*[ptr(t) for t in ts])  # noqa: E731
+    a_w, a_b, a_o = arr(ws), arr(bs), arr(outs)
+    if B2:
+        assert x2.shape[1:] == x.shape[1:]
+        a_w2, a_b2, a_o2 = arr(ws2), arr(bs2), arr(outs2)
+        p2 = (ptr(x2), ctypes.addressof(a_w2), ctypes.addressof(a_b2), ctypes.addressof(a_o2))
+    else:
+        p2 = (None, None, None, None)
+    call("curla_conv3x3_s1_fwd_stack", n, ptr(x), ctypes.addressof(a_w), ctypes.addressof(a_b), ctypes.addressof(a_o), B,
+         p2[0], p2[1], p2[2], p2[3], B2, H, W, C, stream())
+    return True
+
+
+_CU_COUNT = None
+
+
+def cu_count():
+    global _CU_COUNT
+    if _lib._trace_hook is not None:
+        return 256  # (launch-schedule tests without a device: MI355X's count)
+    if _CU_COUNT is None:
+        _CU_COUNT = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    return _CU_COUNT
+
+
 def conv1_pairable(o1: "ObsRef", o2: "ObsRef"):
     """Can the first-layer forwards of two handles share a launch?  Both uint8, from the same ring, same crop."""
     return (o1.is_u8 == 1 and o2.is_u8 == 1 and o1.src.data_ptr() == o2.src.data_ptr() and o1.src.shape == o2.src.shape

@@ -708,3 +708,31 @@ def test_flat_adam_step_pair_is_two_steps():
     for a, b in zip(res[0][:5], res[1][:5]):
         assert torch.equal(a, b)
     assert res[0][5:] == res[1][5:] == ([3] * 4, [3] * 5)
+
+
+@pytest.mark.parametrize("two", [False, True])
+def test_conv_s1_forward_stack_one_launch(ops, two):
+    """curla_conv3x3_s1_fwd_stack: three stride-1 layers of one or two minibatches in ONE launch (a workgroup owns its
+    samples through the layers) -- every layer's activations bit-identical to the per-layer launches.  Batch sizes
+    must be multiples of the persistent grid (2 x CUs); anything else is refused."""
+    G = 2 * ops.cu_count()
+    H = W = 13
+    B1, B2 = 2 * G, G
+    L = 3
+    x1, x2 = torch.relu(rnd(B1, H, W, 32, seed=101)).cuda(), torch.relu(rnd(B2, H, W, 32, seed=102)).cuda()
+    w1 = [(rnd(32, 32, 3, 3, seed=110 + i) * 0.1).cuda() for i in range(L)]
+    w2 = [(rnd(32, 32, 3, 3, seed=120 + i) * 0.1).cuda() for i in range(L)]
+    b1 = [(rnd(32, seed=130 + i) * 0.1).cuda() for i in range(L)]
+    b2 = [(rnd(32, seed=140 + i) * 0.1).cuda() for i in range(L)]
+    mk = lambda B: [torch.full((B, H - 2 * (i + 1), W - 2 * (i + 1), 32), float("nan"), device="cuda") for i in range(L)]  # noqa: E731
+    r1, r2, o1, o2 = mk(B1), mk(B2), mk(B1), mk(B2)
+    for i in range(L):
+        ops.conv_s1_fwd(x1 if i == 0 else r1[i - 1], w1[i], b1[i], r1[i])
+        ops.conv_s1_fwd(x2 if i == 0 else r2[i - 1], w2[i], b2[i], r2[i])
+    if two:
+        assert ops.conv_s1_fwd_stack(x1, w1, b1, o1, x2, w2, b2, o2)
+    else:
+        assert ops.conv_s1_fwd_stack(x1, w1, b1, o1) and ops.conv_s1_fwd_stack(x2, w2, b2, o2)
+    for i in range(L):
+        assert torch.equal(o1[i], r1[i]) and torch.equal(o2[i], r2[i]), i
+    assert not ops.conv_s1_fwd_stack(x1[:G + 1], w1, b1, [t[:G + 1] for t in o1])
