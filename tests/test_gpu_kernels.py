@@ -736,3 +736,33 @@ def test_conv_s1_forward_stack_one_launch(ops, two):
     for i in range(L):
         assert torch.equal(o1[i], r1[i]) and torch.equal(o2[i], r2[i]), i
     assert not ops.conv_s1_fwd_stack(x1[:G + 1], w1, b1, [t[:G + 1] for t in o1])
+
+
+def test_conv_s1_forward_stack_full_size(ops):
+    """The stack launch at BASELINE configs[1] size (the critic phase's [obs | next_obs] online pass of 1024 samples
+    + the target pass of 512, 37x37 -> 35 -> 33 -> 31): every layer bit-identical to per-layer launches, twice in
+    a row into the same buffers (a workgroup reads back its own stores of the previous layer: a stale or late line
+    would show up here)."""
+    G = 2 * ops.cu_count()
+    if 1024 % G or 512 % G:
+        pytest.skip("grid size does not divide the BASELINE batch sizes on this device")
+    H = W = 37
+    L = 3
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x1 = torch.relu(torch.randn(1024, H, W, 32, device="cuda", generator=g))
+    x2 = torch.relu(torch.randn(512, H, W, 32, device="cuda", generator=g))
+    w1 = [torch.randn(32, 32, 3, 3, device="cuda", generator=g) * 0.1 for _ in range(L)]
+    w2 = [torch.randn(32, 32, 3, 3, device="cuda", generator=g) * 0.1 for _ in range(L)]
+    b1 = [torch.randn(32, device="cuda", generator=g) * 0.1 for _ in range(L)]
+    b2 = [torch.randn(32, device="cuda", generator=g) * 0.1 for _ in range(L)]
+    mk = lambda B: [torch.empty(B, H - 2 * (i + 1), W - 2 * (i + 1), 32, device="cuda") for i in range(L)]  # noqa: E731
+    r1, r2, o1, o2 = mk(1024), mk(512), mk(1024), mk(512)
+    for i in range(L):
+        ops.conv_s1_fwd(x1 if i == 0 else r1[i - 1], w1[i], b1[i], r1[i])
+        ops.conv_s1_fwd(x2 if i == 0 else r2[i - 1], w2[i], b2[i], r2[i])
+    for rep in range(2):
+        for t in o1 + o2:
+            t.fill_(float("nan"))
+        assert ops.conv_s1_fwd_stack(x1, w1, b1, o1, x2, w2, b2, o2)
+        for i in range(L):
+            assert torch.equal(o1[i], r1[i]) and torch.equal(o2[i], r2[i]), (rep, i)
