@@ -1064,54 +1064,78 @@ __global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
                    2 * tha + 1, RSb, tid, NTHR);
     __syncthreads();
     const float* const gband = a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32 + li;  // the band's pixels are contiguous
-    const int npix = tha * a.Wo;
-    const int nunits = ((npix + 15) >> 4) << 2;
-    // the lane's pixel p(u) = (u>>2)*16 + (u&3) + 4*kq advances by 4*NW per iteration: (ty, x) are kept
-    // incrementally (no division in the loop); the bytes are multiplied unscaled, `scale` is applied once to
-    // the accumulated sums
-    int ty = ((wave >> 2) * 16 + (wave & 3) + 4 * kq) / a.Wo, x = ((wave >> 2) * 16 + (wave & 3) + 4 * kq) - ty * a.Wo;
-    // fetch() runs for u = wave, wave+NW, ... in order and leaves (ty, x) at the next unit's pixel
-    auto fetch = [&](int u, float (&av)[2], float (&bv)[NT]) {
-      const int p = (u >> 2) * 16 + (u & 3) + 4 * kq;
-      const bool pv = (u < nunits) && (p < npix);
-      const int cy = pv ? ty : 0, cx = pv ? x : 0;
-      const float* gp = pv ? gband + p * 32 : g_zero_px;  // (a zero is loaded, not selected: see g_zero_px)
-      av[0] = gp[0];
-      av[1] = gp[16];
-      const uint8_t* ip = ldsb + 2 * cy * RSb + 2 * cx * C;
+    // Row walk: wave w takes output rows w, w + NW, ... of the band; a k-step ("unit") is 4 consecutive pixels of
+    // one row (lane group kq -> pixel 4j + kq), units are processed in chunks of UNR.  Everything a unit needs is then
+    // at a COMPILE-TIME offset from per-chunk bases: the six byte operands at (row base + koff[t]) + 8 C jj, the two
+    // gradient values at chunk base + 128 jj floats -- no per-unit address arithmetic, no (row, column) bookkeeping
+    // (the pixel-order walk spent ~45 VALU instructions per 12 MFMAs on those: matrix pipe busy 46 %).  The bytes are
+    // multiplied unscaled, `scale` is applied once to the accumulated sums.
+    constexpr int UNR = 5;
+    const int upr = (a.Wo + 3) >> 2;         // units per row
+    const int cpr = (upr + UNR - 1) / UNR;   // chunks per row
+    // gradient values of a chunk (from HBM/L2, one chunk ahead of their use; lanes past the row or the band: zero page)
+    auto gload = [&](int ty, int c, float (&av)[UNR][2]) {
+      const int x0 = 4 * c * UNR + kq;
+      const bool full = ty < tha && 4 * (c + 1) * UNR <= a.Wo;  // (wave-uniform)
+      if (full) {
+        const float* gp = gband + (ty * a.Wo + x0) * 32;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) bv[t] = (float)ip[koff[t]];
-      x += 4 * NW;
-      if (a.Wo >= 4 * NW) {  // wave-uniform: one wrap at most
-        const bool wrap = x >= a.Wo;
-        x = wrap ? x - a.Wo : x;
-        ty = wrap ? ty + 1 : ty;
+        for (int jj = 0; jj < UNR; ++jj) av[jj][0] = gp[128 * jj], av[jj][1] = gp[128 * jj + 16];
       } else {
-        while (x >= a.Wo) x -= a.Wo, ++ty;
+#pragma unroll
+        for (int jj = 0; jj < UNR; ++jj) {
+          const int x = x0 + 4 * jj;
+          const float* gp = (ty < tha && x < a.Wo) ? gband + (ty * a.Wo + x) * 32 : g_zero_px;
+          av[jj][0] = gp[0], av[jj][1] = gp[16];
+        }
       }
     };
-    auto mma = [&](const float (&av)[2], const float (&bv)[NT]) {
-      bsum[0] += av[0];
-      bsum[1] += av[1];
+    auto unit = [&](const uint8_t* ub, const float (&avj)[2]) {
+      float bv[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[t] = (float)ub[koff[t]];
+      bsum[0] += avj[0];
+      bsum[1] += avj[1];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        acc[0][t] = mfma16(av[0], bv[t], acc[0][t]);
-        acc[1][t] = mfma16(av[1], bv[t], acc[1][t]);
+        acc[0][t] = mfma16(avj[0], bv[t], acc[0][t]);
+        acc[1][t] = mfma16(avj[1], bv[t], acc[1][t]);
       }
     };
-    // two register sets: the LDS reads (and byte -> float conversions) of the next unit are in flight while the
-    // MFMAs of the current one issue
-    float aA[2], aB[2], bA[NT], bB[NT];
-    fetch(wave, aA, bA);
-    for (int u = wave; u < nunits; u += 2 * NW) {
-      fetch(u + NW, aB, bB);
+    auto compute = [&](int ty, int c, const float (&av)[UNR][2]) {
+      const uint8_t* rowy = ldsb + __mul24(2 * ty, RSb);
+      if (4 * (c + 1) * UNR <= a.Wo) {  // (wave-uniform) every unit of the chunk is whole: compile-time offsets
+        const uint8_t* rowb = rowy + 2 * (4 * c * UNR + kq) * C;
+#pragma unroll
+        for (int jj = 0; jj < UNR; ++jj) unit(rowb + 8 * C * jj, av[jj]);
+      } else {  // the row's last chunk: units past the row are skipped, lanes past it multiply a zero gradient and
+                // have their byte address clamped into the row
+#pragma unroll
+        for (int jj = 0; jj < UNR; ++jj) {
+          const int xu = 4 * (c * UNR + jj);
+          if (xu < a.Wo) unit(rowy + 2 * min(xu + kq, a.Wo - 1) * C, av[jj]);
+        }
+      }
+    };
+    float avA[UNR][2], avB[UNR][2];
+    int ty = wave, c = 0;
+    if (ty < tha) gload(ty, c, avA);
+    while (ty < tha) {  // (wave-uniform)
+      int nty = ty, nc = c + 1;
+      if (nc == cpr) nc = 0, nty += NW;
+      gload(nty, nc, avB);
       __builtin_amdgcn_sched_barrier(0);
-      mma(aA, bA);
+      compute(ty, c, avA);
       __builtin_amdgcn_sched_barrier(0);
-      fetch(u + 2 * NW, aA, bA);
+      ty = nty, c = nc;
+      if (ty >= tha) break;
+      nc = c + 1;
+      if (nc == cpr) nc = 0, nty += NW;
+      gload(nty, nc, avA);
       __builtin_amdgcn_sched_barrier(0);
-      mma(aB, bB);
+      compute(ty, c, avB);
       __builtin_amdgcn_sched_barrier(0);
+      ty = nty, c = nc;
     }
     __syncthreads();
   }
