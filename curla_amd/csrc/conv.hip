@@ -929,6 +929,7 @@ struct Wgrad1Args {
   float* partial;  // [grid][32*C*9 + 32]
   int B, C, Hs, Ws, Hc, Wc, Ho, Wo, th, nbands;
   float scale;
+  unsigned lds_bytes;  // dynamic LDS of the launch (the uint8 kernel sizes its final cross-wave sum by it)
 };
 
 template <int SRC, int C>
@@ -1148,37 +1149,46 @@ __global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
   bsum[0] += __shfl_xor(bsum[0], 32);
   bsum[1] += __shfl_xor(bsum[1], 16);
   bsum[1] += __shfl_xor(bsum[1], 32);
+  // Cross-wave sum (waves in order: fixed order, reproducible) and the slab.  Every wave deposits its accumulator
+  // tiles lane-contiguously (one ds_write_b128 per tile, no index arithmetic), as many tiles per pass as the LDS
+  // holds for NW waves; after one barrier the threads add the NW copies of their slot and scatter the four sums
+  // straight into the slab -- instead of NW serialised read-modify-write rounds over the output layout.
   const int nw = 32 * C * 9;
-  for (int w = 0; w < NW; ++w) {
-    if (wave == w) {
+  float* slab = a.partial + (size_t)blockIdx.x * (nw + 32);
+  f32x4* l4 = reinterpret_cast<f32x4*>(lds);
+  const int TC = max(1, min(2 * NT, (int)(a.lds_bytes / (NW * 1024))));  // tiles per pass (1 KB per tile and wave)
+  __syncthreads();
+  for (int t0 = 0; t0 < 2 * NT; t0 += TC) {
+    const int nt = min(TC, 2 * NT - t0);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+    for (int q = 0; q < 2 * NT; ++q)  // (tile q = mt * NT + t; compile-time register index, runtime range test)
+      if (q >= t0 && q < t0 + nt) l4[(wave * TC + (q - t0)) * 64 + lane] = acc[q / NT][q % NT];
+    __syncthreads();
+    for (int sl = tid; sl < nt * 64; sl += NTHR) {
+      const int q = t0 + sl / 64, ln = sl & 63;
+      f32x4 v = l4[(0 * TC + (q - t0)) * 64 + ln];
+      for (int w = 1; w < NW; ++w) v += l4[(w * TC + (q - t0)) * 64 + ln];
+      const int mt = q / NT, t = q - mt * NT;
+      const int k = t * 16 + (ln & 15);
+      const int dy = k / KR, rr = k - dy * KR;
+      if (dy < 3 && rr < 3 * C) {
+        const int dx = rr / C, c = rr - dx * C;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const int k = t * 16 + li;
-          const int dy = k / KR, rr = k - dy * KR;
-          if (dy < 3 && rr < 3 * C) {
-            const int dx = rr / C, c = rr - dx * C;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int co = mt * 16 + 4 * kq + r;
-              float* d = lds + (co * C + c) * 9 + dy * 3 + dx;
-              *d = (w == 0) ? acc[mt][t][r] : *d + acc[mt][t][r];
-            }
-          }
-        }
-      if (kq == 0) {
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-          float* d = lds + nw + mt * 16 + li;
-          *d = (w == 0) ? bsum[mt] : *d + bsum[mt];
+        for (int r = 0; r < 4; ++r) {
+          const int co = mt * 16 + 4 * (ln >> 4) + r;
+          slab[(co * C + c) * 9 + dy * 3 + dx] = v[r];
         }
       }
     }
     __syncthreads();
   }
-  float* slab = a.partial + (size_t)blockIdx.x * (nw + 32);
-  for (int i = tid; i < nw + 32; i += NTHR) slab[i] = lds[i];
+  if (kq == 0) lds[(wave * 2 + 0) * 16 + li] = bsum[0], lds[(wave * 2 + 1) * 16 + li] = bsum[1];
+  __syncthreads();
+  if (tid < 32) {
+    float v = lds[tid];  // wave 0: [mt][li] = tid
+    for (int w = 1; w < NW; ++w) v += lds[w * 32 + tid];
+    slab[nw + tid] = v;
+  }
 }
 
 // second pass: dW = sum over workgroup slabs.  32 elements x 32 slab-groups per
@@ -1722,6 +1732,7 @@ static int launch_wgrad1(const void* src, int src_kind, const int64_t* idx, cons
   a.B = B, a.C = C, a.Hs = Hs, a.Ws = Ws, a.Hc = Hc, a.Wc = Wc;
   a.Ho = (Hc - 3) / 2 + 1, a.Wo = (Wc - 3) / 2 + 1;
   a.scale = scale;
+  a.lds_bytes = 0;
   const int nw = 32 * C * 9;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int grid;
@@ -1740,6 +1751,8 @@ static int launch_wgrad1(const void* src, int src_kind, const int64_t* idx, cons
     a.th = (a.Ho + a.nbands - 1) / a.nbands;
     size_t lds = (((size_t)(2 * a.th + 1) * RSb + 15) & ~(size_t)15) + 32;
     if (lds < (size_t)(nw + 32) * sizeof(float)) lds = (size_t)(nw + 32) * sizeof(float);
+    if (lds < (size_t)nwaves * 1024) lds = (size_t)nwaves * 1024;  // the final cross-wave sum: one tile of every wave
+    a.lds_bytes = (unsigned)lds;
     const int nitems = B * a.nbands;
     const int per_cu = nwaves == 4 ? 4 : 2;
     grid = nitems < per_cu * curla_cu_count() ? nitems : per_cu * curla_cu_count();
