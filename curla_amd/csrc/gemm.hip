@@ -32,6 +32,11 @@ struct GemmArgs {
   float alpha;
   int relu, vecA, vecB;
   int stream_c;  // output far larger than the L2s (fc data gradient): streaming stores
+  // two-level batch: item = outer * nb_inner + inner at base + inner * s + outer * s2 (e.g. the twin Q functions of
+  // the target critic and of the critic: twins a block apart inside a flat buffer, the two flat buffers wherever
+  // the allocator put them -- one launch for all four)
+  int nb_inner;
+  long long sA2, sB2, sC2, sBias2, sMask2;
   // nptr > 0: the batch items are unrelated problems of one shape, given by pointer (A = Ap[batch] ...) instead of by
   // stride -- e.g. the fc products of three encoders on three activation tensors in one launch
   int nptr;
@@ -150,15 +155,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int z = blockIdx.z;
   const int batch = z / g.ksplit, ks = z - batch * g.ksplit;
   const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
-  const float* A = g.nptr ? g.Ap[batch] : g.A + batch * g.sA;
-  const float* B = g.nptr ? g.Bp[batch] : g.B + batch * g.sB;
-  float* C = (g.nptr ? g.Cp[batch] : g.C + batch * g.sC) + ks * g.sSplit;
+  const int bo = batch / g.nb_inner, bi = batch - bo * g.nb_inner;
+  const float* A = g.nptr ? g.Ap[batch] : g.A + bi * g.sA + bo * g.sA2;
+  const float* B = g.nptr ? g.Bp[batch] : g.B + bi * g.sB + bo * g.sB2;
+  float* C = (g.nptr ? g.Cp[batch] : g.C + bi * g.sC + bo * g.sC2) + ks * g.sSplit;
   const int kbeg = ks * g.kchunk;
   const int kend = min(g.K, kbeg + g.kchunk);
 
   const bool epi = g.ksplit == 1;
-  const float* bias = (epi && g.bias) ? g.bias + batch * g.sBias : nullptr;
-  const float* mask = (epi && g.mask) ? g.mask + batch * g.sMask : nullptr;
+  const float* bias = (epi && g.bias) ? g.bias + bi * g.sBias + bo * g.sBias2 : nullptr;
+  const float* mask = (epi && g.mask) ? g.mask + bi * g.sMask + bo * g.sMask2 : nullptr;
   // The MFMA is issued with the N-side operand as its row operand, so a lane holds 4 CONSECUTIVE n
   // (rows 4kq..4kq+3 of the 16x16 tile) of ONE m (column li): C, bias and mask move as float4.
   const bool vec_c = (g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
@@ -572,6 +578,26 @@ int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const f
   g.vecA = (lda % 4 == 0) && (strideA % 4 == 0) && aligned16(A);
   g.vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && aligned16(B);
   g.nptr = 0;
+  g.nb_inner = nbatch, g.sA2 = g.sB2 = g.sC2 = g.sBias2 = g.sMask2 = 0;
+  return gemm_launch(g, a_kmajor, b_kmajor, static_cast<hipStream_t>(stream));
+}
+
+int curla_gemm_nested(const float* A, int a_kmajor, int lda, long long strideA, long long strideA2, const float* B,
+                      int b_kmajor, int ldb, long long strideB, long long strideB2, float* C, int ldc, long long strideC,
+                      long long strideC2, int M, int N, int K, int nbatch, int nbatch2, float alpha, const float* bias,
+                      long long strideBias, long long strideBias2, int relu, const float* mask, int ldmask,
+                      long long strideMask, long long strideMask2, void* stream) {
+  CURLA_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && nbatch > 0 && nbatch2 > 0);
+  GemmArgs g;
+  g.A = A, g.B = B, g.C = C, g.bias = bias, g.mask = mask;
+  g.M = M, g.N = N, g.K = K, g.lda = lda, g.ldb = ldb, g.ldc = ldc, g.ldmask = ldmask;
+  g.sA = strideA, g.sB = strideB, g.sC = strideC, g.sBias = strideBias, g.sMask = strideMask, g.sSplit = 0;
+  g.nbatch = nbatch * nbatch2, g.ksplit = 1;
+  g.alpha = alpha, g.relu = relu;
+  g.vecA = (lda % 4 == 0) && (strideA % 4 == 0) && (strideA2 % 4 == 0) && aligned16(A);
+  g.vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && (strideB2 % 4 == 0) && aligned16(B);
+  g.nptr = 0;
+  g.nb_inner = nbatch, g.sA2 = strideA2, g.sB2 = strideB2, g.sC2 = strideC2, g.sBias2 = strideBias2, g.sMask2 = strideMask2;
   return gemm_launch(g, a_kmajor, b_kmajor, static_cast<hipStream_t>(stream));
 }
 
@@ -586,6 +612,7 @@ int curla_gemm_multi(int nprob, const float* const* A, const float* const* B, fl
   g.alpha = 1.f, g.relu = 0;
   g.vecA = (lda % 4 == 0), g.vecB = (ldb % 4 == 0);
   g.nptr = nprob;
+  g.nb_inner = nprob, g.sA2 = g.sB2 = g.sC2 = g.sBias2 = g.sMask2 = 0;
   for (int i = 0; i < nprob; ++i) {
     CURLA_REQUIRE(A[i] && B[i] && C[i]);
     g.Ap[i] = A[i], g.Bp[i] = B[i], g.Cp[i] = C[i];

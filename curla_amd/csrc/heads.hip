@@ -235,14 +235,16 @@ __global__ __launch_bounds__(1024) void colsum3_kernel(Colsum3Args a, int M, lon
 constexpr int kMaxOut = 16;
 
 // out[z][m][n] = bias[z][n] + sum_k h[z][m][k] * W[z][n][k]        (curl_sac.py:73-74,132-133 forward)
-__global__ __launch_bounds__(256) void mlp_out_fwd_kernel(const float* h, long long sH, const float* W, long long sW,
-                                                          const float* bias, long long sB, float* out, long long sOut,
-                                                          int M, int N, int K) {
-  const int z = blockIdx.y;
+// (two-level batch: blockIdx.y = outer * nb_inner + inner; the outer level's strides end in 2)
+__global__ __launch_bounds__(256) void mlp_out_fwd_kernel(const float* h, long long sH, long long sH2, const float* W,
+                                                          long long sW, long long sW2, const float* bias, long long sB,
+                                                          long long sB2, float* out, long long sOut, long long sOut2,
+                                                          int M, int N, int K, int nb_inner) {
+  const int zo = blockIdx.y / nb_inner, zi = blockIdx.y - zo * nb_inner;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= M) return;
-  const float* hr = h + z * sH + (size_t)row * K;
-  const float* Wz = W + z * sW;
+  const float* hr = h + zi * sH + zo * sH2 + (size_t)row * K;
+  const float* Wz = W + zi * sW + zo * sW2;
   float acc[kMaxOut];
 #pragma unroll
   for (int n = 0; n < kMaxOut; ++n) acc[n] = 0.f;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void mlp_out_fwd_kernel(const float* h, long l
   for (int n = 0; n < kMaxOut; ++n)
     if (n < N) {
       const float s = wave_sum(acc[n]);
-      if (lane == 0) out[z * sOut + (size_t)row * N + n] = s + (bias ? bias[z * sB + n] : 0.f);
+      if (lane == 0) out[zi * sOut + zo * sOut2 + (size_t)row * N + n] = s + (bias ? bias[zi * sB + zo * sB2 + n] : 0.f);
     }
 }
 
@@ -830,7 +832,21 @@ int curla_mlp_out_fwd(const float* h, long long strideH, const float* W, long lo
   if (N > kMaxOut || K % 4 != 0 || strideH % 4 != 0 || strideW % 4 != 0) return CURLA_ERR_UNSUPPORTED;
   CURLA_REQUIRE(aligned16(h) && aligned16(W));
   hipLaunchKernelGGL(mlp_out_fwd_kernel, dim3((M + 3) / 4, nbatch), dim3(256), 0, static_cast<hipStream_t>(stream), h,
-                     strideH, W, strideW, bias, strideBias, out, strideOut, M, N, K);
+                     strideH, 0LL, W, strideW, 0LL, bias, strideBias, 0LL, out, strideOut, 0LL, M, N, K, nbatch);
+  return curla_launch_status();
+}
+
+int curla_mlp_out_fwd_nested(const float* h, long long strideH, long long strideH2, const float* W, long long strideW,
+                             long long strideW2, const float* bias, long long strideBias, long long strideBias2,
+                             float* out, long long strideOut, long long strideOut2, int M, int N, int K, int nbatch,
+                             int nbatch2, void* stream) {
+  CURLA_REQUIRE(h && W && out && M > 0 && N > 0 && K > 0 && nbatch > 0 && nbatch2 > 0);
+  if (N > kMaxOut || K % 4 != 0 || strideH % 4 != 0 || strideW % 4 != 0 || strideH2 % 4 != 0 || strideW2 % 4 != 0)
+    return CURLA_ERR_UNSUPPORTED;
+  CURLA_REQUIRE(aligned16(h) && aligned16(W));
+  hipLaunchKernelGGL(mlp_out_fwd_kernel, dim3((M + 3) / 4, nbatch * nbatch2), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), h, strideH, strideH2, W, strideW, strideW2, bias, strideBias,
+                     strideBias2, out, strideOut, strideOut2, M, N, K, nbatch);
   return curla_launch_status();
 }
 

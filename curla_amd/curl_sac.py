@@ -71,14 +71,20 @@ class _Mlp:
         self.stride = stride
 
 
-def _mlp_fwd(x, sx, P, nb, B, din, H, dout, h1, h2, out, relu_out=0):
+def _mlp_fwd(x, sx, P, nb, B, din, H, dout, h1, h2, out, relu_out=0, outer=None):
+    """``outer`` = (n2, sW2): n2 such MLP groups in the same launches, their parameters sW2 floats apart (the target
+    critic's and the critic's twins); x [n2][B, din] and h1 / h2 / out [n2][nb][B, .] then."""
     s = P.stride
-    ops.linear_fwd(x, sx, P.W[0], s, P.b[0], s, h1, B * H, B, H, din, nb, relu=1)
-    ops.linear_fwd(h1, B * H, P.W[1], s, P.b[1], s, h2, B * H, B, H, H, nb, relu=1)
+    o0 = o1 = o2 = None
+    if outer is not None:
+        n2, sW2 = outer
+        o0, o1, o2 = (n2, B * din, sW2, nb * B * H), (n2, nb * B * H, sW2, nb * B * H), (n2, nb * B * H, sW2, nb * B * dout)
+    ops.linear_fwd(x, sx, P.W[0], s, P.b[0], s, h1, B * H, B, H, din, nb, relu=1, outer=o0)
+    ops.linear_fwd(h1, B * H, P.W[1], s, P.b[1], s, h2, B * H, B, H, H, nb, relu=1, outer=o1)
     if dout <= ops.MLP_OUT_MAX and H % 4 == 0 and not relu_out:  # a handful of outputs: row dot products, not a GEMM
-        ops.mlp_out_fwd(h2, B * H, P.W[2], s, P.b[2], s, out, B * dout, B, dout, H, nb)
+        ops.mlp_out_fwd(h2, B * H, P.W[2], s, P.b[2], s, out, B * dout, B, dout, H, nb, outer=o2)
     else:
-        ops.linear_fwd(h2, B * H, P.W[2], s, P.b[2], s, out, B * dout, B, dout, H, nb, relu=relu_out)
+        ops.linear_fwd(h2, B * H, P.W[2], s, P.b[2], s, out, B * dout, B, dout, H, nb, relu=relu_out, outer=o2)
 
 
 def _mlp_bwd(x, sx, P, G, nb, B, din, H, dout, h1, h2, dy, dh2, dh1, dx):
@@ -270,9 +276,14 @@ class _Workspace:
         self.mu, self.pi, self.log_std, self.tanh_ls, self.gpi = f(B, A), f(B, A), f(B, A), f(B, A), f(B, A)
         self.log_pi = f(B, 1)
         # twin Q
-        self.xa, self.dxa = f(B, F + A), f(2, B, F + A)
-        self.q_h1, self.q_h2, self.q_dh1, self.q_dh2 = f(2, B, H), f(2, B, H), f(2, B, H), f(2, B, H)
-        self.q, self.tq, self.dq, self.target_q = f(2, B, 1), f(2, B, 1), f(2, B, 1), f(B, 1)
+        # [0] = the target critic's pass over next_obs, [1] = the critic's over obs: one launch per layer for the four
+        # Q functions (update_critic); the names without a 2 are the critic's halves, what the backward reads
+        self.xa2, self.q_h1_2, self.q_h2_2, self.q2 = f(2, B, F + A), f(2, 2, B, H), f(2, 2, B, H), f(2, 2, B, 1)
+        self.xa, self.q_h1, self.q_h2 = self.xa2[1], self.q_h1_2[1], self.q_h2_2[1]
+        self.tq, self.q = self.q2[0], self.q2[1]
+        self.dxa = f(2, B, F + A)
+        self.q_dh1, self.q_dh2 = f(2, B, H), f(2, B, H)
+        self.dq, self.target_q = f(2, B, 1), f(B, 1)
         # scalars: [0] critic loss, [1..4] actor_loss/alpha_loss/entropy/alpha, [5] curl loss, [6] batch reward
         self.scalars = torch.zeros(8, device=dev, dtype=torch.float32)
         # CURL
@@ -425,8 +436,13 @@ class CurlSacAgent(object):
         total = w_sz + enc_sz + 2 * q_sz
         self._lay = dict(w=(0, w_sz), enc=(w_sz, w_sz + enc_sz), q=(w_sz + enc_sz, total), total=total, qblock=q_sz)
 
+        # target and critic parameters in one allocation, [target | critic]: a fixed distance apart, so the four Q
+        # functions are one two-level batch (update_critic)
+        both = torch.zeros(2 * total, device=dev, dtype=torch.float32)
+        self._twin_outer = total if os.environ.get("CURLA_FOUR_Q", "1") != "0" else None
+
         def build(critic, W, with_grad):
-            flat = torch.zeros(total, device=dev, dtype=torch.float32)
+            flat = both[total:] if with_grad else both[:total]
             gflat = torch.zeros(total, device=dev, dtype=torch.float32) if with_grad else None
             wl_, enc_, q1_, q2_ = critic_groups(critic, W)
             place(wl_, False, flat, gflat, 0)
@@ -687,8 +703,12 @@ class CurlSacAgent(object):
         if not merged:
             tenc.conv_forward(no, ws.acts_tmp)
             tenc.fc_partial(ws.acts_tmp[-1])
-        tenc.ln_from_partial(B, ws.z_t, xa=ws.xa, act=ws.pi)  # xa = cat([z, a'], 1)
-        _mlp_fwd(ws.xa, 0, self.critic_target.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.tq)
+        # the target critic's twins over [z', a'] and the critic's over [z, a] (curl_sac.py:353-358) are four MLPs of
+        # one shape: with all conv outputs there they share their three launches
+        four = merged and self._twin_outer is not None
+        tenc.ln_from_partial(B, ws.z_t, xa=ws.xa2[0] if four else ws.xa, act=ws.pi)  # xa = cat([z, a'], 1)
+        if not four:
+            _mlp_fwd(ws.xa, 0, self.critic_target.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.tq)
 
         # -- current Q estimates + loss + backward (curl_sac.py:357-367)
         if not merged:
@@ -697,7 +717,11 @@ class CurlSacAgent(object):
         rec = self._records(step)
         enc.ln_from_partial(B, ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c, fc_out=ws.fc_out if rec else None, xa=ws.xa,
                             act=action)
-        _mlp_fwd(ws.xa, 0, self.critic.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.q)
+        if four:
+            _mlp_fwd(ws.xa2, 0, self.critic_target.twin(), 2, B, F + A, H, 1, ws.q_h1_2, ws.q_h2_2, ws.q2,
+                     outer=(2, self._twin_outer))
+        else:
+            _mlp_fwd(ws.xa, 0, self.critic.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.q)
         if rec:  # what critic.log() / encoder.log() histogram: the outputs of THIS forward (curl_sac.py:163-167)
             self.critic.outputs['q1'], self.critic.outputs['q2'] = ws.q[0].clone(), ws.q[1].clone()
             enc.record_from(o, ws.acts_main, ws.fc_out, ws.z_c)

@@ -223,9 +223,15 @@ def gemm_multi(As, Bs, Cs, M, N, K, ksplit=1, split_stride=0):
          split_stride, stream())
 
 
-def linear_fwd(x, sx, W, sW, bias, sb, out, so, M, N, K, nb=1, relu=0):
-    """out[z] = act(x[z] @ W[z]^T + bias[z]);  x [M,K], W [N,K] (nn.Linear layout)."""
-    gemm(x, 0, K, sx, W, 0, K, sW, out, N, so, M, N, K, nb, bias=bias, sBias=sb, relu=relu)
+def linear_fwd(x, sx, W, sW, bias, sb, out, so, M, N, K, nb=1, relu=0, outer=None):
+    """out[z] = act(x[z] @ W[z]^T + bias[z]);  x [M,K], W [N,K] (nn.Linear layout).
+    ``outer`` = (n2, sx2, sW2, so2): a second batch level (item (o, z) at base + z * s + o * s2; bias strides as W's)."""
+    if outer is None:
+        gemm(x, 0, K, sx, W, 0, K, sW, out, N, so, M, N, K, nb, bias=bias, sBias=sb, relu=relu)
+    else:
+        n2, sx2, sW2, so2 = outer
+        call("curla_gemm_nested", ptr(x), 0, K, sx, sx2, ptr(W), 0, K, sW, sW2, ptr(out), N, so, so2, M, N, K, nb, n2,
+             1.0, ptr(bias), sb, sW2, relu, None, 0, 0, 0, stream())
 
 
 def linear_dx(dy, sdy, W, sW, out, so, M, N, K, nb=1, mask=None, smask=0):
@@ -258,9 +264,15 @@ def fc_bwd(dz, W, x, dx, dW, B, F_, K):
     call("curla_fc_bwd", ptr(dz), ptr(W), ptr(x), ptr(dx), ptr(dW), B, F_, K, stream())
 
 
-def mlp_out_fwd(h, sh, W, sW, bias, sb, out, so, M, N, K, nb=1):
-    """out[z] = h[z] @ W[z]^T + bias[z] for a last layer with N <= 16 outputs (one wave per row, no GEMM)."""
-    call("curla_mlp_out_fwd", ptr(h), sh, ptr(W), sW, ptr(bias), sb, ptr(out), so, M, N, K, nb, stream())
+def mlp_out_fwd(h, sh, W, sW, bias, sb, out, so, M, N, K, nb=1, outer=None):
+    """out[z] = h[z] @ W[z]^T + bias[z] for a last layer with N <= 16 outputs (one wave per row, no GEMM).
+    ``outer`` = (n2, sh2, sW2, so2) as in linear_fwd."""
+    if outer is None:
+        call("curla_mlp_out_fwd", ptr(h), sh, ptr(W), sW, ptr(bias), sb, ptr(out), so, M, N, K, nb, stream())
+    else:
+        n2, sh2, sW2, so2 = outer
+        call("curla_mlp_out_fwd_nested", ptr(h), sh, sh2, ptr(W), sW, sW2, ptr(bias), sb, sW2, ptr(out), so, so2, M, N,
+             K, nb, n2, stream())
 
 
 def mlp_out_bwd(dy, sdy, h, sh, W, sW, dh, sdh, dW, sdW, M, N, K, nb=1):

@@ -115,6 +115,14 @@ int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const f
                long long strideB, float* C, int ldc, long long strideC, int M, int N, int K, int nbatch, int ksplit,
                long long split_stride, float alpha, const float* bias, long long strideBias, int relu,
                const float* mask, int ldmask, long long strideMask, void* stream);
+/* curla_gemm with a two-level batch: item (outer, inner) at base + inner * stride + outer * stride2 (no split-K).  The
+ * twin Q functions of the target critic and of the critic are one such batch of four: the twins a block apart inside a
+ * flat parameter buffer, the two flat buffers wherever the allocator put them (curl_sac.py:353-358). */
+int curla_gemm_nested(const float* A, int a_kmajor, int lda, long long strideA, long long strideA2, const float* B,
+                      int b_kmajor, int ldb, long long strideB, long long strideB2, float* C, int ldc, long long strideC,
+                      long long strideC2, int M, int N, int K, int nbatch, int nbatch2, float alpha, const float* bias,
+                      long long strideBias, long long strideBias2, int relu, const float* mask, int ldmask,
+                      long long strideMask, long long strideMask2, void* stream);
 /* nprob <= 4 unrelated products of ONE shape in one launch, operands by pointer: C_i (+ split partials) =
  * A_i [M][K] * B_i [N][K]^T, no epilogue -- the fc layers of several encoders on several activation tensors (the
  * critic phase has three, curl_sac.py:350-358).  Each launch less is ~5 us. */
@@ -143,6 +151,10 @@ int curla_fc_bwd(const float* dz, const float* W, const float* x, float* dx, flo
 int curla_mlp_out_fwd(const float* h, long long strideH, const float* W, long long strideW, const float* bias,
                       long long strideBias, float* out, long long strideOut, int M, int N, int K, int nbatch,
                       void* stream);
+int curla_mlp_out_fwd_nested(const float* h, long long strideH, long long strideH2, const float* W, long long strideW,
+                             long long strideW2, const float* bias, long long strideBias, long long strideBias2,
+                             float* out, long long strideOut, long long strideOut2, int M, int N, int K, int nbatch,
+                             int nbatch2, void* stream);
 int curla_mlp_out_bwd(const float* dy, long long strideDy, const float* h, long long strideH, const float* W,
                       long long strideW, float* dh, long long strideDh, float* dW, long long strideDW, int M, int N,
                       int K, int nbatch, void* stream);

@@ -650,6 +650,40 @@ def test_gemm_multi_matches_single_launches(ops):
     check("gemm_multi vs torch", outs[1].sum(0).cpu(), hs[1].cpu() @ Ws[1].cpu().t())
 
 
+@pytest.mark.parametrize("B,din,H", [(24, 53, 64), (130, 54, 128)])
+def test_mlp_forward_two_level_batch(ops, B, din, H):
+    """curla_gemm_nested / curla_mlp_out_fwd_nested: the twin Q functions of two critics (parameters a fixed distance
+    apart, inputs [2][B, din]) in one launch per layer -- bit-identical to one twin launch per critic."""
+    from curla_amd.curl_sac import _mlp_fwd
+
+    class P:
+        pass
+    blk = ((H * din + 3) & ~3) + H + H * H + H + ((H + 3) & ~3) + 4  # one Q function: W0 b0 W1 b1 W2 b2
+    tot = 2 * blk + 8
+    flat = (rnd(2 * tot, seed=301) * 0.1).cuda()
+
+    def mlp(base):
+        o, m = base, P()
+        m.W, m.b, m.stride = [], [], blk
+        for n_out, n_in in ((H, din), (H, H), (1, H)):
+            m.W.append(flat[o:o + n_out * n_in].view(n_out, n_in))
+            o += (n_out * n_in + 3) & ~3
+            m.b.append(flat[o:o + n_out])
+            o += (n_out + 3) & ~3
+        return m
+    x = rnd(2, B, din, seed=302).cuda()
+    ref_h1, ref_h2, ref_q = (torch.empty(2, 2, B, d, device="cuda") for d in (H, H, 1))
+    for o in range(2):
+        _mlp_fwd(x[o], 0, mlp(o * tot), 2, B, din, H, 1, ref_h1[o], ref_h2[o], ref_q[o])
+    h1, h2, q = (torch.full((2, 2, B, d), float("nan"), device="cuda") for d in (H, H, 1))
+    _mlp_fwd(x, 0, mlp(0), 2, B, din, H, 1, h1, h2, q, outer=(2, tot))
+    assert torch.equal(h1, ref_h1) and torch.equal(h2, ref_h2) and torch.equal(q, ref_q)
+    m = mlp(tot + blk)  # the second critic's second twin against torch
+    xc = x[1].cpu()
+    want = torch.relu(torch.relu(xc @ m.W[0].cpu().t() + m.b[0].cpu()) @ m.W[1].cpu().t() + m.b[1].cpu()) @ m.W[2].cpu().t() + m.b[2].cpu()
+    check("nested mlp vs torch", q[1, 1].cpu(), want)
+
+
 @pytest.mark.parametrize("B,H,W", [(3, 13, 16), (2, 37, 37), (300, 9, 9), (5, 17, 15)])
 def test_conv_s1_backward_one_launch(ops, B, H, W):
     """curla_conv3x3_s1_bwd_slabs: weight-gradient slabs and data gradient of a layer in one launch -- bit-identical to
