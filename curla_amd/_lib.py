@@ -49,14 +49,19 @@ SIGNATURES = {
     "curla_critic_td_loss": [vp, vp, c_ll, vp, vp, vp, vp, c_float, c_int, vp, vp, vp, vp],
     "curla_soft_update2": [vp, vp, c_size_t, c_size_t, c_float, c_float, c_float, c_float, vp],
     "curla_adam_step": [vp, vp, vp, vp, c_size_t, c_double, c_double, c_double, c_double, c_ll, vp],
+    "curla_adam_step_scalar64": [vp, vp, vp, vp, c_size_t, c_double, c_double, c_double, c_double, c_ll, vp, vp, vp, vp,
+                                 c_double, c_double, c_double, c_double, c_ll, vp],
     "curla_adam_step2": [vp, vp, vp, vp, vp, vp, c_size_t, c_size_t, c_double, c_double, c_double, c_double, c_ll, c_double,
                          c_double, c_double, c_double, c_ll, vp],
     "curla_gather_transition_scalars": [vp, vp, c_int, c_int, vp, vp, vp, vp],
+    "curla_sample_stage": [vp, vp, c_ll, vp, c_int, c_int, vp, vp, vp, vp],
+    "curla_host_device_pointer": [vp, vp],
     "curla_ln_bwd": [vp, vp, vp, vp, c_int, c_int, vp, vp, vp, vp, vp],
     "curla_ln_bwd_twin": [vp, vp, c_int, vp, vp, vp, c_int, c_int, vp, vp, vp, vp, vp],
     "curla_colsum": [vp, c_int, c_int, c_int, c_ll, vp, c_ll, c_int, vp],
     "curla_colsum3": [vp, c_int, vp, c_int, vp, c_int, c_int, vp, vp, vp, c_ll, c_int, vp],
-    "curla_actor_head_fwd": [vp, vp, c_int, c_int, c_float, c_float, vp, vp, vp, vp, vp, vp],
+    "curla_actor_head_fwd": [vp, vp, c_int, c_int, c_float, c_float, vp, vp, vp, vp, vp, vp, c_int, vp],
+    "curla_fc_ln_fwd_multi": [c_int, vp, c_int, c_ll, c_int, c_int, c_int, c_float, c_int, vp],
     "curla_actor_head_bwd": [vp, vp, c_int, vp, vp, c_float, vp, vp, vp, vp, c_int, c_int, c_float, c_float, vp, vp],
     "curla_concat": [vp, vp, c_int, c_int, c_int, vp, vp],
     "curla_split_sum": [vp, c_ll, c_int, c_int, c_int, vp, vp, vp],

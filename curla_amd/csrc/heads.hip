@@ -30,14 +30,22 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm) {
 
 // ---- fc split-K reduce + bias + LayerNorm (one wave per row; a lane holds features lane, lane+64, ...:
 // NF = ceil(F / 64) <= 4, i.e. F <= 256) ----
+// (blockIdx.y = job: up to kMaxLnJobs encoders' features in one launch -- the actor's, the target critic's and the
+// critic's at the top of update_critic, curl_sac.py:350-358)
+constexpr int kMaxLnJobs = 4;
+struct FcLnJobs {
+  CurlaFcLnJob j[kMaxLnJobs];
+};
+
 template <int NF>
-__global__ void fc_ln_fwd_kernel(const float* P, int nsplit, long long sSplit, int ldp, const float* bias,
-                                 const float* gamma, const float* beta, int B, int F, float eps, float* fc_out,
-                                 float* y, float* xhat, float* rstd, int tanh_out, float* xa, const float* act,
-                                 int A) {
+__global__ void fc_ln_fwd_kernel(FcLnJobs jobs, int nsplit, long long sSplit, int ldp, int B, int F, float eps, int A) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= B) return;
+  const CurlaFcLnJob& jb = jobs.j[blockIdx.y];
+  const float *P = jb.partial, *bias = jb.bias, *gamma = jb.gamma, *beta = jb.beta, *act = jb.act;
+  float *fc_out = jb.fc_out, *y = jb.y, *xhat = jb.xhat, *rstd = jb.rstd, *xa = jb.xa;
+  const int tanh_out = jb.tanh_out;
   float v[NF];
   float tot = 0.f;
 #pragma unroll
@@ -83,7 +91,7 @@ __global__ void fc_ln_fwd_kernel(const float* P, int nsplit, long long sSplit, i
       if (xa) xa[(size_t)row * (F + A) + f] = o;  // torch.cat([z, action], 1) written in place (curl_sac.py:138)
     }
   }
-  if (xa && lane < A) xa[(size_t)row * (F + A) + F + lane] = act[(size_t)row * A + lane];
+  if (xa && act && lane < A) xa[(size_t)row * (F + A) + F + lane] = act[(size_t)row * A + lane];
   if (lane == 0 && rstd) rstd[row] = rs;
 }
 
@@ -121,28 +129,31 @@ __global__ void ln_bwd_kernel(const float* dy, const float* dy2, int ld, const f
 }
 
 // dgamma[f] = sum_b dy*xhat ; dbeta[f] = sum_b dy ; optionally dbias[f] = sum_b dx (the gradient of the fc bias
-// that feeds the LayerNorm: the same walk over the rows)   (one block of 1024 per 64 features)
+// that feeds the LayerNorm: the same walk over the rows).  One block of 1024 per 16 features: 64 row parts, so a
+// thread's rows (8 at B = 512) are all in flight at once and F = 50 is four workgroups instead of one -- the kernel
+// is pure load latency.  The parts are added in a fixed order: the 4 of a wave by lane exchange, the 16 waves in
+// wave order.
 __global__ __launch_bounds__(1024) void ln_param_grad_kernel(const float* dy, const float* dy2, int ld, const float* xhat,
                                                              const float* dx, int B, int F, float* dgamma,
                                                              float* dbeta, float* dbias) {
-  __shared__ float sg[16][64], sb[16][64], sx[16][64];
-  const int fl = threadIdx.x & 63, part = threadIdx.x >> 6;
-  const int f = blockIdx.x * 64 + fl;
+  __shared__ float sg[16][16], sb[16][16], sx[16][16];
+  const int fl = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int f = blockIdx.x * 16 + fl;
   float ag = 0.f, ab = 0.f, ax = 0.f;
   if (f < F) {
     int b = part;
-    for (; b + 7 * 16 < B; b += 8 * 16) {  // 8 rows in flight, accumulated in row order
+    for (; b + 7 * 64 < B; b += 8 * 64) {  // 8 rows in flight, accumulated in row order
       float d[8], x[8], e[8];
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
-        d[k] = dy[(size_t)(b + 16 * k) * ld + f], x[k] = xhat[(size_t)(b + 16 * k) * F + f];
-        if (dy2) d[k] += dy2[(size_t)(b + 16 * k) * ld + f];
-        e[k] = dbias ? dx[(size_t)(b + 16 * k) * F + f] : 0.f;
+        d[k] = dy[(size_t)(b + 64 * k) * ld + f], x[k] = xhat[(size_t)(b + 64 * k) * F + f];
+        if (dy2) d[k] += dy2[(size_t)(b + 64 * k) * ld + f];
+        e[k] = dbias ? dx[(size_t)(b + 64 * k) * F + f] : 0.f;
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) ag += d[k] * x[k], ab += d[k], ax += e[k];
     }
-    for (; b < B; b += 16) {
+    for (; b < B; b += 64) {
       float d = dy[(size_t)b * ld + f];
       if (dy2) d += dy2[(size_t)b * ld + f];
       ag += d * xhat[(size_t)b * F + f];
@@ -150,9 +161,13 @@ __global__ __launch_bounds__(1024) void ln_param_grad_kernel(const float* dy, co
       if (dbias) ax += dx[(size_t)b * F + f];
     }
   }
-  sg[part][fl] = ag, sb[part][fl] = ab, sx[part][fl] = ax;
+  // lanes l, l^16, l^32, l^48 hold the same feature: (p0 + p1) + (p2 + p3) in every lane
+  ag += __shfl_xor(ag, 16), ab += __shfl_xor(ab, 16), ax += __shfl_xor(ax, 16);
+  ag += __shfl_xor(ag, 32), ab += __shfl_xor(ab, 32), ax += __shfl_xor(ax, 32);
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < 16) sg[wave][fl] = ag, sb[wave][fl] = ab, sx[wave][fl] = ax;
   __syncthreads();
-  if (part == 0 && f < F) {
+  if (threadIdx.x < 16 && f < F) {
     float g = sg[0][fl], bsum = sb[0][fl], xs = sx[0][fl];
 #pragma unroll
     for (int k = 1; k < 16; ++k) g += sg[k][fl], bsum += sb[k][fl], xs += sx[k][fl];
@@ -330,8 +345,10 @@ __global__ __launch_bounds__(1024) void mlp_out_bwd_kernel(const float* dy, long
 constexpr int kMaxA = 8;
 constexpr float kHalfLog2Pi = 0.9189385332046727f;
 
+// (pi_xa, optional: pi is also written as the action columns of the Q input rows, pi_xa[b * xa_ld + a])
 __global__ void actor_head_fwd_kernel(const float* out2a, const float* noise, int B, int A, float lo, float hi,
-                                      float* mu_t, float* pi_t, float* log_pi, float* log_std, float* tanh_ls) {
+                                      float* mu_t, float* pi_t, float* log_pi, float* log_std, float* tanh_ls,
+                                      float* pi_xa, int xa_ld) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   float lp = 0.f, corr = 0.f;
@@ -345,7 +362,8 @@ __global__ void actor_head_fwd_kernel(const float* out2a, const float* noise, in
     if (noise) {
       const float n = noise[(size_t)b * A + a];
       const float p = tanhf(mu + n * expf(ls));
-      pi_t[(size_t)b * A + a] = p;
+      if (pi_t) pi_t[(size_t)b * A + a] = p;
+      if (pi_xa) pi_xa[(size_t)b * xa_ld + a] = p;
       lp += -0.5f * n * n - ls;
       corr += logf(fmaxf(1.f - p * p, 0.f) + 1e-6f);
     }
@@ -556,10 +574,27 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
   p = p - (step_size * m) / denom;
 }
 
+// A float64 scalar parameter stepped by the same launch (log_alpha beside the actor's parameters: the reference steps
+// actor_optimizer and log_alpha_optimizer back to back, curl_sac.py:393-404); p == nullptr: none.
+struct AdamScalar64 {
+  double *p, *m, *v;
+  const double* g;
+  double w1, b2, w2, step_size, bc2_sqrt, eps;
+};
+
 __global__ void __launch_bounds__(256) adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, size_t n,
                                                         int vec, float w1, float b2, float w2, float step_size,
-                                                        float bc2_sqrt, float eps) {
+                                                        float bc2_sqrt, float eps, AdamScalar64 sc) {
+  if (sc.p && blockIdx.x == 0 && threadIdx.x == 0) {  // torch's single-tensor Adam, in double
+#pragma clang fp contract(off)
+    const double gs = *sc.g;
+    double ms = *sc.m, vs = *sc.v;
+    ms = (sc.w1 < 0.5) ? ms + sc.w1 * (gs - ms) : gs - (gs - ms) * (1.0 - sc.w1);
+    vs = vs * sc.b2 + (sc.w2 * gs) * gs;
+    *sc.m = ms, *sc.v = vs;
+    *sc.p = *sc.p - sc.step_size * (ms / (sqrt(vs) / sc.bc2_sqrt + sc.eps));
+  }
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
   size_t done = 0;
   if (vec) {
@@ -648,6 +683,26 @@ __global__ void gather_transition_scalars_kernel(const float* sc, const int64_t*
   if (i >= B * (A + 2)) return;
   const int b = i / (A + 2), c = i - b * (A + 2);
   const float v = sc[(size_t)idx[b] * (A + 2) + c];
+  if (c < A)
+    act[(size_t)b * A + c] = v;
+  else if (c == A)
+    rew[b] = v;
+  else
+    nd[b] = v;
+}
+
+// The same gather with the minibatch's index block taken straight from pinned host memory: the block (indices, crop
+// offsets; ~20 KB) is read over PCIe with system-scope loads and written to its device slot by this kernel, the
+// scalar rows are gathered with the indices as they arrive -- no copy-engine transfer (and its queue hand-over, ~15 us
+// of idle stream) in front of every update.  host / dev: the block as 8-byte words, idx = its first B words.
+__global__ void sample_stage_kernel(const unsigned long long* host, unsigned long long* dev, int nwords, const float* sc,
+                                    int B, int A, float* act, float* rew, float* nd) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nwords) dev[i] = __hip_atomic_load(host + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (i >= B * (A + 2)) return;
+  const int b = i / (A + 2), c = i - b * (A + 2);
+  const long long row = (long long)__hip_atomic_load(host + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const float v = sc[(size_t)row * (A + 2) + c];
   if (c < A)
     act[(size_t)b * A + c] = v;
   else if (c == A)
@@ -757,16 +812,21 @@ inline int nblocks(size_t n, int bs, int cap = 4096) {
 
 extern "C" {
 
-int curla_fc_ln_fwd(const float* partial, int nsplit, long long split_stride, int ldp, const float* bias,
-                    const float* gamma, const float* beta, int B, int F, float eps, float* fc_out, float* y,
-                    float* xhat, float* rstd, int tanh_out, float* xa, const float* act, int A, void* stream) {
-  CURLA_REQUIRE(partial && bias && gamma && beta && y && B > 0 && F > 0 && nsplit > 0);
-  CURLA_REQUIRE(!xa || (act && A > 0 && A <= 64));
+int curla_fc_ln_fwd_multi(int njobs, const CurlaFcLnJob* jobs, int nsplit, long long split_stride, int ldp, int B,
+                          int F, float eps, int A, void* stream) {
+  CURLA_REQUIRE(jobs && njobs > 0 && njobs <= kMaxLnJobs && B > 0 && F > 0 && nsplit > 0 && A >= 0 && A <= 64);
+  FcLnJobs js;
+  for (int i = 0; i < njobs; ++i) {
+    const CurlaFcLnJob& j = jobs[i];
+    CURLA_REQUIRE(j.partial && j.bias && j.gamma && j.beta && j.y);
+    CURLA_REQUIRE(!j.xa || A > 0);
+    js.j[i] = j;
+  }
   if (F > 256) return CURLA_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
-#define CURLA_FC_LN(NF)                                                                                         \
-  hipLaunchKernelGGL(fc_ln_fwd_kernel<NF>, dim3((B + 3) / 4), dim3(256), 0, st, partial, nsplit, split_stride, ldp, \
-                     bias, gamma, beta, B, F, eps, fc_out, y, xhat, rstd, tanh_out, xa, act, A)
+#define CURLA_FC_LN(NF)                                                                                          \
+  hipLaunchKernelGGL(fc_ln_fwd_kernel<NF>, dim3((B + 3) / 4, njobs), dim3(256), 0, st, js, nsplit, split_stride, ldp, \
+                     B, F, eps, A)
   switch ((F + 63) / 64) {
     case 1: CURLA_FC_LN(1); break;
     case 2: CURLA_FC_LN(2); break;
@@ -775,6 +835,16 @@ int curla_fc_ln_fwd(const float* partial, int nsplit, long long split_stride, in
   }
 #undef CURLA_FC_LN
   return curla_launch_status();
+}
+
+int curla_fc_ln_fwd(const float* partial, int nsplit, long long split_stride, int ldp, const float* bias,
+                    const float* gamma, const float* beta, int B, int F, float eps, float* fc_out, float* y,
+                    float* xhat, float* rstd, int tanh_out, float* xa, const float* act, int A, void* stream) {
+  CURLA_REQUIRE(!xa || (act && A > 0 && A <= 64));
+  CurlaFcLnJob j;
+  j.partial = partial, j.bias = bias, j.gamma = gamma, j.beta = beta, j.fc_out = fc_out, j.y = y, j.xhat = xhat;
+  j.rstd = rstd, j.xa = xa, j.act = act, j.tanh_out = tanh_out;
+  return curla_fc_ln_fwd_multi(1, &j, nsplit, split_stride, ldp, B, F, eps, xa ? A : 0, stream);
 }
 
 int curla_ln_bwd_twin(const float* dy, const float* dy2, int ld_dy, const float* xhat, const float* rstd,
@@ -794,7 +864,7 @@ int curla_ln_bwd_twin(const float* dy, const float* dy2, int ld_dy, const float*
 #undef CURLA_LN_BWD
   CURLA_REQUIRE(!dbias_in || (dgamma && dbeta));
   if (dgamma && dbeta)
-    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((F + 63) / 64), dim3(1024), 0, st, dy, dy2, ld_dy, xhat, dx, B, F,
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((F + 15) / 16), dim3(1024), 0, st, dy, dy2, ld_dy, xhat, dx, B, F,
                        dgamma, dbeta, dbias_in);
   return curla_launch_status();
 }
@@ -862,11 +932,12 @@ int curla_mlp_out_bwd(const float* dy, long long strideDy, const float* h, long 
 
 int curla_actor_head_fwd(const float* trunk_out, const float* noise, int B, int A, float log_std_min,
                          float log_std_max, float* mu, float* pi, float* log_pi, float* log_std, float* tanh_ls,
-                         void* stream) {
+                         float* pi_xa, int xa_ld, void* stream) {
   CURLA_REQUIRE(trunk_out && B > 0 && A > 0 && A <= kMaxA);
-  CURLA_REQUIRE(!noise || pi);
+  CURLA_REQUIRE(!noise || pi || pi_xa);
+  CURLA_REQUIRE(!pi_xa || (noise && xa_ld >= A));
   hipLaunchKernelGGL(actor_head_fwd_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     trunk_out, noise, B, A, log_std_min, log_std_max, mu, pi, log_pi, log_std, tanh_ls);
+                     trunk_out, noise, B, A, log_std_min, log_std_max, mu, pi, log_pi, log_std, tanh_ls, pi_xa, xa_ld);
   return curla_launch_status();
 }
 
@@ -961,8 +1032,9 @@ int curla_soft_update2(const float* param, float* target, size_t n, size_t split
   return curla_launch_status();
 }
 
-int curla_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
-                    double beta1, double beta2, double eps, long long step, void* stream) {
+static int adam_step_launch(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
+                            double beta1, double beta2, double eps, long long step, const AdamScalar64& sc,
+                            void* stream) {
   CURLA_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1 && beta1 >= 0. && beta1 < 1. &&
                 beta2 >= 0. && beta2 < 1.);
   const double b1 = beta1, b2 = beta2;
@@ -970,8 +1042,28 @@ int curla_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
   const int vec = aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq);
   hipLaunchKernelGGL(adam_step_kernel, dim3(nblocks((n + 3) / 4, 256, 8192)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), param, grad, exp_avg, exp_avg_sq, n, vec, (float)(1.0 - b1),
-                     (float)b2, (float)(1.0 - b2), (float)(lr / bc1), (float)sqrt(bc2), (float)eps);
+                     (float)b2, (float)(1.0 - b2), (float)(lr / bc1), (float)sqrt(bc2), (float)eps, sc);
   return curla_launch_status();
+}
+
+int curla_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
+                    double beta1, double beta2, double eps, long long step, void* stream) {
+  AdamScalar64 none = {};
+  return adam_step_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, none, stream);
+}
+
+int curla_adam_step_scalar64(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
+                             double beta1, double beta2, double eps, long long step, double* param64,
+                             const double* grad64, double* exp_avg64, double* exp_avg_sq64, double lr64, double beta1_64,
+                             double beta2_64, double eps64, long long step64, void* stream) {
+  CURLA_REQUIRE(param64 && grad64 && exp_avg64 && exp_avg_sq64 && step64 >= 1 && beta1_64 >= 0. && beta1_64 < 1. &&
+                beta2_64 >= 0. && beta2_64 < 1.);
+  AdamScalar64 sc;
+  sc.p = param64, sc.g = grad64, sc.m = exp_avg64, sc.v = exp_avg_sq64;
+  sc.w1 = 1.0 - beta1_64, sc.b2 = beta2_64, sc.w2 = 1.0 - beta2_64;
+  sc.step_size = lr64 / (1.0 - pow(beta1_64, (double)step64));
+  sc.bc2_sqrt = sqrt(1.0 - pow(beta2_64, (double)step64)), sc.eps = eps64;
+  return adam_step_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, sc, stream);
 }
 
 static AdamHyper adam_hyper(double lr, double beta1, double beta2, double eps, long long step) {
@@ -1003,6 +1095,30 @@ int curla_gather_transition_scalars(const float* scalars, const int64_t* idx, in
   CURLA_REQUIRE(scalars && idx && action && reward && not_done && B > 0 && A > 0);
   hipLaunchKernelGGL(gather_transition_scalars_kernel, dim3((B * (A + 2) + 255) / 256), dim3(256), 0,
                      static_cast<hipStream_t>(stream), scalars, idx, B, A, action, reward, not_done);
+  return curla_launch_status();
+}
+
+int curla_host_device_pointer(void* host, void** device) {
+  CURLA_REQUIRE(host && device);
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, host, 0) != hipSuccess || !d) {
+    (void)hipGetLastError();
+    return CURLA_ERR_ARG;
+  }
+  *device = d;
+  return CURLA_OK;
+}
+
+int curla_sample_stage(const void* host_block, void* device_block, long long nbytes, const float* scalars, int B, int A,
+                       float* action, float* reward, float* not_done, void* stream) {
+  CURLA_REQUIRE(host_block && device_block && scalars && action && reward && not_done && B > 0 && A > 0);
+  CURLA_REQUIRE(nbytes >= (long long)B * 8 && nbytes % 8 == 0 && nbytes < (1LL << 30));
+  CURLA_REQUIRE(((uintptr_t)host_block | (uintptr_t)device_block) % 8 == 0);
+  const int nwords = (int)(nbytes / 8);
+  const int n = nwords > B * (A + 2) ? nwords : B * (A + 2);
+  hipLaunchKernelGGL(sample_stage_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const unsigned long long*>(host_block), static_cast<unsigned long long*>(device_block),
+                     nwords, scalars, B, A, action, reward, not_done);
   return curla_launch_status();
 }
 

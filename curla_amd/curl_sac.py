@@ -378,8 +378,11 @@ class CurlSacAgent(object):
         cf, cg = self._critic_flat, self._critic_gflat
         self.actor_optimizer = adam(actor_own, self._actor_flat, self._actor_gflat, lr=actor_lr, betas=(actor_beta, 0.999))
         self.critic_optimizer = adam(list(self.critic.parameters()), cf, cg, lr=critic_lr, betas=(critic_beta, 0.999))
-        self.log_alpha_optimizer = torch.optim.Adam([self.log_alpha], lr=alpha_lr, betas=(alpha_beta, 0.999),
-                                                    **(dict(fused=True) if self.device.type == "cuda" else {}))
+        # (beside a FlatAdam actor, log_alpha's step rides in the actor's launch: FlatAdam.step_with_scalar)
+        flat_actor = isinstance(self.actor_optimizer, FlatAdam)
+        self.log_alpha_optimizer = torch.optim.Adam(
+            [self.log_alpha], lr=alpha_lr, betas=(alpha_beta, 0.999),
+            **(dict(foreach=False) if flat_actor else dict(fused=True) if self.device.type == "cuda" else {}))
         self.encoder_optimizer = adam(enc_params, cf, cg, lr=encoder_lr)
         self.cpc_optimizer = adam([self.CURL.W] + enc_params, cf, cg, lr=encoder_lr)
 
@@ -695,32 +698,37 @@ class CurlSacAgent(object):
             CNNEncoder.fc_partial_multi([(self.actor.encoder, h_next), (tenc, ws.acts_tmp[-1]), (enc, ws.acts_main[-1])])
         else:
             self.actor.encoder.fc_partial(h_next)
-        self.actor.encoder.ln_from_partial(B, ws.z_a)
+        # the target critic's twins over [z', a'] and the critic's over [z, a] (curl_sac.py:353-358) are four MLPs of
+        # one shape: with all conv outputs there they share their three launches, and the three encoders' features
+        # (actor, target, critic) their one -- the action columns of [z' | a'] are then written by the policy head
+        four = merged and self._twin_outer is not None
+        rec = self._records(step)
+        if four:
+            CNNEncoder.ln_from_partial_multi(B, [
+                (self.actor.encoder, ws.z_a, {}), (tenc, ws.z_t, dict(xa=ws.xa2[0])),
+                (enc, ws.z_c, dict(xhat=ws.xhat_c, rstd=ws.rstd_c, fc_out=ws.fc_out if rec else None, xa=ws.xa,
+                                   act=action))], A)
+        else:
+            self.actor.encoder.ln_from_partial(B, ws.z_a)
         _mlp_fwd(ws.z_a, 0, _Mlp(self.actor.trunk), 1, B, F, H, 2 * A, ws.a_h1, ws.a_h2, ws.a_out)
         nz = self._noise(ws, noise)
-        ops.actor_head_fwd(ws.a_out, nz, B, A, self.actor.log_std_min, self.actor.log_std_max, pi=ws.pi,
-                           log_pi=ws.log_pi)
-        if not merged:
-            tenc.conv_forward(no, ws.acts_tmp)
-            tenc.fc_partial(ws.acts_tmp[-1])
-        # the target critic's twins over [z', a'] and the critic's over [z, a] (curl_sac.py:353-358) are four MLPs of
-        # one shape: with all conv outputs there they share their three launches
-        four = merged and self._twin_outer is not None
-        tenc.ln_from_partial(B, ws.z_t, xa=ws.xa2[0] if four else ws.xa, act=ws.pi)  # xa = cat([z, a'], 1)
-        if not four:
-            _mlp_fwd(ws.xa, 0, self.critic_target.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.tq)
-
-        # -- current Q estimates + loss + backward (curl_sac.py:357-367)
-        if not merged:
-            enc.conv_forward(o, ws.acts_main)
-            enc.fc_partial(ws.acts_main[-1])
-        rec = self._records(step)
-        enc.ln_from_partial(B, ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c, fc_out=ws.fc_out if rec else None, xa=ws.xa,
-                            act=action)
+        ops.actor_head_fwd(ws.a_out, nz, B, A, self.actor.log_std_min, self.actor.log_std_max,
+                           pi=None if four else ws.pi, log_pi=ws.log_pi, xa=ws.xa2[0] if four else None)
         if four:
             _mlp_fwd(ws.xa2, 0, self.critic_target.twin(), 2, B, F + A, H, 1, ws.q_h1_2, ws.q_h2_2, ws.q2,
                      outer=(2, self._twin_outer))
         else:
+            if not merged:
+                tenc.conv_forward(no, ws.acts_tmp)
+                tenc.fc_partial(ws.acts_tmp[-1])
+            tenc.ln_from_partial(B, ws.z_t, xa=ws.xa, act=ws.pi)  # xa = cat([z, a'], 1)
+            _mlp_fwd(ws.xa, 0, self.critic_target.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.tq)
+            # -- current Q estimates + loss + backward (curl_sac.py:357-367)
+            if not merged:
+                enc.conv_forward(o, ws.acts_main)
+                enc.fc_partial(ws.acts_main[-1])
+            enc.ln_from_partial(B, ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c, fc_out=ws.fc_out if rec else None,
+                                xa=ws.xa, act=action)
             _mlp_fwd(ws.xa, 0, self.critic.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.q)
         if rec:  # what critic.log() / encoder.log() histogram: the outputs of THIS forward (curl_sac.py:163-167)
             self.critic.outputs['q1'], self.critic.outputs['q2'] = ws.q[0].clone(), ws.q[1].clone()
@@ -785,7 +793,13 @@ class CurlSacAgent(object):
             fcs.append((self.critic_target.encoder, ws.acts_tmp[-1]))
             self._pos_fc_done = True
         CNNEncoder.fc_partial_multi(fcs)
-        aenc.ln_from_partial(B, ws.z_a, xhat=ws.xhat_a, rstd=ws.rstd_a)
+        # ... and so are the features: actor's, critic's (kept for the CURL anchor branch; the action columns of
+        # xa = cat([z, pi], 1) come from the policy head below) and the positives'
+        lns = [(aenc, ws.z_a, dict(xhat=ws.xhat_a, rstd=ws.rstd_a)),
+               (enc, ws.z_c, dict(xhat=ws.xhat_c, rstd=ws.rstd_c, xa=ws.xa))]
+        if pos is not None:
+            lns.append((self.critic_target.encoder, ws.z_pos, {}))
+        CNNEncoder.ln_from_partial_multi(B, lns, A)
         self._anchor_cache = obs
 
         trunk = _Mlp(self.actor.trunk)
@@ -793,11 +807,9 @@ class CurlSacAgent(object):
         nz = self._noise(ws, noise)
         lo, hi = self.actor.log_std_min, self.actor.log_std_max
         ops.actor_head_fwd(ws.a_out, nz, B, A, lo, hi, mu=ws.mu, pi=ws.pi, log_pi=ws.log_pi, log_std=ws.log_std,
-                           tanh_ls=ws.tanh_ls)
+                           tanh_ls=ws.tanh_ls, xa=ws.xa)
         if self._records(step):  # what actor.log() histograms (curl_sac.py:92-93): pre-squash mean and std
             self.actor.outputs['mu'], self.actor.outputs['std'] = ws.a_out[:, :A].clone(), ws.log_std.exp()
-        # critic features of the same conv output (kept for the CURL anchor branch), with xa = cat([z, pi], 1)
-        enc.ln_from_partial(B, ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c, xa=ws.xa, act=ws.pi)
         _mlp_fwd(ws.xa, 0, self.critic.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.q)
         ops.actor_loss(ws.q, B, ws.log_pi, ws.log_std, A, self.log_alpha, float(self.target_entropy), B,
                        ws.scalars[1:5], ws.dq, self.log_alpha.grad)
@@ -830,13 +842,18 @@ class CurlSacAgent(object):
             self._allreduce_wait()
         else:
             self._allreduce(self._actor_gflat, self.log_alpha.grad)
-        self.actor_optimizer.step()
+        # actor_optimizer.step() ... log_alpha_optimizer.step() (curl_sac.py:393-404): nothing in between reads
+        # log_alpha (the logged alpha is the loss kernel's), so the two steps share a launch
+        if isinstance(self.actor_optimizer, FlatAdam):
+            FlatAdam.step_with_scalar(self.actor_optimizer, self.log_alpha_optimizer)
+        else:
+            self.actor_optimizer.step()
+            self.log_alpha_optimizer.step()
         if self.log_param_hist_imgs:
             self.actor.log(L, step)
         if step % self.log_interval == 0:
             L.log('train_alpha/loss', ws.scalars[2], step)
             L.log('train_alpha/value', ws.scalars[4], step)
-        self.log_alpha_optimizer.step()
 
     def update_cpc(self, obs_anchor, obs_pos, cpc_kwargs, L, step):
         """curl_sac.py:406-423."""
@@ -857,10 +874,11 @@ class CurlSacAgent(object):
             tenc.conv_forward(op_, ws.acts_tmp)
         if need_anchor:
             CNNEncoder.fc_partial_multi([(enc, ws.acts_main[-1]), (tenc, ws.acts_tmp[-1])])
-            enc.ln_from_partial(B, ws.z_c, xhat=ws.xhat_c, rstd=ws.rstd_c)
-        elif not pos_fc_done:
+            CNNEncoder.ln_from_partial_multi(B, [(enc, ws.z_c, dict(xhat=ws.xhat_c, rstd=ws.rstd_c)),
+                                                 (tenc, ws.z_pos, {})])
+        elif not pos_fc_done:  # (done: the actor phase left the positives' features in ws.z_pos)
             tenc.fc_partial(ws.acts_tmp[-1])
-        tenc.ln_from_partial(B, ws.z_pos)
+            tenc.ln_from_partial(B, ws.z_pos)
 
         W = self.CURL.W
         ops.linear_fwd(ws.z_pos, 0, W, 0, None, 0, ws.WzT, 0, B, F, F)         # (W z_pos^T)^T

@@ -197,6 +197,17 @@ class CNNEncoder(nn.Module):
                       xa=xa, act=act)
         return z
 
+    @staticmethod
+    def ln_from_partial_multi(B, jobs, A=0):
+        """``ln_from_partial`` of several encoders of one shape in ONE launch.  jobs = [(encoder, z, kwargs)], kwargs
+        as ln_from_partial's (an ``xa`` without ``act`` gets only its feature columns written; A = action columns)."""
+        enc0 = jobs[0][0]
+        F = enc0.feature_dim
+        assert all(e.feature_dim == F and e.ksplit(B) == enc0.ksplit(B) and e.ln.eps == enc0.ln.eps for e, _, _ in jobs)
+        ops.fc_ln_fwd_multi([dict(partial=e.partial(B), bias=e.fc.bias, gamma=e.ln.weight, beta=e.ln.bias, y=z,
+                                  tanh_out=0 if e.output_logits else 1, **kw) for e, z, kw in jobs],
+                            enc0.ksplit(B), B * F, F, B, F, enc0.ln.eps, A)
+
     def to_kernel_layout(self):
         """Re-order fc.weight's input columns (c,y,x) -> (y,x,c) in place."""
         if self.fc.nhwc is None:

@@ -4,6 +4,8 @@ Every function enqueues HIP kernels on torch's current stream and returns
 immediately; tensors are only used for their device pointers.  Nothing here
 computes on the host and nothing falls back to PyTorch ops.
 """
+import ctypes
+
 import torch
 
 from . import _lib
@@ -291,6 +293,24 @@ def fc_ln_fwd(partial, nsplit, split_stride, ldp, bias, gamma, beta, B, F, y, fc
          ptr(fc_out), ptr(y), ptr(xhat), ptr(rstd), tanh_out, ptr(xa), ptr(act), A, stream())
 
 
+_FC_LN_PTRS = ("partial", "bias", "gamma", "beta", "fc_out", "y", "xhat", "rstd", "xa", "act")
+
+
+class _FcLnJob(ctypes.Structure):  # CurlaFcLnJob
+    _fields_ = [(n, ctypes.c_void_p) for n in _FC_LN_PTRS] + [("tanh_out", ctypes.c_int)]
+
+
+def fc_ln_fwd_multi(jobs, nsplit, split_stride, ldp, B, F, eps, A):
+    """``jobs``: up to 4 dicts with fc_ln_fwd's per-problem tensors (partial, bias, gamma, beta, y and optionally
+    fc_out, xhat, rstd, xa, act, tanh_out) -- one launch."""
+    arr = (_FcLnJob * len(jobs))()
+    for a, j in zip(arr, jobs):
+        for n in _FC_LN_PTRS:
+            setattr(a, n, ptr(j.get(n)))
+        a.tanh_out = int(j.get("tanh_out", 0))
+    call("curla_fc_ln_fwd_multi", len(jobs), ctypes.addressof(arr), nsplit, split_stride, ldp, B, F, eps, A, stream())
+
+
 def ln_bwd(dy, xhat, rstd, gamma, B, F, dx, dgamma=None, dbeta=None, dbias_in=None, dy2=None, ld=None):
     """LayerNorm backward; ``dbias_in`` (optional) receives the column sums of dx (the fc bias gradient).
     The incoming gradient may be ``dy[:, :F] + dy2[:, :F]`` of two row blocks with row stride ``ld`` (the twin halves
@@ -312,9 +332,11 @@ def colsum3(X0, N0, X1, N1, X2, N2, M, out0, out1, out2, sOut, nb=1):
     call("curla_colsum3", ptr(X0), N0, ptr(X1), N1, ptr(X2), N2, M, ptr(out0), ptr(out1), ptr(out2), sOut, nb, stream())
 
 
-def actor_head_fwd(trunk_out, noise, B, A, lo, hi, mu=None, pi=None, log_pi=None, log_std=None, tanh_ls=None):
+def actor_head_fwd(trunk_out, noise, B, A, lo, hi, mu=None, pi=None, log_pi=None, log_std=None, tanh_ls=None, xa=None):
+    """``xa`` [B, F + A]: pi is also written into its last A columns (the Q functions' input rows)."""
+    pi_xa, ld = (None, 0) if xa is None else (xa.data_ptr() + 4 * (xa.shape[1] - A), xa.shape[1])
     call("curla_actor_head_fwd", ptr(trunk_out), ptr(noise), B, A, lo, hi, ptr(mu), ptr(pi), ptr(log_pi), ptr(log_std),
-         ptr(tanh_ls), stream())
+         ptr(tanh_ls), pi_xa, ld, stream())
 
 
 def actor_head_bwd(gpi, log_alpha, glp_scale, noise, pi, log_std, tanh_ls, B, A, lo, hi, dtrunk_out, glp_rows=None,
@@ -379,6 +401,20 @@ def soft_update2(param_flat, target_flat, split, tau_a, tau_b):
 
 def gather_transition_scalars(sc, idx, B, A, act, rew, nd):
     call("curla_gather_transition_scalars", ptr(sc), ptr(idx), B, A, ptr(act), ptr(rew), ptr(nd), stream())
+
+
+def host_device_pointer(pinned):
+    """Device-visible address of a pinned host tensor (raises if the tensor is not pinned / mapped)."""
+    import ctypes
+    out = ctypes.c_void_p()
+    call("curla_host_device_pointer", pinned.data_ptr(), ctypes.addressof(out))
+    return out.value
+
+
+def sample_stage(host_dev_ptr, dev_block, nbytes, sc, B, A, act, rew, nd):
+    """gather_transition_scalars with the index block read from pinned host memory (``host_dev_ptr`` from
+    host_device_pointer) and written to ``dev_block`` by the same launch."""
+    call("curla_sample_stage", host_dev_ptr, ptr(dev_block), nbytes, ptr(sc), B, A, ptr(act), ptr(rew), ptr(nd), stream())
 
 
 def crop_nchw(frames, idx, h1, w1, B, crop_hw, out_f32=None, out_u8=None):

@@ -172,4 +172,43 @@ class FlatAdam(torch.optim.Adam):
              float(gb["lr"]), float(gb["betas"][0]), float(gb["betas"][1]), float(gb["eps"]), tb + 1, stream())
 
 
+    # -- this optimizer and a float64 scalar's, one launch -----------------------------------------------------------
+    @staticmethod
+    @torch.no_grad()
+    def step_with_scalar(first, scalar_opt):
+        """``first.step(); scalar_opt.step()`` where ``scalar_opt`` is a plain ``torch.optim.Adam`` over ONE float64
+        one-element parameter on the device (log_alpha): its step rides in first's launch.  Anything else (first not a
+        single flat run, a replaced ``step``, no gradient, other Adam options) takes the two steps."""
+        groups = scalar_opt.param_groups
+        p = groups[0]["params"][0] if len(groups) == 1 and len(groups[0]["params"]) == 1 else None
+        g = groups[0] if p is not None else {}
+        ok = isinstance(first, FlatAdam) and type(scalar_opt) is torch.optim.Adam and p is not None and \
+            "step" not in vars(first) and "step" not in vars(scalar_opt) and p.dtype == torch.float64 and \
+            p.numel() == 1 and p.is_cuda and p.grad is not None and p.grad.dtype == torch.float64 and \
+            not (g.get("weight_decay", 0) or g.get("amsgrad") or g.get("maximize") or g.get("capturable") or
+                 g.get("fused") or g.get("differentiable"))
+        run = first._single_run() if ok else None
+        if run is None:
+            first.step()
+            scalar_opt.step()
+            return
+        st = scalar_opt.state[p]
+        if len(st) == 0:  # as torch's Adam initialises it (non-capturable: the step count lives on the host)
+            st["step"] = torch.tensor(0.0, dtype=torch.float32)
+            st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
+        elif st["step"].is_cuda:
+            st["step"] = st["step"].cpu()
+        t64 = int(round(float(st["step"]))) + 1
+        lo, hi, t, grp = run
+        for i in range(len(first._plist)):
+            first._ensure_state(i)
+            first._steps[i] = t + 1
+        call("curla_adam_step_scalar64", first._flat.data_ptr() + 4 * lo, first._gflat.data_ptr() + 4 * lo,
+             first._m.data_ptr() + 4 * (lo - first._lo), first._v.data_ptr() + 4 * (lo - first._lo), hi - lo,
+             float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]), t + 1,
+             p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), float(g["lr"]),
+             float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), t64, stream())
+        st["step"] = torch.tensor(float(t64), dtype=torch.float32)
+
+
 __all__ = ["FlatAdam"]

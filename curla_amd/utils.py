@@ -174,6 +174,7 @@ class ReplayBuffer(object):
     """Buffer to store environment transitions (utils.py:80-236), HBM-resident."""
 
     N_SAMPLE_SLOTS = 2  # minibatches whose references may be alive at once (the current one + one drawn ahead)
+    EVENT_EVERY = 8     # index uploads per recorded event (16 pinned slots)
 
     def __init__(self, obs_shape, action_shape, capacity, batch_size, device, augmentor, transform=None,
                  dedup_frames=False, frame_capacity=None):
@@ -262,10 +263,16 @@ class ReplayBuffer(object):
         B = batch_size
         # the host may run several updates ahead of the GPU: a small ring of pinned slots, each guarded by an
         # event, keeps an index upload's source intact until its async copy has executed
-        self._n_slots, self._slot = 8, 0
+        # (an event record is a packet of its own in the stream, ~5 us: one per EVENT_EVERY uses, and a slot is
+        # re-written only after the first event recorded at or after its last use has completed)
+        self._n_slots, self._slot_use = 16, 0
         nbytes = 2 * B * 8 + B * 4 * 6  # frame indices (obs | next_obs) + the six crop-offset rows
         self._h_index = torch.empty((self._n_slots, nbytes), dtype=torch.uint8, pin_memory=pin)
-        self._slot_events = [None] * self._n_slots
+        self._slot_events = {}
+        # pinned slots are read by the GPU in place (ops.sample_stage): no copy-engine transfer in front of an update
+        self._h_index_dev = ([ops.host_device_pointer(self._h_index[k]) for k in range(self._n_slots)]
+                             if pin and os.environ.get("CURLA_STAGE_COPY", "0") != "1" else None)
+        self._staged = False
         # every minibatch gets its own device index block (and, de-duplicated, its own assembled stacks), so the
         # references of one sample stay valid while the next one is drawn (N_SAMPLE_SLOTS alive at a time)
         self._d_index = torch.empty((self.N_SAMPLE_SLOTS, nbytes), dtype=torch.uint8, device=dev)
@@ -449,10 +456,16 @@ class ReplayBuffer(object):
         """Copy a minibatch's indices and crop offsets into the next device sample slot; returns the slot's
         (guard, idx view [B] int64, offsets view [6, B] int32)."""
         B = self.batch_size
-        k = self._slot
-        self._slot = (k + 1) % self._n_slots
-        if self._slot_events[k] is not None:
-            self._slot_events[k].synchronize()
+        u, every = self._slot_use, self.EVENT_EVERY
+        self._slot_use = u + 1
+        k = u % self._n_slots
+        if u >= self._n_slots:
+            e = (u - self._n_slots) // every
+            ev = self._slot_events.get(e)
+            if ev is not None:
+                ev.synchronize()
+            for old in [i for i in self._slot_events if i < e]:
+                del self._slot_events[old]
         host = self._h_index[k]
         # device layout: idx [B] | idx + capacity [B] (the same transitions in the next_obs half of the double ring)
         # | h1 of obs, next_obs, pos | w1 of obs, next_obs, pos -- so that (obs, next_obs) is ONE run of 2B frame
@@ -466,11 +479,18 @@ class ReplayBuffer(object):
         s = self._sample_slot = (self._sample_slot + 1) % self.N_SAMPLE_SLOTS
         self._sample_gen[s] += 1
         dst = self._d_index[s]
-        dst.copy_(host, non_blocking=True)
-        if self.device.type == "cuda":
+        self._staged = self._h_index_dev is not None
+        if self._staged:  # index block and the transitions' scalars in one launch, the block read from the pinned slot
+            B, A = self.batch_size, self._n_act
+            buf = self._d_scal[s]
+            ops.sample_stage(self._h_index_dev[k], dst, host.numel(), self._sc, B, A, buf[:B * A], buf[B * A:B * A + B],
+                             buf[B * A + B:])
+        else:
+            dst.copy_(host, non_blocking=True)
+        if self.device.type == "cuda" and u % every == every - 1:
             ev = torch.cuda.Event()
             ev.record()
-            self._slot_events[k] = ev
+            self._slot_events[u // every] = ev
         guard = (self._sample_gen, s, self._sample_gen[s])
         d64 = dst[:2 * B * 8].view(torch.int64)
         d32 = dst[2 * B * 8:].view(torch.int32)
@@ -486,7 +506,9 @@ class ReplayBuffer(object):
         buf = self._d_scal[self._sample_slot]
         act, rew, nd = buf[:B * A].view((B,) + tuple(self.actions.shape[1:])), buf[B * A:B * A + B].view(B, 1), \
             buf[B * A + B:].view(B, 1)
-        if self.device.type == "cuda" or _lib_tracing():
+        if self._staged:  # gathered by the launch that staged the indices (_upload_indices)
+            self._staged = False
+        elif self.device.type == "cuda" or _lib_tracing():
             ops.gather_transition_scalars(self._sc, d_idx, B, A, act, rew, nd)
         return act, rew, nd
 

@@ -159,12 +159,24 @@ int curla_mlp_out_bwd(const float* dy, long long strideDy, const float* h, long 
                       long long strideW, float* dh, long long strideDh, float* dW, long long strideDW, int M, int N,
                       int K, int nbatch, void* stream);
 
+/* One problem of curla_fc_ln_fwd_multi (fields as curla_fc_ln_fwd's arguments; fc_out, xhat, rstd, xa, act optional;
+ * xa without act: only the feature columns of the rows are written). */
+typedef struct CurlaFcLnJob {
+  const float *partial, *bias, *gamma, *beta;
+  float *fc_out, *y, *xhat, *rstd, *xa;
+  const float* act;
+  int tanh_out;
+} CurlaFcLnJob;
 /* fc split-K reduce + bias + LayerNorm(eps) [+ tanh] (encoder.py:98-107).  Saves
  * xhat / rstd for the backward when non-NULL.  F <= 256.  `xa` (optional, with `act` [B][A]): also writes the Q
  * functions' input rows xa[b] = [ y[b] | act[b] ], i.e. torch.cat([obs, action], dim=1) (curl_sac.py:138). */
 int curla_fc_ln_fwd(const float* partial, int nsplit, long long split_stride, int ldp, const float* bias,
                     const float* gamma, const float* beta, int B, int F, float eps, float* fc_out, float* y,
                     float* xhat, float* rstd, int tanh_out, float* xa, const float* act, int A, void* stream);
+/* up to 4 such problems of one shape (same B, F, nsplit, strides, eps, A) in one launch: the features of several
+ * encoders over their own split-K partials (actor / target critic / critic, curl_sac.py:350-358) */
+int curla_fc_ln_fwd_multi(int njobs, const CurlaFcLnJob* jobs, int nsplit, long long split_stride, int ldp, int B,
+                          int F, float eps, int A, void* stream);
 /* dx, and (when non-NULL) dgamma, dbeta; dbias_in (optional, needs dgamma/dbeta) = column sums of dx = the gradient of
  * the fc bias feeding the LayerNorm */
 int curla_ln_bwd(const float* dy, const float* xhat, const float* rstd, const float* gamma, int B, int F, float* dx,
@@ -186,10 +198,12 @@ int curla_colsum3(const float* X0, int N0, const float* X1, int N1, const float*
 
 /* ---- squashed-Gaussian policy head (curl_sac.py:20-35, 87-108) ----
  * trunk_out [B][2A] = [mu | raw log_std]; `noise` replaces torch.randn_like
- * (curl_sac.py:97); NULL noise = compute_pi False (select_action). */
+ * (curl_sac.py:97); NULL noise = compute_pi False (select_action).  `pi_xa` (optional, with noise): pi is also
+ * (or, with pi NULL, only) written at pi_xa[b * xa_ld + a] -- the action columns of the Q functions' input rows
+ * [features | action] (curl_sac.py:138, 353). */
 int curla_actor_head_fwd(const float* trunk_out, const float* noise, int B, int A, float log_std_min,
                          float log_std_max, float* mu, float* pi, float* log_pi, float* log_std, float* tanh_ls,
-                         void* stream);
+                         float* pi_xa, int xa_ld, void* stream);
 /* gradient w.r.t. trunk_out of sum(gpi*pi) + glp*log_pi; glp = glp_rows[b] or glp_scale*exp(*log_alpha);
  * gpi[b][a] is read at gpi[b*gpi_ld + a] (+ gpi2[b*gpi_ld + a] when gpi2 is not NULL: the action columns of the twin-Q
  * input gradient summed over the twin in place) */
@@ -239,6 +253,12 @@ int curla_soft_update2(const float* param, float* target, size_t n, size_t split
  * torch's single-tensor Adam, and rounded to float once). */
 int curla_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
                     double beta1, double beta2, double eps, long long step, void* stream);
+/* curla_adam_step plus, in the same launch, the Adam step of ONE float64 scalar parameter with its own optimizer state
+ * and hyper-parameters (log_alpha, stepped right after the actor: curl_sac.py:393-404), in double. */
+int curla_adam_step_scalar64(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
+                             double beta1, double beta2, double eps, long long step, double* param64,
+                             const double* grad64, double* exp_avg64, double* exp_avg_sq64, double lr64, double beta1_64,
+                             double beta2_64, double eps64, long long step64, void* stream);
 /* Two such steps of two optimizers on the same parameters with the same gradient, one after the other, in one pass
  * (encoder_optimizer.step(); cpc_optimizer.step(), curl_sac.py:418-423).  exp_avg2 / exp_avg_sq2 cover n elements, the
  * first n_pre of which (CURL.W) take the second step only; exp_avg1 / exp_avg_sq1 cover the remaining n - n_pre. */
@@ -274,6 +294,15 @@ int curla_crop_nchw(const uint8_t* frames, const int64_t* idx, const int32_t* h1
  * [capacity][A+2] scalar block (action | reward | not_done) into three dense outputs */
 int curla_gather_transition_scalars(const float* scalars, const int64_t* idx, int B, int A, float* action, float* reward,
                                     float* not_done, void* stream);
+/* The same, fed from pinned host memory: `host_block` (device-visible address of a pinned buffer, see
+ * curla_host_device_pointer) holds the minibatch's index block -- B int64 ring rows first, then whatever else the
+ * caller lays out (crop offsets, utils.py:151-156), nbytes in all, a multiple of 8.  The kernel reads it over PCIe,
+ * writes it to `device_block` and gathers the scalar rows: the only host->device traffic of an update, without a
+ * copy-engine transfer in the stream.  The host buffer must stay untouched until the launch has executed. */
+int curla_sample_stage(const void* host_block, void* device_block, long long nbytes, const float* scalars, int B, int A,
+                       float* action, float* reward, float* not_done, void* stream);
+/* device-visible address of a pinned (hipHostMalloc'd / registered) host pointer; CURLA_ERR_ARG if it is not */
+int curla_host_device_pointer(void* host, void** device);
 /* ReplayBuffer.add: one CHW uint8 observation into ring slot `slot` (utils.py:120-128) */
 int curla_store_frame(const uint8_t* chw, uint8_t* frames, long long slot, int C, int H, int W, void* stream);
 /* De-duplicated frame store (next_obs[t] shares k-1 of its k frames with obs[t], and equals obs[t+1]

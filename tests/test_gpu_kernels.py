@@ -364,6 +364,21 @@ def test_concat_split_softupdate_mean(ops):
     ga, gr, gn = torch.empty(5, 3, device="cuda"), torch.empty(5, 1, device="cuda"), torch.empty(5, 1, device="cuda")
     ops.gather_transition_scalars(dev(sc), dev(idx), 5, 3, ga, gr, gn)
     assert torch.equal(ga.cpu(), sc[idx, :3]) and torch.equal(gr.cpu(), sc[idx, 3:4]) and torch.equal(gn.cpu(), sc[idx, 4:5])
+    # the same gather fed from a pinned host block (indices first, anything after), which the launch also copies
+    for B_, extra in ((5, 3), (300, 900), (2, 0)):
+        host = torch.empty(B_ * 8 + extra * 8, dtype=torch.uint8).pin_memory()
+        idx = torch.randint(0, 50, (B_,), generator=torch.Generator().manual_seed(B_))
+        host[:B_ * 8].view(torch.int64).copy_(idx)
+        host[B_ * 8:].copy_(torch.randint(0, 256, (extra * 8,), generator=torch.Generator().manual_seed(7)).to(torch.uint8))
+        blk = torch.zeros_like(host, device="cuda")
+        ga, gr, gn = (torch.empty(B_, n, device="cuda") for n in (3, 1, 1))
+        ops.sample_stage(ops.host_device_pointer(host), blk, host.numel(), dev(sc), B_, 3, ga, gr, gn)
+        torch.cuda.synchronize()
+        assert torch.equal(blk.cpu(), host)
+        assert torch.equal(ga.cpu(), sc[idx, :3]) and torch.equal(gr.cpu(), sc[idx, 3:4]) and torch.equal(gn.cpu(), sc[idx, 4:5])
+    from curla_amd._lib import CurlaHipError
+    with pytest.raises(CurlaHipError):
+        ops.host_device_pointer(torch.empty(64, dtype=torch.uint8))  # pageable memory: no device address
     m = torch.empty(1, device="cuda")
     ops.mean(dev(p[:777]), 777, m)
     check("mean", m.cpu(), p[:777].mean().reshape(1), 1e-5)
@@ -742,6 +757,42 @@ def test_flat_adam_step_pair_is_two_steps():
     for a, b in zip(res[0][:5], res[1][:5]):
         assert torch.equal(a, b)
     assert res[0][5:] == res[1][5:] == ([3] * 4, [3] * 5)
+
+
+def test_flat_adam_step_with_float64_scalar():
+    """FlatAdam.step_with_scalar(actor_optimizer, log_alpha_optimizer) (curl_sac.py:393-404 in one launch): the flat
+    parameters as FlatAdam.step() leaves them, the float64 scalar as torch's own Adam steps it."""
+    from curla_amd.optim import FlatAdam
+    sizes = [(50, 120), (50,), (64, 50), (64,)]
+    gen = torch.Generator().manual_seed(11)
+    grads = [(torch.randn(sum(int(np.prod(z)) + 3 & ~3 for z in sizes) + 8, generator=gen) * 0.01,
+              torch.randn((), generator=gen, dtype=torch.float64)) for _ in range(4)]
+    res = []
+    for fused in (False, True):
+        flat, gflat, params = _flat_params(sizes, "cuda", seed=5)
+        a = torch.tensor(np.log(0.1), device="cuda", requires_grad=True)
+        assert a.dtype == torch.float64
+        a.grad = torch.zeros((), device="cuda", dtype=torch.float64)
+        opt = FlatAdam(params, flat, gflat, lr=1e-3)
+        sopt = torch.optim.Adam([a], lr=1e-4, betas=(0.5, 0.999), foreach=False)
+        for gf, ga in grads:
+            gflat.copy_(gf[:gflat.numel()].cuda())
+            a.grad.copy_(ga)
+            if fused:
+                FlatAdam.step_with_scalar(opt, sopt)
+            else:
+                opt.step()
+                sopt.step()
+        torch.cuda.synchronize()
+        st = sopt.state[a]
+        res.append((flat.clone(), opt._m.clone(), opt._v.clone(), a.detach().clone(), st["exp_avg"].clone(),
+                    st["exp_avg_sq"].clone(), float(st["step"]), list(opt._steps)))
+    for x, y in zip(res[0][:3], res[1][:3]):
+        assert torch.equal(x, y)
+    for x, y in zip(res[0][3:6], res[1][3:6]):  # float64: same formula, torch may contract differently
+        assert abs(float(x) - float(y)) <= 4e-16 * max(1.0, abs(float(x))), (float(x), float(y))
+    assert res[0][6:] == res[1][6:] == (4.0, [4] * 4)
+    assert float(res[1][3]) != float(np.log(0.1))
 
 
 @pytest.mark.parametrize("two", [False, True])

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """From a rocprofv3 --kernel-trace CSV of bench.py: per update, the kernel-busy time, the idle gaps between
 consecutive kernels on the stream, and the kernels that follow the largest gaps.
-Usage: tools/timeline_gaps.py <kernel_trace.csv> [n_last_updates]"""
+Usage: tools/timeline_gaps.py <kernel_trace.csv> [n_last_updates] [--list]   (--list: the last two updates' launches in order)"""
 import collections
 import csv
 import re
@@ -14,11 +14,14 @@ def short(n):
     return n.split("(")[0][:48]
 
 
+want_list = "--list" in sys.argv
+if want_list:
+    sys.argv.remove("--list")
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 nlast = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 # an update starts at the gather of the sampled transitions' scalars (one launch per ReplayBuffer sample)
-starts = [i for i, r in enumerate(rows) if "gather_transition_scalars" in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "gather_transition_scalars" in r["Kernel_Name"] or "sample_stage" in r["Kernel_Name"]]
 starts = starts[-(nlast + 1):]
 tot_busy = tot_gap = 0.0
 gap_by = collections.Counter()
@@ -37,3 +40,12 @@ n = len(starts) - 1
 print(f"{n} updates: kernels busy {tot_busy / n:.1f} us, idle gaps {tot_gap / n:.1f} us per update, {sum(n_by.values()) / n:.0f} launches")
 for k, g in gap_by.most_common(12):
     print(f"  gap before {k:50s} {g / n:7.1f} us/update over {n_by[k] / n:.1f} launches")
+if want_list:
+  for a, b in ((starts[-3], starts[-2]), (starts[-2], starts[-1])):  # two: the actor phase runs every other update
+    t0 = int(rows[a]["Start_Timestamp"])
+    print(f"-- update of {b - a} launches")
+    for j in range(a, b):
+        r = rows[j]
+        g = (int(r["Start_Timestamp"]) - int(rows[j - 1]["End_Timestamp"])) / 1e3
+        d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+        print(f"{j - a:3d} t={(int(r['Start_Timestamp']) - t0) / 1e3:8.1f} gap {g:6.1f} dur {d:7.1f}  {short(r['Kernel_Name'])}")
