@@ -478,6 +478,94 @@ __global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs gx, FcBwdArgs 
     fc_dw_body<NT>(gw, (int)blockIdx.x - nblk);
 }
 
+// ---------------------------------------------------------------------------
+// Products with a SMALL output and a long k: the data gradient of an MLP's first layer ([B x 1024] x [1024 x 54]),
+// its weight gradient ([1024 x 54] over B rows), the CURL bilinear products ([B x B] x [B x 50], [50 x 50] over B
+// rows; curl_sac.py:129-139, 219-220, 406-423).  The tiled kernel gives them a few dozen workgroups that each walk
+// the whole k range one LDS tile at a time -- 12-19 us of latency for 0.1 GFLOP.  Here a workgroup owns ONE 16 x 16
+// output tile, its NW waves split k between them in chunks of 16 (wave w takes chunks w, w + NW, ...), operands go
+// from global memory straight into MFMA registers with every load of a wave in flight at once, and the NW partial
+// tiles are added in wave order through LDS.  k is walked in a permuted order inside a chunk (MFMA step s of
+// quarter-lane-group q multiplies k = 16c + 4q + s), so a row-major operand is one float4 per lane and chunk.
+// ---------------------------------------------------------------------------
+template <bool AK, bool BKM, int NW, int U>
+__global__ __launch_bounds__(64 * NW) void gemm_small_kernel(GemmArgs g) {
+  __shared__ f32x4 red[NW][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int batch = blockIdx.z;
+  const int bo = batch / g.nb_inner, bi = batch - bo * g.nb_inner;
+  const float* A = g.A + bi * g.sA + bo * g.sA2;
+  const float* B = g.B + bi * g.sB + bo * g.sB2;
+  float* C = g.C + bi * g.sC + bo * g.sC2;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+  const int mi = min(m0 + li, g.M - 1), ni = min(n0 + li, g.N - 1);  // (edge lanes re-read the last row; never stored)
+  // a lane's element (row r, k) of chunk c, step s: k = 16c + 4kq + s
+  const float* pa = AK ? A + (size_t)(4 * kq) * g.lda + mi : A + (size_t)mi * g.lda + 4 * kq;
+  const float* pb = BKM ? B + (size_t)(4 * kq) * g.ldb + ni : B + (size_t)ni * g.ldb + 4 * kq;
+  const size_t ca = AK ? (size_t)16 * g.lda : 16, cb = BKM ? (size_t)16 * g.ldb : 16;
+  const int T = (g.K / 16) / NW;  // chunks per wave (the host guarantees K % (16 * NW) == 0)
+  struct Frag {
+    float a[4], b[4];
+  };
+  auto ld = [&](int t, Frag& f) {
+    const size_t c = (size_t)(wave + NW * min(t, T - 1));  // (past the end: the last chunk again, unused)
+    const float* a = pa + c * ca;
+    const float* b = pb + c * cb;
+    if (AK) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) f.a[s] = a[(size_t)s * g.lda];
+    } else if (g.vecA) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(a);
+      f.a[0] = v[0], f.a[1] = v[1], f.a[2] = v[2], f.a[3] = v[3];
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) f.a[s] = a[s];
+    }
+    if (BKM) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) f.b[s] = b[(size_t)s * g.ldb];
+    } else if (g.vecB) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(b);
+      f.b[0] = v[0], f.b[1] = v[1], f.b[2] = v[2], f.b[3] = v[3];
+    } else {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) f.b[s] = b[s];
+    }
+  };
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  Frag cur[U], nxt[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) ld(u, cur[u]);
+  for (int t0 = 0; t0 < T; t0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) ld(t0 + U + u, nxt[u]);  // unconditional: stays in flight under the MFMAs below
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (t0 + u < T) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = mfma16(cur[u].b[s], cur[u].a[s], acc);
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 1; w < NW; ++w) acc += red[w][lane];
+  const int m = m0 + li, n = n0 + 4 * kq;  // (N-side operand first: a lane holds 4 consecutive n of one m)
+  if (m >= g.M || n >= g.N) return;
+  acc = acc * g.alpha;
+  if ((g.ldc % 4 == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && n + 3 < g.N) {
+    *reinterpret_cast<f32x4*>(C + (size_t)m * g.ldc + n) = acc;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n + r < g.N) C[(size_t)m * g.ldc + n + r] = acc[r];
+  }
+}
+
 // sum split-K partials: C[m][n] = sum_s P[s][m][n] (+bias, ReLU)
 __global__ void splitk_reduce_kernel(const float* P, int nsplit, long long sSplit, int M, int N, int ldp, float* C,
                                      int ldc, const float* bias, int relu) {
@@ -497,6 +585,33 @@ extern "C" {
 
 static int gemm_launch(GemmArgs& g, int a_kmajor, int b_kmajor, hipStream_t st) {
   const int M = g.M, N = g.N, K = g.K, nbatch = g.nbatch, ksplit = g.ksplit;
+  {  // small output, long k: one workgroup per 16 x 16 tile, k split over its waves (gemm_small_kernel)
+    static const bool small_on = !(getenv("CURLA_GEMM_SMALL") && atoi(getenv("CURLA_GEMM_SMALL")) == 0);
+    const long long t32 = (long long)((M + 31) / 32) * ((N + 31) / 32) * nbatch;
+    const long long t16 = (long long)((M + 15) / 16) * ((N + 15) / 16) * nbatch;
+    if (small_on && ksplit == 1 && !g.bias && !g.mask && !g.relu && g.nptr == 0 && K >= 256 && K % 64 == 0 &&
+        t32 <= 128 && nbatch <= 65535) {
+      const bool wide = t16 < 64 && K % 256 == 0;  // a handful of tiles: 16 waves each
+      const dim3 grid((N + 15) / 16, (M + 15) / 16, nbatch);
+#define CURLA_GEMM_SMALL(AKM, BKMAJ)                                                              \
+  do {                                                                                            \
+    if (wide)                                                                                     \
+      hipLaunchKernelGGL((gemm_small_kernel<AKM, BKMAJ, 16, 2>), grid, dim3(1024), 0, st, g);     \
+    else                                                                                          \
+      hipLaunchKernelGGL((gemm_small_kernel<AKM, BKMAJ, 4, 8>), grid, dim3(256), 0, st, g);       \
+  } while (0)
+      if (a_kmajor && b_kmajor)
+        CURLA_GEMM_SMALL(true, true);
+      else if (a_kmajor)
+        CURLA_GEMM_SMALL(true, false);
+      else if (b_kmajor)
+        CURLA_GEMM_SMALL(false, true);
+      else
+        CURLA_GEMM_SMALL(false, false);
+#undef CURLA_GEMM_SMALL
+      return curla_launch_status();
+    }
+  }
   int kc = (K + ksplit - 1) / ksplit;
   kc = (kc + BK - 1) / BK * BK;  // chunk boundaries stay float4-aligned
   g.kchunk = kc;

@@ -183,6 +183,26 @@ def test_gemm(ops, M, N, K, ak, bk, nb):
     check(f"gemm mask {M}x{N}x{K} ak{ak} bk{bk} nb{nb}", C2.cpu(), ref_plain * (mask > 0))
 
 
+@pytest.mark.parametrize("ak,bk", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K,nb", [(512, 54, 1024, 2), (50, 50, 512, 1), (37, 70, 256, 3), (1024, 54, 512, 2),
+                                      (16, 16, 64 * 5, 1), (512, 50, 512, 1)])
+def test_gemm_small_output_long_k(ops, M, N, K, ak, bk, nb):
+    """Small outputs with a long k (first-layer data / weight gradients of the MLPs, the CURL bilinear products) take
+    gemm_small_kernel: one workgroup per 16 x 16 tile, k split over its waves."""
+    A, Bm = rnd(nb, M, K, seed=41), rnd(nb, N, K, seed=42)
+    ref = torch.einsum("zmk,znk->zmn", A.double(), Bm.double()).float()
+    Ad = dev(A.transpose(1, 2)) if ak else dev(A)
+    Bd = dev(Bm.transpose(1, 2)) if bk else dev(Bm)
+    lda, ldb = (M if ak else K), (N if bk else K)
+    C = torch.full((nb, M, N + 3), float("nan"), device="cuda")  # (ldc = N + 3: rows not 16-byte aligned)
+    ops.gemm(Ad, ak, lda, M * K, Bd, bk, ldb, N * K, C, N + 3, M * (N + 3), M, N, K, nb, alpha=0.25)
+    check(f"small gemm {M}x{N}x{K} ak{ak} bk{bk}", C[:, :, :N].cpu(), 0.25 * ref, 2e-5)
+    assert torch.isnan(C[:, :, N:]).all()
+    C2 = torch.full((nb, M, N), float("nan"), device="cuda")
+    ops.gemm(Ad, ak, lda, M * K, Bd, bk, ldb, N * K, C2, N, M * N, M, N, K, nb)
+    check(f"small gemm {M}x{N}x{K} ak{ak} bk{bk} dense C", C2.cpu(), ref, 2e-5)
+
+
 @pytest.mark.parametrize("B,Fd,K", [(24, 50, 3456), (9, 130, 800), (5, 64, 288), (3, 256, 512), (515, 50, 64)])
 def test_gemm_splitk_and_fc_ln(ops, B, Fd, K):
     h, W, bias = rnd(B, K, seed=31), rnd(Fd, K, seed=32, scale=0.05), rnd(Fd, seed=33)
