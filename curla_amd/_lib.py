@@ -44,6 +44,11 @@ SIGNATURES = {
     "curla_splitk_reduce": [vp, c_int, c_ll, c_int, c_int, c_int, vp, c_int, vp, c_int, vp],
     "curla_mlp_out_fwd": [vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, c_int, c_int, c_int, c_int, vp],
     "curla_mlp_out_bwd": [vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, c_int, c_int, c_int, c_int, vp],
+    "curla_mlp_out_bwd_bias": [vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, c_int, c_int, c_int, c_int, vp, vp, c_ll,
+                               vp],
+    "curla_gemm_small_shape": [c_int, c_int, c_int, c_int],
+    "curla_gemm_colsum": [vp, c_int, c_int, c_ll, vp, c_int, c_int, c_ll, vp, c_int, c_ll, c_int, c_int, c_int, c_int, vp,
+                          c_ll, vp],
     "curla_fc_ln_fwd": [vp, c_int, c_ll, c_int, vp, vp, vp, c_int, c_int, c_float, vp, vp, vp, vp, c_int, vp, vp, c_int,
                         vp],
     "curla_critic_td_loss": [vp, vp, c_ll, vp, vp, vp, vp, c_float, c_int, vp, vp, vp, vp],
@@ -61,6 +66,7 @@ SIGNATURES = {
     "curla_colsum": [vp, c_int, c_int, c_int, c_ll, vp, c_ll, c_int, vp],
     "curla_colsum3": [vp, c_int, vp, c_int, vp, c_int, c_int, vp, vp, vp, c_ll, c_int, vp],
     "curla_actor_head_fwd": [vp, vp, c_int, c_int, c_float, c_float, vp, vp, vp, vp, vp, vp, c_int, vp],
+    "curla_mlp_out_head_fwd": [vp, vp, vp, vp, c_int, c_int, c_int, vp, c_float, c_float, vp, vp, vp, vp, vp, vp, c_int, vp],
     "curla_fc_ln_fwd_multi": [c_int, vp, c_int, c_ll, c_int, c_int, c_int, c_float, c_int, vp],
     "curla_actor_head_bwd": [vp, vp, c_int, vp, vp, c_float, vp, vp, vp, vp, c_int, c_int, c_float, c_float, vp, vp],
     "curla_concat": [vp, vp, c_int, c_int, c_int, vp, vp],

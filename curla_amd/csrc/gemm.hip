@@ -37,6 +37,10 @@ struct GemmArgs {
   // the allocator put them -- one launch for all four)
   int nb_inner;
   long long sA2, sB2, sC2, sBias2, sMask2;
+  // colsum (small-output kernel only): also colsum[z][m] = alpha * sum_k opA[m][k] (a weight gradient dy^T x with the
+  // bias gradient, the column sums of dy, from the operands it loads anyway)
+  float* colsum;
+  long long sColsum, sColsum2;
   // nptr > 0: the batch items are unrelated problems of one shape, given by pointer (A = Ap[batch] ...) instead of by
   // stride -- e.g. the fc products of three encoders on three activation tensors in one launch
   int nptr;
@@ -468,14 +472,143 @@ __global__ __launch_bounds__(256, 2) void fc_dw_kernel(FcBwdArgs g) {
   fc_dw_body<NT>(g, blockIdx.x);
 }
 
-// both products of the fc backward in ONE launch (they only share their input dz): the first nblk workgroups compute
-// the data gradient (the conv backward waits for it), the rest the weight gradient
+// Both products of the fc backward in ONE pass over the activations: the ReLU mask of the data gradient and the
+// column operand of the weight gradient are the SAME matrix x (the last conv layer's output), and both bodies above
+// read it in the same lane layout -- lane (li, kq) holds x[16t + 4kq + r][nc .. nc+3], r = 0..3, of b-tile t: for the
+// data gradient that is the mask of its four accumulator rows, for the weight gradient the column operand of k-step r
+// (a step multiplies rows 16t + 4kq + r: any order of the batch rows is a valid k order as long as the dz operand
+// follows it).  One workgroup per 64 columns does both, x is read from HBM once instead of twice (63 of 206 MB per
+// launch at B = 512, K = 30752).
+// (B % 16 == 0, 4 (KS - 1) < F <= 4 KS and matrices below 2 GB, checked by the host.)  Every operand goes through
+// buffer loads -- descriptor in SGPRs, a 32-bit lane offset that never changes, the tile / row / k-step part of the
+// address in the scalar offset: with flat addresses the ~45 loads of a tile kept 64-bit lane addresses alive (35 spilled
+// registers, each reload a full wait in front of its load).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float buf_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+
 template <int KS, int NT>
-__global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs gx, FcBwdArgs gw, int nblk) {
-  if ((int)blockIdx.x < nblk)
-    fc_dx_body<KS>(gx, blockIdx.x);
-  else
-    fc_dw_body<NT>(gw, (int)blockIdx.x - nblk);
+__global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs g, float* dW) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NT][4][64 lanes] float4
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * 64;
+  const int ncol = n0 + 4 * li;
+  const bool cvalid = ncol + 3 < g.K;
+  const int nc = cvalid ? ncol : n0;
+  f32x4 wv[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) {
+    const int f = 4 * s + kq;
+    wv[s] = *reinterpret_cast<const f32x4*>(g.W + (size_t)min(f, g.F - 1) * g.K + nc);
+  }
+  f32x4 accw[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) accw[t][c] = f32x4{0, 0, 0, 0};
+  const int ntiles = g.B >> 4;
+  const unsigned dz_bytes = (unsigned)g.B * g.F * 4u, x_bytes = (unsigned)g.B * (unsigned)g.K * 4u;
+  const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc((void*)g.dz, (short)0, (int)dz_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)g.mask, (short)0, (int)x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)g.out, (short)0, (int)x_bytes, 0x00020000);
+  // lane offsets (bytes) inside a b-tile's 16 rows of dz / x; everything else of an address is wave-uniform
+  const unsigned dv_off = (unsigned)(li * g.F + kq) * 4u;  // dz[16t + li][4s + kq]: + 16 s
+  // last k-step: features past F multiply a zero -- their lanes point past the buffer (an out-of-range load returns 0)
+  const unsigned dv_last = 4 * (KS - 1) + kq < g.F ? dv_off : 0x80000000u;
+  unsigned dt_off[NT];                                    // dz[16t + 4kq + r][16ft + li]: + 4 r F
+#pragma unroll
+  for (int ft = 0; ft < NT; ++ft) dt_off[ft] = (unsigned)(4 * kq * g.F + min(16 * ft + li, g.F - 1)) * 4u;
+  const unsigned x_off = ((unsigned)(4 * kq) * (unsigned)g.K + (unsigned)nc) * 4u;  // x[16t + 4kq + r][nc]: + 4 r K
+  const unsigned rowF = 4u * g.F, rowK = 4u * (unsigned)g.K;
+  auto load_dv = [&](int t, float (&dv)[KS]) {
+    const unsigned base = (unsigned)t * 16u * rowF;
+#pragma unroll
+    for (int s = 0; s < KS - 1; ++s) dv[s] = buf_f32(rdz, dv_off, base + 16u * s);
+    dv[KS - 1] = buf_f32(rdz, dv_last, base + 16u * (KS - 1));
+  };
+  auto load_dt = [&](int t, float (&dt)[4][NT]) {
+    const unsigned base = (unsigned)t * 16u * rowF;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ft = 0; ft < NT; ++ft) dt[r][ft] = buf_f32(rdz, dt_off[ft], base + r * rowF);  // (features past F: F-1 again, never stored)
+  };
+  auto load_mk = [&](int t, f32x4 (&mk)[4]) {
+    const unsigned base = (unsigned)t * 16u * rowK;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mk[r] = buf_f32x4(rx, x_off, base + r * rowK);
+  };
+  float dv[KS], dt[4][NT];
+  // x comes from HBM and is requested a whole tile ahead (two register sets); the dz operands are L2 hits and each has
+  // the other product's MFMAs to arrive under
+  auto tile = [&](int t, int tnext, const f32x4 (&mk)[4], f32x4 (&mk_next)[4]) {
+    load_mk(tnext, mk_next);
+    load_dt(t, dt);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = mfma16(dv[s], wv[s][c], acc[c]);
+    __builtin_amdgcn_sched_barrier(0);
+    load_dv(tnext, dv);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ft = 0; ft < NT; ++ft)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) accw[ft][c] = mfma16(dt[r][ft], mk[r][c], accw[ft][c]);
+    const unsigned obase = (unsigned)t * 16u * rowK;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = mk[r][c] > 0.f ? v[c] : 0.f;
+      if (cvalid) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, x_off, obase + r * rowK, 2);  // nt
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  f32x4 mA[4], mB[4];
+  int t = wave;  // this wave's b-tiles: wave, wave + 4, ...
+  if (t < ntiles) {
+    load_mk(t, mA);
+    load_dv(t, dv);
+  }
+  for (; t < ntiles; t += 8) {
+    tile(t, min(t + 4, ntiles - 1), mA, mB);  // (past the end: the last tile again, unused)
+    if (t + 4 < ntiles) tile(t + 4, min(t + 8, ntiles - 1), mB, mA);
+  }
+  // weight gradient: sum over the four waves (b-tiles) in wave order, then wave w writes feature tile(s) w, w+4, ...
+  f32x4* r4 = reinterpret_cast<f32x4*>(red);
+#pragma unroll
+  for (int ft = 0; ft < NT; ++ft)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r4[((wave * NT + ft) * 4 + c) * 64 + lane] = accw[ft][c];
+  __syncthreads();
+  for (int ft = wave; ft < NT; ft += 4) {
+    f32x4 v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      v[c] = r4[((0 * NT + ft) * 4 + c) * 64 + lane];
+#pragma unroll
+      for (int w = 1; w < 4; ++w) v[c] += r4[((w * NT + ft) * 4 + c) * 64 + lane];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = 16 * ft + 4 * kq + r;
+      const f32x4 o = {v[0][r], v[1][r], v[2][r], v[3][r]};
+      if (cvalid && f < g.F) *reinterpret_cast<f32x4*>(dW + (size_t)f * g.K + ncol) = o;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -504,6 +637,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_small_kernel(GemmArgs g) {
   const float* pa = AK ? A + (size_t)(4 * kq) * g.lda + mi : A + (size_t)mi * g.lda + 4 * kq;
   const float* pb = BKM ? B + (size_t)(4 * kq) * g.ldb + ni : B + (size_t)ni * g.ldb + 4 * kq;
   const size_t ca = AK ? (size_t)16 * g.lda : 16, cb = BKM ? (size_t)16 * g.ldb : 16;
+  // colsum: the workgroups of the first column of tiles also add up the A operands they load anyway
+  const bool do_cs = g.colsum && blockIdx.x == 0;  // block-uniform
+  float asum = 0.f;
   const int T = (g.K / 16) / NW;  // chunks per wave (the host guarantees K % (16 * NW) == 0)
   struct Frag {
     float a[4], b[4];
@@ -545,15 +681,28 @@ __global__ __launch_bounds__(64 * NW) void gemm_small_kernel(GemmArgs g) {
       if (t0 + u < T) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc = mfma16(cur[u].b[s], cur[u].a[s], acc);
+        if (do_cs) asum += (cur[u].a[0] + cur[u].a[1]) + (cur[u].a[2] + cur[u].a[3]);
       }
 #pragma unroll
     for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+  }
+  __shared__ float red_cs[NW][16];
+  if (do_cs) {  // the four k-quarters of a row sit in lanes li, li+16, li+32, li+48
+    asum += __shfl_xor(asum, 16);
+    asum += __shfl_xor(asum, 32);
+    if (lane < 16) red_cs[wave][lane] = asum;
   }
   red[wave][lane] = acc;
   __syncthreads();
   if (wave != 0) return;
 #pragma unroll
   for (int w = 1; w < NW; ++w) acc += red[w][lane];
+  if (do_cs && lane < 16 && m0 + lane < g.M) {
+    float t = red_cs[0][lane];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) t += red_cs[w][lane];
+    g.colsum[bi * g.sColsum + bo * g.sColsum2 + m0 + lane] = t * g.alpha;
+  }
   const int m = m0 + li, n = n0 + 4 * kq;  // (N-side operand first: a lane holds 4 consecutive n of one m)
   if (m >= g.M || n >= g.N) return;
   acc = acc * g.alpha;
@@ -583,14 +732,20 @@ __global__ void splitk_reduce_kernel(const float* P, int nsplit, long long sSpli
 
 extern "C" {
 
+// small output, long k: one workgroup per 16 x 16 tile, k split over its waves (gemm_small_kernel)
+static bool small_shape(int M, int N, int K, int nbatch) {
+  static const bool small_on = !(getenv("CURLA_GEMM_SMALL") && atoi(getenv("CURLA_GEMM_SMALL")) == 0);
+  const long long t32 = (long long)((M + 31) / 32) * ((N + 31) / 32) * nbatch;
+  return small_on && K >= 256 && K % 64 == 0 && t32 <= 128 && nbatch <= 65535;
+}
+
 static int gemm_launch(GemmArgs& g, int a_kmajor, int b_kmajor, hipStream_t st) {
   const int M = g.M, N = g.N, K = g.K, nbatch = g.nbatch, ksplit = g.ksplit;
-  {  // small output, long k: one workgroup per 16 x 16 tile, k split over its waves (gemm_small_kernel)
-    static const bool small_on = !(getenv("CURLA_GEMM_SMALL") && atoi(getenv("CURLA_GEMM_SMALL")) == 0);
-    const long long t32 = (long long)((M + 31) / 32) * ((N + 31) / 32) * nbatch;
+  {
     const long long t16 = (long long)((M + 15) / 16) * ((N + 15) / 16) * nbatch;
-    if (small_on && ksplit == 1 && !g.bias && !g.mask && !g.relu && g.nptr == 0 && K >= 256 && K % 64 == 0 &&
-        t32 <= 128 && nbatch <= 65535) {
+    const bool small = ksplit == 1 && !g.bias && !g.mask && !g.relu && g.nptr == 0 && small_shape(M, N, K, nbatch);
+    if (g.colsum && !small) return CURLA_ERR_UNSUPPORTED;
+    if (small) {
       const bool wide = t16 < 64 && K % 256 == 0;  // a handful of tiles: 16 waves each
       const dim3 grid((N + 15) / 16, (M + 15) / 16, nbatch);
 #define CURLA_GEMM_SMALL(AKM, BKMAJ)                                                              \
@@ -693,7 +848,28 @@ int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const f
   g.vecA = (lda % 4 == 0) && (strideA % 4 == 0) && aligned16(A);
   g.vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && aligned16(B);
   g.nptr = 0;
+  g.colsum = nullptr, g.sColsum = g.sColsum2 = 0;
   g.nb_inner = nbatch, g.sA2 = g.sB2 = g.sC2 = g.sBias2 = g.sMask2 = 0;
+  return gemm_launch(g, a_kmajor, b_kmajor, static_cast<hipStream_t>(stream));
+}
+
+int curla_gemm_small_shape(int M, int N, int K, int nbatch) { return small_shape(M, N, K, nbatch) ? 1 : 0; }
+
+int curla_gemm_colsum(const float* A, int a_kmajor, int lda, long long strideA, const float* B, int b_kmajor, int ldb,
+                      long long strideB, float* C, int ldc, long long strideC, int M, int N, int K, int nbatch,
+                      float* colsum, long long strideColsum, void* stream) {
+  CURLA_REQUIRE(A && B && C && colsum && M > 0 && N > 0 && K > 0 && nbatch > 0);
+  GemmArgs g;
+  g.A = A, g.B = B, g.C = C, g.bias = nullptr, g.mask = nullptr;
+  g.M = M, g.N = N, g.K = K, g.lda = lda, g.ldb = ldb, g.ldc = ldc, g.ldmask = 0;
+  g.sA = strideA, g.sB = strideB, g.sC = strideC, g.sBias = 0, g.sMask = 0, g.sSplit = 0;
+  g.nbatch = nbatch, g.ksplit = 1;
+  g.alpha = 1.f, g.relu = 0;
+  g.vecA = (lda % 4 == 0) && (strideA % 4 == 0) && aligned16(A);
+  g.vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && aligned16(B);
+  g.nptr = 0;
+  g.nb_inner = nbatch, g.sA2 = g.sB2 = g.sC2 = g.sBias2 = g.sMask2 = 0;
+  g.colsum = colsum, g.sColsum = strideColsum, g.sColsum2 = 0;
   return gemm_launch(g, a_kmajor, b_kmajor, static_cast<hipStream_t>(stream));
 }
 
@@ -712,6 +888,7 @@ int curla_gemm_nested(const float* A, int a_kmajor, int lda, long long strideA, 
   g.vecA = (lda % 4 == 0) && (strideA % 4 == 0) && (strideA2 % 4 == 0) && aligned16(A);
   g.vecB = (ldb % 4 == 0) && (strideB % 4 == 0) && (strideB2 % 4 == 0) && aligned16(B);
   g.nptr = 0;
+  g.colsum = nullptr, g.sColsum = g.sColsum2 = 0;
   g.nb_inner = nbatch, g.sA2 = strideA2, g.sB2 = strideB2, g.sC2 = strideC2, g.sBias2 = strideBias2, g.sMask2 = strideMask2;
   return gemm_launch(g, a_kmajor, b_kmajor, static_cast<hipStream_t>(stream));
 }
@@ -727,6 +904,7 @@ int curla_gemm_multi(int nprob, const float* const* A, const float* const* B, fl
   g.alpha = 1.f, g.relu = 0;
   g.vecA = (lda % 4 == 0), g.vecB = (ldb % 4 == 0);
   g.nptr = nprob;
+  g.colsum = nullptr, g.sColsum = g.sColsum2 = 0;
   g.nb_inner = nprob, g.sA2 = g.sB2 = g.sC2 = g.sBias2 = g.sMask2 = 0;
   for (int i = 0; i < nprob; ++i) {
     CURLA_REQUIRE(A[i] && B[i] && C[i]);
@@ -795,13 +973,14 @@ int curla_fc_bwd(const float* dz, const float* W, const float* x, float* dx, flo
   int rc = fc_bwd_check(dz, W, dx, B, F, K);
   if (rc != CURLA_OK) return rc;
   if ((rc = fc_bwd_check(dz, x, dW, B, F, K)) != CURLA_OK) return rc;
-  FcBwdArgs gx, gw;
+  FcBwdArgs gx;
   gx.dz = dz, gx.W = W, gx.mask = x, gx.out = dx, gx.B = B, gx.F = F, gx.K = K;
-  gw.dz = dz, gw.W = x, gw.mask = nullptr, gw.out = dW, gw.B = B, gw.F = F, gw.K = K;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int nblk = (K + 63) / 64;
   const int ks = (F + 3) / 4, nt = (F + 15) / 16;
-  if (ks > 13 || ks <= 8 || nt != 4) {  // only the 49..52-feature shape is instantiated as one launch
+  // the one-pass kernel is instantiated for 49..52 features, whole 16-row tiles and matrices below 2 GB (32-bit buffer
+  // offsets); anything else takes the two streaming kernels
+  if (ks != 13 || nt != 4 || B % 16 != 0 || (long long)B * K * 4 >= (1LL << 31)) {
     if ((rc = curla_fc_dx(dz, W, x, dx, B, F, K, stream)) != CURLA_OK) return rc;
     return curla_fc_dw(dz, x, dW, B, F, K, stream);
   }
@@ -813,7 +992,7 @@ int curla_fc_bwd(const float* dz, const float* W, const float* x, float* dx, flo
       return CURLA_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL((fc_bwd_kernel<13, 4>), dim3(2 * nblk), dim3(256), lds, st, gx, gw, nblk);
+  hipLaunchKernelGGL((fc_bwd_kernel<13, 4>), dim3(nblk), dim3(256), lds, st, gx, dW);
   return curla_launch_status();
 }
 

@@ -249,45 +249,116 @@ __global__ __launch_bounds__(1024) void colsum3_kernel(Colsum3Args a, int M, lon
 // data gradient (ReLU mask of the layer below fused) and the weight gradient.
 constexpr int kMaxOut = 16;
 
+// ---- policy head (curl_sac.py:20-35, 87-108), one row: trunk output [mu | raw log_std] -> tanh(mu), pi, log_pi, ... ----
+constexpr int kMaxA = 8;
+constexpr float kHalfLog2Pi = 0.9189385332046727f;
+struct HeadArgs {
+  const float* noise;
+  float *mu_t, *pi_t, *log_pi, *log_std, *tanh_ls, *pi_xa;  // pi_xa: pi also as the action columns of the Q input rows
+  int A, xa_ld;
+  float lo, hi;
+};
+
+__device__ __forceinline__ void actor_head_one(float mu, float raw, int b, int a, const HeadArgs& hd, float& lp,
+                                               float& corr) {
+  const int A = hd.A;
+  const float t = tanhf(raw);
+  const float ls = hd.lo + 0.5f * (hd.hi - hd.lo) * (t + 1.f);
+  if (hd.mu_t) hd.mu_t[(size_t)b * A + a] = tanhf(mu);
+  if (hd.log_std) hd.log_std[(size_t)b * A + a] = ls;
+  if (hd.tanh_ls) hd.tanh_ls[(size_t)b * A + a] = t;
+  if (hd.noise) {
+    const float n = hd.noise[(size_t)b * A + a];
+    const float p = tanhf(mu + n * expf(ls));
+    if (hd.pi_t) hd.pi_t[(size_t)b * A + a] = p;
+    if (hd.pi_xa) hd.pi_xa[(size_t)b * hd.xa_ld + a] = p;
+    lp += -0.5f * n * n - ls;
+    corr += logf(fmaxf(1.f - p * p, 0.f) + 1e-6f);
+  }
+}
+
+// one thread walks the row's actions
+__device__ __forceinline__ void actor_head_row(const float* out2a_row, int b, const HeadArgs& hd) {
+  float lp = 0.f, corr = 0.f;
+  for (int a = 0; a < hd.A; ++a) actor_head_one(out2a_row[a], out2a_row[hd.A + a], b, a, hd, lp, corr);
+  if (hd.noise && hd.log_pi) hd.log_pi[b] = lp - kHalfLog2Pi * hd.A - corr;
+}
+
 // out[z][m][n] = bias[z][n] + sum_k h[z][m][k] * W[z][n][k]        (curl_sac.py:73-74,132-133 forward)
 // (two-level batch: blockIdx.y = outer * nb_inner + inner; the outer level's strides end in 2)
+// HEAD: the outputs are the actor trunk's [mu | raw log_std] and the wave that produced a row also runs the policy
+// head on it (a launch of its own otherwise: a few hundred cycles of work per row behind a 5 us launch)
+// R rows per wave: a weight float4 is loaded once for R rows; a row's sums do not depend on R (R = 1 is what runs).
+template <bool HEAD, int R>
 __global__ __launch_bounds__(256) void mlp_out_fwd_kernel(const float* h, long long sH, long long sH2, const float* W,
                                                           long long sW, long long sW2, const float* bias, long long sB,
                                                           long long sB2, float* out, long long sOut, long long sOut2,
-                                                          int M, int N, int K, int nb_inner) {
+                                                          int M, int N, int K, int nb_inner, HeadArgs hd) {
   const int zo = blockIdx.y / nb_inner, zi = blockIdx.y - zo * nb_inner;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (row >= M) return;
-  const float* hr = h + zi * sH + zo * sH2 + (size_t)row * K;
+  const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R, lane = threadIdx.x & 63;
+  if (row0 >= M) return;
+  const float* hz = h + zi * sH + zo * sH2;
   const float* Wz = W + zi * sW + zo * sW2;
-  float acc[kMaxOut];
+  float acc[R][kMaxOut];
 #pragma unroll
-  for (int n = 0; n < kMaxOut; ++n) acc[n] = 0.f;
+  for (int r = 0; r < R; ++r)
+#pragma unroll
+    for (int n = 0; n < kMaxOut; ++n) acc[r][n] = 0.f;
   for (int k = 4 * lane; k < K; k += 256) {  // (K % 4 == 0 checked by the host)
-    const f32x4 hv = *reinterpret_cast<const f32x4*>(hr + k);
+    f32x4 hv[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r)  // (rows past the end re-read the last one; never stored)
+      hv[r] = *reinterpret_cast<const f32x4*>(hz + (size_t)min(row0 + r, M - 1) * K + k);
 #pragma unroll
     for (int n = 0; n < kMaxOut; ++n)
       if (n < N) {
         const f32x4 wv = *reinterpret_cast<const f32x4*>(Wz + (size_t)n * K + k);
-        acc[n] += hv[0] * wv[0] + hv[1] * wv[1] + hv[2] * wv[2] + hv[3] * wv[3];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          acc[r][n] += hv[r][0] * wv[0] + hv[r][1] * wv[1] + hv[r][2] * wv[2] + hv[r][3] * wv[3];
       }
   }
 #pragma unroll
-  for (int n = 0; n < kMaxOut; ++n)
-    if (n < N) {
-      const float s = wave_sum(acc[n]);
-      if (lane == 0) out[zi * sOut + zo * sOut2 + (size_t)row * N + n] = s + (bias ? bias[zi * sB + zo * sB2 + n] : 0.f);
+  for (int r = 0; r < R; ++r) {
+    const int row = row0 + r;
+    if (row >= M) break;  // wave-uniform
+#pragma unroll
+    for (int n = 0; n < kMaxOut; ++n)
+      if (n < N) {
+        const float s = wave_sum(acc[r][n]);
+        acc[r][n] = s;
+        if (lane == 0)
+          out[zi * sOut + zo * sOut2 + (size_t)row * N + n] = s + (bias ? bias[zi * sB + zo * sB2 + n] : 0.f);
+      }
+    if (HEAD) {
+      // every lane holds the row's outputs: lane a < A takes action a, the two sums over the actions are then added
+      // in action order by lane 0 (the same order as the one-thread walk)
+      float mu = 0.f, raw = 0.f;
+#pragma unroll
+      for (int n = 0; n < kMaxOut; ++n) {
+        const float v = n < N ? acc[r][n] + (bias ? bias[n] : 0.f) : 0.f;
+        if (n == lane) mu = v;
+        if (n == lane + hd.A) raw = v;
+      }
+      float lp = 0.f, corr = 0.f;
+      if (lane < hd.A) actor_head_one(mu, raw, row, lane, hd, lp, corr);
+      float lps = 0.f, cs = 0.f;
+      for (int a = 0; a < hd.A; ++a) lps += __shfl(lp, a), cs += __shfl(corr, a);
+      if (lane == 0 && hd.noise && hd.log_pi) hd.log_pi[row] = lps - kHalfLog2Pi * hd.A - cs;
     }
+  }
 }
 
 // dh[z][m][k] = (h[z][m][k] > 0) * sum_n dy[z][m][n] * W[z][n][k];   dW[z][n][k] = sum_m dy[z][m][n] * h[z][m][k]
 // One block = 16 k-columns x 64 row parts (K/16 x nbatch blocks: 128 for the twin Q functions); a thread's rows are
 // all in flight at once; the 64 partial dW sums are added in part order (fixed order).
 constexpr int kOutRows = 8;  // rows per thread per pass (64 parts x 8 = 512 rows per pass)
+// db_out[z][n] = sum_m dy[z][m][n] and db_h[z][k] = sum_m dh[z][m][k] (optional): the bias gradients of this layer and
+// of the one below -- the block already walks every row of its 16 columns.
 __global__ __launch_bounds__(1024) void mlp_out_bwd_kernel(const float* dy, long long sDy, const float* h,
                                                            long long sH, const float* W, long long sW, float* dh,
                                                            long long sDh, float* dW, long long sDW, int M, int N,
-                                                           int K) {
+                                                           int K, float* db_out, float* db_h, long long sDb) {
   __shared__ float sm[64][17];
   const int z = blockIdx.y;
   const int kl = threadIdx.x & 15, part = threadIdx.x >> 4;
@@ -302,6 +373,8 @@ __global__ __launch_bounds__(1024) void mlp_out_bwd_kernel(const float* dy, long
     wreg[n] = (n < N && kv) ? W[z * sW + (size_t)n * K + k] : 0.f;
     acc[n] = 0.f;
   }
+  float bh = 0.f, bo = 0.f;  // column sums of dh (column k) and, in block 0, of dy (column kl)
+  const bool do_bo = db_out && blockIdx.x == 0 && kl < N;
   for (int m0 = part; m0 < M; m0 += 64 * kOutRows) {
     float hv[kOutRows];
 #pragma unroll
@@ -321,13 +394,40 @@ __global__ __launch_bounds__(1024) void mlp_out_bwd_kernel(const float* dy, long
             s += d * wreg[n];
             acc[n] += d * hv[u];
           }
-        if (kv) dhz[(size_t)m * K + k] = hv[u] > 0.f ? s : 0.f;
+        const float dv = hv[u] > 0.f ? s : 0.f;
+        if (kv) dhz[(size_t)m * K + k] = dv;
+        bh += dv;
+        if (do_bo) bo += dyz[(size_t)m * N + kl];
       }
+    }
+  }
+  // fixed-order sums over the 64 row parts: dW's first row and the two bias sums share one barrier pair (three thread
+  // rows add one array each), dW's remaining rows follow one by one
+  __shared__ float sm_h[64][17], sm_o[64][17];
+  const bool want_o = db_out && blockIdx.x == 0;  // block-uniform
+  __syncthreads();
+  if (dW) sm[part][kl] = acc[0];
+  if (db_h) sm_h[part][kl] = bh;
+  if (want_o) sm_o[part][kl] = bo;
+  __syncthreads();
+  if (part < 3) {
+    const float(*src)[17] = part == 0 ? sm : (part == 1 ? sm_h : sm_o);
+    const bool on = part == 0 ? (dW != nullptr && kv) : (part == 1 ? (db_h != nullptr && kv) : (want_o && kl < N));
+    if (on) {
+      float t = src[0][kl];
+#pragma unroll 8
+      for (int p = 1; p < 64; ++p) t += src[p][kl];
+      if (part == 0)
+        dW[z * sDW + k] = t;
+      else if (part == 1)
+        db_h[z * sDb + k] = t;
+      else
+        db_out[z * sDb + kl] = t;
     }
   }
   if (dW == nullptr) return;  // block-uniform
 #pragma unroll
-  for (int n = 0; n < kMaxOut; ++n)
+  for (int n = 1; n < kMaxOut; ++n)
     if (n < N) {  // block-uniform
       __syncthreads();
       sm[part][kl] = acc[n];
@@ -341,34 +441,11 @@ __global__ __launch_bounds__(1024) void mlp_out_bwd_kernel(const float* dy, long
     }
 }
 
-// ---- policy head ----
-constexpr int kMaxA = 8;
-constexpr float kHalfLog2Pi = 0.9189385332046727f;
-
-// (pi_xa, optional: pi is also written as the action columns of the Q input rows, pi_xa[b * xa_ld + a])
-__global__ void actor_head_fwd_kernel(const float* out2a, const float* noise, int B, int A, float lo, float hi,
-                                      float* mu_t, float* pi_t, float* log_pi, float* log_std, float* tanh_ls,
-                                      float* pi_xa, int xa_ld) {
+// ---- policy head, a launch of its own (acting path; training fuses it into mlp_out_fwd_kernel<true>) ----
+__global__ void actor_head_fwd_kernel(const float* out2a, int B, HeadArgs hd) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  float lp = 0.f, corr = 0.f;
-  for (int a = 0; a < A; ++a) {
-    const float mu = out2a[(size_t)b * 2 * A + a];
-    const float t = tanhf(out2a[(size_t)b * 2 * A + A + a]);
-    const float ls = lo + 0.5f * (hi - lo) * (t + 1.f);
-    if (mu_t) mu_t[(size_t)b * A + a] = tanhf(mu);
-    if (log_std) log_std[(size_t)b * A + a] = ls;
-    if (tanh_ls) tanh_ls[(size_t)b * A + a] = t;
-    if (noise) {
-      const float n = noise[(size_t)b * A + a];
-      const float p = tanhf(mu + n * expf(ls));
-      if (pi_t) pi_t[(size_t)b * A + a] = p;
-      if (pi_xa) pi_xa[(size_t)b * xa_ld + a] = p;
-      lp += -0.5f * n * n - ls;
-      corr += logf(fmaxf(1.f - p * p, 0.f) + 1e-6f);
-    }
-  }
-  if (noise && log_pi) log_pi[b] = lp - kHalfLog2Pi * A - corr;
+  actor_head_row(out2a + (size_t)b * 2 * hd.A, b, hd);
 }
 
 // gradient of (sum_a gpi[a]*pi[a] + glp*log_pi) wrt the trunk output [mu | raw_log_std]
@@ -895,15 +972,25 @@ int curla_colsum3(const float* X0, int N0, const float* X1, int N1, const float*
   return curla_launch_status();
 }
 
+static int mlp_out_fwd_launch(const float* h, long long sH, long long sH2, const float* W, long long sW, long long sW2,
+                              const float* bias, long long sB, long long sB2, float* out, long long sOut, long long sOut2,
+                              int M, int N, int K, int nb, int nb2, void* stream) {
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // (R = 4 rows per wave to share the weight loads was measured for the actor's 8 outputs: 25 us against 14 -- the
+  // layer is load latency, and 128 waves hide less of it than 512)
+  hipLaunchKernelGGL((mlp_out_fwd_kernel<false, 1>), dim3((M + 3) / 4, nb * nb2), dim3(256), 0, st, h, sH, sH2, W, sW,
+                     sW2, bias, sB, sB2, out, sOut, sOut2, M, N, K, nb, HeadArgs{});
+  return curla_launch_status();
+}
+
 int curla_mlp_out_fwd(const float* h, long long strideH, const float* W, long long strideW, const float* bias,
                       long long strideBias, float* out, long long strideOut, int M, int N, int K, int nbatch,
                       void* stream) {
   CURLA_REQUIRE(h && W && out && M > 0 && N > 0 && K > 0 && nbatch > 0);
   if (N > kMaxOut || K % 4 != 0 || strideH % 4 != 0 || strideW % 4 != 0) return CURLA_ERR_UNSUPPORTED;
   CURLA_REQUIRE(aligned16(h) && aligned16(W));
-  hipLaunchKernelGGL(mlp_out_fwd_kernel, dim3((M + 3) / 4, nbatch), dim3(256), 0, static_cast<hipStream_t>(stream), h,
-                     strideH, 0LL, W, strideW, 0LL, bias, strideBias, 0LL, out, strideOut, 0LL, M, N, K, nbatch);
-  return curla_launch_status();
+  return mlp_out_fwd_launch(h, strideH, 0LL, W, strideW, 0LL, bias, strideBias, 0LL, out, strideOut, 0LL, M, N, K, nbatch,
+                            1, stream);
 }
 
 int curla_mlp_out_fwd_nested(const float* h, long long strideH, long long strideH2, const float* W, long long strideW,
@@ -914,30 +1001,62 @@ int curla_mlp_out_fwd_nested(const float* h, long long strideH, long long stride
   if (N > kMaxOut || K % 4 != 0 || strideH % 4 != 0 || strideW % 4 != 0 || strideH2 % 4 != 0 || strideW2 % 4 != 0)
     return CURLA_ERR_UNSUPPORTED;
   CURLA_REQUIRE(aligned16(h) && aligned16(W));
-  hipLaunchKernelGGL(mlp_out_fwd_kernel, dim3((M + 3) / 4, nbatch * nbatch2), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), h, strideH, strideH2, W, strideW, strideW2, bias, strideBias,
-                     strideBias2, out, strideOut, strideOut2, M, N, K, nbatch);
+  return mlp_out_fwd_launch(h, strideH, strideH2, W, strideW, strideW2, bias, strideBias, strideBias2, out, strideOut,
+                            strideOut2, M, N, K, nbatch, nbatch2, stream);
+}
+
+int curla_mlp_out_bwd_bias(const float* dy, long long strideDy, const float* h, long long strideH, const float* W,
+                           long long strideW, float* dh, long long strideDh, float* dW, long long strideDW, int M, int N,
+                           int K, int nbatch, float* db_out, float* db_hidden, long long strideDb, void* stream) {
+  CURLA_REQUIRE(dy && h && W && dh && M > 0 && N > 0 && K > 0 && nbatch > 0);
+  if (N > kMaxOut) return CURLA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(mlp_out_bwd_kernel, dim3((K + 15) / 16, nbatch), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                     dy, strideDy, h, strideH, W, strideW, dh, strideDh, dW, strideDW, M, N, K, db_out, db_hidden,
+                     strideDb);
   return curla_launch_status();
 }
 
 int curla_mlp_out_bwd(const float* dy, long long strideDy, const float* h, long long strideH, const float* W,
                       long long strideW, float* dh, long long strideDh, float* dW, long long strideDW, int M, int N,
                       int K, int nbatch, void* stream) {
-  CURLA_REQUIRE(dy && h && W && dh && M > 0 && N > 0 && K > 0 && nbatch > 0);
-  if (N > kMaxOut) return CURLA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(mlp_out_bwd_kernel, dim3((K + 15) / 16, nbatch), dim3(1024), 0, static_cast<hipStream_t>(stream),
-                     dy, strideDy, h, strideH, W, strideW, dh, strideDh, dW, strideDW, M, N, K);
-  return curla_launch_status();
+  return curla_mlp_out_bwd_bias(dy, strideDy, h, strideH, W, strideW, dh, strideDh, dW, strideDW, M, N, K, nbatch,
+                                nullptr, nullptr, 0, stream);
+}
+
+static int head_args(const float* noise, int B, int A, float log_std_min, float log_std_max, float* mu, float* pi,
+                     float* log_pi, float* log_std, float* tanh_ls, float* pi_xa, int xa_ld, HeadArgs* hd) {
+  CURLA_REQUIRE(B > 0 && A > 0 && A <= kMaxA);
+  CURLA_REQUIRE(!noise || pi || pi_xa);
+  CURLA_REQUIRE(!pi_xa || (noise && xa_ld >= A));
+  hd->noise = noise, hd->mu_t = mu, hd->pi_t = pi, hd->log_pi = log_pi, hd->log_std = log_std, hd->tanh_ls = tanh_ls;
+  hd->pi_xa = pi_xa, hd->A = A, hd->xa_ld = xa_ld, hd->lo = log_std_min, hd->hi = log_std_max;
+  return CURLA_OK;
 }
 
 int curla_actor_head_fwd(const float* trunk_out, const float* noise, int B, int A, float log_std_min,
                          float log_std_max, float* mu, float* pi, float* log_pi, float* log_std, float* tanh_ls,
                          float* pi_xa, int xa_ld, void* stream) {
-  CURLA_REQUIRE(trunk_out && B > 0 && A > 0 && A <= kMaxA);
-  CURLA_REQUIRE(!noise || pi || pi_xa);
-  CURLA_REQUIRE(!pi_xa || (noise && xa_ld >= A));
+  CURLA_REQUIRE(trunk_out);
+  HeadArgs hd;
+  const int rc = head_args(noise, B, A, log_std_min, log_std_max, mu, pi, log_pi, log_std, tanh_ls, pi_xa, xa_ld, &hd);
+  if (rc != CURLA_OK) return rc;
   hipLaunchKernelGGL(actor_head_fwd_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     trunk_out, noise, B, A, log_std_min, log_std_max, mu, pi, log_pi, log_std, tanh_ls, pi_xa, xa_ld);
+                     trunk_out, B, hd);
+  return curla_launch_status();
+}
+
+int curla_mlp_out_head_fwd(const float* h, const float* W, const float* bias, float* trunk_out, int B, int A, int K,
+                           const float* noise, float log_std_min, float log_std_max, float* mu, float* pi,
+                           float* log_pi, float* log_std, float* tanh_ls, float* pi_xa, int xa_ld, void* stream) {
+  CURLA_REQUIRE(h && W && trunk_out && K > 0);
+  HeadArgs hd;
+  const int rc = head_args(noise, B, A, log_std_min, log_std_max, mu, pi, log_pi, log_std, tanh_ls, pi_xa, xa_ld, &hd);
+  if (rc != CURLA_OK) return rc;
+  if (2 * A > kMaxOut || K % 4 != 0) return CURLA_ERR_UNSUPPORTED;
+  CURLA_REQUIRE(aligned16(h) && aligned16(W));
+  hipLaunchKernelGGL((mlp_out_fwd_kernel<true, 1>), dim3((B + 3) / 4, 1), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), h, 0LL, 0LL, W, 0LL, 0LL, bias, 0LL, 0LL, trunk_out, 0LL, 0LL, B,
+                     2 * A, K, 1, hd);
   return curla_launch_status();
 }
 

@@ -71,9 +71,11 @@ class _Mlp:
         self.stride = stride
 
 
-def _mlp_fwd(x, sx, P, nb, B, din, H, dout, h1, h2, out, relu_out=0, outer=None):
+def _mlp_fwd(x, sx, P, nb, B, din, H, dout, h1, h2, out, relu_out=0, outer=None, head=None):
     """``outer`` = (n2, sW2): n2 such MLP groups in the same launches, their parameters sW2 floats apart (the target
-    critic's and the critic's twins); x [n2][B, din] and h1 / h2 / out [n2][nb][B, .] then."""
+    critic's and the critic's twins); x [n2][B, din] and h1 / h2 / out [n2][nb][B, .] then.
+    ``head`` = (noise, lo, hi, outputs): the MLP is the actor trunk and the policy head (ops.actor_head_fwd with these
+    arguments) follows its last layer -- in the same launch when the layer is small enough."""
     s = P.stride
     o0 = o1 = o2 = None
     if outer is not None:
@@ -81,18 +83,29 @@ def _mlp_fwd(x, sx, P, nb, B, din, H, dout, h1, h2, out, relu_out=0, outer=None)
         o0, o1, o2 = (n2, B * din, sW2, nb * B * H), (n2, nb * B * H, sW2, nb * B * H), (n2, nb * B * H, sW2, nb * B * dout)
     ops.linear_fwd(x, sx, P.W[0], s, P.b[0], s, h1, B * H, B, H, din, nb, relu=1, outer=o0)
     ops.linear_fwd(h1, B * H, P.W[1], s, P.b[1], s, h2, B * H, B, H, H, nb, relu=1, outer=o1)
-    if dout <= ops.MLP_OUT_MAX and H % 4 == 0 and not relu_out:  # a handful of outputs: row dot products, not a GEMM
+    small = dout <= ops.MLP_OUT_MAX and H % 4 == 0 and not relu_out
+    if head is not None and small and nb == 1 and outer is None:
+        noise, lo, hi, outs = head
+        ops.mlp_out_head_fwd(h2, P.W[2], P.b[2], out, noise, B, dout // 2, H, lo, hi, **outs)
+        return
+    if small:  # a handful of outputs: row dot products, not a GEMM
         ops.mlp_out_fwd(h2, B * H, P.W[2], s, P.b[2], s, out, B * dout, B, dout, H, nb, outer=o2)
     else:
         ops.linear_fwd(h2, B * H, P.W[2], s, P.b[2], s, out, B * dout, B, dout, H, nb, relu=relu_out, outer=o2)
+    if head is not None:
+        noise, lo, hi, outs = head
+        ops.actor_head_fwd(out, noise, B, dout // 2, lo, hi, **outs)
 
 
 def _mlp_bwd(x, sx, P, G, nb, B, din, H, dout, h1, h2, dy, dh2, dh1, dx):
     """Backward of _mlp_fwd.  G (parameter gradients) and dx are optional."""
     s = P.stride
+    # the three bias gradients (column sums of dy, dh2, dh1) ride in the launches that walk those matrices anyway --
+    # the last layer's backward pass and the first layer's weight-gradient product -- where both take their small forms
+    fold = G is not None and dout <= ops.MLP_OUT_MAX and ops.linear_dw_folds_bias(B, H, din, nb)
     if dout <= ops.MLP_OUT_MAX:  # last layer: data and weight gradient in one pass over h2
         ops.mlp_out_bwd(dy, B * dout, h2, B * H, P.W[2], s, dh2, B * H, G.W[2] if G is not None else None, s, B, dout,
-                        H, nb)
+                        H, nb, db_out=G.b[2] if fold else None, db_hidden=G.b[1] if fold else None, sdb=s)
     else:
         if G is not None:
             ops.linear_dw(dy, B * dout, h2, B * H, G.W[2], s, B, dout, H, nb)
@@ -101,8 +114,9 @@ def _mlp_bwd(x, sx, P, G, nb, B, din, H, dout, h1, h2, dy, dh2, dh1, dx):
         ops.linear_dw(dh2, B * H, h1, B * H, G.W[1], s, B, H, H, nb)
     ops.linear_dx(dh2, B * H, P.W[1], s, dh1, B * H, B, H, H, nb, mask=h1, smask=B * H)
     if G is not None:
-        ops.linear_dw(dh1, B * H, x, sx, G.W[0], s, B, H, din, nb)
-        ops.colsum3(dy, dout, dh2, H, dh1, H, B, G.b[2], G.b[1], G.b[0], s, nb)  # the three bias gradients
+        ops.linear_dw(dh1, B * H, x, sx, G.W[0], s, B, H, din, nb, colsum=G.b[0] if fold else None, s_colsum=s)
+        if not fold:
+            ops.colsum3(dy, dout, dh2, H, dh1, H, B, G.b[2], G.b[1], G.b[0], s, nb)
     if dx is not None:
         ops.linear_dx(dh1, B * H, P.W[0], s, dx, B * din, B, H, din, nb)
 
@@ -136,7 +150,6 @@ class Actor(nn.Module):
         h1 = torch.empty((B, H), device=dev)
         h2 = torch.empty((B, H), device=dev)
         out = torch.empty((B, 2 * A), device=dev)
-        _mlp_fwd(z, 0, _Mlp(self.trunk), 1, B, F, H, 2 * A, h1, h2, out)
         mu = torch.empty((B, A), device=dev)
         log_std = torch.empty((B, A), device=dev)
         pi = log_pi = None
@@ -145,8 +158,9 @@ class Actor(nn.Module):
                 noise = torch.randn((B, A), device=dev)
             pi = torch.empty((B, A), device=dev)
             log_pi = torch.empty((B, 1), device=dev) if compute_log_pi else None
-        ops.actor_head_fwd(out, noise if compute_pi else None, B, A, self.log_std_min, self.log_std_max, mu=mu, pi=pi,
-                           log_pi=log_pi, log_std=log_std)
+        _mlp_fwd(z, 0, _Mlp(self.trunk), 1, B, F, H, 2 * A, h1, h2, out,
+                 head=(noise if compute_pi else None, self.log_std_min, self.log_std_max,
+                       dict(mu=mu, pi=pi, log_pi=log_pi, log_std=log_std)))
         self.outputs['mu'] = out[:, :A]  # the pre-squash mean, as the reference records it (curl_sac.py:92)
         self.outputs['std'] = log_std.exp()
         return mu, pi, log_pi, log_std
@@ -710,10 +724,10 @@ class CurlSacAgent(object):
                                    act=action))], A)
         else:
             self.actor.encoder.ln_from_partial(B, ws.z_a)
-        _mlp_fwd(ws.z_a, 0, _Mlp(self.actor.trunk), 1, B, F, H, 2 * A, ws.a_h1, ws.a_h2, ws.a_out)
         nz = self._noise(ws, noise)
-        ops.actor_head_fwd(ws.a_out, nz, B, A, self.actor.log_std_min, self.actor.log_std_max,
-                           pi=None if four else ws.pi, log_pi=ws.log_pi, xa=ws.xa2[0] if four else None)
+        _mlp_fwd(ws.z_a, 0, _Mlp(self.actor.trunk), 1, B, F, H, 2 * A, ws.a_h1, ws.a_h2, ws.a_out,
+                 head=(nz, self.actor.log_std_min, self.actor.log_std_max,
+                       dict(pi=None if four else ws.pi, log_pi=ws.log_pi, xa=ws.xa2[0] if four else None)))
         if four:
             _mlp_fwd(ws.xa2, 0, self.critic_target.twin(), 2, B, F + A, H, 1, ws.q_h1_2, ws.q_h2_2, ws.q2,
                      outer=(2, self._twin_outer))
@@ -803,11 +817,11 @@ class CurlSacAgent(object):
         self._anchor_cache = obs
 
         trunk = _Mlp(self.actor.trunk)
-        _mlp_fwd(ws.z_a, 0, trunk, 1, B, F, H, 2 * A, ws.a_h1, ws.a_h2, ws.a_out)
         nz = self._noise(ws, noise)
         lo, hi = self.actor.log_std_min, self.actor.log_std_max
-        ops.actor_head_fwd(ws.a_out, nz, B, A, lo, hi, mu=ws.mu, pi=ws.pi, log_pi=ws.log_pi, log_std=ws.log_std,
-                           tanh_ls=ws.tanh_ls, xa=ws.xa)
+        _mlp_fwd(ws.z_a, 0, trunk, 1, B, F, H, 2 * A, ws.a_h1, ws.a_h2, ws.a_out,
+                 head=(nz, lo, hi, dict(mu=ws.mu, pi=ws.pi, log_pi=ws.log_pi, log_std=ws.log_std, tanh_ls=ws.tanh_ls,
+                                        xa=ws.xa)))
         if self._records(step):  # what actor.log() histograms (curl_sac.py:92-93): pre-squash mean and std
             self.actor.outputs['mu'], self.actor.outputs['std'] = ws.a_out[:, :A].clone(), ws.log_std.exp()
         _mlp_fwd(ws.xa, 0, self.critic.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.q)

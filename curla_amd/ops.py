@@ -241,9 +241,26 @@ def linear_dx(dy, sdy, W, sW, out, so, M, N, K, nb=1, mask=None, smask=0):
     gemm(dy, 0, N, sdy, W, 1, K, sW, out, K, so, M, K, N, nb, mask=mask, ldmask=K, sMask=smask)
 
 
-def linear_dw(dy, sdy, x, sx, out, so, M, N, K, nb=1):
-    """out[z] = dy[z]^T @ x[z];  dy [M,N], x [M,K] -> out [N,K]."""
-    gemm(dy, 1, N, sdy, x, 1, K, sx, out, K, so, N, K, M, nb)
+def linear_dw(dy, sdy, x, sx, out, so, M, N, K, nb=1, colsum=None, s_colsum=0):
+    """out[z] = dy[z]^T @ x[z];  dy [M,N], x [M,K] -> out [N,K].
+    ``colsum`` [N] (batch stride s_colsum; only where linear_dw_folds_bias(...)): also the column sums of dy, the
+    bias gradient, from the same launch."""
+    if colsum is None:
+        gemm(dy, 1, N, sdy, x, 1, K, sx, out, K, so, N, K, M, nb)
+    else:
+        call("curla_gemm_colsum", ptr(dy), 1, N, sdy, ptr(x), 1, K, sx, ptr(out), K, so, N, K, M, nb, ptr(colsum),
+             s_colsum, stream())
+
+
+_small_shape_cache = {}
+
+
+def linear_dw_folds_bias(M, N, K, nb=1):
+    """True when linear_dw(dy [M,N], x [M,K]) can carry the bias gradient (curla_gemm_colsum's conditions)."""
+    key = (N, K, M, nb)
+    if key not in _small_shape_cache:
+        _small_shape_cache[key] = bool(_lib.load().curla_gemm_small_shape(N, K, M, nb))
+    return _small_shape_cache[key]
 
 
 def fc_bwd_streams(F_, K):
@@ -277,9 +294,15 @@ def mlp_out_fwd(h, sh, W, sW, bias, sb, out, so, M, N, K, nb=1, outer=None):
              K, nb, n2, stream())
 
 
-def mlp_out_bwd(dy, sdy, h, sh, W, sW, dh, sdh, dW, sdW, M, N, K, nb=1):
-    """dh[z] = (dy[z] @ W[z]) masked by h[z] > 0 and (dW not None) dW[z] = dy[z]^T @ h[z], in one pass over h."""
-    call("curla_mlp_out_bwd", ptr(dy), sdy, ptr(h), sh, ptr(W), sW, ptr(dh), sdh, ptr(dW), sdW, M, N, K, nb, stream())
+def mlp_out_bwd(dy, sdy, h, sh, W, sW, dh, sdh, dW, sdW, M, N, K, nb=1, db_out=None, db_hidden=None, sdb=0):
+    """dh[z] = (dy[z] @ W[z]) masked by h[z] > 0 and (dW not None) dW[z] = dy[z]^T @ h[z], in one pass over h.
+    ``db_out`` [N] / ``db_hidden`` [K] (batch stride sdb): also the column sums of dy / of dh -- the bias gradients of
+    this layer and of the one below."""
+    if db_out is None and db_hidden is None:
+        call("curla_mlp_out_bwd", ptr(dy), sdy, ptr(h), sh, ptr(W), sW, ptr(dh), sdh, ptr(dW), sdW, M, N, K, nb, stream())
+    else:
+        call("curla_mlp_out_bwd_bias", ptr(dy), sdy, ptr(h), sh, ptr(W), sW, ptr(dh), sdh, ptr(dW), sdW, M, N, K, nb,
+             ptr(db_out), ptr(db_hidden), sdb, stream())
 
 
 MLP_OUT_MAX = 16
@@ -337,6 +360,15 @@ def actor_head_fwd(trunk_out, noise, B, A, lo, hi, mu=None, pi=None, log_pi=None
     pi_xa, ld = (None, 0) if xa is None else (xa.data_ptr() + 4 * (xa.shape[1] - A), xa.shape[1])
     call("curla_actor_head_fwd", ptr(trunk_out), ptr(noise), B, A, lo, hi, ptr(mu), ptr(pi), ptr(log_pi), ptr(log_std),
          ptr(tanh_ls), pi_xa, ld, stream())
+
+
+def mlp_out_head_fwd(h, W, bias, trunk_out, noise, B, A, K, lo, hi, mu=None, pi=None, log_pi=None, log_std=None,
+                     tanh_ls=None, xa=None):
+    """The actor trunk's last layer (h [B, K] -> trunk_out [B, 2A]) with the policy head (actor_head_fwd) run by the
+    same launch."""
+    pi_xa, ld = (None, 0) if xa is None else (xa.data_ptr() + 4 * (xa.shape[1] - A), xa.shape[1])
+    call("curla_mlp_out_head_fwd", ptr(h), ptr(W), ptr(bias), ptr(trunk_out), B, A, K, ptr(noise), lo, hi, ptr(mu),
+         ptr(pi), ptr(log_pi), ptr(log_std), ptr(tanh_ls), pi_xa, ld, stream())
 
 
 def actor_head_bwd(gpi, log_alpha, glp_scale, noise, pi, log_std, tanh_ls, B, A, lo, hi, dtrunk_out, glp_rows=None,

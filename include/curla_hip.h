@@ -115,6 +115,16 @@ int curla_gemm(const float* A, int a_kmajor, int lda, long long strideA, const f
                long long strideB, float* C, int ldc, long long strideC, int M, int N, int K, int nbatch, int ksplit,
                long long split_stride, float alpha, const float* bias, long long strideBias, int relu,
                const float* mask, int ldmask, long long strideMask, void* stream);
+/* Products with a small output and a long k (ceil(M/32) * ceil(N/32) * nbatch <= 128 tiles, K >= 256, K % 64 == 0, no
+ * epilogue, no split) are computed by one workgroup per 16 x 16 tile whose waves split k; 1 if the shape qualifies. */
+int curla_gemm_small_shape(int M, int N, int K, int nbatch);
+/* Such a product plus colsum[z][m] = sum_k opA(A[z])[m][k] from the same launch -- a layer's weight gradient dy^T x
+ * [N_out x N_in] with its bias gradient, the column sums of dy (curl_sac.py:70-74,129-133 backward): the workgroups
+ * of the first column of tiles add up the A operands they load anyway.  Needs curla_gemm_small_shape(...);
+ * CURLA_ERR_UNSUPPORTED otherwise. */
+int curla_gemm_colsum(const float* A, int a_kmajor, int lda, long long strideA, const float* B, int b_kmajor, int ldb,
+                      long long strideB, float* C, int ldc, long long strideC, int M, int N, int K, int nbatch,
+                      float* colsum, long long strideColsum, void* stream);
 /* curla_gemm with a two-level batch: item (outer, inner) at base + inner * stride + outer * stride2 (no split-K).  The
  * twin Q functions of the target critic and of the critic are one such batch of four: the twins a block apart inside a
  * flat parameter buffer, the two flat buffers wherever the allocator put them (curl_sac.py:353-358). */
@@ -158,6 +168,11 @@ int curla_mlp_out_fwd_nested(const float* h, long long strideH, long long stride
 int curla_mlp_out_bwd(const float* dy, long long strideDy, const float* h, long long strideH, const float* W,
                       long long strideW, float* dh, long long strideDh, float* dW, long long strideDW, int M, int N,
                       int K, int nbatch, void* stream);
+/* ... and (each optional) the bias gradient of this layer, db_out[z][n] = sum_m dy[z][m][n], and of the layer below,
+ * db_hidden[z][k] = sum_m dh[z][m][k]; both with batch stride strideDb */
+int curla_mlp_out_bwd_bias(const float* dy, long long strideDy, const float* h, long long strideH, const float* W,
+                           long long strideW, float* dh, long long strideDh, float* dW, long long strideDW, int M, int N,
+                           int K, int nbatch, float* db_out, float* db_hidden, long long strideDb, void* stream);
 
 /* One problem of curla_fc_ln_fwd_multi (fields as curla_fc_ln_fwd's arguments; fc_out, xhat, rstd, xa, act optional;
  * xa without act: only the feature columns of the rows are written). */
@@ -204,6 +219,12 @@ int curla_colsum3(const float* X0, int N0, const float* X1, int N1, const float*
 int curla_actor_head_fwd(const float* trunk_out, const float* noise, int B, int A, float log_std_min,
                          float log_std_max, float* mu, float* pi, float* log_pi, float* log_std, float* tanh_ls,
                          float* pi_xa, int xa_ld, void* stream);
+/* The actor trunk's last layer and the policy head in one launch (curl_sac.py:79-108): trunk_out [B][2A] =
+ * h [B][K] @ W [2A][K]^T + bias is written out and the head's outputs follow from it as in curla_actor_head_fwd
+ * (2A <= 16, K % 4 == 0; CURLA_ERR_UNSUPPORTED otherwise). */
+int curla_mlp_out_head_fwd(const float* h, const float* W, const float* bias, float* trunk_out, int B, int A, int K,
+                           const float* noise, float log_std_min, float log_std_max, float* mu, float* pi,
+                           float* log_pi, float* log_std, float* tanh_ls, float* pi_xa, int xa_ld, void* stream);
 /* gradient w.r.t. trunk_out of sum(gpi*pi) + glp*log_pi; glp = glp_rows[b] or glp_scale*exp(*log_alpha);
  * gpi[b][a] is read at gpi[b*gpi_ld + a] (+ gpi2[b*gpi_ld + a] when gpi2 is not NULL: the action columns of the twin-Q
  * input gradient summed over the twin in place) */

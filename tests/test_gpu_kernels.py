@@ -201,6 +201,13 @@ def test_gemm_small_output_long_k(ops, M, N, K, ak, bk, nb):
     C2 = torch.full((nb, M, N), float("nan"), device="cuda")
     ops.gemm(Ad, ak, lda, M * K, Bd, bk, ldb, N * K, C2, N, M * N, M, N, K, nb)
     check(f"small gemm {M}x{N}x{K} ak{ak} bk{bk} dense C", C2.cpu(), ref, 2e-5)
+    if ak and bk:  # the weight-gradient form dy^T x with the bias gradient (row sums of opA) alongside
+        assert ops.linear_dw_folds_bias(K, M, N, nb)
+        C3, cs = torch.full_like(C2, float("nan")), torch.full((nb, M + 2), float("nan"), device="cuda")
+        ops.linear_dw(Ad, M * K, Bd, N * K, C3, M * N, K, M, N, nb, colsum=cs, s_colsum=M + 2)
+        assert torch.equal(C3, C2)
+        check(f"small gemm colsum {M}x{N}x{K}", cs[:, :M].cpu(), A.double().sum(2).float(), 2e-5)
+        assert torch.isnan(cs[:, M:]).all()
 
 
 @pytest.mark.parametrize("B,Fd,K", [(24, 50, 3456), (9, 130, 800), (5, 64, 288), (3, 256, 512), (515, 50, 64)])
@@ -536,6 +543,16 @@ def test_mlp_out_layer(ops, M, N, K, nb):
     dh2 = torch.full((nb, M, K), float("nan"), device="cuda")
     ops.mlp_out_bwd(dev(dy), M * N, dev(h), M * K, Wd, N * K + pad, dh2, M * K, None, 0, M, N, K, nb)  # data gradient only
     assert torch.equal(dh, dh2)
+    # ... and with the two bias gradients (column sums of dy and of dh) from the same launch
+    dh3, dW3 = torch.full_like(dh, float("nan")), torch.full_like(dWd, float("nan"))
+    S = 32 + K + 7  # both live in one gradient block per twin, `S` floats apart: db_out at 0, db_hidden at 32
+    gb = torch.full((nb, S), float("nan"), device="cuda")
+    ops.mlp_out_bwd(dev(dy), M * N, dev(h), M * K, Wd, N * K + pad, dh3, M * K, dW3, N * K + pad, M, N, K, nb,
+                    db_out=gb, db_hidden=gb[0, 32:], sdb=S)
+    assert torch.equal(dh3, dh) and torch.equal(dW3[:, :N * K], dWd[:, :N * K])
+    check(f"mlp_out db_out {M}x{N}x{K} nb{nb}", gb[:, :N].cpu(), dy.sum(1))
+    check(f"mlp_out db_hidden {M}x{N}x{K} nb{nb}", gb[:, 32:32 + K].cpu(), dh.cpu().sum(1))
+    assert bool(torch.isnan(gb[:, N:32]).all()) and bool(torch.isnan(gb[:, 32 + K:]).all())
 
 
 def _flat_params(sizes, device, seed=0):
@@ -740,17 +757,31 @@ def test_conv_s1_backward_one_launch(ops, B, H, W):
 
 
 def test_fc_backward_one_launch(ops):
-    """curla_fc_bwd (data + weight gradient of the encoder fc layer in one launch) is bit-identical to curla_fc_dx +
-    curla_fc_dw; shapes outside the instantiated one fall back to the two launches."""
-    for B, Fd, K in ((24, 50, 3456), (515, 50, 196), (9, 13, 100)):
+    """curla_fc_bwd: data + weight gradient of the encoder fc layer in ONE pass over the activations (the ReLU mask of
+    the one and the column operand of the other are the same matrix).  The data gradient is bit-identical to
+    curla_fc_dx; the weight gradient adds the batch rows in another (fixed) order than curla_fc_dw.  Shapes outside the
+    instantiated one (49..52 features, whole 16-row tiles) fall back to the two launches."""
+    for B, Fd, K, one_pass in ((32, 50, 3456, True), (512, 50, 196, True), (48, 52, 260, True), (64, 49, 64, True),
+                               (24, 50, 3456, False), (515, 50, 196, False), (9, 13, 100, False)):
         dz, W = rnd(B, Fd, seed=95).cuda(), (rnd(Fd, K, seed=96) * 0.1).cuda()
         x = torch.relu(rnd(B, K, seed=97)).cuda()
         dx1, dw1 = torch.empty(B, K, device="cuda"), torch.empty(Fd, K, device="cuda")
         ops.fc_dx(dz, W, dx1, B, Fd, K, mask=x)
         ops.fc_dw(dz, x, dw1, B, Fd, K)
-        dx2, dw2 = torch.full_like(dx1, float("nan")), torch.full_like(dw1, float("nan"))
+        guard = 64  # nothing may be written around the outputs
+        bx, bw = torch.full((B * K + 2 * guard,), float("nan"), device="cuda"), torch.full((Fd * K + 2 * guard,), float("nan"), device="cuda")
+        dx2, dw2 = bx[guard:guard + B * K].view(B, K), bw[guard:guard + Fd * K].view(Fd, K)
         ops.fc_bwd(dz, W, x, dx2, dw2, B, Fd, K)
-        assert torch.equal(dx1, dx2) and torch.equal(dw1, dw2)
+        assert torch.equal(dx1, dx2)
+        if one_pass:
+            check(f"fc_bwd dW {B}x{Fd}x{K}", dw2.cpu(), dz.cpu().double().t().mm(x.cpu().double()).float(), 2e-5)
+            dw3 = torch.empty_like(dw1)
+            ops.fc_bwd(dz, W, x, torch.empty_like(dx1), dw3, B, Fd, K)
+            assert torch.equal(dw2, dw3)  # fixed summation order
+        else:
+            assert torch.equal(dw1, dw2)
+        for buf in (bx, bw):
+            assert bool(torch.isnan(buf[:guard]).all()) and bool(torch.isnan(buf[-guard:]).all())
 
 
 def test_flat_adam_step_pair_is_two_steps():
