@@ -730,9 +730,16 @@ struct WgradS1Args {
 };
 constexpr int kPartialS1 = 32 * 288 + 32;
 
+// WALK: how a lane finds the pixel pair of its k-step.  0: per-lane (row, column) counters, any size.  1 / 2 (even / odd
+// Wo, rows of at least 8 pairs): the k-step's first pair is walked in SCALAR registers and a lane is a constant offset
+// from it (+ one conditional row-wrap correction); the gradient comes through buffer loads whose descriptor ends at the
+// band's end, so pairs past the band read zeros.  The per-lane walk cost ~30 VALU instructions per 24 MFMAs -- and
+// a VALU instruction holds the SIMD's issue port for its 4 cycles while the matrix pipe waits.
+template <int WALK>
 __device__ __forceinline__ void wgrad_s1_body(const WgradS1Args& a, const int bid, const int nblk) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = WALK ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
   // a wave owns the 16 output channels mt*16.. of dW; wave pairs share pixels.
   // Winograd F(3,2) along x (the transpose of the forward's F(2,3)): for a horizontal pair of
@@ -838,33 +845,111 @@ __device__ __forceinline__ void wgrad_s1_body(const WgradS1Args& a, const int bi
         }
       }
     };
+    // ---- WALK 1 / 2: the same two fetchers on a scalar walk ----
+    // k-step of unit u: first pair q0 = (u >> 1) * 8 + uslot at (row sy, pair sj), scalar; lane kq's pair is 2 kq
+    // further, wrapped into the next row when sj + 2 kq >= PW (PW >= 8 > 6: at most once).
+    //   gradient floats from the band start: (sy Wo + 2 sj) 32  [scalar]  +  4 kq 32 + mt 16 + li  [lane]
+    //                                        + (Wo - 2 PW) 32 if wrapped (0 / -32 for even / odd Wo)
+    //   window floats in LDS:                (sy Wi + 2 sj) 36  [scalar]  +  4 kq 36 + li          [lane]
+    //                                        + (Wi - 2 PW) 36 if wrapped
+    // A pair past the band end reads gradient zeros (buffer range) and, in LDS, the last valid pair's window (its
+    // address is clamped: 0 x finite).  Odd Wo: the second pixel of a row's last pair is the next row's first in
+    // memory -- those lanes load from past the buffer instead.
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32), (short)0, WALK ? tha * a.Wo * 128 : 0, 0x00020000);
+    const unsigned g_lane = (unsigned)(4 * kq * 32 + mt * 16 + li) * 4u;
+    const unsigned g_lane_w = g_lane + (unsigned)((a.Wo - 2 * PW) * 128);
+    const unsigned d_lane = (unsigned)(4 * kq * kLdsPix + li) * 4u;
+    const unsigned d_lane_w = d_lane + (unsigned)((a.Wi - 2 * PW) * kLdsPix * 4);
+    const unsigned d_max = (unsigned)(((tha - 1) * a.Wi + 2 * (PW - 1)) * kLdsPix + 15) * 4u;
+    const unsigned d_row = (unsigned)(a.Wi * kLdsPix * 4);
+    int sgy = 0, sgj = uslot, sfy = 0, sfj = uslot;  // (uslot < 2 <= PW)
+    auto sadvance = [&](int& y, int& j) {
+      j += rstep, y += qstep;
+      if (j >= PW) j -= PW, y += 1;
+    };
+    auto gfetch_s = [&](float (&gv)[2]) {
+      const unsigned soff = (unsigned)((sgy * a.Wo + 2 * sgj) * 128);
+      const int jl = sgj + 2 * kq;
+      const bool wrapped = jl >= PW;
+      if (WALK == 1) {  // even Wo: rows of pairs are contiguous, nothing depends on the wrap
+        gv[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, g_lane, soff, 0));
+        gv[1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, g_lane, soff + 128u, 0));
+      } else {
+        const unsigned v0 = wrapped ? g_lane_w : g_lane;
+        const bool last = (jl == PW - 1) || (jl == 2 * PW - 1);
+        const unsigned v1 = last ? 0x80000000u : v0;
+        gv[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, v0, soff, 0));
+        gv[1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, v1, soff + 128u, 0));
+      }
+      sadvance(sgy, sgj);
+    };
+    auto dfetch_s = [&](f32x2 (&dv)[3][4]) {
+      const unsigned sbase = (unsigned)((sfy * a.Wi + 2 * sfj) * kLdsPix * 4);
+      const bool wrapped = sfj + 2 * kq >= PW;
+      const unsigned off = min((wrapped ? d_lane_w : d_lane) + sbase, d_max);
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        const float* row = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + off + dy * d_row);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dv[dy][c] = f32x2{row[c * kLdsPix], row[c * kLdsPix + 16]};
+      }
+      sadvance(sfy, sfj);
+    };
     // software pipeline over this wave's k-steps: window reads (LDS) one step ahead in two register sets, gradient
     // values (HBM/L2) three steps ahead in four; a k-step past the band multiplies zeros and is skipped
     float g0[2], g1[2], g2[2], g3[2];
     f32x2 dA[3][4], dB[3][4];
-    gfetch(uslot, g0), gfetch(uslot + 2, g1), gfetch(uslot + 4, g2);
-    dfetch(uslot, dA);
-    for (int u = uslot; u < nunits; u += 8) {
-      gfetch(u + 6, g3);
-      dfetch(u + 2, dB);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(g0, dA);
-      __builtin_amdgcn_sched_barrier(0);
-      gfetch(u + 8, g0);
-      dfetch(u + 4, dA);
-      __builtin_amdgcn_sched_barrier(0);
-      if (u + 2 < nunits) mma(g1, dB);
-      __builtin_amdgcn_sched_barrier(0);
-      gfetch(u + 10, g1);
-      dfetch(u + 6, dB);
-      __builtin_amdgcn_sched_barrier(0);
-      if (u + 4 < nunits) mma(g2, dA);
-      __builtin_amdgcn_sched_barrier(0);
-      gfetch(u + 12, g2);
-      dfetch(u + 8, dA);
-      __builtin_amdgcn_sched_barrier(0);
-      if (u + 6 < nunits) mma(g3, dB);
-      __builtin_amdgcn_sched_barrier(0);
+    if (WALK) {
+      gfetch_s(g0), gfetch_s(g1), gfetch_s(g2);
+      dfetch_s(dA);
+      for (int u = uslot; u < nunits; u += 8) {
+        gfetch_s(g3);
+        dfetch_s(dB);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(g0, dA);
+        __builtin_amdgcn_sched_barrier(0);
+        gfetch_s(g0);
+        dfetch_s(dA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 2 < nunits) mma(g1, dB);
+        __builtin_amdgcn_sched_barrier(0);
+        gfetch_s(g1);
+        dfetch_s(dB);
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 4 < nunits) mma(g2, dA);
+        __builtin_amdgcn_sched_barrier(0);
+        gfetch_s(g2);
+        dfetch_s(dA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 6 < nunits) mma(g3, dB);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      gfetch(uslot, g0), gfetch(uslot + 2, g1), gfetch(uslot + 4, g2);
+      dfetch(uslot, dA);
+      for (int u = uslot; u < nunits; u += 8) {
+        gfetch(u + 6, g3);
+        dfetch(u + 2, dB);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(g0, dA);
+        __builtin_amdgcn_sched_barrier(0);
+        gfetch(u + 8, g0);
+        dfetch(u + 4, dA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 2 < nunits) mma(g1, dB);
+        __builtin_amdgcn_sched_barrier(0);
+        gfetch(u + 10, g1);
+        dfetch(u + 6, dB);
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 4 < nunits) mma(g2, dA);
+        __builtin_amdgcn_sched_barrier(0);
+        gfetch(u + 12, g2);
+        dfetch(u + 8, dA);
+        __builtin_amdgcn_sched_barrier(0);
+        if (u + 6 < nunits) mma(g3, dB);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     __syncthreads();
   }
@@ -902,15 +987,19 @@ __device__ __forceinline__ void wgrad_s1_body(const WgradS1Args& a, const int bi
   for (int i = tid; i < kPartialS1; i += 256) slab[i] = lds[i];
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) { wgrad_s1_body(a, blockIdx.x, gridDim.x); }
+template <int WALK>
+__global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) {
+  wgrad_s1_body<WALK>(a, blockIdx.x, gridDim.x);
+}
 
 // Weight gradient and data gradient of one layer in ONE launch: both only read the layer's output gradient, so they
 // need not wait for each other.  The first nw workgroups run the weight-gradient body, the rest the data-gradient
 // body; the hardware starts the second set as the first one's workgroups retire, so the tail of one kernel and the
 // ramp of the next overlap instead of being separated by a kernel boundary (4-9 us per launch at these sizes).
+template <int WALK>
 __global__ __launch_bounds__(256, 2) void bwd_s1_kernel(WgradS1Args wa, ConvS1Args da, int nw) {
   if ((int)blockIdx.x < nw)
-    wgrad_s1_body(wa, blockIdx.x, nw);
+    wgrad_s1_body<WALK>(wa, blockIdx.x, nw);
   else
     conv_s1_body<MODE_DGRAD>(da, (int)blockIdx.x - nw, (int)gridDim.x - nw);
 }
@@ -1615,6 +1704,13 @@ size_t curla_conv_wgrad_workspace_floats(int cin) {
   return (size_t)4 * curla_cu_count() * ((size_t)32 * cin * 9 + 32);  // at most four workgroups (slabs) per CU
 }
 
+// which pair walk the weight-gradient body uses (see wgrad_s1_body): scalar for rows of at least 8 pairs
+static int wgrad_walk(int Wo) {
+  static const bool off = getenv("CURLA_WGRAD_WALK") && atoi(getenv("CURLA_WGRAD_WALK")) == 0;  // tuning aid
+  if (off || (Wo + 1) / 2 < 8) return 0;
+  return (Wo & 1) ? 2 : 1;
+}
+
 static int launch_wgrad_s1(const float* in, const float* g, float* workspace, int B, int Hi, int Wi, int channels,
                            hipStream_t st, int* nslabs) {
   CURLA_REQUIRE(in && g && workspace && B > 0 && Hi >= 3 && Wi >= 3);
@@ -1630,9 +1726,20 @@ static int launch_wgrad_s1(const float* in, const float* g, float* workspace, in
   if (lds < kPartialS1 * sizeof(float)) lds = kPartialS1 * sizeof(float);
   const int nitems = B * a.nbands;
   const int grid = nitems < 2 * curla_cu_count() ? nitems : 2 * curla_cu_count();
-  int rc = set_lds(wgrad_s1_kernel, lds);
-  if (rc != CURLA_OK) return rc;
-  hipLaunchKernelGGL(wgrad_s1_kernel, dim3(grid), dim3(256), lds, st, a);
+  int rc;
+  switch (wgrad_walk(a.Wo)) {
+    case 1:
+      if ((rc = set_lds(wgrad_s1_kernel<1>, lds)) != CURLA_OK) return rc;
+      hipLaunchKernelGGL(wgrad_s1_kernel<1>, dim3(grid), dim3(256), lds, st, a);
+      break;
+    case 2:
+      if ((rc = set_lds(wgrad_s1_kernel<2>, lds)) != CURLA_OK) return rc;
+      hipLaunchKernelGGL(wgrad_s1_kernel<2>, dim3(grid), dim3(256), lds, st, a);
+      break;
+    default:
+      if ((rc = set_lds(wgrad_s1_kernel<0>, lds)) != CURLA_OK) return rc;
+      hipLaunchKernelGGL(wgrad_s1_kernel<0>, dim3(grid), dim3(256), lds, st, a);
+  }
   *nslabs = grid;
   return curla_launch_status();
 }
@@ -1689,9 +1796,21 @@ int curla_conv3x3_s1_bwd_slabs(const float* in, const float* g, const float* w, 
   const int items_d = B * da.nbands;
   const int nd = items_d < cap ? items_d : cap;
   const size_t lds = lds_w > lds_d ? lds_w : lds_d;
-  int rc = set_lds(bwd_s1_kernel, lds);
-  if (rc != CURLA_OK) return rc;
-  hipLaunchKernelGGL(bwd_s1_kernel, dim3(nw + nd), dim3(256), lds, static_cast<hipStream_t>(stream), wa, da, nw);
+  int rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (wgrad_walk(Wo)) {
+    case 1:
+      if ((rc = set_lds(bwd_s1_kernel<1>, lds)) != CURLA_OK) return rc;
+      hipLaunchKernelGGL(bwd_s1_kernel<1>, dim3(nw + nd), dim3(256), lds, st, wa, da, nw);
+      break;
+    case 2:
+      if ((rc = set_lds(bwd_s1_kernel<2>, lds)) != CURLA_OK) return rc;
+      hipLaunchKernelGGL(bwd_s1_kernel<2>, dim3(nw + nd), dim3(256), lds, st, wa, da, nw);
+      break;
+    default:
+      if ((rc = set_lds(bwd_s1_kernel<0>, lds)) != CURLA_OK) return rc;
+      hipLaunchKernelGGL(bwd_s1_kernel<0>, dim3(nw + nd), dim3(256), lds, st, wa, da, nw);
+  }
   *nslabs = nw;
   return curla_launch_status();
 }
