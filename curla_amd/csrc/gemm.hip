@@ -951,13 +951,10 @@ int curla_fc_dw(const float* dz, const float* x, float* dW, int B, int F, int K,
   const size_t lds = (size_t)4 * nt * 4 * 64 * sizeof(f32x4);  // 16 KB per feature tile
 #define CURLA_FC_DW(NT)                                                                                               \
   do {                                                                                                                \
-    static bool attr = false;                                                                                         \
-    if (!attr) {                                                                                                      \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(fc_dw_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)((size_t)4 * NT * 4 * 64 * sizeof(f32x4))) != hipSuccess)                           \
-        return CURLA_ERR_LAUNCH;                                                                                      \
-      attr = true;                                                                                                    \
-    }                                                                                                                 \
+    static const hipError_t attr =                                                                                    \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(fc_dw_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)((size_t)4 * NT * 4 * 64 * sizeof(f32x4))); /* once, thread-safe */                   \
+    if (attr != hipSuccess) return CURLA_ERR_LAUNCH;                                                                  \
     hipLaunchKernelGGL(fc_dw_kernel<NT>, grid, dim3(256), lds, st, g);                                                \
   } while (0)
   if (nt == 1) CURLA_FC_DW(1);
@@ -985,13 +982,10 @@ int curla_fc_bwd(const float* dz, const float* W, const float* x, float* dx, flo
     return curla_fc_dw(dz, x, dW, B, F, K, stream);
   }
   const size_t lds = (size_t)4 * 4 * 4 * 64 * sizeof(f32x4);
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fc_bwd_kernel<13, 4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
-      return CURLA_ERR_LAUNCH;
-    attr = true;
-  }
+  // (once per process, thread-safe: a function-local static is initialised exactly once)
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fc_bwd_kernel<13, 4>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) return CURLA_ERR_LAUNCH;
   hipLaunchKernelGGL((fc_bwd_kernel<13, 4>), dim3(nblk), dim3(256), lds, st, gx, dW);
   return curla_launch_status();
 }

@@ -904,6 +904,46 @@ def test_stale_minibatch_handle_is_refused_on_the_device():
         agent.update_critic(old[0], old[1], old[2], old[3], old[4], NullLogger(), 0)
 
 
+def test_pinned_index_slots_survive_a_lagging_gpu():
+    """The index block of a minibatch is read from its pinned host slot by the staging kernel when the GPU gets there;
+    the host may be many samples ahead (16 slots, one event per 8 uploads).  With the stream held up behind ~100 ms of
+    other work, 100 samples are drawn back to back; every one must arrive with ITS indices, offsets and scalars."""
+    import curla_amd
+    aug = curla_amd.RandomCrop((34, 40), (28, 34))
+    B, cap, n = 8, 64, 100
+    rb = curla_amd.ReplayBuffer((9, 34, 40), (2,), cap, B, torch.device("cuda"), aug)
+    rs = np.random.RandomState(0)
+    acts, rews = rs.uniform(-1, 1, (cap, 2)).astype(np.float32), rs.randn(cap).astype(np.float32)
+    rb.add_batch(rs.randint(0, 256, (cap, 9, 34, 40), dtype=np.uint8), acts, rews,
+                 rs.randint(0, 256, (cap, 9, 34, 40), dtype=np.uint8), np.zeros(cap, bool))
+    assert rb._h_index_dev is not None  # the in-place path is the one under test
+    torch.cuda.synchronize()
+    blk = rb._d_index.shape[1]
+    log_idx = torch.zeros((n, blk), dtype=torch.uint8, device="cuda")
+    log_sc = torch.zeros((n, B * 4), dtype=torch.float32, device="cuda")
+    big = torch.randn(4096, 4096, device="cuda")
+    for _ in range(40):  # hold the stream up: the host runs far ahead of the first staging kernel
+        big = (big @ big).clamp_(-1, 1)
+    want = []
+    for i in range(n):
+        idxs = rs.randint(0, cap, B)
+        offs = np.stack([rs.randint(0, 7, B) if j % 2 == 0 else rs.randint(0, 7, B) for j in range(6)]).astype(np.int32)
+        rb.sample_cpc_refs(indices=(idxs, offs))
+        s = rb._sample_slot
+        log_idx[i].copy_(rb._d_index[s])
+        log_sc[i].copy_(rb._d_scal[s])
+        want.append((idxs, offs))
+    torch.cuda.synchronize()
+    li, ls = log_idx.cpu(), log_sc.cpu()
+    for i, (idxs, offs) in enumerate(want):
+        i64 = li[i, :2 * B * 8].view(torch.int64).numpy()
+        o32 = li[i, 2 * B * 8:].view(torch.int32).view(6, B).numpy()
+        assert (i64[:B] == idxs).all() and (i64[B:] == idxs + cap).all(), i
+        assert (o32 == offs[[0, 2, 4, 1, 3, 5]]).all(), i
+        sc = ls[i].numpy()
+        assert (sc[:2 * B].reshape(B, 2) == acts[idxs]).all() and (sc[2 * B:3 * B] == rews[idxs]).all(), i
+
+
 def test_histogram_logging_hooks_record_the_training_forward(tiny):
     """log_param_hist_imgs=True (curl_sac.py:17,112-121,171-180; encoder.py:79-108,118-130): on a logging step
     critic.log() / actor.log() histogram the module outputs of the update's own forward passes -- checked
