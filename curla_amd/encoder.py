@@ -131,8 +131,12 @@ class CNNEncoder(nn.Module):
     def conv_forward(self, obs_ref, acts, conv_params=None):
         """relu(conv_l(...)) for l = 1..L (encoder.py:77-88); acts[l-1] receives layer l."""
         cp = conv_params or self.conv_params()
+        L = self.num_layers
         ops.conv1_fwd(obs_ref, cp[0][0], cp[0][1], acts[0])
-        for i in range(1, self.num_layers):
+        if L > 2 and ops.conv_s1_fwd_stack(acts[0], [cp[i][0] for i in range(1, L)], [cp[i][1] for i in range(1, L)],
+                                           acts[1:L]):
+            return acts[-1]  # (all stride-1 layers in one launch: batches that are whole rounds of the persistent grid)
+        for i in range(1, L):
             ops.conv_s1_fwd(acts[i - 1], cp[i][0], cp[i][1], acts[i])
         return acts[-1]
 
