@@ -1126,8 +1126,12 @@ template <int C, int NW>
 __global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
   constexpr int NTHR = 64 * NW;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  constexpr int KR = (3 * C + 3) & ~3;
-  constexpr int NT = (3 * KR + 15) / 16;
+  // k' = dy * 3C + dx * C + c, unpadded (9C values): NT tiles of 16.  At C = 9 that is 81 = 5 tiles + ONE column; a
+  // sixth tile for it would be a sixth of all MFMAs, so that column (dy = 2, dx = 2, c = C-1) is accumulated by two
+  // VALU FMAs per k-step instead (lane (li, kq) holds the gradient of channels li / 16+li at its pixel anyway).
+  constexpr int K9 = 9 * C;
+  constexpr bool TAIL = (K9 % 16 == 1);
+  constexpr int NT = TAIL ? K9 / 16 : (K9 + 15) / 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int RSb = conv1_row_bytes(a.Wc, C);
@@ -1137,13 +1141,15 @@ __global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
   float bsum[2] = {0.f, 0.f};
+  float atail[2] = {0.f, 0.f};
   int koff[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int k = t * 16 + li;
-    const int dy = k / KR, rr = k - dy * KR;
+    const int dy = k / (3 * C), rr = k - dy * (3 * C);
     koff[t] = (dy < 3) ? dy * RSb + rr : 0;
   }
+  const int koff_tail = 2 * RSb + 3 * C - 1;
   const int nitems = a.B * a.nbands;
   uint8_t* ldsb = reinterpret_cast<uint8_t*>(lds);
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
@@ -1186,6 +1192,11 @@ __global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
       for (int t = 0; t < NT; ++t) bv[t] = (float)ub[koff[t]];
       bsum[0] += avj[0];
       bsum[1] += avj[1];
+      if (TAIL) {
+        const float bt = (float)ub[koff_tail];
+        atail[0] += avj[0] * bt;
+        atail[1] += avj[1] * bt;
+      }
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         acc[0][t] = mfma16(avj[0], bv[t], acc[0][t]);
@@ -1238,6 +1249,14 @@ __global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
   bsum[0] += __shfl_xor(bsum[0], 32);
   bsum[1] += __shfl_xor(bsum[1], 16);
   bsum[1] += __shfl_xor(bsum[1], 32);
+  if (TAIL) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      atail[i] *= a.scale;
+      atail[i] += __shfl_xor(atail[i], 16);
+      atail[i] += __shfl_xor(atail[i], 32);
+    }
+  }
   // Cross-wave sum (waves in order: fixed order, reproducible) and the slab.  Every wave deposits its accumulator
   // tiles lane-contiguously (one ds_write_b128 per tile, no index arithmetic), as many tiles per pass as the LDS
   // holds for NW waves; after one barrier the threads add the NW copies of their slot and scatter the four sums
@@ -1259,8 +1278,8 @@ __global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
       for (int w = 1; w < NW; ++w) v += l4[(w * TC + (q - t0)) * 64 + ln];
       const int mt = q / NT, t = q - mt * NT;
       const int k = t * 16 + (ln & 15);
-      const int dy = k / KR, rr = k - dy * KR;
-      if (dy < 3 && rr < 3 * C) {
+      const int dy = k / (3 * C), rr = k - dy * (3 * C);
+      if (dy < 3) {
         const int dx = rr / C, c = rr - dx * C;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1271,14 +1290,23 @@ __global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
     }
     __syncthreads();
   }
-  if (kq == 0) lds[(wave * 2 + 0) * 16 + li] = bsum[0], lds[(wave * 2 + 1) * 16 + li] = bsum[1];
+  if (kq == 0) {
+    lds[(wave * 2 + 0) * 16 + li] = bsum[0], lds[(wave * 2 + 1) * 16 + li] = bsum[1];
+    if (TAIL) lds[NW * 32 + (wave * 2 + 0) * 16 + li] = atail[0], lds[NW * 32 + (wave * 2 + 1) * 16 + li] = atail[1];
+  }
   __syncthreads();
   if (tid < 32) {
     float v = lds[tid];  // wave 0: [mt][li] = tid
     for (int w = 1; w < NW; ++w) v += lds[w * 32 + tid];
     slab[nw + tid] = v;
+    if (TAIL) {  // the column the tiles leave out: (dy, dx, c) = (2, 2, C-1) of output channel tid
+      float t = lds[NW * 32 + tid];
+      for (int w = 1; w < NW; ++w) t += lds[NW * 32 + w * 32 + tid];
+      slab[(tid * C + (C - 1)) * 9 + 8] = t;
+    }
   }
 }
+
 
 // second pass: dW = sum over workgroup slabs.  32 elements x 32 slab-groups per
 // block; each group adds its slabs in slab order, the 32 group sums are added in
