@@ -491,7 +491,10 @@ __device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned vo
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
 
-template <int KS, int NT>
+// NT feature tiles of 16 go through the matrix pipe; NTAIL further features (F = 16 NT + NTAIL: 50 = 3 x 16 + 2) are
+// accumulated by VALU FMAs on the x values the lane holds anyway -- a fourth tile for two features would be an eighth
+// of the kernel's MFMAs.
+template <int KS, int NT, int NTAIL>
 __global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs g, float* dW) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NT][4][64 lanes] float4
   const int tid = threadIdx.x, lane = tid & 63;
@@ -512,6 +515,10 @@ __global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs g, float* dW) 
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int c = 0; c < 4; ++c) accw[t][c] = f32x4{0, 0, 0, 0};
+  f32x4 atail[NTAIL > 0 ? NTAIL : 1];  // [feature 16 NT + j] x this lane's 4 columns, summed over its rows
+#pragma unroll
+  for (int j = 0; j < (NTAIL > 0 ? NTAIL : 1); ++j) atail[j] = f32x4{0, 0, 0, 0};
+  const unsigned tl_off = (unsigned)(4 * kq * g.F + 16 * NT) * 4u;  // dz[16t + 4kq + r][16 NT + j]: + 4 r F + 4 j
   const int ntiles = g.B >> 4;
   const unsigned dz_bytes = (unsigned)g.B * g.F * 4u, x_bytes = (unsigned)g.B * (unsigned)g.K * 4u;
   const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc((void*)g.dz, (short)0, (int)dz_bytes, 0x00020000);
@@ -544,12 +551,20 @@ __global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs g, float* dW) 
 #pragma unroll
     for (int r = 0; r < 4; ++r) mk[r] = buf_f32x4(rx, x_off, base + r * rowK);
   };
-  float dv[KS], dt[4][NT];
+  auto load_tl = [&](int t, float (&tl)[4][NTAIL > 0 ? NTAIL : 1]) {
+    const unsigned base = (unsigned)t * 16u * rowF;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int j = 0; j < NTAIL; ++j) tl[r][j] = buf_f32(rdz, tl_off, base + r * rowF + 4u * j);
+  };
+  float dv[KS], dt[4][NT], tl[4][NTAIL > 0 ? NTAIL : 1];
   // x comes from HBM and is requested a whole tile ahead (two register sets); the dz operands are L2 hits and each has
   // the other product's MFMAs to arrive under
   auto tile = [&](int t, int tnext, const f32x4 (&mk)[4], f32x4 (&mk_next)[4]) {
     load_mk(tnext, mk_next);
     load_dt(t, dt);
+    if (NTAIL > 0) load_tl(t, tl);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc[4];
 #pragma unroll
@@ -567,6 +582,10 @@ __global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs g, float* dW) 
       for (int ft = 0; ft < NT; ++ft)
 #pragma unroll
         for (int c = 0; c < 4; ++c) accw[ft][c] = mfma16(dt[r][ft], mk[r][c], accw[ft][c]);
+#pragma unroll
+    for (int j = 0; j < NTAIL; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atail[j] += tl[r][j] * mk[r];
     const unsigned obase = (unsigned)t * 16u * rowK;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -589,6 +608,18 @@ __global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs g, float* dW) 
   }
   // weight gradient: sum over the four waves (b-tiles) in wave order, then wave w writes feature tile(s) w, w+4, ...
   f32x4* r4 = reinterpret_cast<f32x4*>(red);
+  f32x4* t4 = r4 + 4 * NT * 4 * 64;  // tail features: [4 waves][NTAIL][16 column groups]
+  if (NTAIL > 0) {
+#pragma unroll
+    for (int j = 0; j < NTAIL; ++j) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {  // the four row quarters (kq) of a column group sit in lanes li, li+16, li+32, li+48
+        atail[j][c] += __shfl_xor(atail[j][c], 16);
+        atail[j][c] += __shfl_xor(atail[j][c], 32);
+      }
+      if (kq == 0) t4[(wave * NTAIL + j) * 16 + li] = atail[j];
+    }
+  }
 #pragma unroll
   for (int ft = 0; ft < NT; ++ft)
 #pragma unroll
@@ -608,6 +639,14 @@ __global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs g, float* dW) 
       const f32x4 o = {v[0][r], v[1][r], v[2][r], v[3][r]};
       if (cvalid && f < g.F) *reinterpret_cast<f32x4*>(dW + (size_t)f * g.K + ncol) = o;
     }
+  }
+  if (NTAIL > 0 && tid < 16 * NTAIL) {  // (after the barrier above)
+    const int j = tid >> 4, cg = tid & 15;
+    f32x4 v = t4[(0 * NTAIL + j) * 16 + cg];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) v += t4[(w * NTAIL + j) * 16 + cg];
+    const int col = n0 + 4 * cg;
+    if (col + 3 < g.K) *reinterpret_cast<f32x4*>(dW + (size_t)(16 * NT + j) * g.K + col) = v;
   }
 }
 
@@ -977,16 +1016,23 @@ int curla_fc_bwd(const float* dz, const float* W, const float* x, float* dx, flo
   const int ks = (F + 3) / 4, nt = (F + 15) / 16;
   // the one-pass kernel is instantiated for 49..52 features, whole 16-row tiles and matrices below 2 GB (32-bit buffer
   // offsets); anything else takes the two streaming kernels
-  if (ks != 13 || nt != 4 || B % 16 != 0 || (long long)B * K * 4 >= (1LL << 31)) {
+  if (ks != 13 || nt != 4 || B % 16 != 0 || (long long)B * K * 4 >= (1LL << 31)) {  // (i.e. F = 49..52)
     if ((rc = curla_fc_dx(dz, W, x, dx, B, F, K, stream)) != CURLA_OK) return rc;
     return curla_fc_dw(dz, x, dW, B, F, K, stream);
   }
-  const size_t lds = (size_t)4 * 4 * 4 * 64 * sizeof(f32x4);
+  const size_t lds = (size_t)4 * 4 * 4 * 64 * sizeof(f32x4);  // (the 3 + 2 form needs less: 48 KB + 2 KB)
   // (once per process, thread-safe: a function-local static is initialised exactly once)
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fc_bwd_kernel<13, 4>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (attr != hipSuccess) return CURLA_ERR_LAUNCH;
-  hipLaunchKernelGGL((fc_bwd_kernel<13, 4>), dim3(nblk), dim3(256), lds, st, gx, dW);
+  if (F == 50) {  // the default feature width: 3 tiles on the matrix pipe + 2 features on VALU FMAs
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fc_bwd_kernel<13, 3, 2>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return CURLA_ERR_LAUNCH;
+    hipLaunchKernelGGL((fc_bwd_kernel<13, 3, 2>), dim3(nblk), dim3(256), lds, st, gx, dW);
+  } else {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fc_bwd_kernel<13, 4, 0>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return CURLA_ERR_LAUNCH;
+    hipLaunchKernelGGL((fc_bwd_kernel<13, 4, 0>), dim3(nblk), dim3(256), lds, st, gx, dW);
+  }
   return curla_launch_status();
 }
 
