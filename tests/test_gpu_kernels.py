@@ -314,6 +314,26 @@ def test_actor_head(ops, B, A):
     mu2 = torch.empty(B, A, device="cuda")
     ops.actor_head_fwd(dev(out.detach()), None, B, A, lo, hi, mu=mu2)
     check(f"actor_head_fwd mu-only B{B}", mu2.cpu(), mu_r.detach())
+    # the head inside the trunk's last-layer launch (curla_mlp_out_head_fwd): same trunk output as the plain layer, same
+    # head outputs as the head kernel fed with it, pi also written into the action columns of the Q input rows
+    K = 64
+    h, W, b = torch.relu(rnd(B, K, seed=45)).cuda(), (rnd(2 * A, K, seed=46) * 0.2).cuda(), rnd(2 * A, seed=47).cuda()
+    o1 = torch.empty(B, 2 * A, device="cuda")
+    ops.mlp_out_fwd(h, 0, W, 0, b, 0, o1, 0, B, 2 * A, K)
+    r_mu, r_pi, r_ls, r_tl = (torch.empty(B, A, device="cuda") for _ in range(4))
+    r_lp = torch.empty(B, 1, device="cuda")
+    ops.actor_head_fwd(o1, dev(noise), B, A, lo, hi, mu=r_mu, pi=r_pi, log_pi=r_lp, log_std=r_ls, tanh_ls=r_tl)
+    o2 = torch.full_like(o1, float("nan"))
+    f_mu, f_pi, f_ls, f_tl = (torch.full((B, A), float("nan"), device="cuda") for _ in range(4))
+    f_lp = torch.full((B, 1), float("nan"), device="cuda")
+    xa = torch.full((B, Fz + A), float("nan"), device="cuda")
+    ops.mlp_out_head_fwd(h, W, b, o2, dev(noise), B, A, K, lo, hi, mu=f_mu, pi=f_pi, log_pi=f_lp, log_std=f_ls,
+                         tanh_ls=f_tl, xa=xa)
+    assert torch.equal(o1, o2)
+    for n, a_, r_ in (("mu", f_mu, r_mu), ("pi", f_pi, r_pi), ("log_std", f_ls, r_ls), ("tanh_ls", f_tl, r_tl)):
+        assert torch.equal(a_, r_), n
+    check(f"fused head log_pi B{B}", f_lp.cpu(), r_lp.cpu(), 1e-6)
+    assert torch.equal(xa[:, Fz:], r_pi) and bool(torch.isnan(xa[:, :Fz]).all())
 
 
 def test_losses(ops):
