@@ -1805,7 +1805,15 @@ int curla_conv3x3_s1_bwd_slabs(const float* in, const float* g, const float* w, 
   wa.nbands = (Ho + wa.th - 1) / wa.th;
   size_t lds_w = (size_t)((wa.th + 2) * Wi + 1) * kLdsPix * sizeof(float);
   if (lds_w < kPartialS1 * sizeof(float)) lds_w = kPartialS1 * sizeof(float);
-  const int cap = 2 * curla_cu_count();
+  // grid: 2 x CUs workgroups of each kind, run one kind after the other -- or, for short launches, ONE workgroup of
+  // each kind per CU side by side (blocks 0..CUs-1 and CUs..2 CUs-1; both persistent over their kind's items).  Side
+  // by side the layer takes as long (143 / 161 / 182 us at B = 512: a CU shared between the two kinds is no busier
+  // than one shared by two of a kind), but the weight gradient leaves half as many slabs for the reduction to read
+  // (14 -> 10 us per backward pass).  Long launches keep the 2 + 2 form: there a few percent of imbalance between the
+  // kinds (the tail runs at one workgroup per CU) costs more than the slabs (B = 1024 at 81 x 81: +0.3 ms per update).
+  static const int split_env = getenv("CURLA_BWD_SPLIT") ? atoi(getenv("CURLA_BWD_SPLIT")) : -1;  // tuning aid: 0 / 1
+  const bool split = split_env >= 0 ? split_env != 0 : (long long)B * Ho * Wo <= (1LL << 20);
+  const int cap = split ? curla_cu_count() : 2 * curla_cu_count();
   const int items_w = B * wa.nbands;
   const int nw = items_w < cap ? items_w : cap;
   // data-gradient part (as launch_conv_s1 in MODE_DGRAD: input = the output gradient [B][Ho][Wo], output [B][Hi][Wi])

@@ -760,8 +760,9 @@ def test_mlp_forward_two_level_batch(ops, B, din, H):
 
 @pytest.mark.parametrize("B,H,W", [(3, 13, 16), (2, 37, 37), (300, 9, 9), (5, 17, 15)])
 def test_conv_s1_backward_one_launch(ops, B, H, W):
-    """curla_conv3x3_s1_bwd_slabs: weight-gradient slabs and data gradient of a layer in one launch -- bit-identical to
-    the two separate kernels."""
+    """curla_conv3x3_s1_bwd_slabs: weight-gradient slabs and data gradient of a layer in one launch.  The data gradient
+    is bit-identical to the separate kernel's; the weight gradient is dealt to as many or half as many workgroups
+    (slabs) as the separate kernel's, i.e. the same sums in another fixed order."""
     x = torch.relu(rnd(B, H, W, 32, seed=91)).cuda()
     g = rnd(B, H - 2, W - 2, 32, seed=92).cuda()
     w = (rnd(32, 32, 3, 3, seed=93) * 0.1).cuda()
@@ -771,11 +772,19 @@ def test_conv_s1_backward_one_launch(ops, B, H, W):
     n1 = ops.conv_s1_wgrad_slabs(x, g, ws1)
     ops.conv_s1_dgrad(g, w, x, gin1)
     n2 = ops.conv_s1_bwd_slabs(x, g, w, gin2, ws2)
-    assert n1 == n2 and torch.equal(gin1, gin2)
+    assert n2 in (n1, min(n1, ops.cu_count())) and torch.equal(gin1, gin2)
     dw1, db1, dw2, db2 = (torch.empty(s, device="cuda") for s in ((32, 32, 3, 3), (32,), (32, 32, 3, 3), (32,)))
     ops.wgrad_reduce_multi([(ws1, n1, dw1, db1)])
     ops.wgrad_reduce_multi([(ws2, n2, dw2, db2)])
-    assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+    if n1 == n2:
+        assert torch.equal(dw1, dw2) and torch.equal(db1, db2)
+    else:
+        check(f"bwd_slabs dW {B}x{H}x{W}", dw2.cpu(), dw1.cpu(), 2e-6)
+        check(f"bwd_slabs db {B}x{H}x{W}", db2.cpu(), db1.cpu(), 2e-6)
+    ws3, gin3, dw3, db3 = torch.zeros_like(ws1), torch.empty_like(x), torch.empty_like(dw1), torch.empty_like(db1)
+    n3 = ops.conv_s1_bwd_slabs(x, g, w, gin3, ws3)
+    ops.wgrad_reduce_multi([(ws3, n3, dw3, db3)])
+    assert n3 == n2 and torch.equal(dw3, dw2) and torch.equal(db3, db2)  # run-to-run reproducible
 
 
 def test_fc_backward_one_launch(ops):
