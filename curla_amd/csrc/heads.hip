@@ -289,16 +289,26 @@ __device__ __forceinline__ void actor_head_row(const float* out2a_row, int b, co
 // HEAD: the outputs are the actor trunk's [mu | raw log_std] and the wave that produced a row also runs the policy
 // head on it (a launch of its own otherwise: a few hundred cycles of work per row behind a 5 us launch)
 // R rows per wave: a weight float4 is loaded once for R rows; a row's sums do not depend on R (R = 1 is what runs).
-template <bool HEAD, int R>
+// LDSW: the block first copies the N weight rows into LDS and its four waves read them from there -- with several
+// rows (the actor's 8 x 1024) every wave otherwise pulls 32 KB through the L2 for itself, 16 MB per launch.
+template <bool HEAD, int R, bool LDSW>
 __global__ __launch_bounds__(256) void mlp_out_fwd_kernel(const float* h, long long sH, long long sH2, const float* W,
                                                           long long sW, long long sW2, const float* bias, long long sB,
                                                           long long sB2, float* out, long long sOut, long long sOut2,
                                                           int M, int N, int K, int nb_inner, HeadArgs hd) {
+  extern __shared__ __attribute__((aligned(16))) float wlds[];
   const int zo = blockIdx.y / nb_inner, zi = blockIdx.y - zo * nb_inner;
   const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R, lane = threadIdx.x & 63;
-  if (row0 >= M) return;
   const float* hz = h + zi * sH + zo * sH2;
   const float* Wz = W + zi * sW + zo * sW2;
+  if (LDSW) {
+    const int n4 = (N * K) >> 2;
+    for (int i = threadIdx.x; i < n4; i += 256)
+      reinterpret_cast<f32x4*>(wlds)[i] = reinterpret_cast<const f32x4*>(Wz)[i];
+    __syncthreads();
+    Wz = wlds;
+  }
+  if (row0 >= M) return;
   float acc[R][kMaxOut];
 #pragma unroll
   for (int r = 0; r < R; ++r)
@@ -978,8 +988,13 @@ static int mlp_out_fwd_launch(const float* h, long long sH, long long sH2, const
   hipStream_t st = static_cast<hipStream_t>(stream);
   // (R = 4 rows per wave to share the weight loads was measured for the actor's 8 outputs: 25 us against 14 -- the
   // layer is load latency, and 128 waves hide less of it than 512)
-  hipLaunchKernelGGL((mlp_out_fwd_kernel<false, 1>), dim3((M + 3) / 4, nb * nb2), dim3(256), 0, st, h, sH, sH2, W, sW,
-                     sW2, bias, sB, sB2, out, sOut, sOut2, M, N, K, nb, HeadArgs{});
+  const size_t wbytes = (size_t)N * K * sizeof(float);
+  if (N >= 2 && wbytes <= 48 * 1024)  // (one row: a wave reads 4 KB once, nothing to share)
+    hipLaunchKernelGGL((mlp_out_fwd_kernel<false, 1, true>), dim3((M + 3) / 4, nb * nb2), dim3(256), wbytes, st, h, sH,
+                       sH2, W, sW, sW2, bias, sB, sB2, out, sOut, sOut2, M, N, K, nb, HeadArgs{});
+  else
+    hipLaunchKernelGGL((mlp_out_fwd_kernel<false, 1, false>), dim3((M + 3) / 4, nb * nb2), dim3(256), 0, st, h, sH, sH2,
+                       W, sW, sW2, bias, sB, sB2, out, sOut, sOut2, M, N, K, nb, HeadArgs{});
   return curla_launch_status();
 }
 
@@ -1054,9 +1069,15 @@ int curla_mlp_out_head_fwd(const float* h, const float* W, const float* bias, fl
   if (rc != CURLA_OK) return rc;
   if (2 * A > kMaxOut || K % 4 != 0) return CURLA_ERR_UNSUPPORTED;
   CURLA_REQUIRE(aligned16(h) && aligned16(W));
-  hipLaunchKernelGGL((mlp_out_fwd_kernel<true, 1>), dim3((B + 3) / 4, 1), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), h, 0LL, 0LL, W, 0LL, 0LL, bias, 0LL, 0LL, trunk_out, 0LL, 0LL, B,
-                     2 * A, K, 1, hd);
+  const size_t wbytes = (size_t)2 * A * K * sizeof(float);
+  if (wbytes <= 48 * 1024)
+    hipLaunchKernelGGL((mlp_out_fwd_kernel<true, 1, true>), dim3((B + 3) / 4, 1), dim3(256), wbytes,
+                       static_cast<hipStream_t>(stream), h, 0LL, 0LL, W, 0LL, 0LL, bias, 0LL, 0LL, trunk_out, 0LL, 0LL,
+                       B, 2 * A, K, 1, hd);
+  else
+    hipLaunchKernelGGL((mlp_out_fwd_kernel<true, 1, false>), dim3((B + 3) / 4, 1), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), h, 0LL, 0LL, W, 0LL, 0LL, bias, 0LL, 0LL, trunk_out, 0LL, 0LL,
+                       B, 2 * A, K, 1, hd);
   return curla_launch_status();
 }
 
