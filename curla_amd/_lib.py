@@ -44,6 +44,7 @@ SIGNATURES = {
     "curla_splitk_reduce": [vp, c_int, c_ll, c_int, c_int, c_int, vp, c_int, vp, c_int, vp],
     "curla_mlp_out_fwd": [vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, c_int, c_int, c_int, c_int, vp],
     "curla_mlp_out_bwd": [vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, c_int, c_int, c_int, c_int, vp],
+    "curla_mlp_out_bwd_loss": [vp, vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, c_int, c_int, vp, vp, c_ll, vp],
     "curla_mlp_out_bwd_bias": [vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, c_int, c_int, c_int, c_int, vp, vp, c_ll,
                                vp],
     "curla_gemm_small_shape": [c_int, c_int, c_int, c_int],

@@ -365,12 +365,53 @@ __global__ __launch_bounds__(256) void mlp_out_fwd_kernel(const float* h, long l
 constexpr int kOutRows = 8;  // rows per thread per pass (64 parts x 8 = 512 rows per pass)
 // db_out[z][n] = sum_m dy[z][m][n] and db_h[z][k] = sum_m dh[z][m][k] (optional): the bias gradients of this layer and
 // of the one below -- the block already walks every row of its 16 columns.
+// GEN: where dy comes from.  0: memory.  1 / 2: the twin Q functions' output gradient is a per-row formula of a few
+// scalars -- the TD error of update_critic (curl_sac.py:350-362) or d(-min(Q1, Q2))/dQ of the actor loss
+// (curl_sac.py:378-383) -- so every block evaluates it for its rows instead of waiting for a loss kernel's launch,
+// and block (0, 0) also adds up that kernel's scalars (loss values, d(alpha loss)/d(log_alpha)).  N == 1, z = twin.
+struct LossGen {
+  const float *q, *tq, *log_pi, *reward, *not_done, *log_std;
+  const double* log_alpha;
+  double* dlog_alpha;
+  float *target_q, *scalars, *dq;
+  long long sTwin;
+  float discount, target_entropy;
+  int A;
+};
+
+// block-wide fixed-order sum of one value per thread (1024 threads); result valid in every thread
+__device__ __forceinline__ float block_sum_1024(float v, float* sm16) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm16[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = sm16[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) t += sm16[w];
+  return t;
+}
+
+template <int GEN>
 __global__ __launch_bounds__(1024) void mlp_out_bwd_kernel(const float* dy, long long sDy, const float* h,
                                                            long long sH, const float* W, long long sW, float* dh,
                                                            long long sDh, float* dW, long long sDW, int M, int N,
-                                                           int K, float* db_out, float* db_h, long long sDb) {
+                                                           int K, float* db_out, float* db_h, long long sDb, LossGen lg) {
   __shared__ float sm[64][17];
   const int z = blockIdx.y;
+  const float alpha = GEN ? (float)exp(*lg.log_alpha) : 0.f;
+  const float inv = GEN ? 1.f / M : 0.f;
+  auto gen = [&](int m, float& target) -> float {  // dy[z][m] (and, GEN 1, the TD target of row m)
+    if (GEN == 1) {
+      const float v = fminf(lg.tq[m], lg.tq[lg.sTwin + m]) - alpha * lg.log_pi[m];
+      target = lg.reward[m] + lg.not_done[m] * lg.discount * v;
+      return 2.f * (lg.q[z * lg.sTwin + m] - target) * inv;
+    }
+    const float q1 = lg.q[m], q2 = lg.q[lg.sTwin + m];
+    target = 0.f;
+    // d(-min)/dq: the smaller one takes -1/B; an exact tie splits it (torch.min backward)
+    if (z == 0) return q1 < q2 ? -inv : (q1 == q2 ? -0.5f * inv : 0.f);
+    return q2 < q1 ? -inv : (q1 == q2 ? -0.5f * inv : 0.f);
+  };
   const int kl = threadIdx.x & 15, part = threadIdx.x >> 4;
   const int k = blockIdx.x * 16 + kl;
   const bool kv = k < K;
@@ -397,17 +438,29 @@ __global__ __launch_bounds__(1024) void mlp_out_bwd_kernel(const float* dy, long
       const int m = m0 + 64 * u;
       if (m < M) {
         float s = 0.f;
-#pragma unroll
-        for (int n = 0; n < kMaxOut; ++n)
-          if (n < N) {
-            const float d = dyz[(size_t)m * N + n];
-            s += d * wreg[n];
-            acc[n] += d * hv[u];
+        if (GEN) {
+          float target;
+          const float d = gen(m, target);
+          s = d * wreg[0];
+          acc[0] += d * hv[u];
+          if (do_bo) bo += d;
+          if (blockIdx.x == 0 && kl == 0) {  // one block per twin also leaves dy (and the target) in memory
+            lg.dq[z * lg.sTwin + m] = d;
+            if (GEN == 1 && z == 0) lg.target_q[m] = target;
           }
+        } else {
+#pragma unroll
+          for (int n = 0; n < kMaxOut; ++n)
+            if (n < N) {
+              const float d = dyz[(size_t)m * N + n];
+              s += d * wreg[n];
+              acc[n] += d * hv[u];
+            }
+          if (do_bo) bo += dyz[(size_t)m * N + kl];
+        }
         const float dv = hv[u] > 0.f ? s : 0.f;
         if (kv) dhz[(size_t)m * K + k] = dv;
         bh += dv;
-        if (do_bo) bo += dyz[(size_t)m * N + kl];
       }
     }
   }
@@ -433,6 +486,40 @@ __global__ __launch_bounds__(1024) void mlp_out_bwd_kernel(const float* dy, long
         db_h[z * sDb + k] = t;
       else
         db_out[z * sDb + kl] = t;
+    }
+  }
+  if (GEN && blockIdx.x == 0 && z == 0) {  // the loss kernel's scalars (block-uniform branch)
+    __shared__ float sm16[16];
+    if (GEN == 1) {
+      float a1 = 0.f, a2 = 0.f;
+      for (int b = threadIdx.x; b < M; b += 1024) {
+        const float v = fminf(lg.tq[b], lg.tq[lg.sTwin + b]) - alpha * lg.log_pi[b];
+        const float t = lg.reward[b] + lg.not_done[b] * lg.discount * v;
+        const float d1 = lg.q[b] - t, d2 = lg.q[lg.sTwin + b] - t;
+        a1 += d1 * d1, a2 += d2 * d2;
+      }
+      const float s1 = block_sum_1024(a1, sm16);
+      const float s2 = block_sum_1024(a2, sm16);
+      if (threadIdx.x == 0) lg.scalars[0] = s1 * inv + s2 * inv;
+    } else {
+      float al = 0.f, hl = 0.f, en = 0.f;
+      for (int b = threadIdx.x; b < M; b += 1024) {
+        al += alpha * lg.log_pi[b] - fminf(lg.q[b], lg.q[lg.sTwin + b]);
+        hl += -lg.log_pi[b] - lg.target_entropy;
+        float e = 0.f;
+        for (int a = 0; a < lg.A; ++a) e += lg.log_std[(size_t)b * lg.A + a];
+        en += 0.5f * lg.A * (1.0f + 1.8378770664093453f) + e;
+      }
+      const float s_al = block_sum_1024(al, sm16);
+      const float s_hl = block_sum_1024(hl, sm16);
+      const float s_en = block_sum_1024(en, sm16);
+      if (threadIdx.x == 0) {
+        lg.scalars[0] = s_al * inv;
+        lg.scalars[1] = alpha * (s_hl * inv);
+        lg.scalars[2] = s_en * inv;
+        lg.scalars[3] = alpha;
+        if (lg.dlog_alpha) *lg.dlog_alpha = (double)(alpha * (s_hl * inv));  // d/dlog_alpha exp(log_alpha)*c = alpha*c
+      }
     }
   }
   if (dW == nullptr) return;  // block-uniform
@@ -1025,9 +1112,35 @@ int curla_mlp_out_bwd_bias(const float* dy, long long strideDy, const float* h, 
                            int K, int nbatch, float* db_out, float* db_hidden, long long strideDb, void* stream) {
   CURLA_REQUIRE(dy && h && W && dh && M > 0 && N > 0 && K > 0 && nbatch > 0);
   if (N > kMaxOut) return CURLA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(mlp_out_bwd_kernel, dim3((K + 15) / 16, nbatch), dim3(1024), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(mlp_out_bwd_kernel<0>, dim3((K + 15) / 16, nbatch), dim3(1024), 0, static_cast<hipStream_t>(stream),
                      dy, strideDy, h, strideH, W, strideW, dh, strideDh, dW, strideDW, M, N, K, db_out, db_hidden,
-                     strideDb);
+                     strideDb, LossGen{});
+  return curla_launch_status();
+}
+
+int curla_mlp_out_bwd_loss(const CurlaLossArgs* loss, const float* h, long long strideH, const float* W,
+                           long long strideW, float* dh, long long strideDh, float* dW, long long strideDW, int B, int K,
+                           float* db_out, float* db_hidden, long long strideDb, void* stream) {
+  CURLA_REQUIRE(loss && h && W && dh && B > 0 && K > 0);
+  CURLA_REQUIRE(loss->q && loss->log_pi && loss->log_alpha && loss->scalars && loss->dq && loss->twin_stride >= B);
+  LossGen lg;
+  lg.q = loss->q, lg.tq = loss->target_q_twin, lg.log_pi = loss->log_pi, lg.reward = loss->reward;
+  lg.not_done = loss->not_done, lg.log_std = loss->log_std, lg.log_alpha = loss->log_alpha;
+  lg.dlog_alpha = loss->dlog_alpha, lg.target_q = loss->target_q, lg.scalars = loss->scalars, lg.dq = loss->dq;
+  lg.sTwin = loss->twin_stride, lg.discount = loss->discount, lg.target_entropy = loss->target_entropy, lg.A = loss->A;
+  const dim3 grid((K + 15) / 16, 2);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (loss->kind == 1) {
+    CURLA_REQUIRE(loss->target_q_twin && loss->reward && loss->not_done && loss->target_q);
+    hipLaunchKernelGGL(mlp_out_bwd_kernel<1>, grid, dim3(1024), 0, st, nullptr, 0LL, h, strideH, W, strideW, dh, strideDh,
+                       dW, strideDW, B, 1, K, db_out, db_hidden, strideDb, lg);
+  } else if (loss->kind == 2) {
+    CURLA_REQUIRE(loss->log_std && loss->A > 0);
+    hipLaunchKernelGGL(mlp_out_bwd_kernel<2>, grid, dim3(1024), 0, st, nullptr, 0LL, h, strideH, W, strideW, dh, strideDh,
+                       dW, strideDW, B, 1, K, db_out, db_hidden, strideDb, lg);
+  } else {
+    return CURLA_ERR_ARG;
+  }
   return curla_launch_status();
 }
 

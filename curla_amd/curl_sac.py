@@ -97,13 +97,22 @@ def _mlp_fwd(x, sx, P, nb, B, din, H, dout, h1, h2, out, relu_out=0, outer=None,
         ops.actor_head_fwd(out, noise, B, dout // 2, lo, hi, **outs)
 
 
-def _mlp_bwd(x, sx, P, G, nb, B, din, H, dout, h1, h2, dy, dh2, dh1, dx):
-    """Backward of _mlp_fwd.  G (parameter gradients) and dx are optional."""
+def _mlp_bwd(x, sx, P, G, nb, B, din, H, dout, h1, h2, dy, dh2, dh1, dx, loss=None):
+    """Backward of _mlp_fwd.  G (parameter gradients) and dx are optional.
+    ``loss`` = (fields, launch): the output gradient dy is that of a loss over the twin Q values -- ``fields`` for
+    ops.mlp_out_bwd_loss, which computes it inside the last layer's backward launch; ``launch()`` runs the loss kernel
+    on its own where that form does not apply."""
     s = P.stride
+    fused_loss = loss is not None and dout == 1 and nb == 2
+    if loss is not None and not fused_loss:
+        loss[1]()
     # the three bias gradients (column sums of dy, dh2, dh1) ride in the launches that walk those matrices anyway --
     # the last layer's backward pass and the first layer's weight-gradient product -- where both take their small forms
     fold = G is not None and dout <= ops.MLP_OUT_MAX and ops.linear_dw_folds_bias(B, H, din, nb)
-    if dout <= ops.MLP_OUT_MAX:  # last layer: data and weight gradient in one pass over h2
+    if fused_loss:
+        ops.mlp_out_bwd_loss(loss[0], h2, B * H, P.W[2], s, dh2, B * H, G.W[2] if G is not None else None, s, B, H,
+                             db_out=G.b[2] if fold else None, db_hidden=G.b[1] if fold else None, sdb=s)
+    elif dout <= ops.MLP_OUT_MAX:  # last layer: data and weight gradient in one pass over h2
         ops.mlp_out_bwd(dy, B * dout, h2, B * H, P.W[2], s, dh2, B * H, G.W[2] if G is not None else None, s, B, dout,
                         H, nb, db_out=G.b[2] if fold else None, db_hidden=G.b[1] if fold else None, sdb=s)
     else:
@@ -747,13 +756,17 @@ class CurlSacAgent(object):
         if rec:  # what critic.log() / encoder.log() histogram: the outputs of THIS forward (curl_sac.py:163-167)
             self.critic.outputs['q1'], self.critic.outputs['q2'] = ws.q[0].clone(), ws.q[1].clone()
             enc.record_from(o, ws.acts_main, ws.fc_out, ws.z_c)
-        # target_Q = r + not_done * gamma * (min Q' - alpha log pi') and the two MSE terms, one launch
-        ops.critic_td_loss(ws.q, ws.tq, B, ws.log_pi, reward, not_done, self.log_alpha, self.discount, B, ws.target_q,
-                           ws.scalars[0:1], ws.dq)
+        # target_Q = r + not_done * gamma * (min Q' - alpha log pi'), the two MSE terms and their gradient dq: computed
+        # inside the backward launch of the Q functions' last layer (a launch of its own otherwise)
+        td = (dict(kind=1, twin_stride=B, q=ws.q, target_q_twin=ws.tq, log_pi=ws.log_pi, reward=reward,
+                   not_done=not_done, log_alpha=self.log_alpha, discount=self.discount, target_q=ws.target_q,
+                   scalars=ws.scalars[0:1], dq=ws.dq),
+              lambda: ops.critic_td_loss(ws.q, ws.tq, B, ws.log_pi, reward, not_done, self.log_alpha, self.discount, B,
+                                         ws.target_q, ws.scalars[0:1], ws.dq))
+        _mlp_bwd(ws.xa, 0, self.critic.twin(), self.critic.twin(grads=True), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.dq,
+                 ws.q_dh2, ws.q_dh1, ws.dxa, loss=td)
         if step % self.log_interval == 0:
             L.log('train_critic/loss', ws.scalars[0], step)
-        _mlp_bwd(ws.xa, 0, self.critic.twin(), self.critic.twin(grads=True), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.dq,
-                 ws.q_dh2, ws.q_dh1, ws.dxa)
         # (d(loss)/d(z) = dxa[0][:, :F] + dxa[1][:, :F], torch.cat's backward: summed inside the LayerNorm backward)
         # data parallel: the bucket is [convs | fc, ln | Q1 | Q2]; everything behind the convs is final before the
         # conv backward starts and is reduced underneath it
@@ -825,16 +838,19 @@ class CurlSacAgent(object):
         if self._records(step):  # what actor.log() histograms (curl_sac.py:92-93): pre-squash mean and std
             self.actor.outputs['mu'], self.actor.outputs['std'] = ws.a_out[:, :A].clone(), ws.log_std.exp()
         _mlp_fwd(ws.xa, 0, self.critic.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.q)
-        ops.actor_loss(ws.q, B, ws.log_pi, ws.log_std, A, self.log_alpha, float(self.target_entropy), B,
-                       ws.scalars[1:5], ws.dq, self.log_alpha.grad)
+        # actor / alpha losses and d(loss)/dQ: inside the backward launch of the Q functions' last layer
+        # backward: Q -> pi -> trunk -> LN -> fc (encoder detached, curl_sac.py:375-376)
+        al = (dict(kind=2, A=A, twin_stride=B, q=ws.q, log_pi=ws.log_pi, log_std=ws.log_std, log_alpha=self.log_alpha,
+                   target_entropy=float(self.target_entropy), scalars=ws.scalars[1:5], dq=ws.dq,
+                   dlog_alpha=self.log_alpha.grad),
+              lambda: ops.actor_loss(ws.q, B, ws.log_pi, ws.log_std, A, self.log_alpha, float(self.target_entropy), B,
+                                     ws.scalars[1:5], ws.dq, self.log_alpha.grad))
+        _mlp_bwd(ws.xa, 0, self.critic.twin(), None, 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.dq, ws.q_dh2, ws.q_dh1,
+                 ws.dxa, loss=al)
         if step % self.log_interval == 0:
             L.log('train_actor/loss', ws.scalars[1], step)
             L.log('train_actor/target_entropy', self.target_entropy, step)
             L.log('train_actor/entropy', ws.scalars[3], step)
-
-        # backward: Q -> pi -> trunk -> LN -> fc (encoder detached, curl_sac.py:375-376)
-        _mlp_bwd(ws.xa, 0, self.critic.twin(), None, 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.dq, ws.q_dh2, ws.q_dh1,
-                 ws.dxa)
         # d(loss)/d(pi) = the action columns of dxa summed over the twin, read in place
         ops.actor_head_bwd(None, self.log_alpha, 1.0 / B, nz, ws.pi, ws.log_std, ws.tanh_ls, B, A, lo, hi, ws.a_dout,
                            twin_dxa=ws.dxa, F=F)

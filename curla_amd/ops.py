@@ -305,6 +305,27 @@ def mlp_out_bwd(dy, sdy, h, sh, W, sW, dh, sdh, dW, sdW, M, N, K, nb=1, db_out=N
              ptr(db_out), ptr(db_hidden), sdb, stream())
 
 
+class _LossArgs(ctypes.Structure):  # CurlaLossArgs
+    _fields_ = [("kind", ctypes.c_int), ("A", ctypes.c_int), ("twin_stride", ctypes.c_longlong)] + \
+               [(n, ctypes.c_void_p) for n in ("q", "target_q_twin", "log_pi", "reward", "not_done", "log_std", "log_alpha",
+                                               "dlog_alpha", "target_q", "scalars", "dq")] + \
+               [("discount", ctypes.c_float), ("target_entropy", ctypes.c_float)]
+
+
+def mlp_out_bwd_loss(loss, h, sh, W, sW, dh, sdh, dW, sdW, B, K, db_out=None, db_hidden=None, sdb=0):
+    """mlp_out_bwd of the twin Q functions' last layer with its output gradient computed from the loss inputs instead
+    of read (``loss``: dict of CurlaLossArgs fields; kind 1 = critic TD loss, 2 = actor / alpha loss): the loss
+    kernel's launch goes away, its scalars and dq are written by this one."""
+    a = _LossArgs()
+    a.kind, a.A, a.twin_stride = loss["kind"], loss.get("A", 0), loss["twin_stride"]
+    for n in ("q", "target_q_twin", "log_pi", "reward", "not_done", "log_std", "log_alpha", "dlog_alpha", "target_q",
+              "scalars", "dq"):
+        setattr(a, n, ptr(loss.get(n)))
+    a.discount, a.target_entropy = loss.get("discount", 0.0), loss.get("target_entropy", 0.0)
+    call("curla_mlp_out_bwd_loss", ctypes.addressof(a), ptr(h), sh, ptr(W), sW, ptr(dh), sdh, ptr(dW), sdW, B, K,
+         ptr(db_out), ptr(db_hidden), sdb, stream())
+
+
 MLP_OUT_MAX = 16
 
 

@@ -182,6 +182,26 @@ typedef struct CurlaFcLnJob {
   const float* act;
   int tanh_out;
 } CurlaFcLnJob;
+/* curla_mlp_out_bwd_bias for the twin Q functions' last layer (one output, two twins `twin_stride` floats apart in q /
+ * target_q_twin / dq) with the output gradient computed in place of being read: the launch of the loss kernel that
+ * would produce it goes away, its scalar results are written by the same launch.
+ *   kind 1 (update_critic, curl_sac.py:350-362, = curla_critic_td_loss): target = reward + not_done * discount *
+ *           (min(target_q_twin) - alpha * log_pi); dq = 2 (q - target) / B; scalars[0] = the critic loss; target_q [B]
+ *   kind 2 (update_actor_and_alpha, curl_sac.py:378-399, = curla_actor_loss): dq = d(-min(Q1, Q2))/dQ / B;
+ *           scalars[0..3] = actor loss, alpha loss, entropy, alpha; *dlog_alpha = d(alpha loss)/d(log_alpha)
+ * dq [2][twin_stride] is also written out (bias-gradient fallbacks, tests). */
+typedef struct CurlaLossArgs {
+  int kind, A;
+  long long twin_stride;
+  const float *q, *target_q_twin, *log_pi, *reward, *not_done, *log_std;
+  const double* log_alpha;
+  double* dlog_alpha;
+  float *target_q, *scalars, *dq;
+  float discount, target_entropy;
+} CurlaLossArgs;
+int curla_mlp_out_bwd_loss(const CurlaLossArgs* loss, const float* h, long long strideH, const float* W,
+                           long long strideW, float* dh, long long strideDh, float* dW, long long strideDW, int B, int K,
+                           float* db_out, float* db_hidden, long long strideDb, void* stream);
 /* fc split-K reduce + bias + LayerNorm(eps) [+ tanh] (encoder.py:98-107).  Saves
  * xhat / rstd for the backward when non-NULL.  F <= 256.  `xa` (optional, with `act` [B][A]): also writes the Q
  * functions' input rows xa[b] = [ y[b] | act[b] ], i.e. torch.cat([obs, action], dim=1) (curl_sac.py:138). */

@@ -372,6 +372,37 @@ def test_losses(ops):
     check("actor_loss scalars", sc.cpu(), torch.stack([actor_loss.detach(), alpha_loss.detach(), ent, alpha.detach()]).float())
     check("actor_loss dq", dq2.cpu(), q2.grad)
     check("dlog_alpha", dla.cpu(), log_alpha.grad)
+    # both losses evaluated INSIDE the backward launch of the twin Q functions' last layer (curla_mlp_out_bwd_loss):
+    # same dq / target bit for bit, same scalars up to the summation order, same layer gradients as mlp_out_bwd fed
+    # with that dq
+    K = 64
+    h = torch.relu(rnd(2, B, K, seed=58)).cuda()
+    S = K + 8
+    Wf = torch.zeros(2, S, device="cuda")
+    Wf[:, :K] = (rnd(2, K, seed=59) * 0.2).cuda()
+    for kind, fields, ref_dq, ref_sc in (
+            (1, dict(q=dev(q.detach()), target_q_twin=dev(tq), log_pi=dev(lp), reward=dev(r), not_done=dev(nd),
+                     discount=0.99), dq3, loss2),
+            (2, dict(q=dev(q2.detach()), log_pi=dev(lp), log_std=dev(ls), A=A, target_entropy=-2.0), dq2, sc)):
+        dh_r, dW_r = torch.empty(2, B, K, device="cuda"), torch.zeros(2, S, device="cuda")
+        gb_r = torch.full((2, S), float("nan"), device="cuda")
+        ops.mlp_out_bwd(ref_dq, B, h, B * K, Wf, S, dh_r, B * K, dW_r, S, B, 1, K, 2, db_out=gb_r, db_hidden=gb_r[0, 4:], sdb=S)
+        dh_f, dW_f = torch.full_like(dh_r, float("nan")), torch.zeros(2, S, device="cuda")
+        gb_f = torch.full((2, S), float("nan"), device="cuda")
+        dq_f, sc_f = torch.full((2, B, 1), float("nan"), device="cuda"), torch.full((4,), float("nan"), device="cuda")
+        tgt_f = torch.full((B, 1), float("nan"), device="cuda")
+        dla_f = torch.zeros((), dtype=torch.float64, device="cuda")
+        ops.mlp_out_bwd_loss(dict(kind=kind, twin_stride=B, log_alpha=d_la, scalars=sc_f, dq=dq_f, target_q=tgt_f,
+                                  dlog_alpha=dla_f, **fields),
+                             h, B * K, Wf, S, dh_f, B * K, dW_f, S, B, K, db_out=gb_f, db_hidden=gb_f[0, 4:], sdb=S)
+        assert torch.equal(dq_f, ref_dq), kind
+        assert torch.equal(dh_f, dh_r) and torch.equal(dW_f, dW_r) and torch.equal(gb_f[:, :4 + K].nan_to_num(7.0), gb_r[:, :4 + K].nan_to_num(7.0))
+        n_sc = 1 if kind == 1 else 4
+        check(f"loss-in-backward scalars kind {kind}", sc_f[:n_sc].cpu(), ref_sc[:n_sc].cpu(), 1e-6)
+        if kind == 1:
+            assert torch.equal(tgt_f, tgt2)
+        else:
+            check("loss-in-backward dlog_alpha", dla_f.cpu(), dla.cpu(), 1e-6)
 
 
 @pytest.mark.parametrize("B", [8, 64, 200, 512])
