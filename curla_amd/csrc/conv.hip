@@ -151,17 +151,21 @@ __device__ __forceinline__ void conv_s1_body(const ConvS1Args& a, const int bid,
           pf[u] = v;
         }
       } else {
-        // zero-padded band: walk (row, col) incrementally (32 pixels per step), no divisions
+        // zero-padded band: walk (row, col) incrementally (32 pixels per step), no divisions.  Buffer loads whose
+        // descriptor spans exactly this sample's image: rows above / below it are out of range and read zeros by
+        // themselves (a negative offset is a huge unsigned one); columns left / right of it would land in a
+        // neighbouring row, so their lanes are pointed past the buffer.  No bounds branches, no 64-bit lane addresses.
+        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(in_base + (size_t)b * a.Hs * a.Ws * 32), (short)0, a.Hs * a.Ws * 128, 0x00020000);
         int r = (tid >> 3) / WT, c = (tid >> 3) - r * WT;
         const int ch = tid & 7;
 #pragma unroll
         for (int u = 0; u < kMaxPf; ++u) {
           const int f = tid + u * 256;
-          f32x4 v = {0, 0, 0, 0};
           const int sy = y0 + r - a.pad, sx = c - a.pad;
-          if (f < n4 && sy >= 0 && sy < a.Hs && sx >= 0 && sx < a.Ws && !(ABL(1) && item != bid))
-            v = *reinterpret_cast<const f32x4*>(in_base + ((size_t)(b * a.Hs + sy) * a.Ws + sx) * 32 + ch * 4);
-          pf[u] = v;
+          const bool ok = f < n4 && (unsigned)sx < (unsigned)a.Ws && !(ABL(1) && item != bid);
+          const unsigned voff = ok ? (unsigned)(((sy * a.Ws + sx) * 32 + ch * 4) * 4) : 0x80000000u;
+          pf[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, voff, 0, 0));
           c += 32;
           if (WT >= 32) {  // wave-uniform: at most one row wrap per 32-pixel step
             const bool wrap = c >= WT;
@@ -195,6 +199,8 @@ __device__ __forceinline__ void conv_s1_body(const ConvS1Args& a, const int bid,
     // per-item (wave-uniform) base pointers: a tile only adds a 32-bit element offset
     float* const out_item = out_base + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
     const float* const aux_item = aux_base + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
+    const __amdgpu_buffer_rsrc_t raux = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)aux_item, (short)0, MODE == MODE_DGRAD ? tha * a.Wo * 128 : 0, 0x00020000);
     int pg = 0;
     bool ppv = false, psecond = false;
     auto epilogue = [&](const f32x4 (&pacc)[4]) {
@@ -237,9 +243,11 @@ __device__ __forceinline__ void conv_s1_body(const ConvS1Args& a, const int bid,
       const int g = (__mul24(ty, a.Wo) + x0) * 32 + mt * 16 + 4 * kq;  // element offset inside the item's output band
       const bool second = x0 + 1 < a.Wo;
       f32x4 ma = {0, 0, 0, 0}, mb = {0, 0, 0, 0};
-      if (MODE == MODE_DGRAD && pv && !ABL(4)) {  // ReLU mask of the layer below: in flight for a whole tile
-        ma = *reinterpret_cast<const f32x4*>(aux_item + g);
-        if (second) mb = *reinterpret_cast<const f32x4*>(aux_item + g + 32);
+      if (MODE == MODE_DGRAD && !ABL(4)) {  // ReLU mask of the layer below: in flight for a whole tile
+        // (buffer loads, no branch: lanes without a pixel point past the item's range and read zeros)
+        ma = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(raux, pv ? (unsigned)g * 4u : 0x80000000u, 0, 0));
+        mb = __builtin_bit_cast(
+            f32x4, __builtin_amdgcn_raw_buffer_load_b128(raux, (pv && second) ? (unsigned)(g + 32) * 4u : 0x80000000u, 0, 0));
       }
       // y(x0) = m0+m1+m2 and y(x0+1) = m1-m2-m3: starting m0 at +bias and m3 at -bias adds the bias to both
       acc[0] = bias4, acc[1] = f32x4{0, 0, 0, 0}, acc[2] = f32x4{0, 0, 0, 0}, acc[3] = -bias4;
