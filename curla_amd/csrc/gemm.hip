@@ -494,7 +494,9 @@ __device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned vo
 // NT feature tiles of 16 go through the matrix pipe; NTAIL further features (F = 16 NT + NTAIL: 50 = 3 x 16 + 2) are
 // accumulated by VALU FMAs on the x values the lane holds anyway -- a fourth tile for two features would be an eighth
 // of the kernel's MFMAs.
-template <int KS, int NT, int NTAIL>
+// DX = false: the weight gradient alone (the actor's fc layer: its conv stack is detached, curl_sac.py:375-376) -- the
+// same walk without the data-gradient half.
+template <int KS, int NT, int NTAIL, bool DX>
 __global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs g, float* dW) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NT][4][64 lanes] float4
   const int tid = threadIdx.x, lane = tid & 63;
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs g, float* dW) 
 #pragma unroll
   for (int s = 0; s < KS; ++s) {
     const int f = 4 * s + kq;
-    wv[s] = *reinterpret_cast<const f32x4*>(g.W + (size_t)min(f, g.F - 1) * g.K + nc);
+    wv[s] = DX ? *reinterpret_cast<const f32x4*>(g.W + (size_t)min(f, g.F - 1) * g.K + nc) : f32x4{0, 0, 0, 0};
   }
   f32x4 accw[NT][4];
 #pragma unroll
@@ -569,12 +571,14 @@ __global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs g, float* dW) 
     f32x4 acc[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) acc[c] = f32x4{0, 0, 0, 0};
+    if (DX) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s)
+      for (int s = 0; s < KS; ++s)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[c] = mfma16(dv[s], wv[s][c], acc[c]);
-    __builtin_amdgcn_sched_barrier(0);
-    load_dv(tnext, dv);
+        for (int c = 0; c < 4; ++c) acc[c] = mfma16(dv[s], wv[s][c], acc[c]);
+      __builtin_amdgcn_sched_barrier(0);
+      load_dv(tnext, dv);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int r = 0; r < 4; ++r)
@@ -586,13 +590,15 @@ __global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs g, float* dW) 
     for (int j = 0; j < NTAIL; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) atail[j] += tl[r][j] * mk[r];
-    const unsigned obase = (unsigned)t * 16u * rowK;
+    if (DX) {
+      const unsigned obase = (unsigned)t * 16u * rowK;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+      for (int r = 0; r < 4; ++r) {
+        f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = mk[r][c] > 0.f ? v[c] : 0.f;
-      if (cvalid) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, x_off, obase + r * rowK, 2);  // nt
+        for (int c = 0; c < 4; ++c) v[c] = mk[r][c] > 0.f ? v[c] : 0.f;
+        if (cvalid) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, x_off, obase + r * rowK, 2);  // nt
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -600,7 +606,7 @@ __global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs g, float* dW) 
   int t = wave;  // this wave's b-tiles: wave, wave + 4, ...
   if (t < ntiles) {
     load_mk(t, mA);
-    load_dv(t, dv);
+    if (DX) load_dv(t, dv);
   }
   for (; t < ntiles; t += 8) {
     tile(t, min(t + 4, ntiles - 1), mA, mB);  // (past the end: the last tile again, unused)
@@ -985,6 +991,16 @@ int curla_fc_dw(const float* dz, const float* x, float* dW, int B, int F, int K,
   FcBwdArgs g;
   g.dz = dz, g.W = x, g.mask = nullptr, g.out = dW, g.B = B, g.F = F, g.K = K;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (F == 50 && B % 16 == 0 && (long long)B * K * 4 < (1LL << 31)) {  // the one-pass kernel's weight-gradient half
+    FcBwdArgs gx;
+    gx.dz = dz, gx.W = nullptr, gx.mask = x, gx.out = nullptr, gx.B = B, gx.F = F, gx.K = K;
+    const size_t lds1 = (size_t)4 * 4 * 4 * 64 * sizeof(f32x4);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fc_bwd_kernel<13, 3, 2, false>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
+    if (attr != hipSuccess) return CURLA_ERR_LAUNCH;
+    hipLaunchKernelGGL((fc_bwd_kernel<13, 3, 2, false>), dim3((K + 63) / 64), dim3(256), lds1, st, gx, dW);
+    return curla_launch_status();
+  }
   const dim3 grid((K + 63) / 64);
   const int nt = (F + 15) / 16;
   const size_t lds = (size_t)4 * nt * 4 * 64 * sizeof(f32x4);  // 16 KB per feature tile
@@ -1023,15 +1039,15 @@ int curla_fc_bwd(const float* dz, const float* W, const float* x, float* dx, flo
   const size_t lds = (size_t)4 * 4 * 4 * 64 * sizeof(f32x4);  // (the 3 + 2 form needs less: 48 KB + 2 KB)
   // (once per process, thread-safe: a function-local static is initialised exactly once)
   if (F == 50) {  // the default feature width: 3 tiles on the matrix pipe + 2 features on VALU FMAs
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fc_bwd_kernel<13, 3, 2>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fc_bwd_kernel<13, 3, 2, true>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return CURLA_ERR_LAUNCH;
-    hipLaunchKernelGGL((fc_bwd_kernel<13, 3, 2>), dim3(nblk), dim3(256), lds, st, gx, dW);
+    hipLaunchKernelGGL((fc_bwd_kernel<13, 3, 2, true>), dim3(nblk), dim3(256), lds, st, gx, dW);
   } else {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fc_bwd_kernel<13, 4, 0>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fc_bwd_kernel<13, 4, 0, true>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return CURLA_ERR_LAUNCH;
-    hipLaunchKernelGGL((fc_bwd_kernel<13, 4, 0>), dim3(nblk), dim3(256), lds, st, gx, dW);
+    hipLaunchKernelGGL((fc_bwd_kernel<13, 4, 0, true>), dim3(nblk), dim3(256), lds, st, gx, dW);
   }
   return curla_launch_status();
 }
