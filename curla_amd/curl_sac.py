@@ -615,7 +615,7 @@ class CurlSacAgent(object):
         st = self._act_stage.get((C, H, W))
         if st is None:
             n = H * W * C
-            pin = torch.empty(n, dtype=torch.uint8).pin_memory()
+            pin = torch.empty(n, dtype=torch.uint8, pin_memory=self.device.type == "cuda")
             ring = torch.zeros(n + 32, dtype=torch.uint8, device=self.device)  # + loader slack (curla_hip.h)
             st = self._act_stage[(C, H, W)] = (pin, pin.numpy().reshape(H, W, C), ring, ring[:n].view(1, H, W, C))
         pin, pin_hwc, ring, frames = st

@@ -86,6 +86,22 @@ def make_dir(dir_path):
     return dir_path
 
 
+def module_hash(module):
+    """Sum of the sums of a module's state_dict tensors -- the reference's cheap "did the weights change" number
+    (utils.py:50-54)."""
+    return sum(t.sum().item() for t in module.state_dict().values())
+
+
+def preprocess_obs(obs, bits=5):
+    """Bit-depth reduction with uniform dequantisation noise, arXiv:1807.03039 (utils.py:67-77; unused by the
+    learner path, kept so that ``utils.`` resolves every name the reference module has)."""
+    assert obs.dtype == torch.float32
+    bins = 2 ** bits
+    if bits < 8:
+        obs = torch.floor(obs / 2 ** (8 - bits))
+    return obs / bins + torch.rand_like(obs) / bins - 0.5
+
+
 class FrameStack(object):
     """Observation wrapper that returns the last ``k`` frames concatenated on the channel axis (utils.py:238-268):
     ``reset`` fills the stack with k copies of the first frame, ``step`` pushes the new frame.  Plain duck-typed
