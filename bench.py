@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the CURL+SAC learner hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c5]
+    python bench.py --gpus N --steps K --warmup W [--config c2|c3|c5] [--no-others] [--dry-run]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one ``CurlSacAgent.update()`` (critic + [actor/alpha + target soft
@@ -13,6 +13,16 @@ configuration (default c2 = configs[1], the one the metric is quoted on):
   c5  B=1024, 168x168x12 (frame_stack 4), color_jiggle, 6 conv layers (configs[4] per GPU)
 With N>1 every rank does the same on its own ring shard and the gradient buckets
 are all-reduced over RCCL (weak scaling).  Prints ONE JSON line on rank 0.
+
+Without ``--config`` the line's ``metric`` / ``value`` / ``config`` are c2's and the same process then measures
+c3 and c5 as well (the c2 ring is freed first) and reports them under ``other_configs`` -- each with its own
+``value``, ``ms_per_step``, ``steps``, ``roofline`` and (N=1) ``cpu_baseline``; ``--no-others`` or an explicit
+``--config`` measures one configuration only.
+
+``--dry-run`` walks the same host path -- launcher respawn, ring shards, rank seeds, data-parallel setup, the
+update loop, the all-reduce report, the one JSON line -- with gloo on the CPU and the kernel calls routed to the
+launch-trace hook (nothing is computed, no GPU is touched): the N>1 plumbing can be rehearsed without a node
+(tests/test_bench_dry_run.py).  Its numbers mean nothing and the line says ``"dry_run": true``.
 """
 import argparse
 import json
@@ -133,28 +143,33 @@ def cpu_baseline(cfg, name):
 
 def committed_counters(cfg_name, kernel):
     """HBM bytes per launch and matrix-pipe busy fraction of ``kernel`` from the committed rocprofv3 PMC summaries
-    (tools/pmc_traffic.sh, tools/pmc_sq.sh: separate --pmc passes, FETCH_SIZE doubled as gfx950 needs).  They are
-    measured offline, so they are only quoted when the summary was taken from the kernel sources this library was
-    built from (the summary records their hash); otherwise null."""
+    (tools/profile_config.sh + tools/pmc_summarize.py: separate --pmc passes, FETCH_SIZE doubled as gfx950 needs).
+    They are measured offline, so they are only quoted when the summary was taken from the kernel sources this
+    library was built from (the summary records their hash); otherwise null.  The newest round's summary wins."""
     from curla_amd import build
     cur = build.source_hash()
     traffic = busy = None
     note = "no committed PMC summary for this configuration"
-    for fn, key in ((f"r02_pmc_traffic_{cfg_name}.json", "traffic"), (f"r02_pmc_sq_{cfg_name}.json", "sq")):
-        try:
-            with open(os.path.join(ROOT, "profiles", fn)) as f:
-                d = json.load(f)
-        except Exception:
-            continue
-        if d.get("_source_hash") != cur:
-            note = f"profiles/{fn} was measured on other kernel sources ({d.get('_source_hash')} != {cur}): not quoted"
-            continue
-        if key == "traffic":
-            traffic = d[kernel]["traffic_bytes"]
-            note = f"profiles/{fn} (rocprofv3 --pmc, same kernel sources {cur})"
-        else:
-            c = d[kernel]
-            busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_BUSY_CU_CYCLES"])
+    for rnd in ("r03", "r02"):
+        for fn, key in ((f"{rnd}_pmc_traffic_{cfg_name}.json", "traffic"), (f"{rnd}_pmc_sq_{cfg_name}.json", "sq")):
+            try:
+                with open(os.path.join(ROOT, "profiles", fn)) as f:
+                    d = json.load(f)
+            except Exception:
+                continue
+            if d.get("_source_hash") != cur:
+                if traffic is None and busy is None:
+                    note = (f"profiles/{fn} was measured on other kernel sources ({d.get('_source_hash')} != {cur}): "
+                            "not quoted")
+                continue
+            if kernel not in d:
+                continue
+            if key == "traffic" and traffic is None:
+                traffic = d[kernel]["traffic_bytes"]
+                note = f"profiles/{fn} (rocprofv3 --pmc, same kernel sources {cur})"
+            elif key == "sq" and busy is None:
+                c = d[kernel]
+                busy = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * c["SQ_BUSY_CU_CYCLES"])
     return traffic, busy, note
 
 
@@ -169,43 +184,82 @@ def respawn_under_torchrun(args):
     sys.exit(subprocess.call(cmd))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None)
-    ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--capacity", type=int, default=CAPACITY)
-    ap.add_argument("--prefill", choices=("device", "host"), default="device")
-    ap.add_argument("--clock-warmup-s", type=float, default=0.6,
-                    help="seconds of scratch conv launches before the warm-up steps (0 for counter-collection runs)")
-    args = ap.parse_args()
-    cfg = CONFIGS[args.config]
-    if args.steps is None:
-        args.steps = 200 if args.config != "c5" else 20
-    if args.warmup is None:
-        args.warmup = 20 if args.config != "c5" else 3
+class Job:
+    """What one rank knows about the run: who it is, where it computes, how it synchronises and measures time."""
 
-    if "RANK" not in os.environ and args.gpus > 1:
-        respawn_under_torchrun(args)
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    # CURLA_BENCH_FORCE_DIST=1: take the RCCL code path with a single rank (1-GPU check of the N>1 branch)
-    distributed = world > 1 or os.environ.get("CURLA_BENCH_FORCE_DIST") == "1"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if distributed:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    def __init__(self, args):
+        self.args = args
+        self.dry = args.dry_run
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={self.world} ranks")
+        # CURLA_BENCH_FORCE_DIST=1: take the RCCL code path with a single rank (1-GPU check of the N>1 branch)
+        self.distributed = self.world > 1 or os.environ.get("CURLA_BENCH_FORCE_DIST") == "1"
+        if self.dry:
+            from curla_amd import _lib
+            self.dev = torch.device("cpu")
+            self.launches = 0
 
+            def hook(name, a):
+                self.launches += 1
+            _lib.set_trace_hook(hook)
+            torch.set_num_threads(2)
+        else:
+            torch.cuda.set_device(self.local_rank)
+            self.dev = torch.device("cuda", self.local_rank)
+        if self.distributed:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            if self.dry:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+
+    def sync(self):
+        if not self.dry:
+            torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.distributed:
+            import torch.distributed as dist
+            dist.barrier()
+        self.sync()
+
+    def cu_count(self):
+        return 256 if self.dry else torch.cuda.get_device_properties(self.dev).multi_processor_count
+
+    def timer(self):
+        """(start, stop -> ms): HIP events on the current stream; the host clock in a dry run."""
+        if self.dry:
+            t = [0.0]
+            return (lambda: t.__setitem__(0, time.perf_counter())), (lambda: 1e3 * (time.perf_counter() - t[0]))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+        def stop():
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1)
+        return e0.record, stop
+
+    def close(self):
+        if self.distributed:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        if self.dry:
+            from curla_amd import _lib
+            _lib.set_trace_hook(None)
+
+
+def measure(job, name, steps, warmup, with_cpu_baseline):
+    """One configuration: build agent + ring shard, prime, warm up, time ``steps`` updates between barriers.
+    Returns the result object on rank 0 (None elsewhere).  Everything it allocated is released on return."""
     import curla_amd
     from curla_amd import ops
+    args, cfg, dev, rank, world = job.args, CONFIGS[name], job.dev, job.rank, job.world
+    launches0 = job.launches if job.dry else 0
 
     C, (H, W), B = cfg["obs"][0], cfg["obs"][1:], cfg["batch"]
     curla_amd.set_seed_everywhere(1)
@@ -217,9 +271,10 @@ def main():
         alpha_lr=1e-4, alpha_beta=0.5, actor_lr=1e-3, actor_beta=0.9, critic_lr=1e-3, critic_beta=0.9, critic_tau=0.01,
         encoder_feature_dim=50, encoder_lr=1e-3, encoder_tau=0.05, num_layers=cfg["layers"], num_filters=32,
         pixel_sac=cfg["pixel_sac"], log_interval=10 ** 9)
-    if distributed:
+    if job.distributed:
         agent.enable_data_parallel(single_rank_collectives=(world == 1))  # rank 0's parameters are broadcast
-    curla_amd.set_seed_everywhere(1 + rank)  # rank-specific sampling / policy-noise streams
+    seed = 1 + rank
+    curla_amd.set_seed_everywhere(seed)  # rank-specific sampling / policy-noise streams
 
     # replay ring shard.  SURVEY.md 8d recipe: obs, next_obs i.i.d. uniform bytes (worst case for any compression),
     # action ~ U(-1,1)^2, reward ~ N(0,1), not_done = 1 except every 50th transition.
@@ -252,32 +307,29 @@ def main():
     L = NullLogger()
     # HIP-event timing of the dominant kernel (stride-1 32->32 conv forward) on the stream it is launched on
     ev_pairs = []
-    real_s1 = ops.conv_s1_fwd
     recording = [False]
+    real = (ops.conv_s1_fwd, ops.conv_s1_fwd2, ops.conv_s1_fwd_stack)
 
-    def timed(real, flops, nbytes, *a):
-        if not recording[0]:
-            return real(*a)
+    def timed(fn, flops, nbytes, *a):
+        if not recording[0] or job.dry:
+            return fn(*a)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        real(*a)
+        fn(*a)
         e1.record()
         ev_pairs.append((e0, e1, flops, nbytes))
 
     def timed_s1(x, w, b, out):
-        return timed(real_s1, 2.0 * x.shape[0] * out.shape[1] * out.shape[2] * 32 * 32 * 9,
+        return timed(real[0], 2.0 * x.shape[0] * out.shape[1] * out.shape[2] * 32 * 32 * 9,
                      4.0 * (x.numel() + out.numel()), x, w, b, out)
 
-    real_s1_2 = ops.conv_s1_fwd2
-
     def timed_s1_2(x, w, b, out, x2, w2, b2, out2):  # two minibatches (own weights each) in one launch
-        return timed(real_s1_2, 2.0 * (x.shape[0] + x2.shape[0]) * out.shape[1] * out.shape[2] * 32 * 32 * 9,
+        return timed(real[1], 2.0 * (x.shape[0] + x2.shape[0]) * out.shape[1] * out.shape[2] * 32 * 32 * 9,
                      4.0 * (x.numel() + out.numel() + x2.numel() + out2.numel()), x, w, b, out, x2, w2, b2, out2)
-    real_stack = ops.conv_s1_fwd_stack
 
     def timed_stack(x, ws, bs, outs, x2=None, ws2=None, bs2=None, outs2=None):  # all stride-1 layers, one launch
-        if not recording[0]:
-            return real_stack(x, ws, bs, outs, x2, ws2, bs2, outs2)
+        if not recording[0] or job.dry:
+            return real[2](x, ws, bs, outs, x2, ws2, bs2, outs2)
         fl = by = 0.0
         for (xin, os_) in ((x, outs), (x2, outs2)):
             if xin is None:
@@ -289,61 +341,58 @@ def main():
                 prev = o
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        ok = real_stack(x, ws, bs, outs, x2, ws2, bs2, outs2)
+        ok = real[2](x, ws, bs, outs, x2, ws2, bs2, outs2)
         e1.record()
         if ok:
             ev_pairs.append((e0, e1, fl, by))
         return ok
-    ops.conv_s1_fwd = timed_s1
-    ops.conv_s1_fwd2 = timed_s1_2
-    ops.conv_s1_fwd_stack = timed_stack
-
-    def barrier():
-        if distributed:
-            import torch.distributed as dist
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # one priming update outside everything (workspaces, split-K buffers and the Adam states are allocated on
-    # first use), so that even --warmup 0 times steady-state steps; then the W untimed warm-up steps
-    step = 0
-    agent.update(rb, L, step)
-    step += 1
-    # the first ~0.5 s of matrix-pipe work in a process runs ~8 % slow while the clocks ramp: burn it on scratch
-    # buffers (no agent state involved) so that short runs (small K and W) also measure the steady state.  The burn
-    # uses a kernel instance no configuration launches (first-layer conv from a float NCHW tensor with C = 3), so the
-    # rocprofv3 per-kernel averages of this command contain the updates' launches only.
-    bx = ops.ObsRef.from_tensor(torch.zeros((512, 3, 84, 84), device=dev))
-    bw, bb = torch.zeros((32, 3, 3, 3), device=dev), torch.zeros(32, device=dev)
-    bo = torch.empty((512, 41, 41, 32), device=dev)
-    t_burn = time.perf_counter()
-    while time.perf_counter() - t_burn < args.clock_warmup_s:
-        for _ in range(200):
-            ops.conv1_fwd(bx, bw, bb, bo)
-        torch.cuda.synchronize()
-    del bx, bw, bb, bo
-    for _ in range(args.warmup):
+    ops.conv_s1_fwd, ops.conv_s1_fwd2, ops.conv_s1_fwd_stack = timed_s1, timed_s1_2, timed_stack
+    try:
+        # one priming update outside everything (workspaces, split-K buffers and the Adam states are allocated on
+        # first use), so that even --warmup 0 times steady-state steps; then the W untimed warm-up steps
+        step = 0
         agent.update(rb, L, step)
         step += 1
-    barrier()
-    # event pairs are taken on a sample of the timed steps spread over the whole region (<= 32 steps): thousands
-    # of pending HIP events slow the runtime itself and would perturb the measurement
-    rec_stride = max(4, args.steps // 32)  # (an instrumented step is ~3 % slower: at most every 4th one)
-    first_step = step
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        recording[0] = (i % rec_stride == 0)
-        agent.update(rb, L, step)
-        step += 1
-    recording[0] = False
-    barrier()
-    dt = time.perf_counter() - t0
+        # the first ~0.5 s of matrix-pipe work in a process runs ~8 % slow while the clocks ramp: burn it on scratch
+        # buffers (no agent state involved) so that short runs (small K and W) also measure the steady state.  The
+        # burn uses a kernel instance no configuration launches (first-layer conv from a float NCHW tensor with
+        # C = 3), so the rocprofv3 per-kernel averages of this command contain the updates' launches only.
+        if not job.dry and args.clock_warmup_s > 0:
+            bx = ops.ObsRef.from_tensor(torch.zeros((512, 3, 84, 84), device=dev))
+            bw, bb = torch.zeros((32, 3, 3, 3), device=dev), torch.zeros(32, device=dev)
+            bo = torch.empty((512, 41, 41, 32), device=dev)
+            t_burn = time.perf_counter()
+            while time.perf_counter() - t_burn < args.clock_warmup_s:
+                for _ in range(200):
+                    ops.conv1_fwd(bx, bw, bb, bo)
+                torch.cuda.synchronize()
+            del bx, bw, bb, bo
+        for _ in range(warmup):
+            agent.update(rb, L, step)
+            step += 1
+        job.barrier()
+        # event pairs are taken on a sample of the timed steps spread over the whole region (<= 32 steps): thousands
+        # of pending HIP events slow the runtime itself and would perturb the measurement
+        rec_stride = max(4, steps // 32)  # (an instrumented step is ~3 % slower: at most every 4th one)
+        first_step = step
+        t0 = time.perf_counter()
+        for i in range(steps):
+            recording[0] = (i % rec_stride == 0)
+            agent.update(rb, L, step)
+            step += 1
+        recording[0] = False
+        job.barrier()
+        dt = time.perf_counter() - t0
+    finally:
+        ops.conv_s1_fwd, ops.conv_s1_fwd2, ops.conv_s1_fwd_stack = real
     # the timed updates must have produced finite numbers (a NaN run would be meaningless)
-    ws = agent._ws(B)
-    assert bool(torch.isfinite(ws.scalars).all()) and bool(torch.isfinite(agent._critic_flat).all()), "non-finite state"
+    if not job.dry:
+        ws = agent._ws(B)
+        assert bool(torch.isfinite(ws.scalars).all()) and bool(torch.isfinite(agent._critic_flat).all()), \
+            "non-finite state"
 
     allreduce = None
-    if distributed:
+    if job.distributed:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -351,53 +400,61 @@ def main():
         # outside the timed region: cost of the gradient all-reduces of one update, each bucket timed alone
         # (SURVEY.md 8e reporting: all-reduce time per phase and the bus bandwidth it reaches)
         lay = agent._lay
-        buckets = {"critic": agent._critic_gflat[lay["enc"][0]:lay["total"]], "actor": agent._actor_gflat,
-                   "cpc": agent._critic_gflat[0:lay["enc"][1]]}
+        buckets = {"critic": agent._critic_gflat[lay["enc"][0]:lay["total"]], "actor": agent._actor_gflat}
+        if not cfg["pixel_sac"]:
+            buckets["cpc"] = agent._critic_gflat[0:lay["enc"][1]]
         allreduce = {"overlapped_with_backward": bool(agent._dp_overlap)}
-        for name, buf in buckets.items():
+        reps = 2 if job.dry else 10
+        for bname, buf in buckets.items():
             scratch = torch.zeros_like(buf)
-            for _ in range(3):
+            for _ in range(1 if job.dry else 3):
                 dist.all_reduce(scratch)
-            torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
+            job.sync()
+            start, stop = job.timer()
+            start()
+            for _ in range(reps):
                 dist.all_reduce(scratch)
-            e1.record()
-            torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 10
+            ms = stop() / reps
             nbytes = scratch.numel() * 4
-            allreduce[name] = {"bytes": nbytes, "ms": ms,
-                               "bus_GBps": 2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9}
+            allreduce[bname] = {"bytes": nbytes, "ms": ms,
+                                "bus_GBps": 2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9}
+        # every rank's shard size and sampling seed, for the line (rank 0 reports what the ranks actually used)
+        mine = torch.tensor([rank, cap, seed, rb.capacity], dtype=torch.int64, device=dev)
+        everyone = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        shards = [dict(rank=int(v[0]), capacity=int(v[1]), seed=int(v[2])) for v in everyone]
+    else:
+        shards = [dict(rank=0, capacity=cap, seed=seed)]
 
+    out = None
     if rank == 0:
         kflops = sum(p[2] for p in ev_pairs)
         kbytes = sum(p[3] for p in ev_pairs)
         kms = sum(p[0].elapsed_time(p[1]) for p in ev_pairs)
         achieved = kflops / (kms * 1e-3) / 1e12 if kms > 0 else 0.0
-        updates_per_s = world * args.steps / dt
-        per_update = sum(flops_per_update(cfg, first_step + i) for i in range(args.steps)) / args.steps
+        updates_per_s = world * steps / dt
+        per_update = sum(flops_per_update(cfg, first_step + i) for i in range(steps)) / steps
         # the dominant kernel: all stride-1 forward layers of two minibatches in one launch when the batch sizes allow,
         # else one launch per layer
-        stacked = B % (2 * torch.cuda.get_device_properties(dev).multi_processor_count) == 0
+        stacked = B % (2 * job.cu_count()) == 0
         kname = "conv_s1_stack_kernel" if stacked else "conv_s1_kernel<0>"
-        traffic, mfma_busy, pmc_note = committed_counters(args.config, kname)
+        traffic, mfma_busy, pmc_note = (None, None, "dry run") if job.dry else committed_counters(name, kname)
         n_launch = max(1, len(ev_pairs))
         avg_ms = kms / n_launch
         out = {
             "metric": cfg["metric"],
             "value": updates_per_s,
             "unit": f"batch-{B} gradient updates/s (sum over ranks)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps,
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": 1e3 * dt / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["workload"], "baseline_config": f"configs[{cfg['baseline_index']}]",
-                       "replay_capacity": cap * world, "prefill": prefill, "parallelism": f"dp{world}",
-                       "priming_updates": 1, "clock_warmup_s": args.clock_warmup_s},
+                       "replay_capacity": cap * world, "shards": shards, "prefill": prefill,
+                       "parallelism": f"dp{world}", "priming_updates": 1, "clock_warmup_s": args.clock_warmup_s},
             "transitions_per_s": updates_per_s * B,
             "conv_algorithmic_gflop_per_update": per_update / 1e9,
-            "conv_roofline_frac_whole_update": per_update * (args.steps / dt) / (PEAK_F32_TFLOPS * 1e12),
+            "conv_roofline_frac_whole_update": per_update * (steps / dt) / (PEAK_F32_TFLOPS * 1e12),
             "roofline": {"bound": "mfma",
                          "kernel": ("conv_s1_stack_kernel (all 3x3 s1 32->32 + bias + ReLU layers of two minibatches per "
                                     "launch, f32 MFMA 16x16x4)") if stacked else
@@ -411,14 +468,65 @@ def main():
                          "hbm_peak_GBps": 8000.0,
                          "mfma_busy_frac_pmc": mfma_busy},
         }
+        if job.dry:
+            out["dry_run"] = True
+            out["kernel_calls_traced"] = job.launches - launches0
         if allreduce is not None:
             out["allreduce"] = allreduce
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.config)
-        print(json.dumps(out), flush=True)
-    if distributed:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+    # release this configuration's HBM before the next one (or the CPU baseline) starts
+    del agent, rb, L
+    if not job.dry:
+        torch.cuda.empty_cache()
+    if out is not None and with_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, name)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
+                    help="measure this configuration only (default: c2, then c3 and c5 under other_configs)")
+    ap.add_argument("--no-others", action="store_true", help="without --config: measure c2 only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--capacity", type=int, default=CAPACITY)
+    ap.add_argument("--prefill", choices=("device", "host"), default="device")
+    ap.add_argument("--clock-warmup-s", type=float, default=0.6,
+                    help="seconds of scratch conv launches before the warm-up steps (0 for counter-collection runs)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="gloo + launch-trace hook on the CPU: the host path of an N-rank run without a GPU")
+    args = ap.parse_args()
+    main_cfg = args.config or "c2"
+    others = [] if (args.config is not None or args.no_others) else [c for c in ("c3", "c5")]
+
+    def budget(name):
+        """(steps, warmup) of a configuration: the command line's for the main one and c3; c5's updates are 15x
+        longer, so it is capped at 20 + 3 (about a second of GPU time)."""
+        k = args.steps if args.steps is not None else (200 if name != "c5" else 20)
+        w = args.warmup if args.warmup is not None else (20 if name != "c5" else 3)
+        if name == "c5" and name != args.config:
+            k, w = min(k, 20), min(w, 3)
+        return k, w
+
+    if "RANK" not in os.environ and args.gpus > 1:
+        respawn_under_torchrun(args)
+    job = Job(args)
+    cpu_bl = not args.no_cpu_baseline and job.world == 1 and not job.dry
+    try:
+        out = measure(job, main_cfg, *budget(main_cfg), cpu_bl)
+        extra = {}
+        for name in others:
+            r = measure(job, name, *budget(name), cpu_bl)
+            if r is not None:
+                extra[name] = r
+        if job.rank == 0:
+            if extra:
+                out["other_configs"] = extra
+            print(json.dumps(out), flush=True)
+    finally:
+        job.close()
 
 
 if __name__ == "__main__":
