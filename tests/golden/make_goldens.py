@@ -22,8 +22,9 @@ Fixtures:
                 even-step update() after 4 warm-up updates from the reference's
                 own init (state, batch, crops, noise, per-phase activations,
                 losses, gradients, post-step snapshots) + acting path.
-  tiny_rank1.npz second minibatch from the same pre-update state (for the
-                 2-rank data-parallel mean-of-gradients definition).
+  tiny_rank1.npz .. tiny_rank7.npz  the next seven minibatches, each from the same
+                 pre-update state (for the 2-, 4- and 8-rank data-parallel
+                 mean-of-gradients definition).
   crop84.npz    random_crop / center-crop bytes + index stream at 84->76.
   c1shape.npz   9x84x84 -> 76x76, hidden 128, B=4, weights from a NumPy
                 recipe (regenerable from seed): losses + per-tensor gradient
@@ -326,11 +327,15 @@ def gen_tiny():
     rec["act/noise"] = noises[0]
     np.savez_compressed(os.path.join(HERE, "tiny.npz"), **rec)
 
-    # rank 1 of the 2-rank DP definition: same state0, the NEXT minibatch/noise in the streams
-    rec1 = Recorder(agent0).run(rb, 4)
-    keep = {k: v for k, v in rec1.items() if k.split("/")[0] in ("batch", "rng", "noise", "scalar")
-            or "/grad/" in k}
-    np.savez_compressed(os.path.join(HERE, "tiny_rank1.npz"), **keep)
+    # ranks 1..7 of the N-rank DP definition (N = 2 and 8): every rank starts from the same state0
+    # (an update() mutates its agent, so each rank gets its own copy, taken before any of them runs) and draws the
+    # NEXT minibatch/noise in the streams
+    replicas = [agent0] + [copy.deepcopy(agent0) for _ in range(6)]
+    for r, replica in enumerate(replicas, start=1):
+        rec_r = Recorder(replica).run(rb, 4)
+        keep = {k: v for k, v in rec_r.items() if k.split("/")[0] in ("batch", "rng", "noise", "scalar")
+                or "/grad/" in k}
+        np.savez_compressed(os.path.join(HERE, "tiny_rank%d.npz" % r), **keep)
     return rec
 
 

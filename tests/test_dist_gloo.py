@@ -1,7 +1,8 @@
-"""Data-parallel gradient exchange, world_size 2 on CPU/gloo:
+"""Data-parallel gradient exchange, world_size 2, 4 and 8 on CPU/gloo:
 the flat gradient buckets all-reduced before each optimizer step must equal the
 mean over ranks of the single-process reference gradients (golden minibatches
-tiny.npz / tiny_rank1.npz), bucket by bucket."""
+tiny.npz = rank 0, tiny_rank{r}.npz = rank r, all recorded from the reference at
+the same pre-update state), bucket by bucket."""
 import os
 import socket
 
@@ -21,6 +22,10 @@ def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+def _fixture(rank):
+    return load("tiny.npz" if rank == 0 else "tiny_rank%d.npz" % rank)
 
 
 def _set_grads(agent, fixture, phase):
@@ -53,8 +58,7 @@ def _worker(rank, world, port, q):
         agent.enable_data_parallel()             # ... and the rank-0 broadcast makes them replicas
         agent.check_replicas()
         bcast = (before.numpy(), agent._replica_checksum().numpy())
-        fx = [load("tiny.npz"), load("tiny_rank1.npz")]
-        mine = fx[rank]
+        mine = _fixture(rank)
         lay = agent._lay
         out = {}
         # critic bucket = [encoder | Q1 | Q2]
@@ -133,25 +137,26 @@ def _worker(rank, world, port, q):
         raise e
 
 
-@pytest.mark.timeout(300)
-def test_two_rank_gradient_mean_matches_reference():
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_n_rank_gradient_mean_matches_reference(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=240) for _ in range(2)]
+    results = [q.get(timeout=480) for _ in range(world)]
     for p in procs:
         p.join(timeout=60)
     for r in results:
         assert not isinstance(r[1], str), r[1]
-    g0, g1 = load("tiny.npz"), load("tiny_rank1.npz")
+    fx = [_fixture(r) for r in range(world)]
     bc = {}
     for rank, out, (sched, cuts, bcast, drift), lay in results:
         for key, got in out.items():
             phase, name = key.split("/", 1)
-            want = 0.5 * (g0[f"{phase}/grad/{name}"].astype(np.float64) + g1[f"{phase}/grad/{name}"].astype(np.float64))
+            want = sum(g[f"{phase}/grad/{name}"].astype(np.float64) for g in fx) / world
             err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
             assert err < 1e-6, (rank, key, err)
         e0, e1, total = lay["enc"][0], lay["enc"][1], lay["total"]
@@ -167,9 +172,13 @@ def test_two_rank_gradient_mean_matches_reference():
         assert sched[True] == crit + [(an - at, True), (1, True), (at, True)] + cpc + crit + cpc, sched[True]
         assert "diverged" in drift and "actor" in drift, drift
         bc[rank] = bcast
-    # the two ranks were seeded differently; after enable_data_parallel both hold rank 0's parameters
-    assert not np.array_equal(bc[0][0], bc[1][0])
-    assert np.array_equal(bc[0][1], bc[1][1]) and np.array_equal(bc[0][0], bc[0][1])
-    # both ranks end with identical reduced gradients
-    for k in results[0][1]:
-        assert np.array_equal(results[0][1][k], results[1][1][k]), k
+    # the ranks were seeded differently; after enable_data_parallel all hold rank 0's parameters
+    assert all(not np.array_equal(bc[0][0], bc[r][0]) for r in range(1, world))
+    assert all(np.array_equal(bc[0][1], bc[r][1]) for r in range(1, world)) and np.array_equal(bc[0][0], bc[0][1])
+    # all ranks end with identical reduced gradients
+    by_rank = {r[0]: r[1] for r in results}
+    for k in by_rank[0]:
+        assert all(np.array_equal(by_rank[0][k], by_rank[r][k]) for r in range(1, world)), k
+    # the minibatches really are different ones (a fixture copied N times would pass everything above)
+    idxs = [tuple(g["rng/idxs"].tolist()) for g in fx]
+    assert len(set(idxs)) == world
