@@ -166,17 +166,39 @@ def color_jiggle(imgs_u8: np.ndarray, params: torch.Tensor, order) -> torch.Tens
 # --------------------------------------------------------------------------
 # networks (PyTorch CPU fp32)
 # --------------------------------------------------------------------------
+class _ReluGivenBranch(torch.autograd.Function):
+    """relu(x) whose DERIVATIVE takes its branch (x > 0 or not) from a given boolean tensor instead of from x.
+    The value is the reference's ``torch.relu`` (encoder.py:81,86) unchanged.  Used by the full-size parity tests
+    only: a pre-activation within rounding of 0 is positive in one fp32 evaluation of the network and not in
+    another (1-2 elements out of 20 million per layer at B=512), and since a conv weight gradient is a sum of
+    ~600k signed, largely cancelling terms, ONE such element moves it by ~1e-4 .. 1e-3 of its size.  Comparing two
+    evaluations element by element is meaningful only when both took the same branch at those elements; the tests
+    assert separately that the disagreeing elements are few and all within rounding of 0."""
+
+    @staticmethod
+    def forward(ctx, x, positive):
+        ctx.save_for_backward(positive)
+        return x.clamp_min(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (positive,) = ctx.saved_tensors
+        return g * positive.to(g.dtype), None
+
+
 def encoder_forward(p: Params, prefix: str, obs: torch.Tensor, num_layers: int,
                     detach: bool = False, output_logits: bool = True,
-                    conv_prefix: Optional[str] = None, outputs: Optional[dict] = None) -> torch.Tensor:
+                    conv_prefix: Optional[str] = None, outputs: Optional[dict] = None,
+                    relu_branches: Optional[list] = None) -> torch.Tensor:
     """CNNEncoder.forward (encoder.py:77-110).  obs: float NCHW in [0,255].
     ``conv_prefix`` lets the actor use the critic's conv tensors (weight tying,
-    encoder.py:112-116 / curl_sac.py:290)."""
+    encoder.py:112-116 / curl_sac.py:290).  ``relu_branches`` (tests only): one boolean NCHW tensor per conv
+    layer, the branch each ReLU's derivative takes (see _ReluGivenBranch); None = the plain ``torch.relu``."""
     cp = conv_prefix if conv_prefix is not None else prefix
     x = obs / 255.0
     for i in range(num_layers):
-        x = torch.relu(F.conv2d(x, p[f"{cp}convs.{i}.weight"], p[f"{cp}convs.{i}.bias"],
-                                stride=2 if i == 0 else 1))
+        x = F.conv2d(x, p[f"{cp}convs.{i}.weight"], p[f"{cp}convs.{i}.bias"], stride=2 if i == 0 else 1)
+        x = torch.relu(x) if relu_branches is None else _ReluGivenBranch.apply(x, relu_branches[i])
         if outputs is not None:
             outputs[f"conv{i + 1}"] = x
     h = x.reshape(x.size(0), -1)
@@ -226,9 +248,10 @@ def actor_forward(actor: Params, critic: Params, obs: torch.Tensor, noise: Optio
 
 
 def critic_forward(critic: Params, obs: torch.Tensor, action: torch.Tensor, num_layers: int,
-                   detach_encoder: bool = False, outputs: Optional[dict] = None):
+                   detach_encoder: bool = False, outputs: Optional[dict] = None, relu_branches: Optional[list] = None):
     """Critic.forward / QFunction.forward (curl_sac.py:135-169)."""
-    z = encoder_forward(critic, "encoder.", obs, num_layers, detach=detach_encoder, outputs=outputs)
+    z = encoder_forward(critic, "encoder.", obs, num_layers, detach=detach_encoder, outputs=outputs,
+                        relu_branches=relu_branches)
     za = torch.cat([z, action], dim=1)
     return mlp3(critic, "Q1.trunk.", za), mlp3(critic, "Q2.trunk.", za)
 
@@ -253,9 +276,11 @@ def _grads(p: Params) -> Dict[str, Optional[torch.Tensor]]:
 
 def critic_phase(actor: Params, critic: Params, critic_target: Params, log_alpha: torch.Tensor,
                  obs, action, reward, next_obs, not_done, noise, *, num_layers: int, discount: float,
-                 log_std_min: float, log_std_max: float, detach_encoder: bool = False):
+                 log_std_min: float, log_std_max: float, detach_encoder: bool = False,
+                 relu_branches: Optional[list] = None):
     """CurlSacAgent.update_critic up to and including backward
-    (curl_sac.py:349-367).  Returns dict(loss, target_Q, q1, q2, grads, enc)."""
+    (curl_sac.py:349-367).  Returns dict(loss, target_Q, q1, q2, grads, enc).
+    ``relu_branches``: see encoder_forward (applies to the critic's differentiated pass over ``obs``)."""
     with torch.no_grad():
         _, policy_action, log_pi, _ = actor_forward(actor, critic, next_obs, noise, num_layers,
                                                     log_std_min, log_std_max)
@@ -266,7 +291,8 @@ def critic_phase(actor: Params, critic: Params, critic_target: Params, log_alpha
         target_Q = target_Q.to(torch.float32)
     c = _leafify(critic)
     enc = {}
-    q1, q2 = critic_forward(c, obs, action, num_layers, detach_encoder=detach_encoder, outputs=enc)
+    q1, q2 = critic_forward(c, obs, action, num_layers, detach_encoder=detach_encoder, outputs=enc,
+                            relu_branches=relu_branches)
     loss = F.mse_loss(q1, target_Q) + F.mse_loss(q2, target_Q)
     loss.backward()
     return dict(loss=loss.detach(), target_Q=target_Q, q1=q1.detach(), q2=q2.detach(),
@@ -297,13 +323,14 @@ def actor_phase(actor: Params, critic: Params, log_alpha: torch.Tensor, obs, noi
                 q1=q1.detach(), q2=q2.detach(), grads=grads, log_alpha_grad=la.grad.detach().clone())
 
 
-def cpc_phase(critic: Params, critic_target: Params, W: torch.Tensor, obs_anchor, obs_pos, *, num_layers: int):
+def cpc_phase(critic: Params, critic_target: Params, W: torch.Tensor, obs_anchor, obs_pos, *, num_layers: int,
+              relu_branches: Optional[list] = None):
     """CurlSacAgent.update_cpc up to backward (curl_sac.py:406-417): anchors
     through the online encoder, positives through the target encoder under
     no_grad, bilinear logits, cross-entropy against arange(B)."""
     enc = _leafify({k: v for k, v in critic.items() if k.startswith("encoder.")})
     Wl = W.detach().clone().requires_grad_(True)
-    z_a = encoder_forward(enc, "encoder.", obs_anchor, num_layers)
+    z_a = encoder_forward(enc, "encoder.", obs_anchor, num_layers, relu_branches=relu_branches)
     with torch.no_grad():
         z_pos = encoder_forward(critic_target, "encoder.", obs_pos, num_layers)
     logits = curl_logits(Wl, z_a, z_pos)

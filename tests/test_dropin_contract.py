@@ -322,13 +322,18 @@ def test_training_loop_call_sequence_on_the_device(tmp_path):
     probe = r["augmentor"].evaluation_augmentation(r["added"][-1][3])
     assert not np.array_equal(other.select_action(probe), agent.select_action(probe))
     other.load(r["model_dir"], "random_crop", 50)
+    # (the loop's last iteration saved at step 50 and then trained once more: the files hold the state at the save)
+    saved = torch.load(os.path.join(r["model_dir"], "random_crop_critic_50.pt"))
+    assert any(not torch.equal(v.cpu(), agent.critic.state_dict()[k].cpu()) for k, v in saved.items())
+    for k, v in saved.items():
+        assert torch.equal(v.cpu(), other.critic.state_dict()[k].cpu()), k
+        assert torch.equal(v.cpu(), other.critic_target.state_dict()[k].cpu()), k   # curl_sac.py:464
+    agent.load(r["model_dir"], "random_crop", 50)
     with utils.eval_mode(agent, other):
         assert np.array_equal(other.select_action(probe), agent.select_action(probe))
         noise = torch.randn(1, 2, device=dev)
         assert np.array_equal(other.sample_action(r["added"][-1][3], noise=noise),
                               agent.sample_action(r["added"][-1][3], noise=noise))
-    for k, v in agent.critic.state_dict().items():
-        assert torch.equal(v, other.critic.state_dict()[k]), k
     assert utils.module_hash(agent.actor) == utils.module_hash(other.actor)
     # the buffer chunks load back into a new buffer (utils.py:204-216)
     rb2 = utils.ReplayBuffer(obs_shape=r["pre_aug_obs_shape"], action_shape=(2,), capacity=64,
