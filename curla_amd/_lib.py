@@ -19,6 +19,7 @@ SIGNATURES = {
     "curla_conv3x3_s1_fwd": [vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp],
     "curla_conv3x3_s1_fwd2": [vp, vp, vp, vp, c_int, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp],
     "curla_conv3x3_s1_fwd_stack": [c_int, vp, vp, vp, vp, c_int, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp],
+    "curla_conv3x3_s1_stack_granule": [],
     "curla_conv1_fwd2": [vp, vp, vp, vp, vp, vp, vp, c_int, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int,
                          c_int, c_float, vp],
     "curla_conv3x3_s1_dgrad": [vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp],

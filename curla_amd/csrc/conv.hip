@@ -17,6 +17,8 @@
 // or stores, the other's waves keep the matrix pipe fed.  What bounds the tile loops is VALU issue time (a VALU
 // instruction and an MFMA cannot issue in the same cycle), so everything in them is counted in instructions:
 // packed fp32 adds for the Winograd transform, division-free pixel walks, epilogues deferred into the next tile.
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 #include "common.h"
@@ -362,6 +364,36 @@ __global__ __launch_bounds__(256, 2) void conv_s1_stack_kernel(ConvS1StackArgs S
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
   }
+}
+
+#include "conv_rw.h"
+
+// Row-walk kernels (conv_rw.h).  Forward: 512-thread workgroups, ONE per CU, persistent over the samples they own;
+// 96 KB of LDS hold the transformed filters of both problems of a layer, so the eight waves draw their steps from one
+// pool (minibatch one and two together) and nothing but the layer boundary synchronises them.
+__global__ __launch_bounds__(512, 2) void conv_rw_fwd_kernel(rw::Args A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  for (int l = 0; l < A.nlayers; ++l) {
+    rw::build_filter<MODE_FWD, 512>(lds, A.p[l][0].w, threadIdx.x);
+    if (A.p[l][1].B > 0) rw::build_filter<MODE_FWD, 512>(lds + rw::kWFloats, A.p[l][1].w, threadIdx.x);
+    __syncthreads();
+    rw::run_layer<MODE_FWD, 8>(A.g[l], A.p[l][0], A.p[l][1], lds, blockIdx.x, gridDim.x);
+    if (l + 1 < A.nlayers) {
+      // this workgroup's outputs of layer l are (only) its own inputs of layer l + 1; the barrier also keeps the
+      // filter in LDS until every wave has finished reading it
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+  }
+}
+
+// data gradient alone (256-thread workgroups: the form that shares a launch with the weight gradient below)
+__global__ __launch_bounds__(256, 2) void conv_rw_dgrad_kernel(rw::Args A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  rw::build_filter<MODE_DGRAD, 256>(lds, A.p[0][0].w, threadIdx.x);
+  __syncthreads();
+  rw::run_layer<MODE_DGRAD, 4>(A.g[0], A.p[0][0], A.p[0][1], lds, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -1012,6 +1044,19 @@ __global__ __launch_bounds__(256, 2) void bwd_s1_kernel(WgradS1Args wa, ConvS1Ar
     conv_s1_body<MODE_DGRAD>(da, (int)blockIdx.x - nw, (int)gridDim.x - nw);
 }
 
+// the same launch with the data gradient in its row-walk form (conv_rw.h)
+template <int WALK>
+__global__ __launch_bounds__(256, 2) void bwd_rw_kernel(WgradS1Args wa, rw::Args da, int nw) {
+  if ((int)blockIdx.x < nw) {
+    wgrad_s1_body<WALK>(wa, blockIdx.x, nw);
+  } else {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    rw::build_filter<MODE_DGRAD, 256>(lds, da.p[0][0].w, threadIdx.x);
+    __syncthreads();
+    rw::run_layer<MODE_DGRAD, 4>(da.g[0], da.p[0][0], da.p[0][1], lds, (int)blockIdx.x - nw, (int)gridDim.x - nw);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // weight gradient of the first layer (stride 2, Cin = C, input re-read from
 // the uint8 frames / float tensor exactly as the forward does).
@@ -1492,9 +1537,65 @@ int set_lds(K kernel, size_t bytes) {
   return CURLA_OK;
 }
 
+// Which stride-1 forward / data-gradient kernels run: the row-walk form (conv_rw.h) unless CURLA_S1_IMPL=band asks for
+// the banded one (kept for A/B timing; both pass the same tests).
+bool use_rw() {
+  static const bool band = getenv("CURLA_S1_IMPL") && !strcmp(getenv("CURLA_S1_IMPL"), "band");
+  return !band;
+}
+
+// The row-walk forward keeps (pixel pair, 32 channels) of a whole row in flight per wave; any width works, the strips
+// only get more numerous.  Limits: byte offsets inside one sample must fit 31 bits.
+bool rw_supported(int Hi, int Wi) { return (long long)(Hi + 2) * (Wi + 2) * 128 < (1LL << 30); }
+
+int launch_rw_fwd(int nlayers, const float* in, const float* const* w, const float* const* bias, float* const* out, int B,
+                  const float* in2, const float* const* w2, const float* const* bias2, float* const* out2, int B2, int Hi,
+                  int Wi, bool owned, hipStream_t st) {
+  rw::Args A;
+  A.nlayers = nlayers;
+  for (int l = 0; l < rw::kMaxLayers; ++l) {
+    const bool on = l < nlayers;
+    const int hi = Hi - 2 * l, wi = Wi - 2 * l;
+    A.g[l] = on ? rw::plan(hi, wi, hi - 2, wi - 2) : rw::Geom{};
+    A.p[l][0] = on ? rw::Problem{l == 0 ? in : out[l - 1], w[l], bias[l], out[l], B} : rw::Problem{};
+    A.p[l][1] = (on && B2 > 0) ? rw::Problem{l == 0 ? in2 : out2[l - 1], w2[l], bias2[l], out2[l], B2} : rw::Problem{};
+    if (on && (hi < 3 || wi < 3)) return CURLA_ERR_UNSUPPORTED;
+  }
+  if (!rw_supported(Hi, Wi)) return CURLA_ERR_UNSUPPORTED;
+  const int cus = curla_cu_count();
+  const int bmax = B > B2 ? B : B2;
+  const int grid = owned ? cus : (bmax < cus ? bmax : cus);
+  const size_t lds = (size_t)(B2 > 0 ? 2 : 1) * rw::kWFloats * sizeof(float);
+  int rc = set_lds(conv_rw_fwd_kernel, lds);
+  if (rc != CURLA_OK) return rc;
+  hipLaunchKernelGGL(conv_rw_fwd_kernel, dim3(grid), dim3(512), lds, st, A);
+  return curla_launch_status();
+}
+
+// data-gradient arguments: input = the layer's output gradient [B][Ho][Wo][32], output [B][Ho+2][Wo+2][32]
+rw::Args rw_dgrad_args(const float* g, const float* w, const float* act_below, float* gin, int B, int Ho, int Wo) {
+  rw::Args A;
+  A.nlayers = 1;
+  for (int l = 0; l < rw::kMaxLayers; ++l) A.g[l] = rw::Geom{}, A.p[l][0] = rw::Problem{}, A.p[l][1] = rw::Problem{};
+  A.g[0] = rw::plan(Ho, Wo, Ho + 2, Wo + 2);
+  A.p[0][0] = rw::Problem{g, w, act_below, gin, B};
+  return A;
+}
+
 int launch_conv_s1(int mode, const float* in, const float* w, const float* aux, float* out, int B, int Hs, int Ws,
                    hipStream_t st, const float* in2 = nullptr, const float* w2 = nullptr, const float* aux2 = nullptr,
                    float* out2 = nullptr, int B2 = 0) {
+  if (use_rw() && rw_supported(Hs, Ws)) {
+    if (mode == MODE_FWD)
+      return launch_rw_fwd(1, in, &w, &aux, &out, B, in2, &w2, &aux2, &out2, B2, Hs, Ws, false, st);
+    const rw::Args A = rw_dgrad_args(in, w, aux, out, B, Hs, Ws);
+    const int cap = 2 * curla_cu_count();
+    const size_t lds = rw::kWFloats * sizeof(float);
+    int rc = set_lds(conv_rw_dgrad_kernel, lds);
+    if (rc != CURLA_OK) return rc;
+    hipLaunchKernelGGL(conv_rw_dgrad_kernel, dim3(B < cap ? B : cap), dim3(256), lds, st, A);
+    return curla_launch_status();
+  }
   ConvS1Args a;
   a.in = in, a.w = w, a.aux = aux, a.out = out;
   a.in2 = in2, a.w2 = w2, a.aux2 = aux2, a.out2 = out2, a.B2 = B2;
@@ -1578,6 +1679,19 @@ int curla_conv3x3_s1_fwd_stack(int nlayers, const float* in, const float* const*
   CURLA_REQUIRE(nlayers > 0 && nlayers <= kMaxStack && in && w && bias && out && B > 0 && Hi >= 3 && Wi >= 3);
   CURLA_REQUIRE(B2 == 0 || (in2 && w2 && bias2 && out2));
   if (channels != 32) return CURLA_ERR_UNSUPPORTED;
+  if (use_rw()) {
+    // ownership of samples by workgroups needs whole rounds of the grid (one workgroup per CU) over each minibatch
+    const int G1 = curla_cu_count();
+    if (B % G1 != 0 || B2 % G1 != 0) return CURLA_ERR_UNSUPPORTED;
+    CURLA_REQUIRE(aligned16(in) && (!B2 || aligned16(in2)));
+    for (int l = 0; l < nlayers; ++l) {
+      CURLA_REQUIRE(w[l] && bias[l] && out[l] && aligned16(w[l]) && aligned16(bias[l]) && aligned16(out[l]));
+      CURLA_REQUIRE(!B2 || (w2[l] && bias2[l] && out2[l] && aligned16(w2[l]) && aligned16(bias2[l]) && aligned16(out2[l])));
+    }
+    if (Hi - 2 * nlayers < 1 || Wi - 2 * nlayers < 1) return CURLA_ERR_UNSUPPORTED;
+    return launch_rw_fwd(nlayers, in, w, bias, out, B, in2, w2, bias2, out2, B2, Hi, Wi, true,
+                         static_cast<hipStream_t>(stream));
+  }
   const int G = 2 * curla_cu_count();
   // ownership of samples by workgroups needs whole rounds of the grid over each minibatch
   if (B % G != 0 || B2 % G != 0) return CURLA_ERR_UNSUPPORTED;
@@ -1605,6 +1719,8 @@ int curla_conv3x3_s1_fwd_stack(int nlayers, const float* in, const float* const*
   hipLaunchKernelGGL(conv_s1_stack_kernel, dim3(G), dim3(256), lds, static_cast<hipStream_t>(stream), S);
   return curla_launch_status();
 }
+
+int curla_conv3x3_s1_stack_granule(void) { return use_rw() ? curla_cu_count() : 2 * curla_cu_count(); }
 
 int curla_conv3x3_s1_dgrad(const float* g, const float* w, const float* act_below, float* gin, int B, int Ho, int Wo,
                            int channels, void* stream) {
@@ -1824,6 +1940,30 @@ int curla_conv3x3_s1_bwd_slabs(const float* in, const float* g, const float* w, 
   const int cap = split ? curla_cu_count() : 2 * curla_cu_count();
   const int items_w = B * wa.nbands;
   const int nw = items_w < cap ? items_w : cap;
+  if (use_rw() && rw_supported(Hi, Wi)) {
+    // data gradient in its row-walk form: workgroup k of its block range owns samples k, k + nd, ...
+    const rw::Args ra = rw_dgrad_args(g, w, in, gin, B, Ho, Wo);
+    const int nd_rw = B < cap ? B : cap;
+    size_t lds_rw = rw::kWFloats * sizeof(float);
+    if (lds_rw < lds_w) lds_rw = lds_w;
+    int rc_rw;
+    hipStream_t st_rw = static_cast<hipStream_t>(stream);
+    switch (wgrad_walk(Wo)) {
+      case 1:
+        if ((rc_rw = set_lds(bwd_rw_kernel<1>, lds_rw)) != CURLA_OK) return rc_rw;
+        hipLaunchKernelGGL(bwd_rw_kernel<1>, dim3(nw + nd_rw), dim3(256), lds_rw, st_rw, wa, ra, nw);
+        break;
+      case 2:
+        if ((rc_rw = set_lds(bwd_rw_kernel<2>, lds_rw)) != CURLA_OK) return rc_rw;
+        hipLaunchKernelGGL(bwd_rw_kernel<2>, dim3(nw + nd_rw), dim3(256), lds_rw, st_rw, wa, ra, nw);
+        break;
+      default:
+        if ((rc_rw = set_lds(bwd_rw_kernel<0>, lds_rw)) != CURLA_OK) return rc_rw;
+        hipLaunchKernelGGL(bwd_rw_kernel<0>, dim3(nw + nd_rw), dim3(256), lds_rw, st_rw, wa, ra, nw);
+    }
+    *nslabs = nw;
+    return curla_launch_status();
+  }
   // data-gradient part (as launch_conv_s1 in MODE_DGRAD: input = the output gradient [B][Ho][Wo], output [B][Hi][Wi])
   ConvS1Args da;
   da.in = g, da.w = w, da.aux = in, da.out = gin;

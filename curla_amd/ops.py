@@ -107,7 +107,7 @@ def conv_s1_fwd_stack(x, ws, bs, outs, x2=None, ws2=None, bs2=None, outs2=None):
     B, H, W, C = x.shape
     n = len(ws)
     B2 = 0 if x2 is None else x2.shape[0]
-    G = 2 * cu_count()
+    G = stack_granule()
     if n > 6 or B % G or B2 % G:
         return False
     P = ctypes.c_void_p * n
@@ -122,6 +122,19 @@ def conv_s1_fwd_stack(x, ws, bs, outs, x2=None, ws2=None, bs2=None, outs2=None):
     call("curla_conv3x3_s1_fwd_stack", n, ptr(x), ctypes.addressof(a_w), ctypes.addressof(a_b), ctypes.addressof(a_o), B,
          p2[0], p2[1], p2[2], p2[3], B2, H, W, C, stream())
     return True
+
+
+_STACK_GRANULE = None
+
+
+def stack_granule():
+    """Batch-size multiple conv_s1_fwd_stack needs (its persistent grid: one workgroup per CU, two in the banded form)."""
+    global _STACK_GRANULE
+    if _lib._trace_hook is not None:
+        return 256  # (launch-schedule tests without a device: MI355X's CU count)
+    if _STACK_GRANULE is None:
+        _STACK_GRANULE = int(_lib.load().curla_conv3x3_s1_stack_granule())
+    return _STACK_GRANULE
 
 
 _CU_COUNT = None

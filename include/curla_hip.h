@@ -67,13 +67,16 @@ int curla_conv3x3_s1_fwd2(const float* in, const float* w, const float* bias, fl
                           void* stream);
 /* The whole stack of stride-1 layers of one or two minibatches (B2 = 0: one) in ONE launch: layer l maps
  * [B][Hi-2l][Wi-2l][32] (in for l = 0, out[l-1] after) to out[l] with w[l], bias[l].  Every activation is written to HBM
- * as by the single-layer calls.  Needs B and B2 to be multiples of twice the CU count (a workgroup of the persistent
- * grid then owns its samples through all layers and only has to wait for itself); CURLA_ERR_UNSUPPORTED otherwise --
- * fall back to one curla_conv3x3_s1_fwd2 per layer. */
+ * as by the single-layer calls.  Needs B and B2 to be multiples of curla_conv3x3_s1_stack_granule() (a workgroup of the
+ * persistent grid then owns its samples through all layers and only has to wait for itself); CURLA_ERR_UNSUPPORTED
+ * otherwise -- fall back to one curla_conv3x3_s1_fwd2 per layer. */
 int curla_conv3x3_s1_fwd_stack(int nlayers, const float* in, const float* const* w, const float* const* bias,
                                float* const* out, int B, const float* in2, const float* const* w2,
                                const float* const* bias2, float* const* out2, int B2, int Hi, int Wi, int channels,
                                void* stream);
+/* Batch-size multiple curla_conv3x3_s1_fwd_stack needs: the size of its persistent grid on the current device (one
+ * workgroup per CU in the row-walk form, two in the banded one). */
+int curla_conv3x3_s1_stack_granule(void);
 
 /* Autograd of the above (what critic_loss.backward() / loss.backward() run,
  * curl_sac.py:366,417).  `g` is the gradient w.r.t. the layer's pre-activation

@@ -912,8 +912,8 @@ def test_flat_adam_step_with_float64_scalar():
 def test_conv_s1_forward_stack_one_launch(ops, two):
     """curla_conv3x3_s1_fwd_stack: three stride-1 layers of one or two minibatches in ONE launch (a workgroup owns its
     samples through the layers) -- every layer's activations bit-identical to the per-layer launches.  Batch sizes
-    must be multiples of the persistent grid (2 x CUs); anything else is refused."""
-    G = 2 * ops.cu_count()
+    must be multiples of the persistent grid (ops.stack_granule()); anything else is refused."""
+    G = ops.stack_granule()
     H = W = 13
     B1, B2 = 2 * G, G
     L = 3
@@ -941,7 +941,7 @@ def test_conv_s1_forward_stack_full_size(ops):
     + the target pass of 512, 37x37 -> 35 -> 33 -> 31): every layer bit-identical to per-layer launches, twice in
     a row into the same buffers (a workgroup reads back its own stores of the previous layer: a stale or late line
     would show up here)."""
-    G = 2 * ops.cu_count()
+    G = ops.stack_granule()
     if 1024 % G or 512 % G:
         pytest.skip("grid size does not divide the BASELINE batch sizes on this device")
     H = W = 37

@@ -108,8 +108,24 @@ def main():
                 report(f"[abl {fl}] conv_s1_dgrad {H}->{H + 2}", timeit(lambda: ops.conv_s1_dgrad(g, w, below, gin)), fl_)
         if flags != [0]:
             lib.curla_debug_ablate(0)
+        # the whole stack of stride-1 layers of two minibatches in one launch, as update() issues it: critic phase
+        # ([obs | next_obs] online + next_obs target) and actor / CURL phase (obs online + positives target)
+        for B1, B2 in ((2 * B, B), (B, B)):
+            x1, x2 = torch.relu(r(B1, 37, 37, 32)), torch.relu(r(B2, 37, 37, 32))
+            ws_, bs_ = [r(32, 32, 3, 3) * 0.1 for _ in range(3)], [r(32) * 0.1 for _ in range(3)]
+            o1 = [torch.empty(B1, 35 - 2 * i, 35 - 2 * i, 32, device=dev) for i in range(3)]
+            o2 = [torch.empty(B2, 35 - 2 * i, 35 - 2 * i, 32, device=dev) for i in range(3)]
+            fl_ = sum(2.0 * (B1 + B2) * (35 - 2 * i) ** 2 * 32 * 32 * 9 for i in range(3))
+            if ops.conv_s1_fwd_stack(x1, ws_, bs_, o1, x2, ws_, bs_, o2):
+                report(f"conv_s1_fwd_stack 37->31, {B1}+{B2}", timeit(lambda: ops.conv_s1_fwd_stack(x1, ws_, bs_, o1, x2, ws_, bs_, o2)), fl_)
         ws = torch.empty(ops.wgrad_workspace_floats(32), device=dev)
         dw, db = torch.empty(32, 32, 3, 3, device=dev), torch.empty(32, device=dev)
+        for H in (37, 35, 33):
+            x = torch.relu(r(B, H, H, 32))
+            g = r(B, H - 2, H - 2, 32)
+            gin = torch.empty_like(x)
+            fl_ = 2.0 * 2 * B * (H - 2) ** 2 * 32 * 32 * 9
+            report(f"conv_s1_bwd_slabs (wgrad + dgrad) {H}", timeit(lambda: ops.conv_s1_bwd_slabs(x, g, w, gin, ws)), fl_)
         for H in (37, 35, 33):
             x = torch.relu(r(B, H, H, 32))
             g = r(B, H - 2, H - 2, 32)
