@@ -1057,6 +1057,24 @@ __global__ __launch_bounds__(256, 2) void bwd_rw_kernel(WgradS1Args wa, rw::Args
   }
 }
 
+#include "conv_rw_wgrad.h"
+
+// weight gradient in its row-walk form (conv_rw_wgrad.h), alone and in one launch with the row-walk data gradient
+__global__ __launch_bounds__(256, 2) void wgrad_rw_kernel(rw::WgradArgs wa) {
+  rw::wgrad_body<4>(wa, blockIdx.x, gridDim.x);
+}
+
+__global__ __launch_bounds__(256, 2) void bwd_rw2_kernel(rw::WgradArgs wa, rw::Args da, int nw) {
+  if ((int)blockIdx.x < nw) {
+    rw::wgrad_body<4>(wa, blockIdx.x, nw);
+  } else {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    rw::build_filter<MODE_DGRAD, 256>(lds, da.p[0][0].w, threadIdx.x);
+    __syncthreads();
+    rw::run_layer<MODE_DGRAD, 4>(da.g[0], da.p[0][0], da.p[0][1], lds, (int)blockIdx.x - nw, (int)gridDim.x - nw);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // weight gradient of the first layer (stride 2, Cin = C, input re-read from
 // the uint8 frames / float tensor exactly as the forward does).
@@ -1543,6 +1561,11 @@ bool use_rw() {
   static const bool band = getenv("CURLA_S1_IMPL") && !strcmp(getenv("CURLA_S1_IMPL"), "band");
   return !band;
 }
+// ... and the weight gradient: CURLA_S1_WGRAD=band keeps the banded kernel beside the row-walk forward / data gradient
+bool use_rw_wgrad() {
+  static const bool band = getenv("CURLA_S1_WGRAD") && !strcmp(getenv("CURLA_S1_WGRAD"), "band");
+  return use_rw() && !band;
+}
 
 // The row-walk forward keeps (pixel pair, 32 channels) of a whole row in flight per wave; any width works, the strips
 // only get more numerous.  Limits: byte offsets inside one sample must fit 31 bits.
@@ -1868,6 +1891,17 @@ static int launch_wgrad_s1(const float* in, const float* g, float* workspace, in
   CURLA_REQUIRE(in && g && workspace && B > 0 && Hi >= 3 && Wi >= 3);
   if (channels != 32) return CURLA_ERR_UNSUPPORTED;
   CURLA_REQUIRE(aligned16(in) && aligned16(g));
+  if (use_rw_wgrad() && rw_supported(Hi, Wi)) {
+    rw::WgradArgs ra{in, g, workspace, B, Hi, Wi, Hi - 2, Wi - 2, rw::plan4(Hi, Wi, Hi - 2, Wi - 2)};
+    const int cap = 2 * curla_cu_count();
+    const int grid = B < cap ? B : cap;
+    const size_t lds = kPartialS1 * sizeof(float);
+    int rc = set_lds(wgrad_rw_kernel, lds);
+    if (rc != CURLA_OK) return rc;
+    hipLaunchKernelGGL(wgrad_rw_kernel, dim3(grid), dim3(256), lds, st, ra);
+    *nslabs = grid;
+    return curla_launch_status();
+  }
   WgradS1Args a;
   a.in = in, a.g = g, a.partial = workspace;
   a.B = B, a.Hi = Hi, a.Wi = Wi, a.Ho = Hi - 2, a.Wo = Wi - 2;
@@ -1920,6 +1954,23 @@ int curla_conv3x3_s1_bwd_slabs(const float* in, const float* g, const float* w, 
   if (channels != 32) return CURLA_ERR_UNSUPPORTED;
   CURLA_REQUIRE(aligned16(in) && aligned16(g) && aligned16(w) && aligned16(gin));
   const int Ho = Hi - 2, Wo = Wi - 2;
+  if (use_rw_wgrad() && rw_supported(Hi, Wi)) {
+    // both halves in their row-walk forms: equal numbers of workgroups of each kind (the two do about the same
+    // number of MFMAs per sample), each owning samples k, k + n, ...
+    static const int split_rw = getenv("CURLA_BWD_SPLIT") ? atoi(getenv("CURLA_BWD_SPLIT")) : -1;
+    const bool split2 = split_rw >= 0 ? split_rw != 0 : (long long)B * Ho * Wo <= (1LL << 20);
+    const int cap2 = split2 ? curla_cu_count() : 2 * curla_cu_count();
+    const int n2 = B < cap2 ? B : cap2;
+    rw::WgradArgs wr{in, g, workspace, B, Hi, Wi, Ho, Wo, rw::plan4(Hi, Wi, Ho, Wo)};
+    const rw::Args dr = rw_dgrad_args(g, w, in, gin, B, Ho, Wo);
+    size_t lds2 = rw::kWFloats * sizeof(float);
+    if (lds2 < kPartialS1 * sizeof(float)) lds2 = kPartialS1 * sizeof(float);
+    int rc2 = set_lds(bwd_rw2_kernel, lds2);
+    if (rc2 != CURLA_OK) return rc2;
+    hipLaunchKernelGGL(bwd_rw2_kernel, dim3(2 * n2), dim3(256), lds2, static_cast<hipStream_t>(stream), wr, dr, n2);
+    *nslabs = n2;
+    return curla_launch_status();
+  }
   // weight-gradient part (as launch_wgrad_s1)
   WgradS1Args wa;
   wa.in = in, wa.g = g, wa.partial = workspace;
