@@ -436,8 +436,8 @@ def measure(job, name, steps, warmup, with_cpu_baseline):
         per_update = sum(flops_per_update(cfg, first_step + i) for i in range(steps)) / steps
         # the dominant kernel: all stride-1 forward layers of two minibatches in one launch when the batch sizes allow,
         # else one launch per layer
-        stacked = B % (2 * job.cu_count()) == 0
-        kname = "conv_s1_stack_kernel" if stacked else "conv_s1_kernel<0>"
+        stacked = B % job.cu_count() == 0  # (ops.stack_granule(): one workgroup per CU owns its samples)
+        kname = "conv_rw_fwd_kernel"
         traffic, mfma_busy, pmc_note = (None, None, "dry run") if job.dry else committed_counters(name, kname)
         n_launch = max(1, len(ev_pairs))
         avg_ms = kms / n_launch
@@ -456,9 +456,11 @@ def measure(job, name, steps, warmup, with_cpu_baseline):
             "conv_algorithmic_gflop_per_update": per_update / 1e9,
             "conv_roofline_frac_whole_update": per_update * (steps / dt) / (PEAK_F32_TFLOPS * 1e12),
             "roofline": {"bound": "mfma",
-                         "kernel": ("conv_s1_stack_kernel (all 3x3 s1 32->32 + bias + ReLU layers of two minibatches per "
-                                    "launch, f32 MFMA 16x16x4)") if stacked else
-                                   "conv_s1_kernel<FWD> (3x3 s1 32->32 + bias + ReLU, f32 MFMA 16x16x4)",
+                         "kernel": ("conv_rw_fwd_kernel (row-walk Winograd F(2,3): all 3x3 s1 32->32 + bias + ReLU layers of "
+                                    "two minibatches per launch, f32 MFMA 16x16x4; FLOPs counted as direct-conv FLOPs)")
+                                   if stacked else
+                                   "conv_rw_fwd_kernel (row-walk Winograd F(2,3): one 3x3 s1 32->32 + bias + ReLU layer per "
+                                   "launch, f32 MFMA 16x16x4; FLOPs counted as direct-conv FLOPs)",
                          "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_TFLOPS, "traffic": traffic,
                          "traffic_unit": "HBM bytes per launch; " + pmc_note,

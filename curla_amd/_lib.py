@@ -110,12 +110,20 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise CurlaHipError(f"{LIB_PATH} is missing: build it with `python -m curla_amd.build` "
                             "(there is no CPU/PyTorch fallback for the learner path)")
-    if LIB_PATH == os.path.join(_HERE, "libcurla_hip.so"):
+    # an in-tree library must come from the sources next to it (a stale .so silently running old kernels is the worst
+    # failure mode of an in-place build).  CURLA_SKIP_SRCHASH=1 turns the check off for a library built some other
+    # way (a C-ABI consumer's own build, an install without the sources).
+    if LIB_PATH == os.path.join(_HERE, "libcurla_hip.so") and os.environ.get("CURLA_SKIP_SRCHASH", "0") != "1":
         from . import build
-        if build.built_hash() != build.source_hash():
+        try:
+            want = build.source_hash()
+        except OSError as e:
+            raise CurlaHipError(f"cannot check {LIB_PATH} against its sources ({e}); set CURLA_SKIP_SRCHASH=1 to load "
+                                "a library that was built elsewhere") from e
+        if build.built_hash() != want:
             raise CurlaHipError(f"{LIB_PATH} was built from other sources than the ones in curla_amd/csrc "
-                                f"(stamp {build.built_hash()} != {build.source_hash()}): rebuild it with "
-                                "`python -m curla_amd.build`")
+                                f"(stamp {build.built_hash()} != {want}): rebuild it with "
+                                "`python -m curla_amd.build` (or CURLA_SKIP_SRCHASH=1 for an externally built library)")
     lib = ctypes.CDLL(LIB_PATH)
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library drift apart

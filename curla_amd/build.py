@@ -19,9 +19,27 @@ ARCH = "gfx950"  # MI355X only
 FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC"]
 
 
+def _compiler_id():
+    """The compiler the stamp belongs to: HIPCC's path and the ROCm release next to it (read from its version file:
+    running `hipcc --version` at every import would cost a second and need the compiler at run time)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.realpath(hipcc)))
+    ver = "unknown"
+    for name in (os.path.join(root, ".info", "version"), "/opt/rocm/.info/version"):
+        try:
+            with open(name) as f:
+                ver = f.read().strip()
+            break
+        except OSError:
+            continue
+    return hipcc + " | rocm " + ver
+
+
 def source_hash():
-    """sha256 (first 16 hex digits) over the kernel sources, the shared header, the C-ABI header and the flags."""
+    """sha256 (first 16 hex digits) over the kernel sources, the shared header, the C-ABI header, the flags and the
+    compiler (HIPCC's path and the ROCm release it belongs to: another release is another build)."""
     h = hashlib.sha256(" ".join(FLAGS).encode())
+    h.update(_compiler_id().encode())
     for path in sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) + [HEADER]:
         h.update(os.path.basename(path).encode())
         with open(path, "rb") as f:

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "../../include/curla_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -49,6 +51,24 @@ static inline int curla_cu_count() {
     cached[dev] = n;
   }
   return n;
+}
+
+// Raise a kernel's dynamic-LDS limit to `bytes` once per (kernel, device).  hipFuncSetAttribute is per-function,
+// per-device process state (not stream-ordered): it is set on first use of a kernel on a device and never lowered, so
+// a process that drives several GPUs configures each of them, and two host threads cannot race each other's limit.
+static inline int curla_set_dyn_lds(const void* fn, size_t bytes) {
+  static std::mutex mu;
+  static const void* done_fn[256];
+  static int done_dev[256];
+  static int ndone = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return CURLA_ERR_LAUNCH;
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < ndone; ++i)
+    if (done_fn[i] == fn && done_dev[i] == dev) return CURLA_OK;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return CURLA_ERR_LAUNCH;
+  if (ndone < 256) done_fn[ndone] = fn, done_dev[ndone] = dev, ++ndone;
+  return CURLA_OK;
 }
 
 #define CURLA_REQUIRE(cond) \

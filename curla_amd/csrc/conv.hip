@@ -1535,24 +1535,12 @@ void plan_bands_conv_s1(int Ho, int Wo, int budget_px, int* th_out, int* h1_out,
     }
 }
 
-// Dynamic LDS limit of a kernel.  hipFuncSetAttribute is per-function process state (not stream-ordered), so it is
-// raised once per kernel to the largest size this library ever asks for -- never lowered, never set per launch:
-// two host threads launching the same kernel with different band sizes cannot race each other's limit.
+// Dynamic LDS limit of a kernel: raised once per (kernel, device) to the largest size this library ever asks for --
+// never lowered, never set per launch (curla_set_dyn_lds, common.h).
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
   if (bytes > (size_t)kMaxLds) return CURLA_ERR_UNSUPPORTED;
-  const void* fn = reinterpret_cast<const void*>(kernel);
-  // (K is a function-pointer type shared by all instantiations with the same signature: the kernels already
-  // configured are kept in a small table rather than one flag per type)
-  static std::mutex mu;
-  static const void* done[64];
-  static int ndone = 0;
-  std::lock_guard<std::mutex> lock(mu);
-  for (int i = 0; i < ndone; ++i)
-    if (done[i] == fn) return CURLA_OK;
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds) != hipSuccess) return CURLA_ERR_LAUNCH;
-  if (ndone < 64) done[ndone++] = fn;
-  return CURLA_OK;
+  return curla_set_dyn_lds(reinterpret_cast<const void*>(kernel), kMaxLds);
 }
 
 // Which stride-1 forward / data-gradient kernels run: the row-walk form (conv_rw.h) unless CURLA_S1_IMPL=band asks for

@@ -995,9 +995,8 @@ int curla_fc_dw(const float* dz, const float* x, float* dW, int B, int F, int K,
     FcBwdArgs gx;
     gx.dz = dz, gx.W = nullptr, gx.mask = x, gx.out = nullptr, gx.B = B, gx.F = F, gx.K = K;
     const size_t lds1 = (size_t)4 * 4 * 4 * 64 * sizeof(f32x4);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fc_bwd_kernel<13, 3, 2, false>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
-    if (attr != hipSuccess) return CURLA_ERR_LAUNCH;
+    if (curla_set_dyn_lds(reinterpret_cast<const void*>(fc_bwd_kernel<13, 3, 2, false>), lds1) != CURLA_OK)
+      return CURLA_ERR_LAUNCH;
     hipLaunchKernelGGL((fc_bwd_kernel<13, 3, 2, false>), dim3((K + 63) / 64), dim3(256), lds1, st, gx, dW);
     return curla_launch_status();
   }
@@ -1006,10 +1005,9 @@ int curla_fc_dw(const float* dz, const float* x, float* dW, int B, int F, int K,
   const size_t lds = (size_t)4 * nt * 4 * 64 * sizeof(f32x4);  // 16 KB per feature tile
 #define CURLA_FC_DW(NT)                                                                                               \
   do {                                                                                                                \
-    static const hipError_t attr =                                                                                    \
-        hipFuncSetAttribute(reinterpret_cast<const void*>(fc_dw_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            (int)((size_t)4 * NT * 4 * 64 * sizeof(f32x4))); /* once, thread-safe */                   \
-    if (attr != hipSuccess) return CURLA_ERR_LAUNCH;                                                                  \
+    if (curla_set_dyn_lds(reinterpret_cast<const void*>(fc_dw_kernel<NT>), (size_t)4 * NT * 4 * 64 * sizeof(f32x4)) != \
+        CURLA_OK) /* once per device, thread-safe */                                                                  \
+      return CURLA_ERR_LAUNCH;                                                                                        \
     hipLaunchKernelGGL(fc_dw_kernel<NT>, grid, dim3(256), lds, st, g);                                                \
   } while (0)
   if (nt == 1) CURLA_FC_DW(1);
@@ -1037,16 +1035,12 @@ int curla_fc_bwd(const float* dz, const float* W, const float* x, float* dx, flo
     return curla_fc_dw(dz, x, dW, B, F, K, stream);
   }
   const size_t lds = (size_t)4 * 4 * 4 * 64 * sizeof(f32x4);  // (the 3 + 2 form needs less: 48 KB + 2 KB)
-  // (once per process, thread-safe: a function-local static is initialised exactly once)
+  // (once per kernel and device, thread-safe: curla_set_dyn_lds)
   if (F == 50) {  // the default feature width: 3 tiles on the matrix pipe + 2 features on VALU FMAs
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fc_bwd_kernel<13, 3, 2, true>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return CURLA_ERR_LAUNCH;
+    if (curla_set_dyn_lds(reinterpret_cast<const void*>(fc_bwd_kernel<13, 3, 2, true>), lds) != CURLA_OK) return CURLA_ERR_LAUNCH;
     hipLaunchKernelGGL((fc_bwd_kernel<13, 3, 2, true>), dim3(nblk), dim3(256), lds, st, gx, dW);
   } else {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fc_bwd_kernel<13, 4, 0, true>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (attr != hipSuccess) return CURLA_ERR_LAUNCH;
+    if (curla_set_dyn_lds(reinterpret_cast<const void*>(fc_bwd_kernel<13, 4, 0, true>), lds) != CURLA_OK) return CURLA_ERR_LAUNCH;
     hipLaunchKernelGGL((fc_bwd_kernel<13, 4, 0, true>), dim3(nblk), dim3(256), lds, st, gx, dW);
   }
   return curla_launch_status();

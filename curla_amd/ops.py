@@ -124,29 +124,27 @@ def conv_s1_fwd_stack(x, ws, bs, outs, x2=None, ws2=None, bs2=None, outs2=None):
     return True
 
 
-_STACK_GRANULE = None
+_PER_DEVICE = {}  # (what, device index) -> value: a process may drive several GPUs
+
+
+def _device_cached(what, compute):
+    key = (what, torch.cuda.current_device())
+    if key not in _PER_DEVICE:
+        _PER_DEVICE[key] = compute()
+    return _PER_DEVICE[key]
 
 
 def stack_granule():
     """Batch-size multiple conv_s1_fwd_stack needs (its persistent grid: one workgroup per CU, two in the banded form)."""
-    global _STACK_GRANULE
     if _lib._trace_hook is not None:
         return 256  # (launch-schedule tests without a device: MI355X's CU count)
-    if _STACK_GRANULE is None:
-        _STACK_GRANULE = int(_lib.load().curla_conv3x3_s1_stack_granule())
-    return _STACK_GRANULE
-
-
-_CU_COUNT = None
+    return _device_cached("stack_granule", lambda: int(_lib.load().curla_conv3x3_s1_stack_granule()))
 
 
 def cu_count():
-    global _CU_COUNT
     if _lib._trace_hook is not None:
         return 256  # (launch-schedule tests without a device: MI355X's count)
-    if _CU_COUNT is None:
-        _CU_COUNT = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-    return _CU_COUNT
+    return _device_cached("cus", lambda: torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count)
 
 
 def conv1_pairable(o1: "ObsRef", o2: "ObsRef"):

@@ -363,17 +363,37 @@ class ReplayBuffer(object):
         ids, new = np.empty(2 * K, dtype=np.int32), []
         frames = np.concatenate([np.asarray(obs, dtype=np.uint8).reshape(K, 3, h, w),
                                  np.asarray(next_obs, dtype=np.uint8).reshape(K, 3, h, w)])
-        for j in range(2 * K):
-            fid, fp = st.lookup(frames[j])
-            if fid is None:
-                fid = st.allocate(frames[j], fp)
-                row[len(new) * f3:(len(new) + 1) * f3] = frames[j].reshape(-1)
-                new.append(fid)
-            st.refs[fid] += 1
-            ids[j] = fid
-        for fid in old:  # the transition this slot held before (ring wrap) lets go of its frames
+        # Room first, nothing touched yet: the frames this transition does not find in the store need a free slot
+        # each (a frame repeated inside the transition is counted once per occurrence: an upper bound), and the
+        # slots that the transition being overwritten (ring wrap) gives back count as free.  Failing here leaves the
+        # store exactly as it was -- a caller that catches the MemoryError (add_batch / load loops) keeps a
+        # consistent buffer.
+        found = [st.lookup(frames[j])[0] for j in range(2 * K)]
+        keeps = collections.Counter(f for f in found if f is not None)
+        gives = collections.Counter(int(f) for f in old if f >= 0)
+        freed = sum(1 for f, n in gives.items() if st.refs[f] - n + keeps.get(f, 0) == 0)
+        if sum(f is None for f in found) > len(st.free) + freed:
+            raise MemoryError("frame store exhausted: the observations handed to add() share fewer frames than a "
+                              "frame-stacked episode does; raise frame_capacity or construct the ReplayBuffer with "
+                              "dedup_frames=False")
+        # 1. hold on to the frames that are already there, 2. let the overwritten transition go (frames it shares with
+        #    the new one stay: held), 3. store the new frames -- in the slots step 2 may just have freed
+        for f in found:
+            if f is not None:
+                st.refs[f] += 1
+        for fid in old:
             if fid >= 0:
                 st.release(int(fid))
+        for j in range(2 * K):
+            fid = found[j]
+            if fid is None:
+                fid, fp = st.lookup(frames[j])  # (an earlier frame of this transition may have just stored it)
+                if fid is None:
+                    fid = st.allocate(frames[j], fp)
+                    row[len(new) * f3:(len(new) + 1) * f3] = frames[j].reshape(-1)
+                    new.append(fid)
+                st.refs[fid] += 1
+            ids[j] = fid
         self._fid_h[i] = ids.reshape(2, K)
         row[self._sc_off:self._sc_off + self._hdr].view(np.int32)[:] = ids
         sc = self._stage_scalars(row, action, reward, done)

@@ -14,12 +14,12 @@ HASH=$(python -c "from curla_amd import build; print(build.source_hash())")
 PSTEPS=6; PWARM=2
 if [ "$CFG" = "c5" ]; then PSTEPS=2; PWARM=1; fi
 if [[ $WHAT == *bench* ]]; then
-  python bench.py --config $CFG > $O/${TAG}_bench_${CFG}.json 2> $O/${TAG}_bench_${CFG}.err || true
+  python bench.py --config $CFG > $O/${TAG}_bench_${CFG}.json 2> $O/${TAG}_bench_${CFG}.err
   tail -1 $O/${TAG}_bench_${CFG}.json | cut -c1-400
 fi
 if [[ $WHAT == *stats* ]]; then
   rm -rf $O/prof_${TAG}_${CFG}
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_${CFG} -- python bench.py --config $CFG --steps $STEPS --warmup $WARM --no-cpu-baseline > $O/prof_${TAG}_${CFG}.log 2>&1 || true
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_${CFG} -- python bench.py --config $CFG --steps $STEPS --warmup $WARM --no-cpu-baseline > $O/prof_${TAG}_${CFG}.log 2>&1
   F=$(find $O/prof_${TAG}_${CFG} -name "*kernel_stats.csv" | head -1)
   python tools/summarize_rocprof.py "$F" $O/${TAG}_kernel_stats_${CFG}.txt "bench.py --config $CFG --steps $STEPS --warmup $WARM (sources $HASH)"
   head -14 $O/${TAG}_kernel_stats_${CFG}.txt
@@ -29,8 +29,8 @@ if [[ $WHAT == *stats* ]]; then
 fi
 if [[ $WHAT == *traffic* ]]; then
   P=$O/pmc_traffic_${TAG}_${CFG}; rm -rf $P
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/fetch -- python bench.py --config $CFG --steps $PSTEPS --warmup $PWARM --no-cpu-baseline --clock-warmup-s 0 > $P.fetch.log 2>&1 || true
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/write -- python bench.py --config $CFG --steps $PSTEPS --warmup $PWARM --no-cpu-baseline --clock-warmup-s 0 > $P.write.log 2>&1 || true
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/fetch -- python bench.py --config $CFG --steps $PSTEPS --warmup $PWARM --no-cpu-baseline --clock-warmup-s 0 > $P.fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/write -- python bench.py --config $CFG --steps $PSTEPS --warmup $PWARM --no-cpu-baseline --clock-warmup-s 0 > $P.write.log 2>&1
   python tools/pmc_summarize.py traffic $P $O/${TAG}_pmc_traffic_${CFG}.json $HASH | head -10
   rm -rf $P
 fi
@@ -42,7 +42,7 @@ if [[ $WHAT == *sq* ]]; then
              "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" \
              "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_INSTS_LDS SQ_CYCLES"; do
     i=$((i+1))
-    rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $P/g$i -- python bench.py --config $CFG --steps $PSTEPS --warmup $PWARM --no-cpu-baseline --clock-warmup-s 0 > $P.g$i.log 2>&1 || echo "group $i failed"
+    rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $P/g$i -- python bench.py --config $CFG --steps $PSTEPS --warmup $PWARM --no-cpu-baseline --clock-warmup-s 0 > $P.g$i.log 2>&1
   done
   python tools/pmc_summarize.py sq $P $O/${TAG}_pmc_sq_${CFG}.json $HASH | tee $O/${TAG}_pmc_sq_${CFG}.txt | head -14
   rm -rf $P
