@@ -374,8 +374,7 @@ __global__ __launch_bounds__(256, 2) void conv_s1_stack_kernel(ConvS1StackArgs S
 __global__ __launch_bounds__(512, 2) void conv_rw_fwd_kernel(rw::Args A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   for (int l = 0; l < A.nlayers; ++l) {
-    rw::build_filter<MODE_FWD, 512>(lds, A.p[l][0].w, threadIdx.x);
-    if (A.p[l][1].B > 0) rw::build_filter<MODE_FWD, 512>(lds + rw::kWFloats, A.p[l][1].w, threadIdx.x);
+    rw::build_filter<MODE_FWD, 512>(lds, A.p[l][0].w, A.p[l][1].B > 0 ? A.p[l][1].w : nullptr, threadIdx.x);
     __syncthreads();
     rw::run_layer<MODE_FWD, 8>(A.g[l], A.p[l][0], A.p[l][1], lds, blockIdx.x, gridDim.x);
     if (l + 1 < A.nlayers) {
@@ -391,7 +390,7 @@ __global__ __launch_bounds__(512, 2) void conv_rw_fwd_kernel(rw::Args A) {
 // data gradient alone (256-thread workgroups: the form that shares a launch with the weight gradient below)
 __global__ __launch_bounds__(256, 2) void conv_rw_dgrad_kernel(rw::Args A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  rw::build_filter<MODE_DGRAD, 256>(lds, A.p[0][0].w, threadIdx.x);
+  rw::build_filter<MODE_DGRAD, 256>(lds, A.p[0][0].w, nullptr, threadIdx.x);
   __syncthreads();
   rw::run_layer<MODE_DGRAD, 4>(A.g[0], A.p[0][0], A.p[0][1], lds, blockIdx.x, gridDim.x);
 }
@@ -495,15 +494,17 @@ __global__ __launch_bounds__(512) void conv1_fwd_kernel(Conv1Args a) {
   const int li = lane & 15, kq = lane >> 4;
   const int RS = conv1_row_stride(a.Wc, C);
 
+  constexpr int KQ = KR / 4;  // k-steps per tap row
   for (int i = tid; i < 32 * C * 9; i += 512) lds[i] = a.w[i];
   __syncthreads();
+  // k = 4 s + kq of the GEMM is (dy, rr) = (s / KQ, 4 (s % KQ) + kq): KR is a multiple of 4, so the tap row is the
+  // same for all lanes of a k-step and a lane's operand sits at a COMPILE-TIME offset (dy, 4 (s % KQ)) from its own
+  // base (pixel, kq) -- one address per tile instead of one add per k-step (a VALU instruction is a cycle the f32
+  // matrix pipe idles: conv_rw.h)
   float wr[NS][2];
-  int koff[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const int k = 4 * s + kq;
-    const int dy = k / KR, rr = k - dy * KR;
-    koff[s] = dy * RS + rr;
+    const int dy = s / KQ, rr = 4 * (s % KQ) + kq;
     const bool ok = rr < 3 * C;
     const int dx = ok ? rr / C : 0, c = ok ? rr - dx * C : 0;
 #pragma unroll
@@ -517,6 +518,7 @@ __global__ __launch_bounds__(512) void conv1_fwd_kernel(Conv1Args a) {
   // persistent: the weight registers above are built once per workgroup, not once per band (a band is ~2 us of
   // tile work at 168x168x12 -- the per-band weight phase was a quarter of the kernel)
   const int nitems = a.B * a.nbands;
+  const int qstep = 128 / a.Wo, rstep = 128 - qstep * a.Wo;  // 8 waves x 16 pixels further
   for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
     const int band = item / a.B, b = item - band * a.B;  // band-major: every workgroup sees every band size
     const int y0 = band * a.th;
@@ -527,29 +529,37 @@ __global__ __launch_bounds__(512) void conv1_fwd_kernel(Conv1Args a) {
 
     const int npix = tha * a.Wo;
     const int ntiles = (npix + 15) >> 4;
+    float* const out_item = a.out + ((size_t)(b * a.Ho + y0) * a.Wo) * 32 + 4 * kq;
+    int ty = (wave * 16 + li) / a.Wo, x = (wave * 16 + li) - ty * a.Wo;  // walked incrementally: no division per tile
     for (int t = wave; t < ntiles; t += 8) {
-      const int p = t * 16 + li;
-      const bool pv = p < npix;
-      const int pc = pv ? p : 0;
-      const int ty = pc / a.Wo, x = pc - ty * a.Wo;
-      const float* base = lds + 2 * ty * RS + 2 * x * C;
-      f32x4 acc[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+      const bool pv = t * 16 + li < npix;
+      if (!pv) ty = 0, x = 0;
+      const float* base = lds + __mul24(2 * ty, RS) + __mul24(2 * x, C) + kq;
+      // the 3 tap rows: RS is a run-time stride, so each row has its own base register; inside a row the k-steps are
+      // immediates.  All NS reads of the tile are issued up front (they are independent of the accumulators).
+      float bv[NS];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) bv[s] = base[(s / KQ) * RS + 4 * (s % KQ)];
+      f32x4 acc[2] = {bias4[0], bias4[1]};  // bias through the accumulators' initial values
 #pragma unroll
       for (int s = 0; s < NS; ++s) {
-        const float bv = base[koff[s]];
-        acc[0] = mfma16(wr[s][0], bv, acc[0]);
-        acc[1] = mfma16(wr[s][1], bv, acc[1]);
+        acc[0] = mfma16(wr[s][0], bv[s], acc[0]);
+        acc[1] = mfma16(wr[s][1], bv[s], acc[1]);
       }
       if (pv) {
-        const size_t g = ((size_t)(b * a.Ho + y0 + ty) * a.Wo + x) * 32 + 4 * kq;
+        float* o = out_item + (__mul24(ty, a.Wo) + x) * 32;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-          f32x4 v = acc[mt] + bias4[mt];
+          f32x4 v = acc[mt];
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + g + mt * 16));
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o + mt * 16));
         }
       }
+      x += rstep, ty += qstep;  // at most one more wrap
+      const bool wrap = x >= a.Wo;
+      x = wrap ? x - a.Wo : x;
+      ty = wrap ? ty + 1 : ty;
     }
     __syncthreads();  // every wave is done with the band before the next one is staged over it
   }
@@ -1051,7 +1061,7 @@ __global__ __launch_bounds__(256, 2) void bwd_rw_kernel(WgradS1Args wa, rw::Args
     wgrad_s1_body<WALK>(wa, blockIdx.x, nw);
   } else {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    rw::build_filter<MODE_DGRAD, 256>(lds, da.p[0][0].w, threadIdx.x);
+    rw::build_filter<MODE_DGRAD, 256>(lds, da.p[0][0].w, nullptr, threadIdx.x);
     __syncthreads();
     rw::run_layer<MODE_DGRAD, 4>(da.g[0], da.p[0][0], da.p[0][1], lds, (int)blockIdx.x - nw, (int)gridDim.x - nw);
   }
@@ -1069,7 +1079,7 @@ __global__ __launch_bounds__(256, 2) void bwd_rw2_kernel(rw::WgradArgs wa, rw::A
     rw::wgrad_body<4>(wa, blockIdx.x, nw);
   } else {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    rw::build_filter<MODE_DGRAD, 256>(lds, da.p[0][0].w, threadIdx.x);
+    rw::build_filter<MODE_DGRAD, 256>(lds, da.p[0][0].w, nullptr, threadIdx.x);
     __syncthreads();
     rw::run_layer<MODE_DGRAD, 4>(da.g[0], da.p[0][0], da.p[0][1], lds, (int)blockIdx.x - nw, (int)gridDim.x - nw);
   }
@@ -1127,22 +1137,30 @@ __global__ __launch_bounds__(512) void wgrad1_kernel(Wgrad1Args a) {
     const float* const gband = a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32 + li;
     const int npix = tha * a.Wo;
     const int nunits = ((npix + 15) >> 4) << 2;
+    // unit u's pixel of lane group kq is p = (u >> 2) * 16 + (u & 3) + 4 kq; this wave's units are u = wave, wave + 8,
+    // ...: p advances by 32 per unit -- walked incrementally as (row, column), no division per unit
+    int p = (wave >> 2) * 16 + (wave & 3) + 4 * kq;
+    int ty = p / a.Wo, x = p - ty * a.Wo;
+    const int qstep = 32 / a.Wo, rstep = 32 - qstep * a.Wo;
     for (int u = wave; u < nunits; u += 8) {
-      const int p = (u >> 2) * 16 + (u & 3) + 4 * kq;
       const bool pv = p < npix;
-      const int pc = pv ? p : 0;
-      const int ty = pc / a.Wo, x = pc - ty * a.Wo;
       const float* gp = pv ? gband + p * 32 : g_zero_px;
       const float a0 = gp[0], a1 = gp[16];
       bsum[0] += a0;
       bsum[1] += a1;
-      const float* ip = lds + 2 * ty * RS + 2 * x * C;
+      const float* ip = lds + (pv ? __mul24(2 * ty, RS) + __mul24(2 * x, C) : 0);
+      float bv[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bv[t] = ip[koff[t]];
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
-        const float bv = ip[koff[t]];
-        acc[0][t] = mfma16(a0, bv, acc[0][t]);
-        acc[1][t] = mfma16(a1, bv, acc[1][t]);
+        acc[0][t] = mfma16(a0, bv[t], acc[0][t]);
+        acc[1][t] = mfma16(a1, bv[t], acc[1][t]);
       }
+      p += 32, x += rstep, ty += qstep;  // at most one more wrap
+      const bool wrap = x >= a.Wo;
+      x = wrap ? x - a.Wo : x;
+      ty = wrap ? ty + 1 : ty;
     }
     __syncthreads();
   }

@@ -91,29 +91,46 @@ __device__ __forceinline__ void filter_transform(float g0, float g1, float g2, f
 
 // OIHW weights -> transformed filter in LDS, laid out so that the A operands of four consecutive MFMAs (cin = 16 q +
 // 4 kq + e, e = 0..3, of output channel 16 mt + li) are ONE 16-byte read per lane and a wave's read is 1 KB contiguous.
+template <int MODE>
+__device__ __forceinline__ void put_filter(float* lds_w, const float (&t)[9], int pr) {
+  const int o = pr >> 5, i = pr & 31;
+  // forward: cout = o, cin = i, taps as stored.  data gradient: cout = i, cin = o, taps flipped in both directions.
+  const int co = MODE == MODE_FWD ? o : i, ci = MODE == MODE_FWD ? i : o;
+  const int mt = co >> 4, li = co & 15, q = ci >> 4, kq = (ci >> 2) & 3, e = ci & 3;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    float u[4];
+    if (MODE == MODE_FWD)
+      filter_transform(t[dy * 3 + 0], t[dy * 3 + 1], t[dy * 3 + 2], u);
+    else
+      filter_transform(t[(2 - dy) * 3 + 2], t[(2 - dy) * 3 + 1], t[(2 - dy) * 3 + 0], u);
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) lds_w[((((dy * 4 + pos) * 2 + q) * 2 + mt) * 64 + kq * 16 + li) * 4 + e] = u[pos];
+  }
+}
+
+// (w1 may be null: one problem.  All loads of a pass are issued before the first LDS write: the filters of both
+// problems cost one memory latency, not two)
 template <int MODE, int NT>
-__device__ __forceinline__ void build_filter(float* lds_w, const float* __restrict__ w, int tid) {
+__device__ __forceinline__ void build_filter(float* lds_w, const float* __restrict__ w0, const float* __restrict__ w1,
+                                             int tid) {
   // thread <- (o, i) pairs of the OIHW tensor: 9 contiguous floats each, consecutive threads consecutive pairs
-  for (int pr = tid; pr < 1024; pr += NT) {
-    const float* src = w + pr * 9;
-    float t[9];
+  constexpr int NP = 1024 / NT;
+  float t0[NP][9], t1[NP][9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) t[k] = src[k];
-    const int o = pr >> 5, i = pr & 31;
-    // forward: cout = o, cin = i, taps as stored.  data gradient: cout = i, cin = o, taps flipped in both directions.
-    const int co = MODE == MODE_FWD ? o : i, ci = MODE == MODE_FWD ? i : o;
-    const int mt = co >> 4, li = co & 15, q = ci >> 4, kq = (ci >> 2) & 3, e = ci & 3;
+  for (int u = 0; u < NP; ++u) {
+    const int pr = tid + u * NT;
 #pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      float u[4];
-      if (MODE == MODE_FWD)
-        filter_transform(t[dy * 3 + 0], t[dy * 3 + 1], t[dy * 3 + 2], u);
-      else
-        filter_transform(t[(2 - dy) * 3 + 2], t[(2 - dy) * 3 + 1], t[(2 - dy) * 3 + 0], u);
+    for (int k = 0; k < 9; ++k) t0[u][k] = w0[pr * 9 + k];
+    if (w1) {
 #pragma unroll
-      for (int pos = 0; pos < 4; ++pos)
-        lds_w[((((dy * 4 + pos) * 2 + q) * 2 + mt) * 64 + kq * 16 + li) * 4 + e] = u[pos];
+      for (int k = 0; k < 9; ++k) t1[u][k] = w1[pr * 9 + k];
     }
+  }
+#pragma unroll
+  for (int u = 0; u < NP; ++u) {
+    put_filter<MODE>(lds_w, t0[u], tid + u * NT);
+    if (w1) put_filter<MODE>(lds_w + kWFloats, t1[u], tid + u * NT);
   }
 }
 

@@ -13,7 +13,8 @@
 // once and transforms that window three times (once per row tap); with two waves per pixel set that is 12 packed adds
 // + ~15 address / bookkeeping instructions per 24 MFMAs -- and on this chip a VALU cycle is a cycle the f32 matrix
 // pipe idles (conv_rw.h).  Here the four lane groups of a wave own four pair COLUMNS and walk DOWN: at step t they load
-// input row t (window of their pair, their channel of both input tiles: 8 dwords) and gradient row t (2 dwords),
+// input row t (window of their pair, two adjacent input channels = their column of both input tiles: 4 x 8 bytes)
+// and gradient row t (2 dwords),
 // transform the window ONCE (4 packed adds) and multiply it with the gradient rows t (tap 0), t-1 (tap 1) and t-2
 // (tap 2), whose transformed values (4 registers per row) stay in registers for their three steps.  10 VALU
 // instructions per 24 MFMAs, no LDS, no barrier until the final sum; loads are issued three steps ahead, rows and
@@ -121,22 +122,22 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bid, co
           (void*)(a.in + (size_t)b * a.Hi * a.Wi * 32), (short)0, a.Hi * in_row, 0x00020000);
       const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
           (void*)(a.g + (size_t)b * a.Ho * a.Wo * 32), (short)0, a.Ho * g_row, 0x00020000);
-      // window pixel c of input row Y + t, channel li of tile ct (+64 bytes); gradient pixels x0 / x0 + 1 of row Y + t,
+      // window pixel c of input row Y + t, channels 2 li (tile 0) and 2 li + 1 (tile 1); gradient pixels x0 / x0 + 1 of row Y + t,
       // channel mt*16 + li.  A lane without a column, and the second pixel of an odd row's last pair, point far out
       // of range (zeros); rows advance through the scalar offset, rows past the image are out of range by themselves.
       unsigned vd[4];
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        vd[c] = (lane_on && x0 + c < a.Wi) ? (unsigned)((Y * a.Wi + x0 + c) * 128 + li * 4) : 0x80000000u;
+        vd[c] = (lane_on && x0 + c < a.Wi) ? (unsigned)((Y * a.Wi + x0 + c) * 128 + li * 8) : 0x80000000u;
       const unsigned vg0 = lane_on ? (unsigned)((Y * a.Wo + x0) * 128 + (mt * 16 + li) * 4) : 0x80000000u;
       const unsigned vg1 = (lane_on && x0 + 1 < a.Wo) ? vg0 + 128u : 0x80000000u;
 
       auto issue = [&](WgLoads& L, int t) {
         const unsigned sd = (unsigned)(t * in_row), sg_ = (unsigned)(t * g_row);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          L.d[c][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rin, vd[c], sd, 0));
-          L.d[c][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rin, vd[c] + 64u, sd, 0));
+        for (int c = 0; c < 4; ++c) {  // input channels 2 li and 2 li + 1 (the lane's column of the two cin tiles): 8 bytes
+          const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rin, vd[c], sd, 0));
+          L.d[c][0] = v[0], L.d[c][1] = v[1];
         }
         L.g[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, vg0, sg_, 0));
         L.g[1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, vg1, sg_, 0));
@@ -218,7 +219,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bid, co
           for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-              const int co = mt * 16 + 4 * kq + r, ci = ct * 16 + li;
+              const int co = mt * 16 + 4 * kq + r, ci = 2 * li + ct;  // (tile ct holds the input channels of parity ct)
               float* d = lds + co * 288 + ci * 9 + dy * 3 + dx;
               *d = (w == 0) ? dw[dx][r] : *d + dw[dx][r];
             }

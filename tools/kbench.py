@@ -156,6 +156,19 @@ def main():
         if flags != [0]:
             lib.curla_debug_ablate(0)
 
+    if "c5first" in args.what:  # the float NHWC first-layer kernels of BASELINE configs[4] (168x168x12 -> 83x83x32)
+        Bc = 256
+        xin = torch.rand(Bc, 168, 168, 12, device=dev) * 255.0
+        obs = ops.ObsRef.from_nhwc(xin)
+        w0, b0 = r(32, 12, 3, 3) * 0.1, r(32) * 0.1
+        out = torch.empty(Bc, 83, 83, 32, device=dev)
+        g = r(Bc, 83, 83, 32)
+        dw0, db0 = torch.empty(32, 12, 3, 3, device=dev), torch.empty(32, device=dev)
+        ws0 = torch.empty(ops.wgrad_workspace_floats(12), device=dev)
+        fl_ = 2.0 * Bc * 83 * 83 * 32 * 12 * 9
+        report(f"conv1_fwd float NHWC 168x168x12, B={Bc}", timeit(lambda: ops.conv1_fwd(obs, w0, b0, out)), fl_)
+        report(f"conv1_wgrad(+reduce) float NHWC, B={Bc}", timeit(lambda: ops.conv1_wgrad(obs, g, dw0, db0, ws0)), fl_)
+
     if "gemm" in args.what:
         H, F, K = 1024, 50, 30752
         for nb in (1, 2):
