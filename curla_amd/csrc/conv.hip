@@ -395,6 +395,20 @@ __global__ __launch_bounds__(256, 2) void conv_rw_dgrad_kernel(rw::Args A) {
   rw::run_layer<MODE_DGRAD, 4>(A.g[0], A.p[0][0], A.p[0][1], lds, blockIdx.x, gridDim.x);
 }
 
+#include "conv1_rw.h"
+
+// first layer from a float NHWC minibatch in row-walk form (conv1_rw.h): 512-thread workgroups, one per CU, persistent
+// over the samples they own (8 waves share a sample's steps: small minibatches still fill the SIMDs twice)
+template <int C>
+__global__ __launch_bounds__(512, 2) void conv1_rw_fwd_kernel(rw::Conv1Args a) {
+  rw::conv1_body<C, 8>(a, blockIdx.x, gridDim.x);
+}
+
+template <int C>
+__global__ __launch_bounds__(512, 2) void wgrad1_rw_kernel(rw::Wgrad1Args a) {
+  rw::wgrad1_body<C, 8>(a, blockIdx.x, gridDim.x);
+}
+
 // ---------------------------------------------------------------------------
 // first layer: Cin = C (9 or 12 ...), stride 2, input either the uint8 replay
 // frames (gather by index + random-crop offsets + /255 fused into the load) or
@@ -1852,6 +1866,20 @@ static int conv1_fwd_impl(const void* src, int src_kind, const int64_t* idx, con
     if (rc != CURLA_OK) return rc;
     return curla_launch_status();
   }
+  if (src_kind == 2 && use_rw() && (long long)Hc * Wc * C * 4 < (1LL << 30)) {
+    // float NHWC minibatch: row walk, nothing staged (conv1_rw.h)
+    rw::Conv1Args ra;
+    ra.src = static_cast<const float*>(src), ra.w = w, ra.bias = bias, ra.out = out;
+    ra.B = B, ra.Hc = Hc, ra.Wc = Wc, ra.Ho = a.Ho, ra.Wo = a.Wo, ra.scale = scale;
+    ra.g.Hi = Hc, ra.g.Wi = Wc, ra.g.Ho = a.Ho, ra.g.Wo = a.Wo;
+    rw::plan_units(ra.g, a.Ho, a.Wo, 16);
+    const int cap = curla_cu_count();
+    const int grid_rw = B < cap ? B : cap;
+#define CONV1_RW_LAUNCH(CC) hipLaunchKernelGGL((conv1_rw_fwd_kernel<CC>), dim3(grid_rw), dim3(512), 0, st, ra)
+    if (C == 12) CONV1_RW_LAUNCH(12); else if (C == 9) CONV1_RW_LAUNCH(9); else if (C == 6) CONV1_RW_LAUNCH(6); else CONV1_RW_LAUNCH(3);
+#undef CONV1_RW_LAUNCH
+    return curla_launch_status();
+  }
   // two workgroups per CU so one stages while the other computes
   a.th = plan_band_conv1(a.Ho, a.Wo, Wc, C, 0, 76 * 1024);
   a.nbands = (a.Ho + a.th - 1) / a.th;
@@ -2096,6 +2124,27 @@ static int launch_wgrad1(const void* src, int src_kind, const int64_t* idx, cons
   const int nw = 32 * C * 9;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int grid;
+  if (src_kind == 2 && use_rw() && (long long)Hc * Wc * C * 4 < (1LL << 30)) {
+    // float NHWC minibatch: row walk, nothing staged (conv1_rw.h)
+    rw::Wgrad1Args ra;
+    ra.src = static_cast<const float*>(src), ra.g = g, ra.partial = workspace;
+    ra.B = B, ra.Hc = Hc, ra.Wc = Wc, ra.Ho = a.Ho, ra.Wo = a.Wo, ra.scale = scale;
+    ra.gg.Hi = Hc, ra.gg.Wi = Wc, ra.gg.Ho = a.Ho, ra.gg.Wo = a.Wo;
+    rw::plan_units(ra.gg, a.Ho, a.Wo, 4);
+    const int cap = curla_cu_count();
+    grid = B < cap ? B : cap;
+    const size_t lds = (size_t)(nw + 32) * sizeof(float);
+#define WGRAD1_RW_LAUNCH(CC)                                                                     \
+  {                                                                                              \
+    rc = set_lds(wgrad1_rw_kernel<CC>, lds);                                                     \
+    if (rc == CURLA_OK) hipLaunchKernelGGL((wgrad1_rw_kernel<CC>), dim3(grid), dim3(512), lds, st, ra); \
+  }
+    if (C == 12) WGRAD1_RW_LAUNCH(12) else if (C == 9) WGRAD1_RW_LAUNCH(9) else if (C == 6) WGRAD1_RW_LAUNCH(6) else WGRAD1_RW_LAUNCH(3)
+#undef WGRAD1_RW_LAUNCH
+    if (rc != CURLA_OK) return rc;
+    *nslabs = grid;
+    return curla_launch_status();
+  }
   if (src_kind == 1 && !(ABL_HOST & 256)) {
     // uint8 ring, input band kept as bytes: two 512-thread workgroups per CU (<= 76 KB of LDS each).
     const int RSb = ((Wc * C + 15) & ~15) + 16;

@@ -62,25 +62,30 @@ struct Args {
   Problem p[kMaxLayers][2];  // second problem: B = 0 when absent
 };
 
-// host: strip plan of one geometry
-inline Geom plan(int Hi, int Wi, int Ho, int Wo) {
-  Geom g;
-  g.Hi = Hi, g.Wi = Wi, g.Ho = Ho, g.Wo = Wo;
-  const int PW = (Wo + 1) / 2;
-  g.nfull = PW / 16, g.brem = PW % 16;
+// host: strips of `per` columns over `cols` column units and Ho rows (see "Strips" above): full strips of Ho steps,
+// and the remaining columns cut into vertical segments of nr rows so that `per` lane groups are (column, segment) units
+inline void plan_units(Geom& g, int Ho, int cols, int per) {
+  g.nfull = cols / per, g.brem = cols % per;
   g.nr = g.nseg = g.ntr = 0;
   if (g.brem) {
-    // segments of nr rows: brem * ceil(Ho / nr) units on 16 lanes per strip; cost = strips x nr steps
+    // segments of nr rows: brem * ceil(Ho / nr) units on `per` lane groups per strip; cost = strips x nr steps
     long best = -1;
     for (int nr = 1; nr <= Ho; ++nr) {
       const int nseg = (Ho + nr - 1) / nr;
-      const int ntr = (g.brem * nseg + 15) / 16;
+      const int ntr = (g.brem * nseg + per - 1) / per;
       // a step costs the same whatever it computes; short segments also spend 2 of their nr + 2 row loads on halo
       const long cost = (long)ntr * nr * 64 + (long)ntr * 2 * 8;
       if (best < 0 || cost <= best) best = cost, g.nr = nr, g.nseg = nseg, g.ntr = ntr;
     }
   }
   g.steps = g.nfull * Ho + g.ntr * g.nr;
+}
+
+// strip plan of the stride-1 forward / data gradient: 16 pixel-pair columns per wave
+inline Geom plan(int Hi, int Wi, int Ho, int Wo) {
+  Geom g;
+  g.Hi = Hi, g.Wi = Wi, g.Ho = Ho, g.Wo = Wo;
+  plan_units(g, Ho, (Wo + 1) / 2, 16);
   return g;
 }
 

@@ -31,23 +31,11 @@ struct WgradArgs {
   Geom gg;          // strips of 4 pair columns over the GRADIENT image (plan4)
 };
 
-// strips of 4 columns (one per lane group)
+// strips of 4 pair columns (one per lane group)
 inline Geom plan4(int Hi, int Wi, int Ho, int Wo) {
   Geom g;
   g.Hi = Hi, g.Wi = Wi, g.Ho = Ho, g.Wo = Wo;
-  const int PW = (Wo + 1) / 2;
-  g.nfull = PW / 4, g.brem = PW % 4;
-  g.nr = g.nseg = g.ntr = 0;
-  if (g.brem) {
-    long best = -1;
-    for (int nr = 1; nr <= Ho; ++nr) {
-      const int nseg = (Ho + nr - 1) / nr;
-      const int ntr = (g.brem * nseg + 3) / 4;
-      const long cost = (long)ntr * nr * 64 + (long)ntr * 2 * 8;  // (steps, then the two halo steps of every strip)
-      if (best < 0 || cost <= best) best = cost, g.nr = nr, g.nseg = nseg, g.ntr = ntr;
-    }
-  }
-  g.steps = g.nfull * Ho + g.ntr * g.nr;
+  plan_units(g, Ho, (Wo + 1) / 2, 4);
   return g;
 }
 

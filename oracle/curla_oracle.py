@@ -212,16 +212,20 @@ def encoder_forward(p: Params, prefix: str, obs: torch.Tensor, num_layers: int,
     return h_norm if output_logits else torch.tanh(h_norm)
 
 
-def mlp3(p: Params, prefix: str, x: torch.Tensor) -> torch.Tensor:
-    """Linear-ReLU-Linear-ReLU-Linear trunk (curl_sac.py:70-74,129-133)."""
-    x = torch.relu(F.linear(x, p[f"{prefix}0.weight"], p[f"{prefix}0.bias"]))
-    x = torch.relu(F.linear(x, p[f"{prefix}2.weight"], p[f"{prefix}2.bias"]))
+def mlp3(p: Params, prefix: str, x: torch.Tensor, relu_branches: Optional[list] = None) -> torch.Tensor:
+    """Linear-ReLU-Linear-ReLU-Linear trunk (curl_sac.py:70-74,129-133).  ``relu_branches`` (tests only): the
+    branch each of the two ReLUs' derivatives takes, as two boolean [B, hidden] tensors (see _ReluGivenBranch: a hidden
+    unit within rounding of 0 moves a trunk weight gradient by ~1/sqrt(B) of a row's size)."""
+    act = (lambda h, i: torch.relu(h)) if relu_branches is None else (lambda h, i: _ReluGivenBranch.apply(h, relu_branches[i]))
+    x = act(F.linear(x, p[f"{prefix}0.weight"], p[f"{prefix}0.bias"]), 0)
+    x = act(F.linear(x, p[f"{prefix}2.weight"], p[f"{prefix}2.bias"]), 1)
     return F.linear(x, p[f"{prefix}4.weight"], p[f"{prefix}4.bias"])
 
 
 def actor_forward(actor: Params, critic: Params, obs: torch.Tensor, noise: Optional[torch.Tensor],
                   num_layers: int, log_std_min: float, log_std_max: float,
-                  detach_encoder: bool = False, compute_pi: bool = True, compute_log_pi: bool = True):
+                  detach_encoder: bool = False, compute_pi: bool = True, compute_log_pi: bool = True,
+                  trunk_branches: Optional[list] = None):
     """Actor.forward + gaussian_logprob + squash (curl_sac.py:20-35,79-110).
     The conv tensors come from ``critic`` (tied); fc/ln/trunk from ``actor``.
     ``noise`` replaces ``torch.randn_like(mu)`` (curl_sac.py:97)."""
@@ -230,7 +234,7 @@ def actor_forward(actor: Params, critic: Params, obs: torch.Tensor, noise: Optio
         if k.startswith("encoder.convs."):
             merged[k] = v
     z = encoder_forward(merged, "encoder.", obs, num_layers, detach=detach_encoder)
-    mu, log_std = mlp3(merged, "trunk.", z).chunk(2, dim=-1)
+    mu, log_std = mlp3(merged, "trunk.", z, trunk_branches).chunk(2, dim=-1)
     log_std = torch.tanh(log_std)
     log_std = log_std_min + 0.5 * (log_std_max - log_std_min) * (log_std + 1)
     pi = log_pi = None
@@ -248,12 +252,15 @@ def actor_forward(actor: Params, critic: Params, obs: torch.Tensor, noise: Optio
 
 
 def critic_forward(critic: Params, obs: torch.Tensor, action: torch.Tensor, num_layers: int,
-                   detach_encoder: bool = False, outputs: Optional[dict] = None, relu_branches: Optional[list] = None):
-    """Critic.forward / QFunction.forward (curl_sac.py:135-169)."""
+                   detach_encoder: bool = False, outputs: Optional[dict] = None, relu_branches: Optional[list] = None,
+                   q_branches: Optional[list] = None):
+    """Critic.forward / QFunction.forward (curl_sac.py:135-169).  ``q_branches`` (tests only): [Q1's, Q2's] pair of
+    mlp3 ``relu_branches``."""
     z = encoder_forward(critic, "encoder.", obs, num_layers, detach=detach_encoder, outputs=outputs,
                         relu_branches=relu_branches)
     za = torch.cat([z, action], dim=1)
-    return mlp3(critic, "Q1.trunk.", za), mlp3(critic, "Q2.trunk.", za)
+    qb = q_branches if q_branches is not None else (None, None)
+    return mlp3(critic, "Q1.trunk.", za, qb[0]), mlp3(critic, "Q2.trunk.", za, qb[1])
 
 
 def curl_logits(W: torch.Tensor, z_a: torch.Tensor, z_pos: torch.Tensor) -> torch.Tensor:
@@ -277,7 +284,7 @@ def _grads(p: Params) -> Dict[str, Optional[torch.Tensor]]:
 def critic_phase(actor: Params, critic: Params, critic_target: Params, log_alpha: torch.Tensor,
                  obs, action, reward, next_obs, not_done, noise, *, num_layers: int, discount: float,
                  log_std_min: float, log_std_max: float, detach_encoder: bool = False,
-                 relu_branches: Optional[list] = None):
+                 relu_branches: Optional[list] = None, q_branches: Optional[list] = None):
     """CurlSacAgent.update_critic up to and including backward
     (curl_sac.py:349-367).  Returns dict(loss, target_Q, q1, q2, grads, enc).
     ``relu_branches``: see encoder_forward (applies to the critic's differentiated pass over ``obs``)."""
@@ -292,7 +299,7 @@ def critic_phase(actor: Params, critic: Params, critic_target: Params, log_alpha
     c = _leafify(critic)
     enc = {}
     q1, q2 = critic_forward(c, obs, action, num_layers, detach_encoder=detach_encoder, outputs=enc,
-                            relu_branches=relu_branches)
+                            relu_branches=relu_branches, q_branches=q_branches)
     loss = F.mse_loss(q1, target_Q) + F.mse_loss(q2, target_Q)
     loss.backward()
     return dict(loss=loss.detach(), target_Q=target_Q, q1=q1.detach(), q2=q2.detach(),
@@ -301,7 +308,8 @@ def critic_phase(actor: Params, critic: Params, critic_target: Params, log_alpha
 
 
 def actor_phase(actor: Params, critic: Params, log_alpha: torch.Tensor, obs, noise, *,
-                num_layers: int, log_std_min: float, log_std_max: float, target_entropy: float):
+                num_layers: int, log_std_min: float, log_std_max: float, target_entropy: float,
+                trunk_branches: Optional[list] = None, q_branches: Optional[list] = None):
     """CurlSacAgent.update_actor_and_alpha up to the two backward calls
     (curl_sac.py:373-403).  Live gradients: the actor's own fc/ln/trunk and
     log_alpha; gradients deposited on critic tensors are dead in the reference
@@ -309,8 +317,8 @@ def actor_phase(actor: Params, critic: Params, log_alpha: torch.Tensor, obs, noi
     a = _leafify(actor)
     la = log_alpha.detach().clone().requires_grad_(True)
     _, pi, log_pi, log_std = actor_forward(a, critic, obs, noise, num_layers, log_std_min, log_std_max,
-                                           detach_encoder=True)
-    q1, q2 = critic_forward(critic, obs, pi, num_layers, detach_encoder=True)
+                                           detach_encoder=True, trunk_branches=trunk_branches)
+    q1, q2 = critic_forward(critic, obs, pi, num_layers, detach_encoder=True, q_branches=q_branches)
     actor_Q = torch.min(q1, q2)
     actor_loss = (la.exp().detach() * log_pi - actor_Q).mean()
     entropy = 0.5 * log_std.shape[1] * (1.0 + np.log(2 * np.pi)) + log_std.sum(dim=-1)

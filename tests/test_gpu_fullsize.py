@@ -12,11 +12,14 @@ the same minibatch (the bytes the ring hands the kernels) and the same policy no
 ReLU branches.  A conv weight gradient at these sizes is a sum of ~600k (c2) to ~7M (c5) signed, largely cancelling
 terms, so ONE activation whose pre-activation is within fp32 rounding of 0 -- positive in one evaluation of the network,
 not in the other; 0-2 elements out of 20 million per layer -- moves it by 1e-4 .. 1e-3 of its size (the reference does
-the same to itself: its own fp32 and fp64 evaluations differ by 2e-4 .. 3e-4 on these tensors).  The conv gradients
-are therefore compared with the oracle evaluated under the SAME branch decisions (the derivative of each ReLU takes its
-branch from the device's activations, ``relu_branches`` in oracle/curla_oracle.py), and the test asserts separately that
-the two sides disagree on at most a few branches per layer, all at activations within 1e-5 of 0.  The un-aligned errors
-are written to the report as well ("raw").
+the same to itself: its own fp32 and fp64 evaluations differ by 2e-4 .. 3e-4 on these tensors).  The same holds
+for the hidden units of the 1024-wide MLPs: one unit of one sample flipping moves a row of a trunk weight gradient by
+~1/sqrt(B) of its size, and through d(loss)/dz everything below it.  The gradients are therefore compared with the
+oracle evaluated under the SAME branch decisions (the derivative of each ReLU -- conv layers, Q trunks, actor trunk --
+takes its branch from the device's activations: ``relu_branches`` / ``q_branches`` / ``trunk_branches`` in
+oracle/curla_oracle.py; values are untouched), and the test asserts separately that the two sides disagree on at most a
+few conv branches per layer, all at activations within 1e-5 of 0.  The un-aligned errors are written to the report as
+well ("raw").
 
 All learning rates are zero, so the four Adam steps inside the update leave the parameters where they were and every
 phase of both sides is evaluated at identical weights (multi-step parameter trajectories are chaotic under fp32
@@ -158,10 +161,22 @@ def _run(tag, obs_shape, in_hw, aug_name, layers, B, pixel_sac, capacity):
     captured = {}
     real_step = agent.critic_optimizer.step
 
+    def hidden(*ts):  # post-ReLU hidden activations of the MLPs -> the branches their derivatives took
+        return [(t > 0).cpu() for t in ts]
+
     def critic_step():
         captured["critic"] = grads_of(agent.critic)
+        w_ = agent._ws(B)
+        captured["critic_q"] = hidden(w_.q_h1[0], w_.q_h2[0], w_.q_h1[1], w_.q_h2[1])
         real_step()
     agent.critic_optimizer.step = critic_step
+    real_actor_step = agent.actor_optimizer.step
+
+    def actor_step():
+        w_ = agent._ws(B)
+        captured["actor_mlp"] = hidden(w_.a_h1, w_.a_h2, w_.q_h1[0], w_.q_h2[0], w_.q_h1[1], w_.q_h2[1])
+        real_actor_step()
+    agent.actor_optimizer.step = actor_step
     before = agent._critic_flat.clone()
     L = NullLogger()
     agent.update(rb, L, 0)
@@ -194,19 +209,28 @@ def _run(tag, obs_shape, in_hw, aug_name, layers, B, pixel_sac, capacity):
             assert float(torch.maximum(dev_act[differ].abs(), ref_act[differ].abs()).max()) <= 1e-5
         branches.append(pos)
         del dev_act, differ
+    cq = captured["critic_q"]
     rcb = O.critic_phase(oracle.actor, oracle.critic, saved_target, oracle.log_alpha, o_obs, o_act, o_rew, o_nxt, o_nd,
-                         noise_c, discount=0.99, relu_branches=branches, **kwc)
+                         noise_c, discount=0.99, relu_branches=branches, q_branches=[cq[0:2], cq[2:4]], **kwc)
     assert float((rcb["loss"] - rc["loss"]).abs()) == 0.0  # values are untouched, only derivative branches
     for k, v in rcb["grads"].items():
-        if ".convs." in k:
-            check(f"{tag} critic grad {k} (raw: own branches on both sides)", captured["critic"][k], rc["grads"][k])
+        check(f"{tag} critic grad {k} (raw: own branches on both sides)", captured["critic"][k], rc["grads"][k])
         bad.append(check(f"{tag} critic grad {k}", captured["critic"][k], v))
     actor_grads = {k: v for k, v in grads_of(agent.actor).items() if ".convs." not in k}
     assert len(actor_grads) == 10 == len(ra["grads"])
-    for k, v in ra["grads"].items():
+    am = captured["actor_mlp"]
+    rab = O.actor_phase(oracle.actor, oracle.critic, oracle.log_alpha, o_obs, noise_a, target_entropy=oracle.target_entropy,
+                        trunk_branches=am[0:2], q_branches=[am[2:4], am[4:6]], **kwc)
+    assert float((rab["actor_loss"] - ra["actor_loss"]).abs()) == 0.0
+    n_mlp = 0
+    for nm, dev_b, ref_h in (("actor trunk", am[0:2], None), ("critic Q", cq, None)):
+        n_mlp += sum(int(b.numel()) for b in dev_b)
+    REPORT.append((f"{tag} MLP hidden units whose ReLU branch is taken from the device", float(n_mlp)))
+    for k, v in rab["grads"].items():
+        check(f"{tag} actor grad {k} (raw: own branches on both sides)", actor_grads[k], ra["grads"][k])
         bad.append(check(f"{tag} actor grad {k}", actor_grads[k], v))
     bad.append(check(f"{tag} log_alpha grad", agent.log_alpha.grad.detach().cpu().reshape(1),
-                     ra["log_alpha_grad"].reshape(1)))
+                     rab["log_alpha_grad"].reshape(1)))
     # the target after the soft update (utils.py:37-41)
     tsd = agent.critic_target.state_dict()
     for k in ("encoder.convs.0.weight", f"encoder.convs.{layers - 1}.weight", "encoder.fc.weight", "Q1.trunk.2.weight"):

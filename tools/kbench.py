@@ -157,7 +157,7 @@ def main():
             lib.curla_debug_ablate(0)
 
     if "c5first" in args.what:  # the float NHWC first-layer kernels of BASELINE configs[4] (168x168x12 -> 83x83x32)
-        Bc = 256
+        Bc = 1024
         xin = torch.rand(Bc, 168, 168, 12, device=dev) * 255.0
         obs = ops.ObsRef.from_nhwc(xin)
         w0, b0 = r(32, 12, 3, 3) * 0.1, r(32) * 0.1
