@@ -100,6 +100,51 @@ __global__ void color_jiggle_kernel(const uint8_t* frames, const int64_t* idx, c
   }
 }
 
+// The same with one thread per PIXEL (all K frames of the stack) and one grid row per sample: no 64-bit division per
+// element (the flat form spends ~100 instructions on i % k, i / k, pix / (H W)), the pixel's 3 K bytes as aligned
+// dwords when 3 K is a multiple of 4 (frame_stack 4: three dwords), its 3 K floats as 16-byte stores.  The arithmetic
+// per RGB triple is the flat kernel's (jiggle_rgb), so the results are bit-identical.
+template <int K>
+__global__ __launch_bounds__(256) void color_jiggle_pixel_kernel(const uint8_t* frames, const int64_t* idx,
+                                                                   const float* params, const int* order, int HW,
+                                                                   float* out) {
+  constexpr int C = 3 * K;
+  const int b = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const int o0 = order[0], o1 = order[1], o2 = order[2], o3 = order[3];
+  const int64_t fi = idx ? idx[b] : b;
+  const uint8_t* src = frames + ((size_t)fi * HW + p) * C;
+  uint8_t px[C];
+  if (C % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0) {
+#pragma unroll
+    for (int u = 0; u < C / 4; ++u) {
+      const uint32_t d = reinterpret_cast<const uint32_t*>(src)[u];
+      px[4 * u] = d & 0xff, px[4 * u + 1] = (d >> 8) & 0xff, px[4 * u + 2] = (d >> 16) & 0xff, px[4 * u + 3] = d >> 24;
+    }
+  } else {
+#pragma unroll
+    for (int u = 0; u < C; ++u) px[u] = src[u];
+  }
+  float v[C];
+  constexpr float k255 = 1.f / 255.f;
+#pragma unroll
+  for (int fr = 0; fr < K; ++fr) {
+    float r = px[3 * fr] * k255, g = px[3 * fr + 1] * k255, bl = px[3 * fr + 2] * k255;
+    jiggle_rgb(r, g, bl, params + ((size_t)b * K + fr) * 4, o0, o1, o2, o3);
+    v[3 * fr] = r * 255.f, v[3 * fr + 1] = g * 255.f, v[3 * fr + 2] = bl * 255.f;
+  }
+  float* dst = out + ((size_t)b * HW + p) * C;
+  if (C % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+#pragma unroll
+    for (int u = 0; u < C / 4; ++u)
+      reinterpret_cast<f32x4*>(dst)[u] = f32x4{v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]};
+  } else {
+#pragma unroll
+    for (int u = 0; u < C; ++u) dst[u] = v[u];
+  }
+}
+
 // the same on the reference's tensor contract: float NCHW [B][C][H][W] in [0,255] in and out
 // (ColorJiggle.training_augmentation(image_batch), augmentations.py:105-136; in == out is allowed)
 __global__ void color_jiggle_nchw_kernel(const float* in, const float* params, const int* order, int B, int C, int H,
@@ -183,8 +228,18 @@ extern "C" {
 int curla_color_jiggle(const uint8_t* frames, const int64_t* idx, const float* params, const int32_t* order, int B,
                        int C, int H, int W, float* out, void* stream) {
   CURLA_REQUIRE(frames && params && order && out && B > 0 && C > 0 && C % 3 == 0 && H > 0 && W > 0);
-  hipLaunchKernelGGL(color_jiggle_kernel, dim3(blocks_for((size_t)B * H * W * (C / 3))), dim3(256), 0,
-                     static_cast<hipStream_t>(stream), frames, idx, params, order, B, C, H, W, out);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int K = C / 3, HW = H * W;
+  if (K >= 1 && K <= 4 && B <= 65535 && (long long)H * W < (1LL << 30)) {
+    const dim3 grid((HW + 255) / 256, B);
+    if (K == 4) hipLaunchKernelGGL(color_jiggle_pixel_kernel<4>, grid, dim3(256), 0, st, frames, idx, params, order, HW, out);
+    else if (K == 3) hipLaunchKernelGGL(color_jiggle_pixel_kernel<3>, grid, dim3(256), 0, st, frames, idx, params, order, HW, out);
+    else if (K == 2) hipLaunchKernelGGL(color_jiggle_pixel_kernel<2>, grid, dim3(256), 0, st, frames, idx, params, order, HW, out);
+    else hipLaunchKernelGGL(color_jiggle_pixel_kernel<1>, grid, dim3(256), 0, st, frames, idx, params, order, HW, out);
+    return curla_launch_status();
+  }
+  hipLaunchKernelGGL(color_jiggle_kernel, dim3(blocks_for((size_t)B * H * W * (C / 3))), dim3(256), 0, st, frames, idx,
+                     params, order, B, C, H, W, out);
   return curla_launch_status();
 }
 

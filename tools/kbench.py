@@ -166,6 +166,14 @@ def main():
         dw0, db0 = torch.empty(32, 12, 3, 3, device=dev), torch.empty(32, device=dev)
         ws0 = torch.empty(ops.wgrad_workspace_floats(12), device=dev)
         fl_ = 2.0 * Bc * 83 * 83 * 32 * 12 * 9
+        import curla_amd
+        aug = curla_amd.ColorJiggle((168, 168))
+        ring = torch.randint(0, 256, (512 * 168 * 168 * 12 + 32,), dtype=torch.uint8, device=dev)[:512 * 168 * 168 * 12].view(512, 168, 168, 12)
+        jidx = torch.randint(0, 512, (Bc,), device=dev)
+        params, order = aug.draw_params(Bc * 4)
+        params, order = params.to(dev), order.to(dev)
+        us = timeit(lambda: ops.color_jiggle(ring, jidx, params, order, Bc, xin))
+        print(f"{'color_jiggle 168x168x12 -> float NHWC, B=' + str(Bc):46s} {us:9.1f} us  {(Bc * 168 * 168 * 12 * 5) / us / 1e6:7.2f} TB/s", flush=True)
         report(f"conv1_fwd float NHWC 168x168x12, B={Bc}", timeit(lambda: ops.conv1_fwd(obs, w0, b0, out)), fl_)
         report(f"conv1_wgrad(+reduce) float NHWC, B={Bc}", timeit(lambda: ops.conv1_wgrad(obs, g, dw0, db0, ws0)), fl_)
 
