@@ -14,10 +14,11 @@ configuration (default c2 = configs[1], the one the metric is quoted on):
 With N>1 every rank does the same on its own ring shard and the gradient buckets
 are all-reduced over RCCL (weak scaling).  Prints ONE JSON line on rank 0.
 
-Without ``--config`` the line's ``metric`` / ``value`` / ``config`` are c2's and the same process then measures
-c3 and c5 as well (the c2 ring is freed first) and reports them under ``other_configs`` -- each with its own
-``value``, ``ms_per_step``, ``steps``, ``roofline`` and (N=1) ``cpu_baseline``; ``--no-others`` or an explicit
-``--config`` measures one configuration only.
+Without ``--config`` the line's ``metric`` / ``value`` / ``config`` are c2's and, at N = 1, the same process then
+measures c3 and c5 as well (the c2 ring is freed first) and reports them under ``other_configs`` -- each with its own
+``value``, ``ms_per_step``, ``steps``, ``roofline`` and ``cpu_baseline``; ``--no-others`` or an explicit ``--config``
+measures one configuration only.  At N > 1 only c2 is measured unless ``--others`` asks for all three (a failure in a
+secondary configuration of a multi-GPU job would take the headline line down with it).
 
 ``--dry-run`` walks the same host path -- launcher respawn, ring shards, rank seeds, data-parallel setup, the
 update loop, the all-reduce report, the one JSON line -- with gloo on the CPU and the kernel calls routed to the
@@ -492,6 +493,9 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
                     help="measure this configuration only (default: c2, then c3 and c5 under other_configs)")
     ap.add_argument("--no-others", action="store_true", help="without --config: measure c2 only")
+    ap.add_argument("--others", action="store_true",
+                    help="measure c3 and c5 after c2 at N > 1 as well (default: only at N = 1 -- a multi-GPU run that "
+                         "fails in a secondary configuration would take the headline line down with it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--capacity", type=int, default=CAPACITY)
     ap.add_argument("--prefill", choices=("device", "host"), default="device")
@@ -501,7 +505,8 @@ def main():
                     help="gloo + launch-trace hook on the CPU: the host path of an N-rank run without a GPU")
     args = ap.parse_args()
     main_cfg = args.config or "c2"
-    others = [] if (args.config is not None or args.no_others) else [c for c in ("c3", "c5")]
+    world_env = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    others = [] if (args.config is not None or args.no_others or (world_env > 1 and not args.others)) else ["c3", "c5"]
 
     def budget(name):
         """(steps, warmup) of a configuration: the command line's for the main one and c3; c5's updates are 15x

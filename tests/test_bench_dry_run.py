@@ -53,7 +53,8 @@ def _check_line(d, n, capacity, buckets):
 
 
 def test_four_ranks_through_the_self_respawn_all_configs():
-    d = _run([sys.executable, "bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1", "--dry-run", "--capacity", "512"])
+    d = _run([sys.executable, "bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1", "--dry-run", "--capacity", "512",
+              "--others"])
     _check_line(d, 4, 512, ("critic", "actor", "cpc"))
     assert d["metric"].startswith("SAC+CURL gradient updates/sec, batch=512")
     assert d["config"]["baseline_config"] == "configs[1]"
@@ -72,7 +73,7 @@ def test_four_ranks_through_the_self_respawn_all_configs():
 def test_eight_ranks_through_the_drivers_launcher_command():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), "bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1",
-           "--dry-run", "--capacity", "1000", "--no-others"]
+           "--dry-run", "--capacity", "1000"]  # (N > 1 without --others: the headline configuration only)
     d = _run(cmd)
     _check_line(d, 8, 1000, ("critic", "actor", "cpc"))
     assert "other_configs" not in d
