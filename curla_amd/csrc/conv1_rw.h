@@ -77,29 +77,28 @@ __device__ __forceinline__ void conv1_body(const Conv1Args& a, const int bid, co
         x = 16 * G.nfull + col, y0 = sg * G.nr;
       }
       const int Y = y0 + sb;
-      const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(a.src + (size_t)b * a.Hc * a.Wc * C), (short)0, a.Hc * in_row, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(a.out + (size_t)b * a.Ho * a.Wo * 32), (short)0, a.Ho * out_row, 0x00020000);
-      // the lane group's E values of input row r: (r Wc + 2x) C + E kq floats into the sample; rows advance through the
-      // scalar offset; a lane without a column and rows past the image are out of range (zeros, nothing stored)
-      const unsigned vin = lane_on ? (unsigned)((2 * x * C + E * kq) * 4) : 0x80000000u;
+      const __amdgpu_buffer_rsrc_t rin = uniform_rsrc(a.src + (size_t)b * a.Hc * a.Wc * C, a.Hc * in_row);
+      const __amdgpu_buffer_rsrc_t rout = uniform_rsrc(a.out + (size_t)b * a.Ho * a.Wo * 32, a.Ho * out_row);
+      // the lane group's E values of input row 2 Y + r: ((2 Y + r) Wc + 2x) C + E kq floats into the sample; the lane's own
+      // first row is part of its offset (lanes of a remainder strip start at different rows), r advances through the
+      // (wave-uniform) scalar offset; a lane without a column and rows past the image are out of range (zeros, nothing stored)
+      const unsigned vin = lane_on ? (unsigned)(((2 * Y * a.Wc + 2 * x) * C + E * kq) * 4) : 0x80000000u;
       unsigned vo = lane_on ? (unsigned)((Y * a.Wo + x) * 128 + kq * 16) : 0x80000000u;
 
       struct Row {
         f32x4 v[NL];
       };
-      auto load_row = [&](Row& R, int r) {  // input row r of the sample
-        const unsigned so = (unsigned)(r * in_row);
+      auto load_row = [&](Row& R, int r) {  // input row 2 Y + r of the sample
+        const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(r * in_row));
 #pragma unroll
         for (int u = 0; u < NL; ++u)
           R.v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, vin + 16u * u, so, 0));
       };
       // output row t of the piece from the three input rows r0 (= 2 (Y + t)), r1, r2; the next step's two new rows
-      // (2 (Y + t) + 3, + 4) are requested first and land during this step's MFMAs
+      // (2 (Y + t) + 3, + 4: scalar offsets 2 t + 3, 2 t + 4) are requested first and land during this step's MFMAs
       auto step = [&](const Row& r0, const Row& r1, const Row& r2, Row& p0, Row& p1, const int t) {
-        load_row(p0, 2 * (Y + t) + 3);
-        load_row(p1, 2 * (Y + t) + 4);
+        load_row(p0, 2 * t + 3);
+        load_row(p1, 2 * t + 4);
         __builtin_amdgcn_sched_barrier(0);
         f32x4 acc[2];
 #pragma unroll
@@ -126,7 +125,7 @@ __device__ __forceinline__ void conv1_body(const Conv1Args& a, const int bid, co
       };
 
       Row S0, S1, S2, S3, S4;
-      load_row(S0, 2 * Y), load_row(S1, 2 * Y + 1), load_row(S2, 2 * Y + 2);
+      load_row(S0, 0), load_row(S1, 1), load_row(S2, 2);
       for (int t = 0;;) {  // rows of step t sit in sets (2t, 2t+1, 2t+2) mod 5
         step(S0, S1, S2, S3, S4, t);
         if (++t >= n) break;
@@ -213,10 +212,8 @@ __device__ __forceinline__ void wgrad1_body(const Wgrad1Args& a, const int bid, 
         x = 4 * G.nfull + col, y0 = sg * G.nr;
       }
       const int Y = y0 + sb;
-      const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(a.src + (size_t)b * a.Hc * a.Wc * C), (short)0, a.Hc * in_row, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(a.g + (size_t)b * a.Ho * a.Wo * 32), (short)0, a.Ho * g_row, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rin = uniform_rsrc(a.src + (size_t)b * a.Hc * a.Wc * C, a.Hc * in_row);
+      const __amdgpu_buffer_rsrc_t rg = uniform_rsrc(a.g + (size_t)b * a.Ho * a.Wo * 32, a.Ho * g_row);
       // unit u = li + 16 h -> (dy, group): four patch values of input row 2 (Y + t) + dy at floats 2 x C + 4 group
       unsigned vin[2];
 #pragma unroll
@@ -232,7 +229,8 @@ __device__ __forceinline__ void wgrad1_body(const Wgrad1Args& a, const int bid, 
         f32x2 g;
       };
       auto issue = [&](Ld& L, int t) {
-        const unsigned sd = (unsigned)(2 * t * in_row), sg_ = (unsigned)(t * g_row);
+        const unsigned sd = __builtin_amdgcn_readfirstlane((unsigned)(2 * t * in_row));
+        const unsigned sg_ = __builtin_amdgcn_readfirstlane((unsigned)(t * g_row));
         L.d[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, vin[0], sd, 0));
         L.d[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, vin[1], sd, 0));
         L.g = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rg, vg, sg_, 0));

@@ -36,6 +36,19 @@ namespace rw {
 
 constexpr int kWFloats = 3 * 4 * 2 * 2 * 256;  // transformed filter of one problem in LDS: [dy][pos][q][mt][kq][li][e]
 
+// A raw buffer descriptor over [p, p + bytes) whose words are PROVABLY wave-uniform: built from readfirstlane'd address
+// halves.  hipcc wraps every buffer load / store whose descriptor (or scalar offset) it cannot prove uniform in a
+// waterfall loop (cdna_hip_programming.md T20) -- ~10 instructions per access and the accesses serialise; the first
+// versions of the float first-layer kernels and the weight gradient ran with 20-40 such loops.  All descriptors of the
+// row-walk kernels are made here, and their scalar offsets go through readfirstlane.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* p, int bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)a);
+  const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi32 << 32) | lo32), (short)0,
+                                           __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 struct Geom {
   int Hi, Wi;    // input rows / columns
   int Ho, Wo;    // output rows / columns (forward: Hi-2, Wi-2; data gradient: Hi+2, Wi+2)
@@ -202,13 +215,10 @@ __device__ __forceinline__ void run_layer(const Geom& G, const Problem& P0, cons
       const int Y = y0 + sb;
       const int x0 = 2 * j;
       // per-sample descriptors: everything outside the sample's image reads zeros / is not stored
-      const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(P.in + (size_t)b * G.Hi * G.Wi * 32), (short)0, G.Hi * in_row, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(P.out + (size_t)b * G.Ho * G.Wo * 32), (short)0, G.Ho * out_row, 0x00020000);
-      const __amdgpu_buffer_rsrc_t raux = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(MODE == MODE_DGRAD ? P.aux + (size_t)b * G.Ho * G.Wo * 32 : P.aux), (short)0,
-          MODE == MODE_DGRAD ? G.Ho * out_row : 128, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rin = uniform_rsrc(P.in + (size_t)b * G.Hi * G.Wi * 32, G.Hi * in_row);
+      const __amdgpu_buffer_rsrc_t rout = uniform_rsrc(P.out + (size_t)b * G.Ho * G.Wo * 32, G.Ho * out_row);
+      const __amdgpu_buffer_rsrc_t raux = uniform_rsrc(MODE == MODE_DGRAD ? P.aux + (size_t)b * G.Ho * G.Wo * 32 : P.aux,
+                                                       MODE == MODE_DGRAD ? G.Ho * out_row : 128);
       // window pixel c of input row (Y - pad + t): byte offset inside the sample, or far out of range (a column
       // outside the image; a row outside it is out of range by itself: negative offsets are huge unsigned ones)
       unsigned voff[4];

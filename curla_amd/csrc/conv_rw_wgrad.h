@@ -106,10 +106,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bid, co
         j = 4 * G.nfull + col, y0 = sg * G.nr;
       }
       const int Y = y0 + sb, x0 = 2 * j;
-      const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(a.in + (size_t)b * a.Hi * a.Wi * 32), (short)0, a.Hi * in_row, 0x00020000);
-      const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
-          (void*)(a.g + (size_t)b * a.Ho * a.Wo * 32), (short)0, a.Ho * g_row, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rin = uniform_rsrc(a.in + (size_t)b * a.Hi * a.Wi * 32, a.Hi * in_row);
+      const __amdgpu_buffer_rsrc_t rg = uniform_rsrc(a.g + (size_t)b * a.Ho * a.Wo * 32, a.Ho * g_row);
       // window pixel c of input row Y + t, channels 2 li (tile 0) and 2 li + 1 (tile 1); gradient pixels x0 / x0 + 1 of row Y + t,
       // channel mt*16 + li.  A lane without a column, and the second pixel of an odd row's last pair, point far out
       // of range (zeros); rows advance through the scalar offset, rows past the image are out of range by themselves.
@@ -121,7 +119,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const int bid, co
       const unsigned vg1 = (lane_on && x0 + 1 < a.Wo) ? vg0 + 128u : 0x80000000u;
 
       auto issue = [&](WgLoads& L, int t) {
-        const unsigned sd = (unsigned)(t * in_row), sg_ = (unsigned)(t * g_row);
+        const unsigned sd = __builtin_amdgcn_readfirstlane((unsigned)(t * in_row));  // (an SGPR: a scalar offset the compiler
+        const unsigned sg_ = __builtin_amdgcn_readfirstlane((unsigned)(t * g_row));  //  cannot prove uniform costs a waterfall loop)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {  // input channels 2 li and 2 li + 1 (the lane's column of the two cin tiles): 8 bytes
           const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rin, vd[c], sd, 0));
