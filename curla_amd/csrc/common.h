@@ -53,21 +53,29 @@ static inline int curla_cu_count() {
   return n;
 }
 
-// Raise a kernel's dynamic-LDS limit to `bytes` once per (kernel, device).  hipFuncSetAttribute is per-function,
-// per-device process state (not stream-ordered): it is set on first use of a kernel on a device and never lowered, so
-// a process that drives several GPUs configures each of them, and two host threads cannot race each other's limit.
+// Make sure a kernel's dynamic-LDS limit on the current device is at least `bytes`.  hipFuncSetAttribute is per-function,
+// per-device process state (not stream-ordered): the largest size asked for so far is remembered per (kernel, device)
+// and the limit is only ever RAISED -- a process that drives several GPUs configures each of them, two host threads
+// cannot race each other's limit, and a launch that needs more than an earlier one of the same kernel gets it.
 static inline int curla_set_dyn_lds(const void* fn, size_t bytes) {
   static std::mutex mu;
   static const void* done_fn[256];
   static int done_dev[256];
+  static size_t done_bytes[256];
   static int ndone = 0;
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return CURLA_ERR_LAUNCH;
   std::lock_guard<std::mutex> lock(mu);
+  int slot = -1;
   for (int i = 0; i < ndone; ++i)
-    if (done_fn[i] == fn && done_dev[i] == dev) return CURLA_OK;
+    if (done_fn[i] == fn && done_dev[i] == dev) {
+      if (bytes <= done_bytes[i]) return CURLA_OK;
+      slot = i;
+      break;
+    }
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) return CURLA_ERR_LAUNCH;
-  if (ndone < 256) done_fn[ndone] = fn, done_dev[ndone] = dev, ++ndone;
+  if (slot < 0 && ndone < 256) slot = ndone++;
+  if (slot >= 0) done_fn[slot] = fn, done_dev[slot] = dev, done_bytes[slot] = bytes;
   return CURLA_OK;
 }
 

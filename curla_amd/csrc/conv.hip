@@ -409,6 +409,28 @@ __global__ __launch_bounds__(512, 2) void wgrad1_rw_kernel(rw::Wgrad1Args a) {
   rw::wgrad1_body<C, 8>(a, blockIdx.x, gridDim.x);
 }
 
+#include "conv1_u8_rw.h"
+
+// workgroup shape of the uint8 row-walk forward: two 512-thread workgroups per CU (4 waves per SIMD).  Five 256-thread
+// ones (5 waves per SIMD, what ~100 VGPRs allow) were slower inside update(): 402 against 407 update()/s
+constexpr int kC1U8Threads = 512, kC1U8PerCU = 2;
+
+// first layer straight from the uint8 ring in row-walk form (conv1_u8_rw.h): 512-thread workgroups, two per CU, equal
+// shares of the pool of steps of both minibatches (the second with its own weights: both images sit in LDS)
+template <int C>
+__global__ __launch_bounds__(kC1U8Threads, kC1U8PerCU) void conv1_u8_rw_fwd_kernel(rw::Conv1U8Args a) {
+  __shared__ __attribute__((aligned(16))) float lds_img[2 * rw::conv1_u8_image_floats<C>()];
+  rw::conv1_u8_stage_weights<C, kC1U8Threads>(lds_img, a.p[0].w, a.p[0].bias, a.scale, threadIdx.x);
+  if (a.p[1].B > 0)
+    rw::conv1_u8_stage_weights<C, kC1U8Threads>(lds_img + rw::conv1_u8_image_floats<C>(), a.p[1].w, a.p[1].bias, a.scale,
+                                                threadIdx.x);
+  __syncthreads();
+  if ((a.Ws * C) % 4 == 0)
+    rw::conv1_u8_body<C, kC1U8Threads / 64, true>(a, lds_img, blockIdx.x, gridDim.x);
+  else
+    rw::conv1_u8_body<C, kC1U8Threads / 64, false>(a, lds_img, blockIdx.x, gridDim.x);
+}
+
 // ---------------------------------------------------------------------------
 // first layer: Cin = C (9 or 12 ...), stride 2, input either the uint8 replay
 // frames (gather by index + random-crop offsets + /255 fused into the load) or
@@ -495,6 +517,18 @@ __device__ __forceinline__ void conv1_stage(float* lds, const void* src, const i
       const int t = i / Wc;
       const int r = t % rows, c = t / rows;
       lds[r * RS + x * C + c] = img[((size_t)c * Hc + r0 + r) * Wc + x] * scale;
+    }
+  }
+  // The k-steps of a tap row cover KR = 3C rounded up to 4 values: at an odd crop width the last pixel's run ends at
+  // the row's end and its padding value is the float BEHIND the row.  Its weight is zero, but 0 x (whatever bit
+  // pattern an earlier kernel left in LDS: NaN, Inf) is NaN, which the ReLU then turns into 0 -- a wrong, finite
+  // output.  The slack behind every row is zeroed here (the uint8 path wrote whole groups of four: behind those).
+  {
+    const int first = SRC == SRC_U8 ? (rowf + 3) & ~3 : rowf;
+    const int pad = RS - first;  // 4..7 floats
+    for (int i = tid; i < rows * pad; i += nthreads) {
+      const int r = i / pad, e = i - r * pad;
+      lds[r * RS + first + e] = 0.f;
     }
   }
 }
@@ -1582,6 +1616,12 @@ bool use_rw() {
   return !band;
 }
 // ... and the weight gradient: CURLA_S1_WGRAD=band keeps the banded kernel beside the row-walk forward / data gradient
+// CURLA_C1_U8=band: the LDS-banded uint8 first-layer kernels instead of the row-walk ones
+bool use_rw_u8() {
+  static const bool band = getenv("CURLA_C1_U8") && !strcmp(getenv("CURLA_C1_U8"), "band");
+  return use_rw() && !band;
+}
+
 bool use_rw_wgrad() {
   static const bool band = getenv("CURLA_S1_WGRAD") && !strcmp(getenv("CURLA_S1_WGRAD"), "band");
   return use_rw() && !band;
@@ -1845,6 +1885,26 @@ static int conv1_fwd_impl(const void* src, int src_kind, const int64_t* idx, con
   hipStream_t st = static_cast<hipStream_t>(stream);
   const size_t wl = (size_t)32 * C * 9 * sizeof(float);
   if (second && src_kind != 1) return CURLA_ERR_UNSUPPORTED;
+  if (src_kind == 1 && use_rw_u8() && (long long)Hs * Ws * C < (1LL << 30) &&
+      (long long)(B + a.B2) * a.Ho * ((a.Wo + 15) / 16 + 1) < (1LL << 28)) {
+    // uint8 ring: row walk, nothing staged (conv1_u8_rw.h)
+    rw::Conv1U8Args ra;
+    ra.src = static_cast<const uint8_t*>(src);
+    ra.p[0] = rw::Conv1U8Problem{idx, h1, w1, w, bias, out, B};
+    ra.p[1] = rw::Conv1U8Problem{a.idx2, a.h1_2, a.w1_2, a.w2, a.bias2, a.out2, a.B2};
+    ra.Hs = Hs, ra.Ws = Ws, ra.Ho = a.Ho, ra.Wo = a.Wo, ra.scale = scale;
+    ra.g.Hi = Hc, ra.g.Wi = Wc, ra.g.Ho = a.Ho, ra.g.Wo = a.Wo;
+    rw::plan_units(ra.g, a.Ho, a.Wo, 16);
+    // kC1U8PerCU workgroups per CU; fewer when a workgroup's share of the pool would drop below a few steps per wave
+    const int cap = kC1U8PerCU * curla_cu_count();
+    const long long pool = (long long)(B + a.B2) * ra.g.steps;
+    const int want = (int)((pool + 63) / 64);
+    const int grid_rw = want < cap ? (want < 1 ? 1 : want) : cap;
+#define CONV1_U8_RW_LAUNCH(CC) hipLaunchKernelGGL((conv1_u8_rw_fwd_kernel<CC>), dim3(grid_rw), dim3(kC1U8Threads), 0, st, ra)
+    if (C == 9) CONV1_U8_RW_LAUNCH(9); else if (C == 12) CONV1_U8_RW_LAUNCH(12); else if (C == 6) CONV1_U8_RW_LAUNCH(6); else CONV1_U8_RW_LAUNCH(3);
+#undef CONV1_U8_RW_LAUNCH
+    return curla_launch_status();
+  }
   if (src_kind == 1 && !(ABL_HOST & 128)) {
     // uint8 ring: the band stays bytes in LDS; the tallest band that leaves room for two workgroups per CU
     const int RSb = ((Wc * C + 15) & ~15) + 16;

@@ -14,6 +14,14 @@
 
 namespace rw {
 
+// ReLU as one integer max on the bit pattern (positive floats order like their bits, everything with the sign bit set
+// is a negative integer): fmaxf(x, 0) costs two instructions on an MFMA result, which is not known to be canonical --
+// IEEE mode makes the compiler quiet it first (v_max_f32 x, x, x)
+__device__ __forceinline__ float relu_bits(float x) {
+  const int b = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
 struct Conv1Args {
   const float* src;   // [B][Hc][Wc][C] float NHWC in [0, 255]
   const float* w;     // OIHW [32][C][3][3]
@@ -117,7 +125,7 @@ __device__ __forceinline__ void conv1_body(const Conv1Args& a, const int bid, co
         for (int mt = 0; mt < 2; ++mt) {
           f32x4 v = acc[mt];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          for (int r = 0; r < 4; ++r) v[r] = relu_bits(v[r]);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rout,
                                                  vo + mt * 64u, 0, 2);
         }

@@ -29,9 +29,12 @@ def _run(cmd):
     # gloo's C++ side reports its connections on stdout ("[Gloo] Rank r is connected to ..."); anything else on
     # stdout must be the ONE JSON line, from rank 0 only
     # (the ranks' reports interleave, so they are recognised by their text, not by their first characters)
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip() and "peer ranks" not in ln and not ln.startswith("[Gloo]")]
-    assert len(lines) == 1, lines
-    return json.loads(lines[0])
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip() and "peer ranks" not in ln and "[Gloo]" not in ln]
+    # (a library's report can also land on the same line as another rank's: what must hold is ONE JSON object, and
+    # nothing on stdout that is not a Gloo connection report)
+    objs = [ln for ln in lines if ln.lstrip().startswith("{")]
+    assert len(objs) == 1 and len(lines) == 1, lines
+    return json.loads(objs[0])
 
 
 def _check_line(d, n, capacity, buckets):

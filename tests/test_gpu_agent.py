@@ -403,6 +403,9 @@ def test_other_config_geometries_vs_oracle(name, obs_shape, layers, pixel_sac, B
     ref_critic = O.critic_phase(oracle.actor, oracle.critic, oracle.critic_target, oracle.log_alpha, f(obs_all),
                                 torch.from_numpy(act_all[idxs]), torch.from_numpy(rew_all[idxs])[:, None], f(nxt_all),
                                 torch.ones(B, 1), nc, num_layers=layers, discount=0.99, log_std_min=-10, log_std_max=2)
+    oracle_pre = {nm: {k: v.detach().clone() for k, v in getattr(oracle, nm).items()}
+                  for nm in ("actor", "critic", "critic_target")}  # (oracle.update steps its parameters in place)
+    log_alpha_pre = oracle.log_alpha.detach().clone()
     ref = oracle.update(f(obs_all), torch.from_numpy(act_all[idxs]), torch.from_numpy(rew_all[idxs])[:, None], f(nxt_all),
                         torch.ones(B, 1), f(obs_all), nc, na, step=0)
     L = NullLogger()
@@ -417,24 +420,68 @@ def test_other_config_geometries_vs_oracle(name, obs_shape, layers, pixel_sac, B
         opt.step = step
     capture("critic", agent.critic, agent.critic_optimizer)
     obs, act, rew, nxt, nd, kw = rb.sample_cpc_refs(indices=(idxs, offs))
+    # The actor and CURL phases run on parameters that have been through an Adam step, and one Adam step of a gradient
+    # element within rounding of zero is chaotic (its first update is lr * sign: SURVEY.md D11) -- two correct fp32
+    # evaluations of the critic phase can leave the critic 2 lr apart in single elements.  So each later phase is held
+    # to RTOL against the oracle evaluated on THIS agent's parameters as they stand when the phase starts, and to a
+    # looser bound against the oracle's own chained update.
+    snap = lambda module, like: {k: module.state_dict()[k].detach().cpu().clone() for k in like}  # noqa: E731
     agent.update_critic(obs, act, rew, nxt, nd, L, 0, noise=nc.cuda())
+    # ReLU branches (tests/test_gpu_fullsize.py has the long form of this argument): a conv activation within rounding
+    # of zero -- positive in one fp32 evaluation, not in the other -- changes no VALUE but switches a whole term of the
+    # weight gradients on or off, which at B = 4 is 1e-3 of a tensor.  The activations are compared as values, the two
+    # sides may only disagree on branches where both are within 1e-5 of zero, and the gradients are compared with the
+    # oracle differentiating along the device's branches (un-aligned errors go to the report as "raw").
+    ws = agent._ws(B)
+    branches = []
+    for i in range(layers):
+        dev_act = ws.acts_main[i].permute(0, 3, 1, 2).cpu()  # obs under the pre-step weights (the critic phase's pass)
+        ref_act = ref_critic["enc"][f"conv{i + 1}"]
+        check(f"{name} activations conv{i + 1}", dev_act, ref_act)
+        differ = (dev_act > 0) != (ref_act > 0)
+        assert int(differ.sum()) <= 4, (i, int(differ.sum()))
+        if differ.any():
+            assert float(torch.maximum(dev_act[differ].abs(), ref_act[differ].abs()).max()) <= 1e-5
+        branches.append(dev_act > 0)
+    ref_critic_b = O.critic_phase(oracle_pre["actor"], oracle_pre["critic"], oracle_pre["critic_target"], log_alpha_pre,
+                                  f(obs_all), torch.from_numpy(act_all[idxs]), torch.from_numpy(rew_all[idxs])[:, None],
+                                  f(nxt_all), torch.ones(B, 1), nc, num_layers=layers, discount=0.99, log_std_min=-10,
+                                  log_std_max=2, relu_branches=branches)
+    assert float((ref_critic_b["loss"] - ref_critic["loss"]).abs()) == 0.0  # values untouched, only derivative branches
+    ref_actor = O.actor_phase(snap(agent.actor, oracle.actor), snap(agent.critic, oracle.critic),
+                              agent.log_alpha.detach().cpu().clone(), f(obs_all), na, num_layers=layers, log_std_min=-10,
+                              log_std_max=2, target_entropy=oracle.target_entropy)
     agent.update_actor_and_alpha(obs, L, 0, noise=na.cuda())
     agent.soft_update_targets()
     if not pixel_sac:
+        ref_cpc = O.cpc_phase(snap(agent.critic, oracle.critic), snap(agent.critic_target, oracle.critic_target),
+                              agent.CURL.W.detach().cpu().clone(), f(obs_all), f(obs_all), num_layers=layers)
         agent.update_cpc(kw["obs_anchor"], kw["obs_pos"], kw, L, 0)
     check(f"{name} critic loss", L.scalars["train_critic/loss"], ref["critic_loss"])
-    check(f"{name} actor loss", L.scalars["train_actor/loss"], ref["actor_loss"])
+    check(f"{name} actor loss (phase)", L.scalars["train_actor/loss"], ref_actor["actor_loss"])
+    check(f"{name} actor loss (chained)", L.scalars["train_actor/loss"], ref["actor_loss"], 5e-3)
     if not pixel_sac:
         # feature 130 with W ~ U(0,1): logits of magnitude ~40 whose softmax is close to one-hot, so the loss is a
         # small difference of large numbers -- 5e-4 there (the gradients below stay at 1e-4)
-        check(f"{name} curl loss", L.scalars["train/curl_loss"], ref["curl_loss"], 5e-4 if feat > 64 else RTOL)
-    for k, v in ref_critic["grads"].items():
+        check(f"{name} curl loss (phase)", L.scalars["train/curl_loss"], ref_cpc["loss"], 5e-4 if feat > 64 else RTOL)
+        check(f"{name} curl loss (chained)", L.scalars["train/curl_loss"], ref["curl_loss"], 5e-3)
+    for k, v in ref_critic_b["grads"].items():
+        REPORT.append((f"{name} critic grad {k} (raw: own branches on both sides)", rel_err(grads["critic"][k], ref_critic["grads"][k])))
         check(f"{name} critic grad {k}", grads["critic"][k], v)
     # post-Adam conv parameters (fc.weight is left out: its entries are ~lr-sized, so one Adam step of a
     # near-zero gradient element is chaotic -- SURVEY.md D11)
     sd = agent.critic.state_dict()
+    # Element by element: where the gradient is within rounding of zero the two sides may take Adam's first step in
+    # opposite directions (2 lr apart, ~5e-3 of the largest weight; a conv ReLU branch that differs moves ~1e-3 of every
+    # gradient below it through zero) -- a few elements in a hundred at most; everything else agrees to 1e-4.  A wrong
+    # optimizer (rate, order, state) would move all of them.
     for k in ("encoder.convs.0.weight", f"encoder.convs.{layers - 1}.weight"):
-        check(f"{name} params after update {k}", sd[k].cpu(), oracle.critic[k].detach(), 1e-3)
+        got, want = sd[k].cpu(), oracle.critic[k].detach()
+        d = (got - want).abs() / want.abs().max()
+        off = float((d > RTOL).float().mean())
+        REPORT.append((f"{name} params after update {k}: fraction of elements off by > 1e-4", off))
+        REPORT.append((f"{name} params after update {k}: largest deviation", float(d.max())))
+        assert off <= 0.03 and float(d.max()) <= 2e-2, (k, off, float(d.max()))
     assert len(grads["critic"]) == 8 + 2 * layers + 8
 
 

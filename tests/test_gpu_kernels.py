@@ -105,6 +105,8 @@ CONV1_CASES = [  # C, Hs, Ws, Hc, Wc, B
     (9, 34, 40, 28, 34, 8), (9, 84, 84, 76, 76, 4), (9, 84, 84, 84, 84, 3), (12, 50, 46, 41, 37, 5), (3, 20, 23, 17, 19, 6),
     (6, 31, 45, 25, 39, 7),  # frame_stack 2; 31*45*6 bytes per frame is not a multiple of 4
     (3, 21, 21, 21, 21, 5),  # odd-sized frames, no crop
+    (9, 76, 135, 76, 135, 4),  # the reference's own thesis shape (encoder.py:42-43), no crop; row pitch 1215 = 3 mod 4
+    (12, 37, 41, 30, 33, 9),  # row pitch 492 = 0 mod 4, odd crop origins: aligned loads + byte shift
 ]
 
 

@@ -1,0 +1,14 @@
+"""Call the first-layer kernel test body repeatedly in one process; print every assertion that fires."""
+import sys, os, traceback
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+from tests import test_gpu_kernels as T
+from curla_amd import ops
+n_bad = 0
+for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10):
+    for case in T.CONV1_CASES:
+        try:
+            T.test_crop_and_conv1_u8(ops, *case)
+        except AssertionError as e:
+            n_bad += 1
+            print("rep", rep, case, "->", str(e)[:200], flush=True)
+print("failures:", n_bad)

@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--ablate", type=str, default="")
     ap.add_argument("--B", type=int, default=512)
     ap.add_argument("--what", type=str, default="conv,gemm,misc")
+    ap.add_argument("--slots", type=int, default=2048, help="c1only: ring slots (2048 = 130 MB: Infinity-Cache resident)")
+    ap.add_argument("--outs", type=int, default=1, help="c1only: rotate over this many output buffers")
     args = ap.parse_args()
     if args.build_ablate:
         print(build_ablate())
@@ -70,9 +72,10 @@ def main():
     torch.cuda.synchronize()
 
     if "c1only" in args.what:  # just the two first-layer kernels (for rocprofv3 --pmc passes)
-        store = torch.randint(0, 256, (2048 * 84 * 84 * 9 + 32,), dtype=torch.uint8, device=dev)
-        ring = store[:2048 * 84 * 84 * 9].view(2048, 84, 84, 9)
-        idx = torch.randint(0, 2048, (B,), device=dev)
+        NS = args.slots
+        store = torch.randint(0, 256, (NS * 84 * 84 * 9 + 32,), dtype=torch.uint8, device=dev)
+        ring = store[:NS * 84 * 84 * 9].view(NS, 84, 84, 9)
+        idx = torch.randint(0, NS, (B,), device=dev)
         h1 = torch.randint(0, 8, (B,), device=dev, dtype=torch.int32)
         w1 = torch.randint(0, 8, (B,), device=dev, dtype=torch.int32)
         obs = ops.ObsRef.from_ring(ring, idx, h1, w1, B, (76, 76))
@@ -85,7 +88,33 @@ def main():
         for fl in flags:
             if flags != [0]:
                 lib.curla_debug_ablate(fl)
-            report(f"[abl {fl}] conv1_fwd u8", timeit(lambda: ops.conv1_fwd(obs, w0, b, out)), fl_)
+            outs = [out] + [torch.empty_like(out) for _ in range(args.outs - 1)]
+            it = [0]
+
+            def fwd():
+                it[0] += 1
+                ops.conv1_fwd(obs, w0, b, outs[it[0] % len(outs)])
+            report(f"[abl {fl}] conv1_fwd u8", timeit(fwd), fl_)
+            # two minibatches of one ring in one launch, as update() issues it: [obs | next_obs] online + next_obs target
+            B2 = B // 2
+            idx2 = torch.randint(0, NS, (B2,), device=dev)
+            obs2 = ops.ObsRef.from_ring(ring, idx2, h1[:B2].contiguous(), w1[:B2].contiguous(), B2, (76, 76))
+            w02, b2, out2 = r(32, 9, 3, 3) * 0.1, r(32) * 0.1, torch.empty(B2, 37, 37, 32, device=dev)
+            report(f"[abl {fl}] conv1_fwd2 u8 {B}+{B2}", timeit(lambda: ops.conv1_fwd2(obs, w0, b, out, obs2, w02, b2, out2)), fl_ * 1.5)
+            big = torch.empty(B + B2, 37, 37, 32, device=dev)
+            report(f"[abl {fl}] conv1_fwd2 u8 {B}+{B2} one out buffer", timeit(lambda: ops.conv1_fwd2(obs, w0, b, big[:B], obs2, w02, b2, big[B:])), fl_ * 1.5)
+            report(f"[abl {fl}] conv1_fwd2 u8 {B}+{B2} same weights", timeit(lambda: ops.conv1_fwd2(obs, w0, b, out, obs2, w0, b, out2)), fl_ * 1.5)
+            # fresh ring slots every launch (a fixed index set stays in the Infinity Cache from one launch to the next)
+            sets = [ops.ObsRef.from_ring(ring, torch.randint(0, NS, (B,), device=dev), h1, w1, B, (76, 76)) for _ in range(16)]
+            it2 = [0]
+
+            def fwd_fresh():
+                it2[0] += 1
+                ops.conv1_fwd(sets[it2[0] % 16], w0, b, out)
+            report(f"[abl {fl}] conv1_fwd u8 fresh slots", timeit(fwd_fresh, iters=32), fl_)
+            idx3 = torch.cat([idx, idx2])
+            obs3 = ops.ObsRef.from_ring(ring, idx3, torch.cat([h1, h1[:B2]]), torch.cat([w1, w1[:B2]]), B + B2, (76, 76))
+            report(f"[abl {fl}] conv1_fwd u8 {B + B2} one problem", timeit(lambda: ops.conv1_fwd(obs3, w0, b, big)), fl_ * 1.5)
             report(f"[abl {fl}] conv1_wgrad u8", timeit(lambda: ops.conv1_wgrad(obs, g, dw0, db, ws0)), fl_)
         if flags != [0]:
             lib.curla_debug_ablate(0)
