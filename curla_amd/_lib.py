@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcurla_hip.so")
 
 c_int, c_ll, c_float, c_size_t, vp = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
+c_u64 = ctypes.c_ulonglong
 c_double = ctypes.c_double
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/curla_hip.h
@@ -37,6 +38,8 @@ SIGNATURES = {
     "curla_fc_dx": [vp, vp, vp, vp, c_int, c_int, c_int, vp],
     "curla_fc_dw": [vp, vp, vp, c_int, c_int, c_int, vp],
     "curla_fc_bwd": [vp, vp, vp, vp, vp, c_int, c_int, c_int, vp],
+    "curla_fc_bwd_ln": [vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, c_int, vp, vp, vp, vp],
+    "curla_fc_dw_ln": [vp, vp, vp, c_int, c_int, c_int, vp, c_int, vp, vp, vp, vp],
     "curla_gemm_nested": [vp, c_int, c_int, c_ll, c_ll, vp, c_int, c_int, c_ll, c_ll, vp, c_int, c_ll, c_ll, c_int, c_int, c_int,
                           c_int, c_int, c_float, vp, c_ll, c_ll, c_int, vp, c_int, c_ll, c_ll, vp],
     "curla_mlp_out_fwd_nested": [vp, c_ll, c_ll, vp, c_ll, c_ll, vp, c_ll, c_ll, vp, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int,
@@ -56,6 +59,8 @@ SIGNATURES = {
     "curla_critic_td_loss": [vp, vp, c_ll, vp, vp, vp, vp, c_float, c_int, vp, vp, vp, vp],
     "curla_soft_update2": [vp, vp, c_size_t, c_size_t, c_float, c_float, c_float, c_float, vp],
     "curla_adam_step": [vp, vp, vp, vp, c_size_t, c_double, c_double, c_double, c_double, c_ll, vp],
+    "curla_adam_step_lerp": [vp, vp, vp, vp, c_size_t, c_double, c_double, c_double, c_double, c_ll, vp, c_size_t,
+                             c_float, c_float, c_float, c_float, vp],
     "curla_adam_step_scalar64": [vp, vp, vp, vp, c_size_t, c_double, c_double, c_double, c_double, c_ll, vp, vp, vp, vp,
                                  c_double, c_double, c_double, c_double, c_ll, vp],
     "curla_adam_step2": [vp, vp, vp, vp, vp, vp, c_size_t, c_size_t, c_double, c_double, c_double, c_double, c_ll, c_double,
@@ -65,10 +70,14 @@ SIGNATURES = {
     "curla_host_device_pointer": [vp, vp],
     "curla_ln_bwd": [vp, vp, vp, vp, c_int, c_int, vp, vp, vp, vp, vp],
     "curla_ln_bwd_twin": [vp, vp, c_int, vp, vp, vp, c_int, c_int, vp, vp, vp, vp, vp],
+    "curla_ln_bwd_partial": [vp, vp, c_int, vp, vp, vp, c_int, c_int, vp, vp, vp, vp],
     "curla_colsum": [vp, c_int, c_int, c_int, c_ll, vp, c_ll, c_int, vp],
     "curla_colsum3": [vp, c_int, vp, c_int, vp, c_int, c_int, vp, vp, vp, c_ll, c_int, vp],
     "curla_actor_head_fwd": [vp, vp, c_int, c_int, c_float, c_float, vp, vp, vp, vp, vp, vp, c_int, vp],
     "curla_mlp_out_head_fwd": [vp, vp, vp, vp, c_int, c_int, c_int, vp, c_float, c_float, vp, vp, vp, vp, vp, vp, c_int, vp],
+    "curla_actor_head_fwd_rng": [vp, vp, c_u64, c_u64, c_int, c_int, c_float, c_float, vp, vp, vp, vp, vp, vp, c_int, vp],
+    "curla_mlp_out_head_fwd_rng": [vp, vp, vp, vp, c_int, c_int, c_int, vp, c_u64, c_u64, c_float, c_float, vp, vp, vp, vp,
+                                   vp, vp, c_int, vp],
     "curla_fc_ln_fwd_multi": [c_int, vp, c_int, c_ll, c_int, c_int, c_int, c_float, c_int, vp],
     "curla_actor_head_bwd": [vp, vp, c_int, vp, vp, c_float, vp, vp, vp, vp, c_int, c_int, c_float, c_float, vp, vp],
     "curla_concat": [vp, vp, c_int, c_int, c_int, vp, vp],

@@ -97,6 +97,10 @@ __device__ __forceinline__ void conv1_u8_stage_weights(float* img, const float* 
 // pool; a workgroup takes an equal contiguous share of it and its waves equal shares of that, cut wherever they fall
 // (pieces of strips).  Whole samples per workgroup would leave most of the chip waiting for the workgroups that got one
 // sample more (1024 samples on 341 workgroups: one of them runs 4 instead of 3 -- a third longer than the rest).
+// steps between a row's request and its use (1: 90.6 us, 2: 86.4, 4: 88.4 at 1024 samples from fresh ring slots; the
+// unrolled rotation below is written for 2)
+constexpr int kDepth = 2;
+
 template <int C, int NW, bool AL>
 __device__ __forceinline__ void conv1_u8_body(const Conv1U8Args& a, const float* lds_img, const int bid, const int nblk) {
   constexpr int E = (3 * C + 3) / 4;               // operand bytes per lane group and input row
@@ -214,8 +218,8 @@ __device__ __forceinline__ void conv1_u8_body(const Conv1U8Args& a, const float*
         Raw a, b;
       };
       auto step = [&](const Row& r0, Row& r1, Row& r2, const Pair& cur, Pair& nxt, const int t) {
-        load_row(nxt.a, 2 * t + 5);
-        load_row(nxt.b, 2 * t + 6);
+        load_row(nxt.a, 2 * t + 2 * kDepth + 1);
+        load_row(nxt.b, 2 * t + 2 * kDepth + 2);
         // (the barriers pin the requests to the top of the step -- left alone the compiler sinks them below the
         // conversions to reuse the byte registers, and every step then waits out most of a memory latency -- and keep
         // the conversions together, one hazard gap for all of them instead of one per k-step)

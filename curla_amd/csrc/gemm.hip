@@ -496,9 +496,42 @@ __device__ __forceinline__ f32x4 buf_f32x4(__amdgpu_buffer_rsrc_t r, unsigned vo
 // of the kernel's MFMAs.
 // DX = false: the weight gradient alone (the actor's fc layer: its conv stack is detached, curl_sac.py:375-376) -- the
 // same walk without the data-gradient half.
+// The LayerNorm parameter gradients that curla_ln_bwd_partial left as per-workgroup partial sums [nparts][3][F] (dgamma,
+// dbeta, fc bias gradient): summed in partial order by ONE extra workgroup of this launch (the last), eight loads in
+// flight -- a launch less per LayerNorm backward.  partial == nullptr: nothing to do, no extra workgroup.
+struct LnReduce {
+  const float* partial;
+  int nparts, F;
+  float *dgamma, *dbeta, *dbias;
+};
+__device__ __forceinline__ void ln_reduce_block(const LnReduce& r) {
+  for (int i = threadIdx.x; i < 3 * r.F; i += blockDim.x) {
+    const int q = i / r.F, f = i - q * r.F;
+    float* out = q == 0 ? r.dgamma : q == 1 ? r.dbeta : r.dbias;
+    if (!out) continue;
+    const float* p = r.partial + i;
+    const size_t st = (size_t)3 * r.F;
+    float a = 0.f;
+    int k = 0;
+    for (; k + 8 <= r.nparts; k += 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = p[(k + u) * st];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a += t[u];
+    }
+    for (; k < r.nparts; ++k) a += p[k * st];
+    out[f] = a;
+  }
+}
+
 template <int KS, int NT, int NTAIL, bool DX>
-__global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs g, float* dW) {
+__global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs g, float* dW, LnReduce lnr) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [4 waves][NT][4][64 lanes] float4
+  if (lnr.partial && blockIdx.x == gridDim.x - 1) {  // (the grid has one workgroup more than column blocks)
+    ln_reduce_block(lnr);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, kq = lane >> 4;
@@ -985,7 +1018,18 @@ int curla_fc_dx(const float* dz, const float* W, const float* mask, float* dx, i
   return curla_launch_status();
 }
 
-int curla_fc_dw(const float* dz, const float* x, float* dW, int B, int F, int K, void* stream) {
+// a separate launch for the deferred LayerNorm sums, for the shapes whose fc backward does not take the one-pass kernel
+__global__ void ln_reduce_kernel(LnReduce r) { ln_reduce_block(r); }
+
+static int ln_reduce_args(LnReduce& r, const float* partial, int nparts, int F, float* dgamma, float* dbeta,
+                          float* dbias) {
+  r.partial = partial, r.nparts = nparts, r.F = F, r.dgamma = dgamma, r.dbeta = dbeta, r.dbias = dbias;
+  if (!partial) return CURLA_OK;
+  CURLA_REQUIRE(nparts > 0 && dgamma && dbeta);
+  return CURLA_OK;
+}
+
+static int fc_dw_impl(const float* dz, const float* x, float* dW, int B, int F, int K, void* stream, const LnReduce& lnr) {
   int rc = fc_bwd_check(dz, x, dW, B, F, K);
   if (rc != CURLA_OK) return rc;
   FcBwdArgs g;
@@ -997,9 +1041,11 @@ int curla_fc_dw(const float* dz, const float* x, float* dW, int B, int F, int K,
     const size_t lds1 = (size_t)4 * 4 * 4 * 64 * sizeof(f32x4);
     if (curla_set_dyn_lds(reinterpret_cast<const void*>(fc_bwd_kernel<13, 3, 2, false>), lds1) != CURLA_OK)
       return CURLA_ERR_LAUNCH;
-    hipLaunchKernelGGL((fc_bwd_kernel<13, 3, 2, false>), dim3((K + 63) / 64), dim3(256), lds1, st, gx, dW);
+    hipLaunchKernelGGL((fc_bwd_kernel<13, 3, 2, false>), dim3((K + 63) / 64 + (lnr.partial ? 1 : 0)), dim3(256), lds1, st,
+                       gx, dW, lnr);
     return curla_launch_status();
   }
+  if (lnr.partial) hipLaunchKernelGGL(ln_reduce_kernel, dim3(1), dim3(256), 0, st, lnr);
   const dim3 grid((K + 63) / 64);
   const int nt = (F + 15) / 16;
   const size_t lds = (size_t)4 * nt * 4 * 64 * sizeof(f32x4);  // 16 KB per feature tile
@@ -1018,8 +1064,20 @@ int curla_fc_dw(const float* dz, const float* x, float* dW, int B, int F, int K,
   return curla_launch_status();
 }
 
-int curla_fc_bwd(const float* dz, const float* W, const float* x, float* dx, float* dW, int B, int F, int K,
-                 void* stream) {
+int curla_fc_dw(const float* dz, const float* x, float* dW, int B, int F, int K, void* stream) {
+  return fc_dw_impl(dz, x, dW, B, F, K, stream, LnReduce{});
+}
+
+int curla_fc_dw_ln(const float* dz, const float* x, float* dW, int B, int F, int K, const float* ln_partial, int nparts,
+                   float* dgamma, float* dbeta, float* dbias_in, void* stream) {
+  LnReduce r;
+  int rc = ln_reduce_args(r, ln_partial, nparts, F, dgamma, dbeta, dbias_in);
+  if (rc != CURLA_OK) return rc;
+  return fc_dw_impl(dz, x, dW, B, F, K, stream, r);
+}
+
+static int fc_bwd_impl(const float* dz, const float* W, const float* x, float* dx, float* dW, int B, int F, int K,
+                       void* stream, const LnReduce& lnr) {
   int rc = fc_bwd_check(dz, W, dx, B, F, K);
   if (rc != CURLA_OK) return rc;
   if ((rc = fc_bwd_check(dz, x, dW, B, F, K)) != CURLA_OK) return rc;
@@ -1032,18 +1090,31 @@ int curla_fc_bwd(const float* dz, const float* W, const float* x, float* dx, flo
   // offsets); anything else takes the two streaming kernels
   if (ks != 13 || nt != 4 || B % 16 != 0 || (long long)B * K * 4 >= (1LL << 31)) {  // (i.e. F = 49..52)
     if ((rc = curla_fc_dx(dz, W, x, dx, B, F, K, stream)) != CURLA_OK) return rc;
-    return curla_fc_dw(dz, x, dW, B, F, K, stream);
+    return fc_dw_impl(dz, x, dW, B, F, K, stream, lnr);
   }
   const size_t lds = (size_t)4 * 4 * 4 * 64 * sizeof(f32x4);  // (the 3 + 2 form needs less: 48 KB + 2 KB)
   // (once per kernel and device, thread-safe: curla_set_dyn_lds)
   if (F == 50) {  // the default feature width: 3 tiles on the matrix pipe + 2 features on VALU FMAs
     if (curla_set_dyn_lds(reinterpret_cast<const void*>(fc_bwd_kernel<13, 3, 2, true>), lds) != CURLA_OK) return CURLA_ERR_LAUNCH;
-    hipLaunchKernelGGL((fc_bwd_kernel<13, 3, 2, true>), dim3(nblk), dim3(256), lds, st, gx, dW);
+    hipLaunchKernelGGL((fc_bwd_kernel<13, 3, 2, true>), dim3(nblk + (lnr.partial ? 1 : 0)), dim3(256), lds, st, gx, dW, lnr);
   } else {
     if (curla_set_dyn_lds(reinterpret_cast<const void*>(fc_bwd_kernel<13, 4, 0, true>), lds) != CURLA_OK) return CURLA_ERR_LAUNCH;
-    hipLaunchKernelGGL((fc_bwd_kernel<13, 4, 0, true>), dim3(nblk), dim3(256), lds, st, gx, dW);
+    hipLaunchKernelGGL((fc_bwd_kernel<13, 4, 0, true>), dim3(nblk + (lnr.partial ? 1 : 0)), dim3(256), lds, st, gx, dW, lnr);
   }
   return curla_launch_status();
+}
+
+int curla_fc_bwd(const float* dz, const float* W, const float* x, float* dx, float* dW, int B, int F, int K,
+                 void* stream) {
+  return fc_bwd_impl(dz, W, x, dx, dW, B, F, K, stream, LnReduce{});
+}
+
+int curla_fc_bwd_ln(const float* dz, const float* W, const float* x, float* dx, float* dW, int B, int F, int K,
+                    const float* ln_partial, int nparts, float* dgamma, float* dbeta, float* dbias_in, void* stream) {
+  LnReduce r;
+  int rc = ln_reduce_args(r, ln_partial, nparts, F, dgamma, dbeta, dbias_in);
+  if (rc != CURLA_OK) return rc;
+  return fc_bwd_impl(dz, W, x, dx, dW, B, F, K, stream, r);
 }
 
 int curla_splitk_reduce(const float* partial, int nsplit, long long split_stride, int M, int N, int ldp, float* C,

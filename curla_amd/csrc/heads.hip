@@ -98,21 +98,28 @@ __global__ void fc_ln_fwd_kernel(FcLnJobs jobs, int nsplit, long long sSplit, in
 // dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat)).  The incoming gradient is dy[b*ld + f]
 // (+ dy2[b*ld + f] when dy2 is given: the two halves of the twin-Q input gradient, torch.cat's backward at
 // curl_sac.py:138, summed here instead of in a pass of their own)
+// `partial` (optional) [gridDim.x][3][F]: the workgroup's four rows' contributions to dgamma (dy xhat), dbeta (dy) and
+// the fc bias gradient (dx), added in wave (= row) order -- the column sums over the whole batch are finished by one
+// extra workgroup of the NEXT launch that walks these rows anyway, the fc backward (curla_fc_bwd_ln / curla_fc_dw_ln),
+// instead of by a launch of their own (ln_param_grad_kernel).
 template <int NF>
 __global__ void ln_bwd_kernel(const float* dy, const float* dy2, int ld, const float* xhat, const float* rstd,
-                              const float* gamma, int B, int F, float* dx) {
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+                              const float* gamma, int B, int F, float* dx, float* partial) {
+  __shared__ float part[4][3][NF * 64];
+  const int wave = threadIdx.x >> 6;
+  const int row = blockIdx.x * (blockDim.x >> 6) + wave;
   const int lane = threadIdx.x & 63;
-  if (row >= B) return;
-  float g[NF], xh[NF], s1 = 0.f, s2 = 0.f;
+  const bool live = row < B;
+  if (!live && !partial) return;
+  float g[NF], xh[NF], d[NF], s1 = 0.f, s2 = 0.f;
 #pragma unroll
   for (int j = 0; j < NF; ++j) {
     const int f = lane + 64 * j;
-    g[j] = 0.f, xh[j] = 0.f;
-    if (f < F) {
-      float d = dy[(size_t)row * ld + f];
-      if (dy2) d += dy2[(size_t)row * ld + f];
-      g[j] = d * gamma[f];
+    g[j] = 0.f, xh[j] = 0.f, d[j] = 0.f;
+    if (live && f < F) {
+      d[j] = dy[(size_t)row * ld + f];
+      if (dy2) d[j] += dy2[(size_t)row * ld + f];
+      g[j] = d[j] * gamma[f];
       xh[j] = xhat[(size_t)row * F + f];
     }
     s1 += g[j];
@@ -120,11 +127,20 @@ __global__ void ln_bwd_kernel(const float* dy, const float* dy2, int ld, const f
   }
   const float m1 = wave_sum(s1) / F;
   const float m2 = wave_sum(s2) / F;
-  const float rs = rstd[row];
+  const float rs = live ? rstd[row] : 0.f;
 #pragma unroll
   for (int j = 0; j < NF; ++j) {
     const int f = lane + 64 * j;
-    if (f < F) dx[(size_t)row * F + f] = rs * (g[j] - m1 - xh[j] * m2);
+    const float o = rs * (g[j] - m1 - xh[j] * m2);
+    if (live && f < F) dx[(size_t)row * F + f] = o;
+    if (partial) part[wave][0][f] = d[j] * xh[j], part[wave][1][f] = d[j], part[wave][2][f] = live ? o : 0.f;
+  }
+  if (partial) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * F; i += blockDim.x) {
+      const int q = i / F, f = i - q * F;
+      partial[(size_t)blockIdx.x * 3 * F + i] = ((part[0][q][f] + part[1][q][f]) + part[2][q][f]) + part[3][q][f];
+    }
   }
 }
 
@@ -257,7 +273,36 @@ struct HeadArgs {
   float *mu_t, *pi_t, *log_pi, *log_std, *tanh_ls, *pi_xa;  // pi_xa: pi also as the action columns of the Q input rows
   int A, xa_ld;
   float lo, hi;
+  // noise_gen != nullptr (noise == nullptr then): the standard-normal draws of `torch.randn_like(mu)` (curl_sac.py:97)
+  // are produced HERE -- element i from the Philox4x32-10 stream (rng_seed, counter rng_offset + i / 4, output i % 4),
+  // Box-Muller -- and stored to noise_gen[i] for the backward pass, instead of by a launch of their own
+  float* noise_gen;
+  unsigned long long rng_seed, rng_offset;
 };
+
+__device__ __forceinline__ void philox4x32_10(unsigned long long seed, unsigned long long ctr, unsigned (&out)[4]) {
+  unsigned c0 = (unsigned)ctr, c1 = (unsigned)(ctr >> 32), c2 = 0u, c3 = 0u;
+  unsigned k0 = (unsigned)seed, k1 = (unsigned)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1;
+    c1 = (unsigned)p1, c3 = (unsigned)p0, c0 = n0, c2 = n2;
+    k0 += 0x9E3779B9u, k1 += 0xBB67AE85u;
+  }
+  out[0] = c0, out[1] = c1, out[2] = c2, out[3] = c3;
+}
+
+// standard normal number i of the stream: Box-Muller on two of the four 32-bit outputs of counter i / 4
+__device__ __forceinline__ float philox_normal(unsigned long long seed, unsigned long long offset, unsigned i) {
+  unsigned r[4];
+  philox4x32_10(seed, offset + (i >> 2), r);
+  const unsigned a = r[(i & 2)], b = r[(i & 2) + 1];
+  const float u1 = ((float)(a >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+  const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);          // [0, 1)
+  const float rad = sqrtf(-2.0f * logf(u1)), ang = 6.283185307179586f * u2;
+  return (i & 1) ? rad * sinf(ang) : rad * cosf(ang);
+}
 
 __device__ __forceinline__ void actor_head_one(float mu, float raw, int b, int a, const HeadArgs& hd, float& lp,
                                                float& corr) {
@@ -267,8 +312,14 @@ __device__ __forceinline__ void actor_head_one(float mu, float raw, int b, int a
   if (hd.mu_t) hd.mu_t[(size_t)b * A + a] = tanhf(mu);
   if (hd.log_std) hd.log_std[(size_t)b * A + a] = ls;
   if (hd.tanh_ls) hd.tanh_ls[(size_t)b * A + a] = t;
-  if (hd.noise) {
-    const float n = hd.noise[(size_t)b * A + a];
+  if (hd.noise || hd.noise_gen) {
+    float n;
+    if (hd.noise_gen) {
+      n = philox_normal(hd.rng_seed, hd.rng_offset, (unsigned)(b * A + a));
+      hd.noise_gen[(size_t)b * A + a] = n;
+    } else {
+      n = hd.noise[(size_t)b * A + a];
+    }
     const float p = tanhf(mu + n * expf(ls));
     if (hd.pi_t) hd.pi_t[(size_t)b * A + a] = p;
     if (hd.pi_xa) hd.pi_xa[(size_t)b * hd.xa_ld + a] = p;
@@ -281,7 +332,7 @@ __device__ __forceinline__ void actor_head_one(float mu, float raw, int b, int a
 __device__ __forceinline__ void actor_head_row(const float* out2a_row, int b, const HeadArgs& hd) {
   float lp = 0.f, corr = 0.f;
   for (int a = 0; a < hd.A; ++a) actor_head_one(out2a_row[a], out2a_row[hd.A + a], b, a, hd, lp, corr);
-  if (hd.noise && hd.log_pi) hd.log_pi[b] = lp - kHalfLog2Pi * hd.A - corr;
+  if ((hd.noise || hd.noise_gen) && hd.log_pi) hd.log_pi[b] = lp - kHalfLog2Pi * hd.A - corr;
 }
 
 // out[z][m][n] = bias[z][n] + sum_k h[z][m][k] * W[z][n][k]        (curl_sac.py:73-74,132-133 forward)
@@ -354,7 +405,7 @@ __global__ __launch_bounds__(256) void mlp_out_fwd_kernel(const float* h, long l
       if (lane < hd.A) actor_head_one(mu, raw, row, lane, hd, lp, corr);
       float lps = 0.f, cs = 0.f;
       for (int a = 0; a < hd.A; ++a) lps += __shfl(lp, a), cs += __shfl(corr, a);
-      if (lane == 0 && hd.noise && hd.log_pi) hd.log_pi[row] = lps - kHalfLog2Pi * hd.A - cs;
+      if (lane == 0 && (hd.noise || hd.noise_gen) && hd.log_pi) hd.log_pi[row] = lps - kHalfLog2Pi * hd.A - cs;
     }
   }
 }
@@ -756,10 +807,23 @@ struct AdamScalar64 {
   double w1, b2, w2, step_size, bc2_sqrt, eps;
 };
 
+// The target network's soft update in the same pass: target <- tau p + (1 - tau) target with the parameter this launch
+// has just stepped (utils.py:37-41 right after critic_optimizer.step(), curl_sac.py:367,442-445); elements [0, split)
+// take (tau_a, omt_a), the rest (tau_b, omt_b).  tgt == nullptr: none.
+struct AdamLerp {
+  float* tgt;
+  size_t split;
+  float tau_a, omt_a, tau_b, omt_b;
+};
+__device__ __forceinline__ float lerp_one(float p, float t, float tau, float omt) {
+#pragma clang fp contract(off)
+  return tau * p + omt * t;  // two roundings of the products and one of the sum, as soft_update_kernel
+}
+
 __global__ void __launch_bounds__(256) adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, size_t n,
                                                         int vec, float w1, float b2, float w2, float step_size,
-                                                        float bc2_sqrt, float eps, AdamScalar64 sc) {
+                                                        float bc2_sqrt, float eps, AdamScalar64 sc, AdamLerp lp) {
   if (sc.p && blockIdx.x == 0 && threadIdx.x == 0) {  // torch's single-tensor Adam, in double
 #pragma clang fp contract(off)
     const double gs = *sc.g;
@@ -785,10 +849,20 @@ __global__ void __launch_bounds__(256) adam_step_kernel(float* __restrict__ p, c
       reinterpret_cast<f32x4*>(p)[i] = pp;
       reinterpret_cast<f32x4*>(m)[i] = mm;
       reinterpret_cast<f32x4*>(v)[i] = vv;
+      if (lp.tgt) {  // (vec implies target and split are 16-byte granular too: a float4 lies on one side of split)
+        f32x4 tt = reinterpret_cast<f32x4*>(lp.tgt)[i];
+        const bool a = 4 * i < lp.split;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tt[e] = lerp_one(pp[e], tt[e], a ? lp.tau_a : lp.tau_b, a ? lp.omt_a : lp.omt_b);
+        reinterpret_cast<f32x4*>(lp.tgt)[i] = tt;
+      }
     }
     done = n4 << 2;
   }
-  for (size_t i = done + tid; i < n; i += stride) adam_one(p[i], g[i], m[i], v[i], w1, b2, w2, step_size, bc2_sqrt, eps);
+  for (size_t i = done + tid; i < n; i += stride) {
+    adam_one(p[i], g[i], m[i], v[i], w1, b2, w2, step_size, bc2_sqrt, eps);
+    if (lp.tgt) lp.tgt[i] = lerp_one(p[i], lp.tgt[i], i < lp.split ? lp.tau_a : lp.tau_b, i < lp.split ? lp.omt_a : lp.omt_b);
+  }
 }
 
 // Two Adam steps of two optimizers on the SAME parameters with the same gradient, back to back, in one pass (the
@@ -1027,19 +1101,36 @@ int curla_ln_bwd_twin(const float* dy, const float* dy2, int ld_dy, const float*
   CURLA_REQUIRE(dy && xhat && rstd && gamma && dx && B > 0 && F > 0 && ld_dy >= F);
   if (F > 256) return CURLA_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
-#define CURLA_LN_BWD(NF)                                                                                               \
-  hipLaunchKernelGGL(ln_bwd_kernel<NF>, dim3((B + 3) / 4), dim3(256), 0, st, dy, dy2, ld_dy, xhat, rstd, gamma, B, F, dx)
-  switch ((F + 63) / 64) {
-    case 1: CURLA_LN_BWD(1); break;
-    case 2: CURLA_LN_BWD(2); break;
-    case 3: CURLA_LN_BWD(3); break;
-    default: CURLA_LN_BWD(4); break;
-  }
-#undef CURLA_LN_BWD
   CURLA_REQUIRE(!dbias_in || (dgamma && dbeta));
+  float* const no_partial = nullptr;
+#define CURLA_LN_BWD(NF, PART)                                                                                          \
+  hipLaunchKernelGGL(ln_bwd_kernel<NF>, dim3((B + 3) / 4), dim3(256), 0, st, dy, dy2, ld_dy, xhat, rstd, gamma, B, F, dx, \
+                     PART)
+  switch ((F + 63) / 64) {
+    case 1: CURLA_LN_BWD(1, no_partial); break;
+    case 2: CURLA_LN_BWD(2, no_partial); break;
+    case 3: CURLA_LN_BWD(3, no_partial); break;
+    default: CURLA_LN_BWD(4, no_partial); break;
+  }
   if (dgamma && dbeta)
     hipLaunchKernelGGL(ln_param_grad_kernel, dim3((F + 15) / 16), dim3(1024), 0, st, dy, dy2, ld_dy, xhat, dx, B, F,
                        dgamma, dbeta, dbias_in);
+  return curla_launch_status();
+}
+
+int curla_ln_bwd_partial(const float* dy, const float* dy2, int ld_dy, const float* xhat, const float* rstd,
+                         const float* gamma, int B, int F, float* dx, float* partial, int* nparts, void* stream) {
+  CURLA_REQUIRE(dy && xhat && rstd && gamma && dx && partial && nparts && B > 0 && F > 0 && ld_dy >= F);
+  if (F > 256) return CURLA_ERR_UNSUPPORTED;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch ((F + 63) / 64) {
+    case 1: CURLA_LN_BWD(1, partial); break;
+    case 2: CURLA_LN_BWD(2, partial); break;
+    case 3: CURLA_LN_BWD(3, partial); break;
+    default: CURLA_LN_BWD(4, partial); break;
+  }
+#undef CURLA_LN_BWD
+  *nparts = (B + 3) / 4;
   return curla_launch_status();
 }
 
@@ -1158,6 +1249,18 @@ static int head_args(const float* noise, int B, int A, float log_std_min, float 
   CURLA_REQUIRE(!pi_xa || (noise && xa_ld >= A));
   hd->noise = noise, hd->mu_t = mu, hd->pi_t = pi, hd->log_pi = log_pi, hd->log_std = log_std, hd->tanh_ls = tanh_ls;
   hd->pi_xa = pi_xa, hd->A = A, hd->xa_ld = xa_ld, hd->lo = log_std_min, hd->hi = log_std_max;
+  hd->noise_gen = nullptr, hd->rng_seed = 0, hd->rng_offset = 0;
+  return CURLA_OK;
+}
+
+// the same with the noise drawn inside the kernel (written to noise_out [B][A])
+static int head_args_rng(float* noise_out, unsigned long long seed, unsigned long long offset, int B, int A,
+                         float log_std_min, float log_std_max, float* mu, float* pi, float* log_pi, float* log_std,
+                         float* tanh_ls, float* pi_xa, int xa_ld, HeadArgs* hd) {
+  CURLA_REQUIRE(noise_out);
+  const int rc = head_args(noise_out, B, A, log_std_min, log_std_max, mu, pi, log_pi, log_std, tanh_ls, pi_xa, xa_ld, hd);
+  if (rc != CURLA_OK) return rc;
+  hd->noise = nullptr, hd->noise_gen = noise_out, hd->rng_seed = seed, hd->rng_offset = offset;
   return CURLA_OK;
 }
 
@@ -1173,6 +1276,35 @@ int curla_actor_head_fwd(const float* trunk_out, const float* noise, int B, int 
   return curla_launch_status();
 }
 
+int curla_actor_head_fwd_rng(const float* trunk_out, float* noise_out, unsigned long long seed,
+                             unsigned long long offset, int B, int A, float log_std_min, float log_std_max, float* mu,
+                             float* pi, float* log_pi, float* log_std, float* tanh_ls, float* pi_xa, int xa_ld,
+                             void* stream) {
+  CURLA_REQUIRE(trunk_out);
+  HeadArgs hd;
+  const int rc = head_args_rng(noise_out, seed, offset, B, A, log_std_min, log_std_max, mu, pi, log_pi, log_std, tanh_ls,
+                               pi_xa, xa_ld, &hd);
+  if (rc != CURLA_OK) return rc;
+  hipLaunchKernelGGL(actor_head_fwd_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     trunk_out, B, hd);
+  return curla_launch_status();
+}
+
+static int mlp_out_head_launch(const float* h, const float* W, const float* bias, float* trunk_out, int B, int A, int K,
+                               const HeadArgs& hd, void* stream);
+
+int curla_mlp_out_head_fwd_rng(const float* h, const float* W, const float* bias, float* trunk_out, int B, int A, int K,
+                               float* noise_out, unsigned long long seed, unsigned long long offset, float log_std_min,
+                               float log_std_max, float* mu, float* pi, float* log_pi, float* log_std, float* tanh_ls,
+                               float* pi_xa, int xa_ld, void* stream) {
+  CURLA_REQUIRE(h && W && trunk_out && K > 0);
+  HeadArgs hd;
+  const int rc = head_args_rng(noise_out, seed, offset, B, A, log_std_min, log_std_max, mu, pi, log_pi, log_std, tanh_ls,
+                               pi_xa, xa_ld, &hd);
+  if (rc != CURLA_OK) return rc;
+  return mlp_out_head_launch(h, W, bias, trunk_out, B, A, K, hd, stream);
+}
+
 int curla_mlp_out_head_fwd(const float* h, const float* W, const float* bias, float* trunk_out, int B, int A, int K,
                            const float* noise, float log_std_min, float log_std_max, float* mu, float* pi,
                            float* log_pi, float* log_std, float* tanh_ls, float* pi_xa, int xa_ld, void* stream) {
@@ -1180,6 +1312,11 @@ int curla_mlp_out_head_fwd(const float* h, const float* W, const float* bias, fl
   HeadArgs hd;
   const int rc = head_args(noise, B, A, log_std_min, log_std_max, mu, pi, log_pi, log_std, tanh_ls, pi_xa, xa_ld, &hd);
   if (rc != CURLA_OK) return rc;
+  return mlp_out_head_launch(h, W, bias, trunk_out, B, A, K, hd, stream);
+}
+
+static int mlp_out_head_launch(const float* h, const float* W, const float* bias, float* trunk_out, int B, int A, int K,
+                               const HeadArgs& hd, void* stream) {
   if (2 * A > kMaxOut || K % 4 != 0) return CURLA_ERR_UNSUPPORTED;
   CURLA_REQUIRE(aligned16(h) && aligned16(W));
   const size_t wbytes = (size_t)2 * A * K * sizeof(float);
@@ -1287,16 +1424,26 @@ int curla_soft_update2(const float* param, float* target, size_t n, size_t split
 
 static int adam_step_launch(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
                             double beta1, double beta2, double eps, long long step, const AdamScalar64& sc,
-                            void* stream) {
+                            void* stream, const AdamLerp& lp = AdamLerp{}) {
   CURLA_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1 && beta1 >= 0. && beta1 < 1. &&
                 beta2 >= 0. && beta2 < 1.);
   const double b1 = beta1, b2 = beta2;
   const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
-  const int vec = aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq);
+  const int vec = aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq) &&
+                  (!lp.tgt || (aligned16(lp.tgt) && lp.split % 4 == 0));
   hipLaunchKernelGGL(adam_step_kernel, dim3(nblocks((n + 3) / 4, 256, 8192)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), param, grad, exp_avg, exp_avg_sq, n, vec, (float)(1.0 - b1),
-                     (float)b2, (float)(1.0 - b2), (float)(lr / bc1), (float)sqrt(bc2), (float)eps, sc);
+                     (float)b2, (float)(1.0 - b2), (float)(lr / bc1), (float)sqrt(bc2), (float)eps, sc, lp);
   return curla_launch_status();
+}
+
+int curla_adam_step_lerp(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
+                         double beta1, double beta2, double eps, long long step, float* target, size_t split, float tau_a,
+                         float one_minus_tau_a, float tau_b, float one_minus_tau_b, void* stream) {
+  CURLA_REQUIRE(target && split <= n);
+  AdamScalar64 none = {};
+  AdamLerp lp{target, split, tau_a, one_minus_tau_a, tau_b, one_minus_tau_b};
+  return adam_step_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, none, stream, lp);
 }
 
 int curla_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,

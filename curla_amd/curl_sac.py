@@ -291,6 +291,7 @@ class _Workspace:
         self.z_a, self.z_t, self.z_c, self.z_pos = f(B, F), f(B, F), f(B, F), f(B, F)
         self.xhat_c, self.rstd_c, self.xhat_a, self.rstd_a = f(B, F), f(B), f(B, F), f(B)
         self.dz, self.dfc = f(B, F), f(B, F)
+        self.ln_partial = f(ops.ln_partial_floats(B, F))  # LayerNorm parameter-gradient partial sums (ops.ln_bwd defer=)
         self.fc_out = f(B, F)  # pre-LayerNorm features, only written on histogram-logging steps
         # actor trunk
         self.a_h1, self.a_h2, self.a_out = f(B, H), f(B, H), f(B, 2 * A)
@@ -490,6 +491,9 @@ class CurlSacAgent(object):
         place(actor_own, False, self._actor_flat, self._actor_gflat, 0)
         self.log_alpha.grad = torch.zeros((), device=dev, dtype=torch.float64)
 
+    _soft_update_hint = False   # set by update() around update_critic(): a target soft update follows the critic's step
+    _soft_update_done = False
+
     def _ws(self, B):
         if B not in self._workspaces:
             from . import _lib
@@ -647,18 +651,20 @@ class CurlSacAgent(object):
         B, F, K, L = obs_ref.B, enc.feature_dim, enc.flat_dim, enc.num_layers
         acts = ws.acts_main
         dy, dy2 = (dz, None) if twin_ld is None else (dz[0], dz[1])
-        ops.ln_bwd(dy, xhat, rstd, enc.ln.weight, B, F, ws.dfc, dgamma=enc.ln.weight.grad, dbeta=enc.ln.bias.grad,
-                   dbias_in=enc.fc.bias.grad, dy2=dy2, ld=twin_ld)
-        h = acts[-1]
         streams = ops.fc_bwd_streams(F, K)
+        # (the LayerNorm's parameter gradients and the fc bias gradient -- column sums over the batch -- are left as
+        # partial sums and finished inside the fc backward's launch, when that is one of the streaming kernels)
+        ln = ops.ln_bwd(dy, xhat, rstd, enc.ln.weight, B, F, ws.dfc, dgamma=enc.ln.weight.grad, dbeta=enc.ln.bias.grad,
+                        dbias_in=enc.fc.bias.grad, dy2=dy2, ld=twin_ld, defer=ws.ln_partial if streams else None)
+        h = acts[-1]
         cur = L % 2
         g = ws.gviews[cur][L - 1]
         if streams and conv_grads:
             # fc weight gradient and the data gradient into the conv stack (ReLU mask of the last conv layer fused)
             # in one launch: both only read dfc
-            ops.fc_bwd(ws.dfc, enc.fc.weight, h, g, enc.fc.weight.grad, B, F, K)
+            ops.fc_bwd(ws.dfc, enc.fc.weight, h, g, enc.fc.weight.grad, B, F, K, ln=ln)
         elif streams:
-            ops.fc_dw(ws.dfc, h, enc.fc.weight.grad, B, F, K)
+            ops.fc_dw(ws.dfc, h, enc.fc.weight.grad, B, F, K, ln=ln)
         else:
             ops.linear_dw(ws.dfc, 0, h, 0, enc.fc.weight.grad, 0, B, F, K)
         if dense_done is not None:
@@ -687,11 +693,27 @@ class CurlSacAgent(object):
         return self.log_param_hist_imgs and step % LOG_FREQ == 0
 
     def _noise(self, ws, noise):
-        if noise is None:
-            ws.noise.normal_()
-        else:
+        """(noise buffer, rng): explicit ``noise`` is copied into the buffer (rng None).  Without it
+        (``torch.randn_like``, curl_sac.py:97) the policy-head launch draws the numbers itself and writes them into the
+        buffer: rng = (seed, offset) of the device's default torch generator, whose Philox offset is advanced here as a
+        ``normal_()`` would advance it -- so torch.manual_seed, get_rng_state / set_rng_state (checkpoints) and the
+        per-rank seeds keep their meaning.  Where the generator does not expose its offset: a ``normal_()`` launch."""
+        if noise is not None:
             ws.noise.copy_(noise)
-        return ws.noise
+            return ws.noise, None
+        if ws.noise.is_cuda and not self._noise_launch:
+            try:
+                gen = torch.cuda.default_generators[ws.noise.device.index if ws.noise.device.index is not None
+                                                    else torch.cuda.current_device()]
+                off = gen.get_offset()
+                gen.set_offset(off + 4 * ((ws.noise.numel() + 3) // 4))
+                return ws.noise, (gen.initial_seed(), off // 4)
+            except (AttributeError, RuntimeError):
+                type(self)._noise_launch = True
+        ws.noise.normal_()
+        return ws.noise, None
+
+    _noise_launch = False  # True: this torch build's generator has no get_offset / set_offset
 
     # ------------------------------------------------------------------ phases
     def update_critic(self, obs, action, reward, next_obs, not_done, L, step, noise=None):
@@ -733,10 +755,10 @@ class CurlSacAgent(object):
                                    act=action))], A)
         else:
             self.actor.encoder.ln_from_partial(B, ws.z_a)
-        nz = self._noise(ws, noise)
+        nz, rng = self._noise(ws, noise)
         _mlp_fwd(ws.z_a, 0, _Mlp(self.actor.trunk), 1, B, F, H, 2 * A, ws.a_h1, ws.a_h2, ws.a_out,
                  head=(nz, self.actor.log_std_min, self.actor.log_std_max,
-                       dict(pi=None if four else ws.pi, log_pi=ws.log_pi, xa=ws.xa2[0] if four else None)))
+                       dict(pi=None if four else ws.pi, log_pi=ws.log_pi, xa=ws.xa2[0] if four else None, rng=rng)))
         if four:
             _mlp_fwd(ws.xa2, 0, self.critic_target.twin(), 2, B, F + A, H, 1, ws.q_h1_2, ws.q_h2_2, ws.q2,
                      outer=(2, self._twin_outer))
@@ -791,7 +813,16 @@ class CurlSacAgent(object):
             for p, g in saved:
                 p.grad = g
         else:
-            self.critic_optimizer.step()
+            # update() announces a target soft update right behind this step (curl_sac.py:442-445): it reads what the
+            # step writes, so both share one pass over the critic's flat parameters when the optimizer is the flat one
+            fused = False
+            if self._soft_update_hint:
+                (e0, e1), (_, q1) = lay["enc"], lay["q"]
+                fused = FlatAdam.step_with_lerp(self.critic_optimizer, self._target_flat, e0, q1, e1 - e0,
+                                                self.encoder_tau, self.critic_tau)
+                self._soft_update_done = fused
+            if not fused:
+                self.critic_optimizer.step()
         if self.log_param_hist_imgs:
             self.critic.log(L, step)
 
@@ -830,11 +861,11 @@ class CurlSacAgent(object):
         self._anchor_cache = obs
 
         trunk = _Mlp(self.actor.trunk)
-        nz = self._noise(ws, noise)
+        nz, rng = self._noise(ws, noise)
         lo, hi = self.actor.log_std_min, self.actor.log_std_max
         _mlp_fwd(ws.z_a, 0, trunk, 1, B, F, H, 2 * A, ws.a_h1, ws.a_h2, ws.a_out,
                  head=(nz, lo, hi, dict(mu=ws.mu, pi=ws.pi, log_pi=ws.log_pi, log_std=ws.log_std, tanh_ls=ws.tanh_ls,
-                                        xa=ws.xa)))
+                                        xa=ws.xa, rng=rng)))
         if self._records(step):  # what actor.log() histograms (curl_sac.py:92-93): pre-squash mean and std
             self.actor.outputs['mu'], self.actor.outputs['std'] = ws.a_out[:, :A].clone(), ws.log_std.exp()
         _mlp_fwd(ws.xa, 0, self.critic.twin(), 2, B, F + A, H, 1, ws.q_h1, ws.q_h2, ws.q)
@@ -860,10 +891,11 @@ class CurlSacAgent(object):
         if overlap:  # bucket = [fc, ln | trunk]: the trunk gradients are final here, fc / ln follow
             cut = self._grad_offset(self.actor.trunk[0].weight, self._actor_gflat)
             self._allreduce(self._actor_gflat[cut:], self.log_alpha.grad, async_op=True)
-        ops.ln_bwd(ws.dz, ws.xhat_a, ws.rstd_a, aenc.ln.weight, B, F, ws.dfc, dgamma=aenc.ln.weight.grad,
-                   dbeta=aenc.ln.bias.grad, dbias_in=aenc.fc.bias.grad)
-        if ops.fc_bwd_streams(F, enc.flat_dim):
-            ops.fc_dw(ws.dfc, h, aenc.fc.weight.grad, B, F, enc.flat_dim)
+        streams = ops.fc_bwd_streams(F, enc.flat_dim)
+        ln = ops.ln_bwd(ws.dz, ws.xhat_a, ws.rstd_a, aenc.ln.weight, B, F, ws.dfc, dgamma=aenc.ln.weight.grad,
+                        dbeta=aenc.ln.bias.grad, dbias_in=aenc.fc.bias.grad, defer=ws.ln_partial if streams else None)
+        if streams:
+            ops.fc_dw(ws.dfc, h, aenc.fc.weight.grad, B, F, enc.flat_dim, ln=ln)
         else:
             ops.linear_dw(ws.dfc, 0, h, 0, aenc.fc.weight.grad, 0, B, F, enc.flat_dim)
 
@@ -964,12 +996,18 @@ class CurlSacAgent(object):
 
         do_cpc = (not self.pixel_sac) and step % self.cpc_update_freq == 0
         if not only_cpc:
-            self.update_critic(obs, action, reward, next_obs, not_done, L, step)
+            soft = step % self.critic_target_update_freq == 0
+            self._soft_update_hint, self._soft_update_done = soft, False
+            try:
+                self.update_critic(obs, action, reward, next_obs, not_done, L, step)
+            finally:
+                self._soft_update_hint = False
             # The target soft update reads the critic's parameters, which the actor phase does not touch (it steps the
             # actor's own tensors and log_alpha): applied BEFORE the actor phase it gives the same numbers as after
             # it (curl_sac.py:437-445), and the target encoder is then final when the actor phase encodes obs -- so
-            # the positives' target pass can share those launches.
-            if step % self.critic_target_update_freq == 0:
+            # the positives' target pass can share those launches.  (Normally it has already happened: inside the
+            # critic's Adam launch.)
+            if soft and not self._soft_update_done:
                 self.soft_update_targets()
             if step % self.actor_update_freq == 0:
                 if do_cpc and isinstance(cpc_kwargs.get("obs_pos"), ObsRef):

@@ -284,14 +284,26 @@ def fc_dx(dz, W, out, B, F_, K, mask=None):
     call("curla_fc_dx", ptr(dz), ptr(W), ptr(mask), ptr(out), B, F_, K, stream())
 
 
-def fc_dw(dz, x, out, B, F_, K):
-    """out = dz^T @ x;  dz [B,F], x [B,K] -> out [F,K] (the encoder fc weight gradient)."""
-    call("curla_fc_dw", ptr(dz), ptr(x), ptr(out), B, F_, K, stream())
+def fc_dw(dz, x, out, B, F_, K, ln=None):
+    """out = dz^T @ x;  dz [B,F], x [B,K] -> out [F,K] (the encoder fc weight gradient).
+    ``ln``: the token of a deferred ``ln_bwd`` -- its parameter gradients are finished in this launch."""
+    if ln is None:
+        call("curla_fc_dw", ptr(dz), ptr(x), ptr(out), B, F_, K, stream())
+    else:
+        part, n, dgamma, dbeta, dbias = ln
+        call("curla_fc_dw_ln", ptr(dz), ptr(x), ptr(out), B, F_, K, ptr(part), n, ptr(dgamma), ptr(dbeta), ptr(dbias),
+             stream())
 
 
-def fc_bwd(dz, W, x, dx, dW, B, F_, K):
-    """dx = (dz @ W) masked by x > 0 and dW = dz^T @ x in one launch (x = the fc layer's input, a ReLU output)."""
-    call("curla_fc_bwd", ptr(dz), ptr(W), ptr(x), ptr(dx), ptr(dW), B, F_, K, stream())
+def fc_bwd(dz, W, x, dx, dW, B, F_, K, ln=None):
+    """dx = (dz @ W) masked by x > 0 and dW = dz^T @ x in one launch (x = the fc layer's input, a ReLU output).
+    ``ln``: as for fc_dw."""
+    if ln is None:
+        call("curla_fc_bwd", ptr(dz), ptr(W), ptr(x), ptr(dx), ptr(dW), B, F_, K, stream())
+    else:
+        part, n, dgamma, dbeta, dbias = ln
+        call("curla_fc_bwd_ln", ptr(dz), ptr(W), ptr(x), ptr(dx), ptr(dW), B, F_, K, ptr(part), n, ptr(dgamma),
+             ptr(dbeta), ptr(dbias), stream())
 
 
 def mlp_out_fwd(h, sh, W, sW, bias, sb, out, so, M, N, K, nb=1, outer=None):
@@ -366,10 +378,24 @@ def fc_ln_fwd_multi(jobs, nsplit, split_stride, ldp, B, F, eps, A):
     call("curla_fc_ln_fwd_multi", len(jobs), ctypes.addressof(arr), nsplit, split_stride, ldp, B, F, eps, A, stream())
 
 
-def ln_bwd(dy, xhat, rstd, gamma, B, F, dx, dgamma=None, dbeta=None, dbias_in=None, dy2=None, ld=None):
+def ln_partial_floats(B, F):
+    """Size of the partial-sum buffer ``ln_bwd(..., defer=)`` fills: [ceil(B / 4)][3][F]."""
+    return ((B + 3) // 4) * 3 * F
+
+
+def ln_bwd(dy, xhat, rstd, gamma, B, F, dx, dgamma=None, dbeta=None, dbias_in=None, dy2=None, ld=None, defer=None):
     """LayerNorm backward; ``dbias_in`` (optional) receives the column sums of dx (the fc bias gradient).
     The incoming gradient may be ``dy[:, :F] + dy2[:, :F]`` of two row blocks with row stride ``ld`` (the twin halves
-    of d(loss)/d[z | a], read in place)."""
+    of d(loss)/d[z | a], read in place).
+    ``defer`` = a float buffer of ln_partial_floats(B, F): the parameter gradients are left as partial sums in it and
+    the returned token must be handed to the ``fc_bwd`` / ``fc_dw`` that follows (``ln=``), which finishes them in its
+    own launch.  Returns None when nothing was deferred."""
+    if defer is not None and dgamma is not None:
+        import ctypes
+        n = ctypes.c_int(0)
+        call("curla_ln_bwd_partial", ptr(dy), ptr(dy2), F if ld is None else ld, ptr(xhat), ptr(rstd), ptr(gamma), B, F,
+             ptr(dx), ptr(defer), ctypes.addressof(n), stream())
+        return (defer, n.value, dgamma, dbeta, dbias_in)
     if dy2 is None and ld in (None, F):
         call("curla_ln_bwd", ptr(dy), ptr(xhat), ptr(rstd), ptr(gamma), B, F, ptr(dx), ptr(dgamma), ptr(dbeta),
              ptr(dbias_in), stream())
@@ -387,18 +413,30 @@ def colsum3(X0, N0, X1, N1, X2, N2, M, out0, out1, out2, sOut, nb=1):
     call("curla_colsum3", ptr(X0), N0, ptr(X1), N1, ptr(X2), N2, M, ptr(out0), ptr(out1), ptr(out2), sOut, nb, stream())
 
 
-def actor_head_fwd(trunk_out, noise, B, A, lo, hi, mu=None, pi=None, log_pi=None, log_std=None, tanh_ls=None, xa=None):
-    """``xa`` [B, F + A]: pi is also written into its last A columns (the Q functions' input rows)."""
+def actor_head_fwd(trunk_out, noise, B, A, lo, hi, mu=None, pi=None, log_pi=None, log_std=None, tanh_ls=None, xa=None,
+                   rng=None):
+    """``xa`` [B, F + A]: pi is also written into its last A columns (the Q functions' input rows).
+    ``rng`` = (seed, offset): the noise is drawn inside the launch (Philox stream, see curla_hip.h) and WRITTEN to
+    ``noise``; the caller owns the offset bookkeeping (ceil(B A / 4) counters per call)."""
     pi_xa, ld = (None, 0) if xa is None else (xa.data_ptr() + 4 * (xa.shape[1] - A), xa.shape[1])
+    if rng is not None:
+        call("curla_actor_head_fwd_rng", ptr(trunk_out), ptr(noise), int(rng[0]) & (2 ** 64 - 1), int(rng[1]), B, A, lo, hi,
+             ptr(mu), ptr(pi), ptr(log_pi), ptr(log_std), ptr(tanh_ls), pi_xa, ld, stream())
+        return
     call("curla_actor_head_fwd", ptr(trunk_out), ptr(noise), B, A, lo, hi, ptr(mu), ptr(pi), ptr(log_pi), ptr(log_std),
          ptr(tanh_ls), pi_xa, ld, stream())
 
 
 def mlp_out_head_fwd(h, W, bias, trunk_out, noise, B, A, K, lo, hi, mu=None, pi=None, log_pi=None, log_std=None,
-                     tanh_ls=None, xa=None):
+                     tanh_ls=None, xa=None, rng=None):
     """The actor trunk's last layer (h [B, K] -> trunk_out [B, 2A]) with the policy head (actor_head_fwd) run by the
-    same launch."""
+    same launch.  ``rng``: as for actor_head_fwd."""
     pi_xa, ld = (None, 0) if xa is None else (xa.data_ptr() + 4 * (xa.shape[1] - A), xa.shape[1])
+    if rng is not None:
+        call("curla_mlp_out_head_fwd_rng", ptr(h), ptr(W), ptr(bias), ptr(trunk_out), B, A, K, ptr(noise),
+             int(rng[0]) & (2 ** 64 - 1), int(rng[1]), lo, hi, ptr(mu), ptr(pi), ptr(log_pi), ptr(log_std), ptr(tanh_ls),
+             pi_xa, ld, stream())
+        return
     call("curla_mlp_out_head_fwd", ptr(h), ptr(W), ptr(bias), ptr(trunk_out), B, A, K, ptr(noise), lo, hi, ptr(mu),
          ptr(pi), ptr(log_pi), ptr(log_std), ptr(tanh_ls), pi_xa, ld, stream())
 

@@ -172,6 +172,31 @@ class FlatAdam(torch.optim.Adam):
              float(gb["lr"]), float(gb["betas"][0]), float(gb["betas"][1]), float(gb["eps"]), tb + 1, stream())
 
 
+    # -- this optimizer's step and the target copy's soft update, one launch ---------------------------------------
+    @staticmethod
+    @torch.no_grad()
+    def step_with_lerp(opt, target_flat, lo, hi, split, tau_a, tau_b):
+        """``opt.step()`` followed by ``target[lo:hi] <- tau * flat[lo:hi] + (1 - tau) * target[lo:hi]`` (tau_a for
+        [lo, lo + split), tau_b behind) in ONE launch, when ``opt`` is a FlatAdam whose live parameters are exactly the
+        flat run [lo, hi) with one step count and a ``step`` that has not been replaced.  Returns False -- having done
+        nothing -- when that does not hold: the caller then takes the two steps."""
+        if not isinstance(opt, FlatAdam) or "step" in vars(opt):
+            return False
+        run = opt._single_run()
+        # (the run ends with its last parameter, the announced block may include up to 3 floats of alignment padding
+        # behind it: zeros in both copies, which a soft update leaves as they are)
+        if run is None or run[0] != lo or not (run[1] <= hi <= run[1] + 3):
+            return False
+        _, hi, t, g = run
+        for i in range(len(opt._plist)):
+            opt._ensure_state(i)
+            opt._steps[i] = t + 1
+        call("curla_adam_step_lerp", opt._flat.data_ptr() + 4 * lo, opt._gflat.data_ptr() + 4 * lo,
+             opt._m.data_ptr() + 4 * (lo - opt._lo), opt._v.data_ptr() + 4 * (lo - opt._lo), hi - lo, float(g["lr"]),
+             float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), t + 1, target_flat.data_ptr() + 4 * lo, split,
+             float(tau_a), float(1.0 - tau_a), float(tau_b), float(1.0 - tau_b), stream())
+        return True
+
     # -- this optimizer and a float64 scalar's, one launch -----------------------------------------------------------
     @staticmethod
     @torch.no_grad()

@@ -155,6 +155,12 @@ int curla_fc_dw(const float* dz, const float* x, float* dW, int B, int F, int K,
  * workgroups compute dx and whose rest compute dW. */
 int curla_fc_bwd(const float* dz, const float* W, const float* x, float* dx, float* dW, int B, int F, int K,
                  void* stream);
+/* curla_fc_bwd / curla_fc_dw that also finish the LayerNorm parameter gradients curla_ln_bwd_partial left as partial sums
+ * (dgamma[f], dbeta[f], dbias_in[f] = sum over the nparts partials, in order; dbias_in may be NULL). */
+int curla_fc_bwd_ln(const float* dz, const float* W, const float* x, float* dx, float* dW, int B, int F, int K,
+                    const float* ln_partial, int nparts, float* dgamma, float* dbeta, float* dbias_in, void* stream);
+int curla_fc_dw_ln(const float* dz, const float* x, float* dW, int B, int F, int K, const float* ln_partial, int nparts,
+                   float* dgamma, float* dbeta, float* dbias_in, void* stream);
 
 /* Last layer of the actor trunk / the Q functions (curl_sac.py:73-74, 132-133): hidden -> N outputs, N <= 16
  * (Q: 1, actor: 2|A|), batched over `nbatch` identically laid-out networks `stride*` floats apart.
@@ -225,6 +231,11 @@ int curla_ln_bwd(const float* dy, const float* xhat, const float* rstd, const fl
 int curla_ln_bwd_twin(const float* dy, const float* dy2, int ld_dy, const float* xhat, const float* rstd,
                       const float* gamma, int B, int F, float* dx, float* dgamma, float* dbeta, float* dbias_in,
                       void* stream);
+/* curla_ln_bwd_twin without the launch that finishes the parameter gradients: dx as above, and per-workgroup partial sums
+ * of dgamma / dbeta / the fc bias gradient into `partial` ([*nparts][3][F] floats, *nparts = ceil(B / 4)).  The fc
+ * backward that follows (curla_fc_bwd_ln / curla_fc_dw_ln) adds them up in one extra workgroup of its own launch. */
+int curla_ln_bwd_partial(const float* dy, const float* dy2, int ld_dy, const float* xhat, const float* rstd,
+                         const float* gamma, int B, int F, float* dx, float* partial, int* nparts, void* stream);
 /* out[z][n] = sum_m X[z][m][n] (bias gradients) */
 int curla_colsum(const float* X, int M, int N, int ldx, long long strideX, float* out, long long strideOut, int nbatch,
                  void* stream);
@@ -248,6 +259,18 @@ int curla_actor_head_fwd(const float* trunk_out, const float* noise, int B, int 
 int curla_mlp_out_head_fwd(const float* h, const float* W, const float* bias, float* trunk_out, int B, int A, int K,
                            const float* noise, float log_std_min, float log_std_max, float* mu, float* pi,
                            float* log_pi, float* log_std, float* tanh_ls, float* pi_xa, int xa_ld, void* stream);
+/* The two forms above with the standard-normal noise of `torch.randn_like(mu)` (curl_sac.py:97) drawn INSIDE the launch
+ * instead of read: element i = b * A + a is Box-Muller on outputs (i % 4) & 2, + 1 of Philox4x32-10 with key `seed` and
+ * counter `offset + i / 4` (cos branch for even i, sin for odd), and is also stored to noise_out [B][A] (the backward
+ * pass reads it).  The caller advances `offset` by ceil(B A / 4) per call. */
+int curla_actor_head_fwd_rng(const float* trunk_out, float* noise_out, unsigned long long seed,
+                             unsigned long long offset, int B, int A, float log_std_min, float log_std_max, float* mu,
+                             float* pi, float* log_pi, float* log_std, float* tanh_ls, float* pi_xa, int xa_ld,
+                             void* stream);
+int curla_mlp_out_head_fwd_rng(const float* h, const float* W, const float* bias, float* trunk_out, int B, int A, int K,
+                               float* noise_out, unsigned long long seed, unsigned long long offset, float log_std_min,
+                               float log_std_max, float* mu, float* pi, float* log_pi, float* log_std, float* tanh_ls,
+                               float* pi_xa, int xa_ld, void* stream);
 /* gradient w.r.t. trunk_out of sum(gpi*pi) + glp*log_pi; glp = glp_rows[b] or glp_scale*exp(*log_alpha);
  * gpi[b][a] is read at gpi[b*gpi_ld + a] (+ gpi2[b*gpi_ld + a] when gpi2 is not NULL: the action columns of the twin-Q
  * input gradient summed over the twin in place) */
@@ -297,6 +320,13 @@ int curla_soft_update2(const float* param, float* target, size_t n, size_t split
  * torch's single-tensor Adam, and rounded to float once). */
 int curla_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
                     double beta1, double beta2, double eps, long long step, void* stream);
+/* curla_adam_step plus, in the same launch, the soft update of the target copy of the same flat run with the freshly
+ * stepped parameters (critic_optimizer.step() ... soft_update_params x3, curl_sac.py:367,442-445): target[i] <- tau p[i]
+ * + (1 - tau) target[i], elements [0, split) with (tau_a, one_minus_tau_a), the rest with (tau_b, one_minus_tau_b);
+ * the same arithmetic as curla_adam_step followed by curla_soft_update2. */
+int curla_adam_step_lerp(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
+                         double beta1, double beta2, double eps, long long step, float* target, size_t split, float tau_a,
+                         float one_minus_tau_a, float tau_b, float one_minus_tau_b, void* stream);
 /* curla_adam_step plus, in the same launch, the Adam step of ONE float64 scalar parameter with its own optimizer state
  * and hyper-parameters (log_alpha, stepped right after the actor: curl_sac.py:393-404), in double. */
 int curla_adam_step_scalar64(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,

@@ -157,7 +157,7 @@ def _run(tag, obs_shape, in_hw, aug_name, layers, B, pixel_sac, capacity):
     # ---- the device: ONE update() call on that minibatch and that noise
     rb.sample_cpc_refs = lambda: (obs, act, rew, nxt, nd, kw)
     noises = iter([noise_c.to(dev), noise_a.to(dev)])
-    agent._noise = lambda ws, noise: ws.noise.copy_(next(noises))
+    agent._noise = lambda ws, noise: (ws.noise.copy_(next(noises)), None)  # (buffer, rng): explicit noise, no in-kernel draw
     captured = {}
     real_step = agent.critic_optimizer.step
 

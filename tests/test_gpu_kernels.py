@@ -820,6 +820,93 @@ def test_conv_s1_backward_one_launch(ops, B, H, W):
     assert n3 == n2 and torch.equal(dw3, dw2) and torch.equal(db3, db2)  # run-to-run reproducible
 
 
+def test_policy_noise_drawn_inside_the_head_launch(ops):
+    """rng=(seed, offset): the head draws its own standard-normal noise (Philox4x32-10 + Box-Muller, curla_hip.h) and
+    stores it; everything downstream of the noise is bit-identical to the explicit-noise form fed with those numbers;
+    the stream is a pure function of (seed, offset), consecutive calls with advanced offsets do not overlap, and the
+    numbers look like N(0, 1)."""
+    lo, hi = -10.0, 2.0
+    B, A = 32768, 8
+    out = rnd(B, 2 * A, seed=61).cuda()
+    f = lambda *sh: torch.full(sh, float("nan"), device="cuda")  # noqa: E731
+
+    def draw(seed, off, head="head"):
+        nz, pi, lp = f(B, A), f(B, A), f(B, 1)
+        if head == "head":
+            ops.actor_head_fwd(out, nz, B, A, lo, hi, pi=pi, log_pi=lp, rng=(seed, off))
+        else:  # inside the trunk's last-layer launch
+            K = 64
+            h, W, b = torch.relu(rnd(B, K, seed=62)).cuda(), (rnd(2 * A, K, seed=63) * 0.2).cuda(), rnd(2 * A, seed=64).cuda()
+            ops.mlp_out_head_fwd(h, W, b, f(B, 2 * A), nz, B, A, K, lo, hi, pi=pi, log_pi=lp, rng=(seed, off))
+        return nz, pi, lp
+    n1, p1, l1 = draw(1234, 10)
+    assert bool(torch.isfinite(n1).all())
+    x = n1.double().flatten()
+    m, sd = float(x.mean()), float(x.std())
+    kurt, skew = float(((x - m) ** 4).mean() / sd ** 4), float(((x - m) ** 3).mean() / sd ** 3)
+    assert abs(m) < 0.01 and abs(sd - 1) < 0.01 and abs(kurt - 3) < 0.06 and abs(skew) < 0.02, (m, sd, kurt, skew)
+    assert float(x.abs().max()) > 4.0  # tails are there (262144 draws: P(no |x| > 4) ~ 1e-7)
+    # neighbours in the stream are uncorrelated (Box-Muller pairs share a radius: cos / sin of one angle)
+    assert abs(float((x[:-1] * x[1:]).mean())) < 0.01
+    # explicit-noise form on the same numbers: identical outputs
+    pi2, lp2 = f(B, A), f(B, 1)
+    ops.actor_head_fwd(out, n1, B, A, lo, hi, pi=pi2, log_pi=lp2)
+    assert torch.equal(p1, pi2) and torch.equal(l1, lp2)
+    # a pure function of (seed, offset); the trunk-launch form draws the same stream
+    n1b, _, _ = draw(1234, 10)
+    n3, _, _ = draw(1234, 10, head="trunk")
+    assert torch.equal(n1, n1b) and torch.equal(n1, n3)
+    # next call's offset = + ceil(B A / 4): no number of the first call repeats at the same position or shifted by it
+    n4, _, _ = draw(1234, 10 + B * A // 4)
+    assert not bool((n4 == n1).any())
+    n5, _, _ = draw(1234, 10 + 1)  # one counter further = the stream shifted by four numbers
+    assert torch.equal(n5.flatten()[:-4], n1.flatten()[4:])
+    n6, _, _ = draw(1235, 10)
+    assert not bool((n6 == n1).any())
+
+
+@pytest.mark.parametrize("B,Fd,K,twin", [(512, 50, 196, True), (32, 50, 3456, False), (515, 50, 196, False), (9, 13, 100, True),
+                                          (24, 130, 64, False)])
+def test_ln_param_grads_finished_inside_the_fc_backward(ops, B, Fd, K, twin):
+    """ops.ln_bwd(..., defer=) + ops.fc_bwd / fc_dw(..., ln=): dx, the fc products and the LayerNorm / fc-bias gradients
+    against the three-launch path (LayerNorm backward, its parameter-gradient launch, fc backward) -- dx and the fc
+    products bit-identical, the column sums within rounding (another fixed order) and reproducible run to run."""
+    if not ops.fc_bwd_streams(Fd, K):
+        pytest.skip("the fc backward of this shape does not take the streaming kernels")
+    gamma = (1 + 0.1 * rnd(Fd, seed=51)).cuda()
+    xhat, rstd = rnd(B, Fd, seed=52).cuda(), (0.5 + rnd(B, seed=53).abs()).cuda()
+    ld = Fd + 3 if twin else Fd
+    dy = rnd(2, B, ld, seed=54).cuda()
+    dy2 = dy[1] if twin else None
+    W, x = (rnd(Fd, K, seed=55) * 0.1).cuda(), torch.relu(rnd(B, K, seed=56)).cuda()
+    f = lambda *sh: torch.full(sh, float("nan"), device="cuda")  # noqa: E731
+    for with_dx in (True, False):
+        dx1, dg1, db1, dbi1, g1, dw1 = f(B, Fd), f(Fd), f(Fd), f(Fd), f(B, K), f(Fd, K)
+        ops.ln_bwd(dy[0], xhat, rstd, gamma, B, Fd, dx1, dgamma=dg1, dbeta=db1, dbias_in=dbi1, dy2=dy2, ld=ld)
+        if with_dx:
+            ops.fc_bwd(dx1, W, x, g1, dw1, B, Fd, K)
+        else:
+            ops.fc_dw(dx1, x, dw1, B, Fd, K)
+        res = []
+        for _ in range(2):
+            dx2, dg2, db2, dbi2, g2, dw2 = f(B, Fd), f(Fd), f(Fd), f(Fd), f(B, K), f(Fd, K)
+            part = f(ops.ln_partial_floats(B, Fd))
+            tok = ops.ln_bwd(dy[0], xhat, rstd, gamma, B, Fd, dx2, dgamma=dg2, dbeta=db2, dbias_in=dbi2, dy2=dy2, ld=ld,
+                             defer=part)
+            assert tok is not None and bool(torch.isnan(dg2).all())  # not finished yet
+            if with_dx:
+                ops.fc_bwd(dx2, W, x, g2, dw2, B, Fd, K, ln=tok)
+            else:
+                ops.fc_dw(dx2, x, dw2, B, Fd, K, ln=tok)
+            res.append((dg2, db2, dbi2))
+            assert torch.equal(dx1, dx2) and torch.equal(dw1, dw2) and (not with_dx or torch.equal(g1, g2))
+            check(f"deferred ln dgamma {B}x{Fd}", dg2.cpu(), dg1.cpu(), 2e-6)
+            check(f"deferred ln dbeta {B}x{Fd}", db2.cpu(), db1.cpu(), 2e-6)
+            check(f"deferred fc dbias {B}x{Fd}", dbi2.cpu(), dbi1.cpu(), 2e-6)
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+
+
 def test_fc_backward_one_launch(ops):
     """curla_fc_bwd: data + weight gradient of the encoder fc layer in ONE pass over the activations (the ReLU mask of
     the one and the column operand of the other are the same matrix).  The data gradient is bit-identical to
@@ -872,6 +959,37 @@ def test_flat_adam_step_pair_is_two_steps():
     for a, b in zip(res[0][:5], res[1][:5]):
         assert torch.equal(a, b)
     assert res[0][5:] == res[1][5:] == ([3] * 4, [3] * 5)
+
+
+def test_flat_adam_step_with_target_lerp():
+    """FlatAdam.step_with_lerp(critic_optimizer, target, ...) (critic_optimizer.step() and the three soft_update_params
+    that follow it, curl_sac.py:367,442-445, in one launch): exactly the parameters, moments and targets of step()
+    followed by ops.soft_update2; refused (nothing done) when the optimizer's run is not the announced one."""
+    from curla_amd import ops
+    from curla_amd.optim import FlatAdam
+    sizes = [(32, 9, 3, 3), (32,), (50, 1203), (50,), (64, 52), (64,), (1, 64), (1,)]
+    res = []
+    for fused in (False, True):
+        flat, gflat, params = _flat_params(sizes, "cuda", seed=7)
+        n = flat.numel()
+        target = (flat + 0.01 * torch.randn(n, generator=torch.Generator().manual_seed(2)).cuda()).contiguous()
+        opt = FlatAdam(params, flat, gflat, lr=1e-3, betas=(0.9, 0.999))
+        lo, hi = opt._lo, opt._hi
+        split = (params[4].data_ptr() - flat.data_ptr()) // 4 - lo  # "encoder" = the first four tensors
+        gen = torch.Generator().manual_seed(13)
+        for _ in range(3):
+            gflat.copy_(torch.randn(gflat.shape, generator=gen).cuda() * 0.01)
+            if fused:
+                assert not FlatAdam.step_with_lerp(opt, target, lo + 4, hi, split, 0.05, 0.01)  # not its run: refused
+                assert FlatAdam.step_with_lerp(opt, target, lo, hi, split, 0.05, 0.01)
+            else:
+                opt.step()
+                ops.soft_update2(flat[lo:hi], target[lo:hi], split, 0.05, 0.01)
+        torch.cuda.synchronize()
+        res.append((flat.clone(), opt._m.clone(), opt._v.clone(), target.clone(), list(opt._steps)))
+    for a, b in zip(res[0][:4], res[1][:4]):
+        assert torch.equal(a, b)
+    assert res[0][4] == res[1][4] == [3] * len(sizes)
 
 
 def test_flat_adam_step_with_float64_scalar():

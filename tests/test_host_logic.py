@@ -230,7 +230,11 @@ def test_update_schedule_launch_counts():
     assert sum(even.values()) <= 65 and sum(odd.values()) <= 46
     # fc backward: data + weight gradient in one launch where the conv stack gets a gradient (critic, CURL), the
     # weight gradient alone in the actor phase (encoder detached)
-    assert even["curla_fc_bwd"] == 2 and even["curla_fc_dw"] == 1 and even["curla_fc_dx"] == 0
+    # -- and each of them finishes the LayerNorm / fc-bias gradients its LayerNorm backward left as partial sums
+    # (curla_ln_bwd_partial): no parameter-gradient launch of their own
+    assert even["curla_fc_bwd_ln"] == 2 and even["curla_fc_dw_ln"] == 1 and even["curla_fc_dx"] == 0
+    assert even["curla_fc_bwd"] == 0 and even["curla_fc_dw"] == 0
+    assert even["curla_ln_bwd_partial"] == 3 and even["curla_ln_bwd"] == 0 and even["curla_ln_bwd_twin"] == 0
     assert even["curla_split_sum"] == 0
     assert even["curla_gemm"] <= 40 and even["curla_concat"] == 0 and even["curla_td_target"] == 0
     # only_cpc (train.py:425): no SAC phases
