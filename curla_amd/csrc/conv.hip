@@ -1616,10 +1616,13 @@ bool use_rw() {
   return !band;
 }
 // ... and the weight gradient: CURLA_S1_WGRAD=band keeps the banded kernel beside the row-walk forward / data gradient
-// CURLA_C1_U8=band: the LDS-banded uint8 first-layer kernels instead of the row-walk ones
-bool use_rw_u8() {
-  static const bool band = getenv("CURLA_C1_U8") && !strcmp(getenv("CURLA_C1_U8"), "band");
-  return use_rw() && !band;
+// CURLA_C1_U8=rw: the row-walk uint8 first-layer forward (conv1_u8_rw.h) instead of the LDS-banded one.  Measured on
+// 1024 + 512 / 512 + 512 samples of configs[1]: alone, re-reading the same ring slots out of the Infinity Cache, the
+// row walk takes 100 / 66 us against 128 / 86; on slots drawn afresh for every launch from a ring of gigabytes -- what
+// update() does -- 114 us on average against 104 (rocprofv3, same box).  The default is what update() runs fastest.
+bool use_rw_u8() {  // (read at every call -- two per update -- so that one process can run both: the tests do)
+  const char* e = getenv("CURLA_C1_U8");
+  return use_rw() && e && !strcmp(e, "rw");
 }
 
 bool use_rw_wgrad() {

@@ -15,6 +15,14 @@
 // every row of its piece -- the loads are aligned dwords and v_alignbyte shifts the run into place (AL = true).  A wave owns 16 output columns and all 32 output
 // channels and walks down: output row y needs input rows 2y, 2y+1, 2y+2, the last of which is the next row's first, so
 // a step loads and converts two new rows (2 loads, 2 E conversions) for 6 E MFMAs.  No LDS, no barrier.
+//
+// Status: OPT-IN (CURLA_C1_U8=rw).  Alone -- the same ring slots re-read out of the Infinity Cache from launch to
+// launch -- it is the faster kernel (1024 samples of 76x76x9: 66-71 us against 85; 1536: 100-105 against 128).  On slots
+// drawn afresh from a ring of gigabytes for every launch, which is what update() does, it is the slower one: 114 us on
+// average against 104 under rocprofv3 on the same box (88 against 88 per 1024 samples in the microbenchmark).  More
+// prefetch distance (1 / 2 / 4 steps: 90.6 / 86.4 / 88.4 us), five waves per SIMD instead of four, and pulling a
+// workgroup's crops into the L2 in one coalesced burst first (92 against 82) did not change that; the banded kernel,
+// which reads a crop once in one burst and then works out of LDS, does not see the difference.  DESIGN.md section 6.
 #pragma once
 
 namespace rw {

@@ -110,8 +110,21 @@ CONV1_CASES = [  # C, Hs, Ws, Hc, Wc, B
 ]
 
 
+@pytest.fixture(params=["band", "rw"])
+def u8_impl(request):
+    """Both uint8 first-layer forwards: the LDS-banded default and the row walk (CURLA_C1_U8=rw, conv1_u8_rw.h)."""
+    import os
+    old = os.environ.get("CURLA_C1_U8")
+    os.environ["CURLA_C1_U8"] = request.param
+    yield request.param
+    if old is None:
+        del os.environ["CURLA_C1_U8"]
+    else:
+        os.environ["CURLA_C1_U8"] = old
+
+
 @pytest.mark.parametrize("C,Hs,Ws,Hc,Wc,B", CONV1_CASES)
-def test_crop_and_conv1_u8(ops, C, Hs, Ws, Hc, Wc, B):
+def test_crop_and_conv1_u8(ops, u8_impl, C, Hs, Ws, Hc, Wc, B):
     from oracle import curla_oracle as O
     N = 11
     frames, ring = _ring(N, C, Hs, Ws, seed=C + Hs)
@@ -135,7 +148,7 @@ def test_crop_and_conv1_u8(ops, C, Hs, Ws, Hc, Wc, B):
     obs = ops.ObsRef.from_ring(ring, d_idx, d_h1, d_w1, B, (Hc, Wc))
     out = torch.full((B, Ho, Wo, 32), float("nan"), device="cuda")
     ops.conv1_fwd(obs, dev(w), dev(b), out)
-    check(f"conv1_fwd u8 C{C} {Hs}x{Ws}->{Hc}x{Wc}", nchw(out), ref)
+    check(f"conv1_fwd u8 [{u8_impl}] C{C} {Hs}x{Ws}->{Hc}x{Wc}", nchw(out), ref)
     # float NCHW source (reference tensor contract)
     out2 = torch.full((B, Ho, Wo, 32), float("nan"), device="cuda")
     ops.conv1_fwd(ops.ObsRef.from_tensor(out_f), dev(w), dev(b), out2)
@@ -718,7 +731,7 @@ def test_conv_s1_fwd_two_problems(ops, B1, B2, H, W):
 
 
 @pytest.mark.parametrize("B1,B2,C", [(6, 3, 9), (3, 5, 12)])
-def test_conv1_fwd_two_problems(ops, B1, B2, C):
+def test_conv1_fwd_two_problems(ops, u8_impl, B1, B2, C):
     """curla_conv1_fwd2: two gathers from one uint8 ring with their own indices, crop offsets and weights."""
     Hs, Ws, Hc, Wc = 30, 34, 26, 28
     g = torch.Generator().manual_seed(71)
