@@ -464,6 +464,11 @@ def measure(job, name, steps, warmup, with_cpu_baseline):
                                    "launch, f32 MFMA 16x16x4; FLOPs counted as direct-conv FLOPs)",
                          "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_F32_TFLOPS, "traffic": traffic,
+                         # `achieved` counts the ALGORITHMIC (direct-convolution) FLOPs of SURVEY.md 8(d); the kernel is
+                         # Winograd F(2,3) along x and executes 2/3 of them, so `frac` can exceed 1.  What the matrix
+                         # pipe really does is `executed`: compare THAT with the peak, and `mfma_busy_frac_pmc` with 1.
+                         "executed": achieved / 1.5, "executed_frac": achieved / 1.5 / PEAK_F32_TFLOPS,
+                         "executed_note": "MFMA FLOPs issued = algorithmic / 1.5 (Winograd F(2,3) in one dimension)",
                          "traffic_unit": "HBM bytes per launch; " + pmc_note,
                          "algorithmic_bytes_per_launch": kbytes / n_launch,
                          "launches": len(ev_pairs), "avg_launch_ms": avg_ms,
