@@ -523,6 +523,7 @@ __device__ __forceinline__ void conv1_stage(float* lds, const void* src, const i
   // the row's end and its padding value is the float BEHIND the row.  Its weight is zero, but 0 x (whatever bit
   // pattern an earlier kernel left in LDS: NaN, Inf) is NaN, which the ReLU then turns into 0 -- a wrong, finite
   // output.  The slack behind every row is zeroed here (the uint8 path wrote whole groups of four: behind those).
+#ifndef CURLA_TEST_NO_SLACK_ZERO  // (defined only by a one-off build that checks the regression test can fail)
   {
     const int first = SRC == SRC_U8 ? (rowf + 3) & ~3 : rowf;
     const int pad = RS - first;  // 4..7 floats
@@ -531,6 +532,7 @@ __device__ __forceinline__ void conv1_stage(float* lds, const void* src, const i
       lds[r * RS + first + e] = 0.f;
     }
   }
+#endif
 }
 
 template <int SRC, int C>

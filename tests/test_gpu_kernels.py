@@ -101,6 +101,26 @@ def _ring(N, C, Hs, Ws, seed):
     return frames, ring
 
 
+def _poison_lds(ops):
+    """Leave NaN bit patterns (0xFF bytes) in the LDS of every CU: the banded uint8 forward keeps its crops as bytes in
+    LDS, so a ring full of 255s does it.  A kernel that reads LDS it has not written (and multiplies it by a zero
+    weight) then produces NaNs deterministically instead of once in a few hundred runs."""
+    import os
+    old = os.environ.pop("CURLA_C1_U8", None)
+    try:
+        store = torch.full((84 * 84 * 9 + 32,), 255, dtype=torch.uint8, device="cuda")
+        ring = store[:84 * 84 * 9].view(1, 84, 84, 9)
+        B = 1024
+        z64, z32 = torch.zeros(B, dtype=torch.int64, device="cuda"), torch.zeros(B, dtype=torch.int32, device="cuda")
+        obs = ops.ObsRef.from_ring(ring, z64, z32, z32, B, (84, 84))
+        out = torch.empty(B, 41, 41, 32, device="cuda")
+        ops.conv1_fwd(obs, torch.zeros(32, 9, 3, 3, device="cuda"), torch.zeros(32, device="cuda"), out)
+        torch.cuda.synchronize()
+    finally:
+        if old is not None:
+            os.environ["CURLA_C1_U8"] = old
+
+
 CONV1_CASES = [  # C, Hs, Ws, Hc, Wc, B
     (9, 34, 40, 28, 34, 8), (9, 84, 84, 76, 76, 4), (9, 84, 84, 84, 84, 3), (12, 50, 46, 41, 37, 5), (3, 20, 23, 17, 19, 6),
     (6, 31, 45, 25, 39, 7),  # frame_stack 2; 31*45*6 bytes per frame is not a multiple of 4
@@ -149,10 +169,22 @@ def test_crop_and_conv1_u8(ops, u8_impl, C, Hs, Ws, Hc, Wc, B):
     out = torch.full((B, Ho, Wo, 32), float("nan"), device="cuda")
     ops.conv1_fwd(obs, dev(w), dev(b), out)
     check(f"conv1_fwd u8 [{u8_impl}] C{C} {Hs}x{Ws}->{Hc}x{Wc}", nchw(out), ref)
-    # float NCHW source (reference tensor contract)
+    # float NCHW source (reference tensor contract); with NaN patterns in whatever LDS the kernel does not write itself
+    # (at an odd crop width the last pixel's padded k-step reads one float behind the row: it must be a zero, not
+    # "anything times a zero weight")
+    _poison_lds(ops)
     out2 = torch.full((B, Ho, Wo, 32), float("nan"), device="cuda")
     ops.conv1_fwd(ops.ObsRef.from_tensor(out_f), dev(w), dev(b), out2)
     check(f"conv1_fwd f32 C{C} {Hc}x{Wc}", nchw(out2), ref)
+    # float NHWC source (the augmented minibatches), banded form
+    if u8_impl == "band":
+        os_env = __import__("os").environ
+        keep = os_env.get("CURLA_S1_IMPL")
+        _poison_lds(ops)
+        out3 = torch.full((B, Ho, Wo, 32), float("nan"), device="cuda")
+        ops.conv1_fwd(ops.ObsRef.from_nhwc(out_f.permute(0, 2, 3, 1).contiguous()), dev(w), dev(b), out3)
+        check(f"conv1_fwd f32 NHWC C{C} {Hc}x{Wc}", nchw(out3), ref)
+        assert keep == os_env.get("CURLA_S1_IMPL")
     # weight gradient, both sources
     g = rnd(B, 32, Ho, Wo, seed=13) * (ref > 0)
     wl = w.clone().requires_grad_(True)
