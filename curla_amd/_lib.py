@@ -40,6 +40,8 @@ SIGNATURES = {
     "curla_fc_bwd": [vp, vp, vp, vp, vp, c_int, c_int, c_int, vp],
     "curla_fc_bwd_ln": [vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, c_int, vp, vp, vp, vp],
     "curla_fc_dw_ln": [vp, vp, vp, c_int, c_int, c_int, vp, c_int, vp, vp, vp, vp],
+    "curla_fc_bwd_ln2": [vp, vp, vp, vp, vp, c_int, c_int, c_int, vp, c_int, vp, vp, vp, vp, c_int, c_int, vp, vp],
+    "curla_curl_head": [vp, vp, vp, vp, vp, vp, c_int, c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "curla_gemm_nested": [vp, c_int, c_int, c_ll, c_ll, vp, c_int, c_int, c_ll, c_ll, vp, c_int, c_ll, c_ll, c_int, c_int, c_int,
                           c_int, c_int, c_float, vp, c_ll, c_ll, c_int, vp, c_int, c_ll, c_ll, vp],
     "curla_mlp_out_fwd_nested": [vp, c_ll, c_ll, vp, c_ll, c_ll, vp, c_ll, c_ll, vp, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int,

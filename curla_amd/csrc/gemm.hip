@@ -503,8 +503,29 @@ struct LnReduce {
   const float* partial;
   int nparts, F;
   float *dgamma, *dbeta, *dbias;
+  // a second set of partial sums for the same workgroup (the CURL head's dW partials, curla_curl_head):
+  // xout[i] = sum over xparts partials of xpartial[p * xlen + i]; xpartial == nullptr: none
+  const float* xpartial;
+  int xparts, xlen;
+  float* xout;
 };
 __device__ __forceinline__ void ln_reduce_block(const LnReduce& r) {
+  if (r.xpartial) {
+    for (int i = threadIdx.x; i < r.xlen; i += blockDim.x) {
+      const float* p = r.xpartial + i;
+      float a = 0.f;
+      int k = 0;
+      for (; k + 8 <= r.xparts; k += 8) {
+        float t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t[u] = p[(size_t)(k + u) * r.xlen];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a += t[u];
+      }
+      for (; k < r.xparts; ++k) a += p[(size_t)k * r.xlen];
+      r.xout[i] = a;
+    }
+  }
   for (int i = threadIdx.x; i < 3 * r.F; i += blockDim.x) {
     const int q = i / r.F, f = i - q * r.F;
     float* out = q == 0 ? r.dgamma : q == 1 ? r.dbeta : r.dbias;
@@ -1024,6 +1045,7 @@ __global__ void ln_reduce_kernel(LnReduce r) { ln_reduce_block(r); }
 static int ln_reduce_args(LnReduce& r, const float* partial, int nparts, int F, float* dgamma, float* dbeta,
                           float* dbias) {
   r.partial = partial, r.nparts = nparts, r.F = F, r.dgamma = dgamma, r.dbeta = dbeta, r.dbias = dbias;
+  r.xpartial = nullptr, r.xparts = r.xlen = 0, r.xout = nullptr;
   if (!partial) return CURLA_OK;
   CURLA_REQUIRE(nparts > 0 && dgamma && dbeta);
   return CURLA_OK;
@@ -1114,6 +1136,17 @@ int curla_fc_bwd_ln(const float* dz, const float* W, const float* x, float* dx, 
   LnReduce r;
   int rc = ln_reduce_args(r, ln_partial, nparts, F, dgamma, dbeta, dbias_in);
   if (rc != CURLA_OK) return rc;
+  return fc_bwd_impl(dz, W, x, dx, dW, B, F, K, stream, r);
+}
+
+int curla_fc_bwd_ln2(const float* dz, const float* W, const float* x, float* dx, float* dW, int B, int F, int K,
+                     const float* ln_partial, int nparts, float* dgamma, float* dbeta, float* dbias_in,
+                     const float* extra_partial, int extra_parts, int extra_len, float* extra_out, void* stream) {
+  CURLA_REQUIRE(ln_partial && extra_partial && extra_out && extra_parts > 0 && extra_len > 0);
+  LnReduce r;
+  int rc = ln_reduce_args(r, ln_partial, nparts, F, dgamma, dbeta, dbias_in);
+  if (rc != CURLA_OK) return rc;
+  r.xpartial = extra_partial, r.xparts = extra_parts, r.xlen = extra_len, r.xout = extra_out;
   return fc_bwd_impl(dz, W, x, dx, dW, B, F, K, stream, r);
 }
 

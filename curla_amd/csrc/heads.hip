@@ -750,6 +750,259 @@ __global__ void curl_ce_kernel(const float* logits, int B, int ld, float* row_lo
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The CURL head in ONE launch (curl_sac.py:211-222, 406-417 and their autograd): from the anchor features z_a, the
+// positives' z_pos and (W z_pos^T)^T to the row losses, d(loss)/d(fc output) of the anchor encoder (LayerNorm backward
+// included) and the partial sums of dW and of the LayerNorm / fc-bias gradients -- what used to be seven launches of
+// ~5 us each (logits, cross-entropy, three small products, LayerNorm backward), one of which the host could not enqueue
+// in time.  One 512-thread workgroup per 16 anchor rows:
+//   A  logits[16][B] = z_a rows . wz^T on the matrix pipe (a wave takes every eighth 16-column tile; k walked as 4
+//      contiguous runs so that both operands are plain row reads), row max / sum of exponentials across lanes, tiles
+//      and waves, dlogits = (softmax - I) / B into LDS;
+//   B  dz = dlogits . wz and T = dlogits . z_pos (16 x F each, k = B): one (feature tile, matrix) pair per wave, the
+//      A operand from LDS, the B operand one float per lane and step from L2;
+//   C  LayerNorm backward of the 16 dz rows (a wave per row), their contributions to dgamma / dbeta / fc-bias gradient,
+//      and the 16-row partial of dW[i][k] = sum_a z_a[a][i] T[a][k].
+// The partial sums are finished by the extra workgroup of the fc backward that follows (curla_fc_bwd_ln).
+// ---------------------------------------------------------------------------------------------------------------------
+struct CurlHeadArgs {
+  const float *za, *zp, *wz;         // [B][F]
+  const float *xhat, *rstd, *gamma;  // LayerNorm state of the anchor encoder: [B][F], [B], [F]
+  float* row_loss;                   // [B]
+  float* dfc;                        // [B][F]
+  float* ln_partial;                 // [B / 16][3][F]
+  float* w_partial;                  // [B / 16][F * F]
+  float *logits, *dlogits, *dz;      // optional: [B][B], [B][B], [B][F]
+  int B, F;
+};
+
+constexpr int kCurlMaxKQ = 13;  // k per lane group of phase A: F <= 52
+
+// NTILE = B / 128: the 16-column logits tiles a wave owns in phase A (compile-time, so that all of a phase's operand
+// loads are issued together: the kernel is a chain of memory latencies, not of arithmetic)
+template <int NTILE>
+__global__ __launch_bounds__(512) void curl_head_kernel(CurlHeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int B = 128 * NTILE, QB = B / 4;  // QB: k (= logits column) per lane group in phase B
+  constexpr int LD = B + 4;                   // dlogits rows in LDS (16-byte aligned rows)
+  // phase B's operand (one float per lane and k-step) is requested before phase A when it fits the register file
+  // next to phase A's tiles; else in runs of 32 in front of their MFMAs
+  constexpr bool PRELOAD = NTILE <= 4;
+  const int F = a.F;
+  float* dl = lds;                      // [16][LD]
+  float* zs = dl + 16 * LD;             // [16][64]   z_a rows of this block
+  float* t0 = zs + 16 * 64;             // [2][16][64] dz tile, T tile
+  float* red = t0 + 2 * 16 * 64;        // [8][16] row maxima, then [8][16] row sums
+  float* dg = red + 2 * 8 * 16;         // [16] diagonal logits
+  float* pr = dg + 16;                  // [8][3][64] LayerNorm partials per wave
+  float* pq = pr + 8 * 3 * 64;          // [2][4][16][64] phase B: k-quarter partial tiles
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int r0 = blockIdx.x * 16;
+  constexpr int KQ = kCurlMaxKQ;        // k per lane group of phase A: 4 KQ - 3 <= F <= 4 KQ (checked by the host)
+
+  // ---- operand loads of phases A and B, all in flight together.  The texture addresser is shared by the CU's eight
+  // waves and spends its time per ADDRESS, not per byte: a lane's k-run of phase A (KQ consecutive floats of a row) is
+  // read as 16-byte pieces (4-byte aligned) + single floats, phase B's operand as one 16-byte load per k-step (below)
+  float af[KQ], bf[NTILE][KQ];
+  const int k0 = min(KQ * kq, F - KQ);  // (the last lane group's run is moved back into the row; see phase A)
+  {
+    auto load_run = [&](float (&dst)[KQ], const float* p) {
+#pragma unroll
+      for (int s4 = 0; s4 + 4 <= KQ; s4 += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + s4);
+        dst[s4] = v[0], dst[s4 + 1] = v[1], dst[s4 + 2] = v[2], dst[s4 + 3] = v[3];
+      }
+#pragma unroll
+      for (int s1 = KQ & ~3; s1 < KQ; ++s1) dst[s1] = p[s1];
+    };
+    load_run(af, a.za + (size_t)(r0 + li) * F + k0);
+#pragma unroll
+    for (int i = 0; i < NTILE; ++i) load_run(bf[i], a.wz + (size_t)(16 * (wave + 8 * i) + li) * F + k0);
+  }
+  // phase B: wave -> (matrix, quarter of k): all four feature tiles, tile t's column li is feature 4 li + t, so ONE
+  // 16-byte load per lane and k-step feeds four MFMAs and a lane group's 16 lanes read 256 contiguous bytes
+  const int mat = wave >> 2, kquart = wave & 3;  // matrix 0: wz -> dz, 1: z_pos -> T
+  constexpr int KW = B / 16;                      // k per lane group and wave
+  const int cbase = kquart * (B / 4) + KW * kq;   // first logits column (= row of wz / z_pos) of this lane group
+  const int nfull = F >> 2, nrest = F & 3;        // lanes li < nfull: four features; lane nfull: the remaining nrest
+  // every lane issues the same 16-byte load: lanes li < nfull at their four features, the others at the row's LAST four
+  // floats (in range), from which lane nfull picks its nrest features; lanes beyond hold zeros
+  const float* mrow = (mat ? a.zp : a.wz) + (size_t)cbase * F + (li < nfull ? 4 * li : F - 4);
+  f32x4 bv[PRELOAD ? KW : 8];
+  auto load_bv = [&](f32x4& v, int c) { v = *reinterpret_cast<const f32x4*>(mrow + (size_t)c * F); };
+  auto fix_bv = [&](f32x4& v) {  // (features 4 nfull + t sit at position t + 4 - nrest of the row's last four floats)
+    if (li >= nfull) {
+      const f32x4 w = v;
+      const bool mine = li == nfull;
+      v[0] = (mine && nrest > 0) ? (nrest == 1 ? w[3] : nrest == 2 ? w[2] : w[1]) : 0.f;
+      v[1] = (mine && nrest > 1) ? (nrest == 2 ? w[3] : w[2]) : 0.f;
+      v[2] = (mine && nrest > 2) ? w[3] : 0.f;
+      v[3] = 0.f;
+    }
+  };
+  if (PRELOAD) {
+#pragma unroll
+    for (int c = 0; c < KW; ++c) load_bv(bv[c], c);
+  }
+  for (int i = tid; i < 16 * 64; i += 512) {
+    const int r = i >> 6, f = i & 63;
+    zs[i] = f < F ? a.za[(size_t)(r0 + r) * F + f] : 0.f;
+  }
+  // ---- A: logits of rows r0 .. r0 + 15.  A lane group's run starts at k0 = min(KQ kq, F - KQ): the k below KQ kq of the
+  // moved run belong to the previous group and are dropped (a zero on the z_a side is enough)
+#pragma unroll
+  for (int s = 0; s < KQ; ++s) af[s] = k0 + s >= KQ * kq ? af[s] : 0.f;
+  f32x4 lg[NTILE];
+#pragma unroll
+  for (int i = 0; i < NTILE; ++i) {
+    lg[i] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < kCurlMaxKQ; ++s) lg[i] = mfma16(af[s], bf[i][s], lg[i]);
+  }
+  // lane (li, kq) holds logits[r0 + 4 kq + r][16 (wave + 8 i) + li]
+  float mx[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float m = lg[0][r];
+#pragma unroll
+    for (int i = 1; i < NTILE; ++i) m = fmaxf(m, lg[i][r]);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (li == 0) red[wave * 16 + 4 * kq + r] = m;
+  }
+#pragma unroll
+  for (int i = 0; i < NTILE; ++i) {
+    const int col = 16 * (wave + 8 * i) + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (col == r0 + 4 * kq + r) dg[4 * kq + r] = lg[i][r];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float m = red[4 * kq + r];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) m = fmaxf(m, red[w * 16 + 4 * kq + r]);
+    mx[r] = m;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NTILE; ++i) sum += expf(lg[i][r] - m);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o);
+    if (li == 0) red[128 + wave * 16 + 4 * kq + r] = sum;
+  }
+  __syncthreads();
+  const float inv = 1.f / B;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float sum = red[128 + 4 * kq + r];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) sum += red[128 + w * 16 + 4 * kq + r];
+    const float lse = logf(sum) + mx[r];
+    const int row = r0 + 4 * kq + r;
+    if (wave == 0 && li == 0) a.row_loss[row] = lse - dg[4 * kq + r];
+#pragma unroll
+    for (int i = 0; i < NTILE; ++i) {
+      const int col = 16 * (wave + 8 * i) + li;
+      const float d = (expf(lg[i][r] - lse) - (col == row ? 1.f : 0.f)) * inv;
+      dl[(4 * kq + r) * LD + col] = d;
+      if (a.logits) a.logits[(size_t)row * B + col] = lg[i][r];
+      if (a.dlogits) a.dlogits[(size_t)row * B + col] = d;
+    }
+  }
+  __syncthreads();
+  // ---- B: dz = dl . wz (waves 0-3), T = dl . z_pos (waves 4-7); a wave multiplies its quarter of k into all four
+  // feature tiles (four independent accumulator chains), the quarters are then added in order through LDS
+  {
+    const float* arow = dl + li * LD + cbase;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0, 0, 0, 0};
+    if (PRELOAD) {
+#pragma unroll
+      for (int c = 0; c < KW; ++c) fix_bv(bv[c]);
+#pragma unroll
+      for (int c0 = 0; c0 < KW; c0 += 4) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(arow + c0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc[t] = mfma16(av[u], bv[c0 + u][t], acc[t]);
+      }
+    } else {
+      for (int c0 = 0; c0 < KW; c0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) load_bv(bv[u], c0 + u);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fix_bv(bv[u]);
+#pragma unroll
+        for (int u4 = 0; u4 < 8; u4 += 4) {
+          const f32x4 av = *reinterpret_cast<const f32x4*>(arow + c0 + u4);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = mfma16(av[u], bv[u4 + u][t], acc[t]);
+        }
+      }
+    }
+    // lane (li, kq) of tile t: rows 4 kq + r, feature 4 li + t.  Quarter partials -> qp[mat][kquart][row][feature]
+    float* qp = pq + ((mat * 4 + kquart) * 16) * 64;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) qp[(4 * kq + r) * 64 + 4 * li + t] = acc[t][r];
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * 16 * 64; i += 512) {  // dz tile, T tile: the four k quarters in order
+    const int m = i >> 10, rf = i & 1023;
+    const float* q = pq + (m * 4 * 16) * 64 + rf;
+    t0[i] = ((q[0] + q[16 * 64]) + q[2 * 16 * 64]) + q[3 * 16 * 64];
+  }
+  __syncthreads();
+  // ---- C1: LayerNorm backward of rows 2 wave, 2 wave + 1 (lane = feature); partial column sums in row order
+  {
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    const bool fv = lane < F;
+    const float gm = fv ? a.gamma[lane] : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = 2 * wave + rr, grow = r0 + row;
+      const float d = fv ? t0[row * 64 + lane] : 0.f;
+      const float xh = fv ? a.xhat[(size_t)grow * F + lane] : 0.f;
+      const float g = d * gm;
+      const float m1 = wave_sum(g) / F, m2 = wave_sum(g * xh) / F;
+      const float o = a.rstd[grow] * (g - m1 - xh * m2);
+      if (fv) {
+        a.dfc[(size_t)grow * F + lane] = o;
+        if (a.dz) a.dz[(size_t)grow * F + lane] = d;
+      }
+      p0 += d * xh, p1 += d, p2 += fv ? o : 0.f;
+    }
+    pr[(wave * 3 + 0) * 64 + lane] = p0, pr[(wave * 3 + 1) * 64 + lane] = p1, pr[(wave * 3 + 2) * 64 + lane] = p2;
+  }
+  // ---- C2: this block's 16 rows of dW[i][k] = sum_a z_a[a][i] T[a][k]
+  {
+    const float* T = t0 + 16 * 64;
+    float* wp = a.w_partial + (size_t)blockIdx.x * F * F;
+    for (int idx = tid; idx < F * F; idx += 512) {
+      const int i = idx / F, k = idx - i * F;
+      float acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc += zs[r * 64 + i] * T[r * 64 + k];
+      wp[idx] = acc;
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < 3 * F; i += 512) {
+    const int q = i / F, f = i - q * F;
+    float v = pr[(0 * 3 + q) * 64 + f];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) v += pr[(w * 3 + q) * 64 + f];
+    a.ln_partial[(size_t)blockIdx.x * 3 * F + i] = v;
+  }
+}
+
 __global__ void mean_kernel(const float* x, int n, float* out) {
   __shared__ float sm[4];
   float a = 0.f;
@@ -1398,6 +1651,39 @@ int curla_curl_ce(const float* logits, int B, int ld, float* row_loss, float* lo
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(curl_ce_kernel, dim3((B + 3) / 4), dim3(256), 0, st, logits, B, ld, row_loss, dlogits);
   if (loss) hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, row_loss, B, loss);  // only when it is logged
+  return curla_launch_status();
+}
+
+int curla_curl_head(const float* z_a, const float* z_pos, const float* wz, const float* xhat, const float* rstd,
+                    const float* gamma, int B, int F, float* row_loss, float* loss, float* dfc, float* ln_partial,
+                    int* nparts, float* w_partial, float* logits, float* dlogits, float* dz, void* stream) {
+  CURLA_REQUIRE(z_a && z_pos && wz && xhat && rstd && gamma && row_loss && dfc && ln_partial && nparts && w_partial);
+  // 128-row multiples (every wave of a block takes whole column tiles), at most 1024 rows (accumulator tiles per wave),
+  // 49..52 features (phase A's k per lane group is compiled in: 13)
+  if (B <= 0 || B % 128 != 0 || B > 1024 || F <= 4 * kCurlMaxKQ - 4 || F > 4 * kCurlMaxKQ) return CURLA_ERR_UNSUPPORTED;
+  CurlHeadArgs a;
+  a.za = z_a, a.zp = z_pos, a.wz = wz, a.xhat = xhat, a.rstd = rstd, a.gamma = gamma, a.row_loss = row_loss, a.dfc = dfc;
+  a.ln_partial = ln_partial, a.w_partial = w_partial, a.logits = logits, a.dlogits = dlogits, a.dz = dz, a.B = B, a.F = F;
+  const size_t lds = (size_t)(16 * (B + 4) + 16 * 64 + 2 * 16 * 64 + 2 * 8 * 16 + 16 + 8 * 3 * 64 + 2 * 4 * 16 * 64) * sizeof(float);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+#define CURLA_CURL_HEAD(NTILE)                                                                                  \
+  case NTILE:                                                                                                    \
+    if (curla_set_dyn_lds(reinterpret_cast<const void*>(curl_head_kernel<NTILE>), lds) != CURLA_OK) return CURLA_ERR_LAUNCH; \
+    hipLaunchKernelGGL(curl_head_kernel<NTILE>, dim3(B / 16), dim3(512), lds, st, a);                          \
+    break
+  switch (B / 128) {
+    CURLA_CURL_HEAD(1);
+    CURLA_CURL_HEAD(2);
+    CURLA_CURL_HEAD(3);
+    CURLA_CURL_HEAD(4);
+    CURLA_CURL_HEAD(5);
+    CURLA_CURL_HEAD(6);
+    CURLA_CURL_HEAD(7);
+    default: CURLA_CURL_HEAD(8);
+  }
+#undef CURLA_CURL_HEAD
+  if (loss) hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, st, row_loss, B, loss);  // only when it is logged
+  *nparts = B / 16;
   return curla_launch_status();
 }
 

@@ -292,6 +292,7 @@ class _Workspace:
         self.xhat_c, self.rstd_c, self.xhat_a, self.rstd_a = f(B, F), f(B), f(B, F), f(B)
         self.dz, self.dfc = f(B, F), f(B, F)
         self.ln_partial = f(ops.ln_partial_floats(B, F))  # LayerNorm parameter-gradient partial sums (ops.ln_bwd defer=)
+        self.w_partial = f(max(1, B // 16) * F * F)       # CURL.W gradient partial sums (ops.curl_head)
         self.fc_out = f(B, F)  # pre-LayerNorm features, only written on histogram-logging steps
         # actor trunk
         self.a_h1, self.a_h2, self.a_out = f(B, H), f(B, H), f(B, 2 * A)
@@ -491,6 +492,7 @@ class CurlSacAgent(object):
         place(actor_own, False, self._actor_flat, self._actor_gflat, 0)
         self.log_alpha.grad = torch.zeros((), device=dev, dtype=torch.float64)
 
+    _curl_unfused = os.environ.get("CURLA_CURL_HEAD") == "unfused"  # the CURL head as separate launches (A/B, tests)
     _soft_update_hint = False   # set by update() around update_critic(): a target soft update follows the critic's step
     _soft_update_done = False
 
@@ -642,7 +644,8 @@ class CurlSacAgent(object):
             return pi.cpu().data.numpy().flatten()
 
     # ------------------------------------------------------------------ building blocks
-    def _encoder_backward(self, ws, obs_ref, dz, xhat, rstd, enc, conv_grads=True, dense_done=None, twin_ld=None):
+    def _encoder_backward(self, ws, obs_ref, dz, xhat, rstd, enc, conv_grads=True, dense_done=None, twin_ld=None,
+                          ln_token=None):
         """Backward of fc+LN and (optionally) the conv stack from d(loss)/d(z);
         writes .grad of enc.{ln,fc,convs}.  ``dense_done()`` is called once the fc / LayerNorm gradients are
         final, i.e. before the conv backward is enqueued (data parallel: their all-reduce starts there).
@@ -654,8 +657,11 @@ class CurlSacAgent(object):
         streams = ops.fc_bwd_streams(F, K)
         # (the LayerNorm's parameter gradients and the fc bias gradient -- column sums over the batch -- are left as
         # partial sums and finished inside the fc backward's launch, when that is one of the streaming kernels)
-        ln = ops.ln_bwd(dy, xhat, rstd, enc.ln.weight, B, F, ws.dfc, dgamma=enc.ln.weight.grad, dbeta=enc.ln.bias.grad,
-                        dbias_in=enc.fc.bias.grad, dy2=dy2, ld=twin_ld, defer=ws.ln_partial if streams else None)
+        # (``ln_token``: the CURL head's launch has already done the LayerNorm backward into ws.dfc and left its
+        # partial sums -- and those of CURL.W's gradient -- for the fc backward to finish)
+        ln = ln_token if ln_token is not None else ops.ln_bwd(
+            dy, xhat, rstd, enc.ln.weight, B, F, ws.dfc, dgamma=enc.ln.weight.grad, dbeta=enc.ln.bias.grad,
+            dbias_in=enc.fc.bias.grad, dy2=dy2, ld=twin_ld, defer=ws.ln_partial if streams else None)
         h = acts[-1]
         cur = L % 2
         g = ws.gviews[cur][L - 1]
@@ -944,23 +950,31 @@ class CurlSacAgent(object):
 
         W = self.CURL.W
         ops.linear_fwd(ws.z_pos, 0, W, 0, None, 0, ws.WzT, 0, B, F, F)         # (W z_pos^T)^T
-        ops.linear_fwd(ws.z_c, 0, ws.WzT, 0, None, 0, ws.logits, 0, B, B, F)   # z_a (W z_pos^T)
         logged = step % self.log_interval == 0  # the mean of the row losses is only needed when it is logged
-        ops.curl_ce(ws.logits, B, B, ws.row_loss, ws.scalars[5:6] if logged else None, ws.dlogits)
-        ops.linear_dx(ws.dlogits, 0, ws.WzT, 0, ws.dz, 0, B, B, F)             # d z_a
-        ops.linear_dw(ws.dlogits, 0, ws.z_c, 0, ws.dWzT, 0, B, B, F)           # d (W z_pos^T)^T
-        ops.linear_dw(ws.dWzT, 0, ws.z_pos, 0, W.grad, 0, B, F, F)             # d W
+        # logits, cross-entropy, d z_a, the LayerNorm backward and the partial sums of dW in ONE launch where the
+        # shapes allow (and the fc backward is a streaming kernel, whose extra workgroup finishes the partial sums)
+        token = None
+        if ops.curl_head_supported(B, F) and ops.fc_bwd_streams(F, enc.flat_dim) and not self._curl_unfused:
+            token = ops.curl_head(ws.z_c, ws.z_pos, ws.WzT, ws.xhat_c, ws.rstd_c, enc.ln.weight, B, F, ws.row_loss, ws.dfc,
+                                  ws.ln_partial, ws.w_partial, enc.ln.weight.grad, enc.ln.bias.grad, enc.fc.bias.grad,
+                                  W.grad, loss=ws.scalars[5:6] if logged else None, logits=ws.logits, dz=ws.dz)
+        else:
+            ops.linear_fwd(ws.z_c, 0, ws.WzT, 0, None, 0, ws.logits, 0, B, B, F)   # z_a (W z_pos^T)
+            ops.curl_ce(ws.logits, B, B, ws.row_loss, ws.scalars[5:6] if logged else None, ws.dlogits)
+            ops.linear_dx(ws.dlogits, 0, ws.WzT, 0, ws.dz, 0, B, B, F)             # d z_a
+            ops.linear_dw(ws.dlogits, 0, ws.z_c, 0, ws.dWzT, 0, B, B, F)           # d (W z_pos^T)^T
+            ops.linear_dw(ws.dWzT, 0, ws.z_pos, 0, W.grad, 0, B, F, F)             # d W
         # data parallel: the bucket is [W | convs | fc, ln]; the encoder gradients are reduced ONCE and consumed by
         # both encoder_optimizer and cpc_optimizer
         e1 = self._lay["enc"][1]
         if self._dp_active and self._dp_overlap:
             cut = self._grad_offset(enc.fc.weight, self._critic_gflat)
-            self._encoder_backward(ws, oa, ws.dz, ws.xhat_c, ws.rstd_c, enc,
+            self._encoder_backward(ws, oa, ws.dz, ws.xhat_c, ws.rstd_c, enc, ln_token=token,
                                    dense_done=lambda: self._allreduce(self._critic_gflat[cut:e1], async_op=True))
             self._allreduce(self._critic_gflat[0:cut], async_op=True)
             self._allreduce_wait()
         else:
-            self._encoder_backward(ws, oa, ws.dz, ws.xhat_c, ws.rstd_c, enc)
+            self._encoder_backward(ws, oa, ws.dz, ws.xhat_c, ws.rstd_c, enc, ln_token=token)
             self._allreduce(self._critic_gflat[0:e1])
         if isinstance(self.encoder_optimizer, FlatAdam):
             FlatAdam.step_pair(self.encoder_optimizer, self.cpc_optimizer)  # both steps in one pass over the encoder

@@ -300,6 +300,10 @@ def fc_bwd(dz, W, x, dx, dW, B, F_, K, ln=None):
     ``ln``: as for fc_dw."""
     if ln is None:
         call("curla_fc_bwd", ptr(dz), ptr(W), ptr(x), ptr(dx), ptr(dW), B, F_, K, stream())
+    elif len(ln) > 5:  # (curl_head's token: a second set of partial sums rides along)
+        part, n, dgamma, dbeta, dbias, xpart, xn, xlen, xout = ln
+        call("curla_fc_bwd_ln2", ptr(dz), ptr(W), ptr(x), ptr(dx), ptr(dW), B, F_, K, ptr(part), n, ptr(dgamma),
+             ptr(dbeta), ptr(dbias), ptr(xpart), xn, xlen, ptr(xout), stream())
     else:
         part, n, dgamma, dbeta, dbias = ln
         call("curla_fc_bwd_ln", ptr(dz), ptr(W), ptr(x), ptr(dx), ptr(dW), B, F_, K, ptr(part), n, ptr(dgamma),
@@ -479,6 +483,23 @@ def critic_td_loss(q, tq, twin_stride, log_pi, reward, not_done, log_alpha, disc
 def actor_loss(q, twin_stride, log_pi, log_std, A, log_alpha, target_entropy, B, scalars4, dq, dlog_alpha):
     call("curla_actor_loss", ptr(q), twin_stride, ptr(log_pi), ptr(log_std), A, ptr(log_alpha), target_entropy, B,
          ptr(scalars4), ptr(dq), ptr(dlog_alpha), stream())
+
+
+def curl_head_supported(B, F_):
+    return B % 128 == 0 and B <= 1024 and 49 <= F_ <= 52
+
+
+def curl_head(z_a, z_pos, wz, xhat, rstd, gamma, B, F_, row_loss, dfc, ln_partial, w_partial, dgamma, dbeta, dbias, dW,
+              loss=None, logits=None, dlogits=None, dz=None):
+    """The CURL head in one launch (curla_curl_head).  Returns the token for ``fc_bwd(..., ln=)``, which finishes
+    dgamma / dbeta / dbias (LayerNorm and fc-bias gradients of the anchor encoder) and dW (CURL.W's gradient)."""
+    import ctypes
+    n = ctypes.c_int(0)
+    call("curla_curl_head", ptr(z_a), ptr(z_pos), ptr(wz), ptr(xhat), ptr(rstd), ptr(gamma), B, F_, ptr(row_loss),
+         ptr(loss), ptr(dfc), ptr(ln_partial), ctypes.addressof(n), ptr(w_partial), ptr(logits), ptr(dlogits), ptr(dz),
+         stream())
+    nparts = n.value if n.value else B // 16  # (call tracing without a device leaves the count untouched)
+    return (ln_partial, nparts, dgamma, dbeta, dbias, w_partial, nparts, F_ * F_, dW)
 
 
 def curl_ce(logits, B, ld, row_loss, loss, dlogits=None):

@@ -161,6 +161,11 @@ int curla_fc_bwd_ln(const float* dz, const float* W, const float* x, float* dx, 
                     const float* ln_partial, int nparts, float* dgamma, float* dbeta, float* dbias_in, void* stream);
 int curla_fc_dw_ln(const float* dz, const float* x, float* dW, int B, int F, int K, const float* ln_partial, int nparts,
                    float* dgamma, float* dbeta, float* dbias_in, void* stream);
+/* curla_fc_bwd_ln that also finishes a second set of partial sums in the same extra workgroup:
+ * extra_out[i] = sum over p < extra_parts of extra_partial[p * extra_len + i] (the CURL head's dW partials). */
+int curla_fc_bwd_ln2(const float* dz, const float* W, const float* x, float* dx, float* dW, int B, int F, int K,
+                     const float* ln_partial, int nparts, float* dgamma, float* dbeta, float* dbias_in,
+                     const float* extra_partial, int extra_parts, int extra_len, float* extra_out, void* stream);
 
 /* Last layer of the actor trunk / the Q functions (curl_sac.py:73-74, 132-133): hidden -> N outputs, N <= 16
  * (Q: 1, actor: 2|A|), batched over `nbatch` identically laid-out networks `stride*` floats apart.
@@ -304,6 +309,17 @@ int curla_actor_loss(const float* q, long long twin_stride, const float* log_pi,
 /* CrossEntropyLoss(logits, arange(B)) and d/dlogits (curl_sac.py:221,411-413); `loss` (the mean of row_loss) may be
  * NULL when the scalar is not going to be logged */
 int curla_curl_ce(const float* logits, int B, int ld, float* row_loss, float* loss, float* dlogits, void* stream);
+/* The CURL head in one launch (curl_sac.py:211-222,406-417 and their autograd), given the anchor features z_a, the
+ * positives' z_pos and wz = (W z_pos^T)^T = z_pos W^T, all [B][F]: logits = z_a wz^T (optionally stored), row_loss[a] =
+ * logsumexp(logits[a]) - logits[a][a] (their mean into `loss` when it is not NULL), dlogits = (softmax - I) / B
+ * (optionally stored), dz = dlogits wz (optionally stored), dfc = the LayerNorm backward of dz with the anchor encoder's
+ * (xhat, rstd, gamma), and per block of 16 rows the partial sums of dgamma / dbeta / fc-bias gradient (ln_partial
+ * [*nparts][3][F], *nparts = B / 16) and of dW[i][k] = sum_a z_a[a][i] (dlogits z_pos)[a][k] (w_partial [*nparts][F * F]),
+ * which curla_fc_bwd_ln2 adds up.  B % 128 == 0, B <= 1024, 49 <= F <= 52; else CURLA_ERR_UNSUPPORTED (the separate
+ * launches compute the same quantities). */
+int curla_curl_head(const float* z_a, const float* z_pos, const float* wz, const float* xhat, const float* rstd,
+                    const float* gamma, int B, int F, float* row_loss, float* loss, float* dfc, float* ln_partial,
+                    int* nparts, float* w_partial, float* logits, float* dlogits, float* dz, void* stream);
 int curla_mean(const float* x, int n, float* out, void* stream);
 
 /* target <- tau*param + (1-tau)*target over a flat parameter block (utils.py:37-41) */

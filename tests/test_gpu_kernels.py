@@ -466,6 +466,67 @@ def test_curl_ce(ops, B):
     check(f"curl_ce dlogits B{B}", dl.cpu(), logits.grad)
 
 
+@pytest.mark.parametrize("B,Fd,K", [(128, 50, 64), (512, 50, 196), (256, 49, 128), (1024, 52, 64), (384, 51, 64)])
+def test_curl_head_one_launch(ops, B, Fd, K):
+    """curla_curl_head + curla_fc_bwd_ln2: the CURL phase from (z_a, z_pos, W) to the loss, d(loss)/d(fc output) of the
+    anchor encoder, the LayerNorm / fc-bias gradients and dW -- against autograd through the reference's formulas
+    (curl_sac.py:211-222, 411-413: logits = z_a W z_pos^T, minus the row max, cross-entropy against arange(B)) with the
+    anchor features as a LayerNorm output, as in the encoder (encoder.py:101)."""
+    assert ops.curl_head_supported(B, Fd)
+    fc = rnd(B, Fd, seed=201).requires_grad_(True)          # pre-LayerNorm features of the anchors
+    gamma = (1 + 0.1 * rnd(Fd, seed=202)).requires_grad_(True)
+    beta = (0.1 * rnd(Fd, seed=203)).requires_grad_(True)
+    z_pos = rnd(B, Fd, seed=204) * 0.7
+    W = torch.rand(Fd, Fd, generator=torch.Generator().manual_seed(205)).requires_grad_(True)
+    z_a = F.layer_norm(fc, (Fd,), gamma, beta, 1e-5)
+    logits = z_a @ (W @ z_pos.t())
+    loss = F.cross_entropy(logits - logits.max(1)[0][:, None], torch.arange(B))
+    loss.backward()
+    with torch.no_grad():
+        mean = fc.mean(1, keepdim=True)
+        rstd_ref = (fc.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+        xhat_ref = (fc - mean) * rstd_ref
+    f = lambda *sh: torch.full(sh, float("nan"), device="cuda")  # noqa: E731
+    za_d, zp_d, W_d = dev(z_a.detach()), dev(z_pos), dev(W.detach())
+    wz = f(B, Fd)
+    ops.linear_fwd(zp_d, 0, W_d, 0, None, 0, wz, 0, B, Fd, Fd)
+    row_loss, lsum, dfc, lg, dlg, dz = f(B), f(1), f(B, Fd), f(B, B), f(B, B), f(B, Fd)
+    lnp, wp = f(ops.ln_partial_floats(B, Fd)), f((B // 16) * Fd * Fd)
+    dgam, dbet, dbias, dW = f(Fd), f(Fd), f(Fd), f(Fd, Fd)
+    tok = ops.curl_head(za_d, zp_d, wz, dev(xhat_ref), dev(rstd_ref.flatten()), dev(gamma.detach()), B, Fd, row_loss, dfc,
+                        lnp, wp, dgam, dbet, dbias, dW, loss=lsum, logits=lg, dlogits=dlg, dz=dz)
+    assert bool(torch.isnan(dgam).all()) and bool(torch.isnan(dW).all())  # finished by the fc backward
+    # the fc backward that follows in the agent (any activations will do here)
+    Wfc, x = (rnd(Fd, K, seed=206) * 0.1).cuda(), torch.relu(rnd(B, K, seed=207)).cuda()
+    gx, dwfc = f(B, K), f(Fd, K)
+    ops.fc_bwd(dfc, Wfc, x, gx, dwfc, B, Fd, K, ln=tok)
+    check(f"curl_head logits B{B} F{Fd}", lg.cpu(), logits.detach(), 2e-6)
+    check(f"curl_head loss B{B}", lsum.cpu(), loss.detach().reshape(1))
+    z_a.retain_grad()
+    check(f"curl_head d fc_out B{B}", dfc.cpu(), fc.grad, 2e-5)
+    check(f"curl_head dgamma B{B}", dgam.cpu(), gamma.grad, 2e-5)
+    check(f"curl_head dbeta B{B}", dbet.cpu(), beta.grad, 2e-5)
+    check(f"curl_head fc dbias B{B}", dbias.cpu(), fc.grad.sum(0), 2e-5)
+    check(f"curl_head dW B{B}", dW.cpu(), W.grad, 2e-5)
+    # the separate launches compute the same intermediate quantities
+    lg2, rl2, dl2, dz2 = f(B, B), f(B), f(B, B), f(B, Fd)
+    ops.linear_fwd(za_d, 0, wz, 0, None, 0, lg2, 0, B, B, Fd)
+    ops.curl_ce(lg2, B, B, rl2, None, dl2)
+    ops.linear_dx(dl2, 0, wz, 0, dz2, 0, B, B, Fd)
+    check("curl_head row losses vs curl_ce", row_loss.cpu(), rl2.cpu(), 2e-6)
+    check("curl_head dlogits vs curl_ce", dlg.cpu(), dl2.cpu(), 2e-5)
+    check("curl_head dz vs the separate product", dz.cpu(), dz2.cpu(), 2e-5)
+    # fc products untouched by the extra reduction work, and everything reproducible
+    gx2, dwfc2 = f(B, K), f(Fd, K)
+    ops.fc_bwd(dfc, Wfc, x, gx2, dwfc2, B, Fd, K)
+    assert torch.equal(gx, gx2) and torch.equal(dwfc, dwfc2)
+    dfc3, dW3, dgam3 = f(B, Fd), f(Fd, Fd), f(Fd)
+    tok3 = ops.curl_head(za_d, zp_d, wz, dev(xhat_ref), dev(rstd_ref.flatten()), dev(gamma.detach()), B, Fd, f(B), dfc3,
+                         lnp, wp, dgam3, f(Fd), f(Fd), dW3)
+    ops.fc_bwd(dfc3, Wfc, x, f(B, K), f(Fd, K), B, Fd, K, ln=tok3)
+    assert torch.equal(dfc3, dfc) and torch.equal(dW3, dW) and torch.equal(dgam3, dgam)
+
+
 def test_concat_split_softupdate_mean(ops):
     B, Fd, A = 9, 50, 2
     z, a = rnd(B, Fd, seed=71), rnd(B, A, seed=72)
