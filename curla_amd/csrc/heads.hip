@@ -755,12 +755,12 @@ __global__ void curl_ce_kernel(const float* logits, int B, int ld, float* row_lo
 // positives' z_pos and (W z_pos^T)^T to the row losses, d(loss)/d(fc output) of the anchor encoder (LayerNorm backward
 // included) and the partial sums of dW and of the LayerNorm / fc-bias gradients -- what used to be seven launches of
 // ~5 us each (logits, cross-entropy, three small products, LayerNorm backward), one of which the host could not enqueue
-// in time.  One 512-thread workgroup per 16 anchor rows:
+// in time.  TWO 512-thread workgroups per 16 anchor rows (both do A; one does dz and C1, the other T and C2):
 //   A  logits[16][B] = z_a rows . wz^T on the matrix pipe (a wave takes every eighth 16-column tile; k walked as 4
 //      contiguous runs so that both operands are plain row reads), row max / sum of exponentials across lanes, tiles
 //      and waves, dlogits = (softmax - I) / B into LDS;
-//   B  dz = dlogits . wz and T = dlogits . z_pos (16 x F each, k = B): one (feature tile, matrix) pair per wave, the
-//      A operand from LDS, the B operand one float per lane and step from L2;
+//   B  dz = dlogits . wz or T = dlogits . z_pos (16 x F, k = B): a wave takes an eighth of k for all four feature tiles,
+//      the A operand from LDS, the B operand one 16-byte load per lane and step from L2;
 //   C  LayerNorm backward of the 16 dz rows (a wave per row), their contributions to dgamma / dbeta / fc-bias gradient,
 //      and the 16-row partial of dW[i][k] = sum_a z_a[a][i] T[a][k].
 // The partial sums are finished by the extra workgroup of the fc backward that follows (curla_fc_bwd_ln).
@@ -787,18 +787,19 @@ __global__ __launch_bounds__(512) void curl_head_kernel(CurlHeadArgs a) {
   constexpr int LD = B + 4;                   // dlogits rows in LDS (16-byte aligned rows)
   // phase B's operand (one float per lane and k-step) is requested before phase A when it fits the register file
   // next to phase A's tiles; else in runs of 32 in front of their MFMAs
-  constexpr bool PRELOAD = NTILE <= 4;
+  constexpr bool PRELOAD = NTILE <= 4;  // (B / 32 <= 16 operand registers x 4)
   const int F = a.F;
   float* dl = lds;                      // [16][LD]
   float* zs = dl + 16 * LD;             // [16][64]   z_a rows of this block
-  float* t0 = zs + 16 * 64;             // [2][16][64] dz tile, T tile
+  float* t0 = zs + 16 * 64;             // [16][64] the product's tile (dz or T); (second half unused)
   float* red = t0 + 2 * 16 * 64;        // [8][16] row maxima, then [8][16] row sums
   float* dg = red + 2 * 8 * 16;         // [16] diagonal logits
   float* pr = dg + 16;                  // [8][3][64] LayerNorm partials per wave
-  float* pq = pr + 8 * 3 * 64;          // [2][4][16][64] phase B: k-quarter partial tiles
+  float* pq = pr + 8 * 3 * 64;          // [8][16][64] phase B: the waves' k-eighth partial tiles
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
-  const int r0 = blockIdx.x * 16;
+  const int rblk = blockIdx.x >> 1, mat = blockIdx.x & 1;  // two workgroups per 16 rows: matrix 0 (wz -> dz), 1 (z_pos -> T)
+  const int r0 = rblk * 16;
   constexpr int KQ = kCurlMaxKQ;        // k per lane group of phase A: 4 KQ - 3 <= F <= 4 KQ (checked by the host)
 
   // ---- operand loads of phases A and B, all in flight together.  The texture addresser is shared by the CU's eight
@@ -820,16 +821,15 @@ __global__ __launch_bounds__(512) void curl_head_kernel(CurlHeadArgs a) {
 #pragma unroll
     for (int i = 0; i < NTILE; ++i) load_run(bf[i], a.wz + (size_t)(16 * (wave + 8 * i) + li) * F + k0);
   }
-  // phase B: wave -> (matrix, quarter of k): all four feature tiles, tile t's column li is feature 4 li + t, so ONE
+  // phase B: wave -> an eighth of k, all four feature tiles; tile t's column li is feature 4 li + t, so ONE
   // 16-byte load per lane and k-step feeds four MFMAs and a lane group's 16 lanes read 256 contiguous bytes
-  const int mat = wave >> 2, kquart = wave & 3;  // matrix 0: wz -> dz, 1: z_pos -> T
-  constexpr int KW = B / 16;                      // k per lane group and wave
-  const int cbase = kquart * (B / 4) + KW * kq;   // first logits column (= row of wz / z_pos) of this lane group
+  constexpr int KW = B / 32;                      // k per lane group and wave
+  const int cbase = wave * (B / 8) + KW * kq;     // first logits column (= row of wz / z_pos) of this lane group
   const int nfull = F >> 2, nrest = F & 3;        // lanes li < nfull: four features; lane nfull: the remaining nrest
   // every lane issues the same 16-byte load: lanes li < nfull at their four features, the others at the row's LAST four
   // floats (in range), from which lane nfull picks its nrest features; lanes beyond hold zeros
   const float* mrow = (mat ? a.zp : a.wz) + (size_t)cbase * F + (li < nfull ? 4 * li : F - 4);
-  f32x4 bv[PRELOAD ? KW : 8];
+  f32x4 bv[KW <= 16 ? KW : 8];
   auto load_bv = [&](f32x4& v, int c) { v = *reinterpret_cast<const f32x4*>(mrow + (size_t)c * F); };
   auto fix_bv = [&](f32x4& v) {  // (features 4 nfull + t sit at position t + 4 - nrest of the row's last four floats)
     if (li >= nfull) {
@@ -901,19 +901,20 @@ __global__ __launch_bounds__(512) void curl_head_kernel(CurlHeadArgs a) {
     for (int w = 1; w < 8; ++w) sum += red[128 + w * 16 + 4 * kq + r];
     const float lse = logf(sum) + mx[r];
     const int row = r0 + 4 * kq + r;
-    if (wave == 0 && li == 0) a.row_loss[row] = lse - dg[4 * kq + r];
+    if (mat == 0 && wave == 0 && li == 0) a.row_loss[row] = lse - dg[4 * kq + r];
 #pragma unroll
     for (int i = 0; i < NTILE; ++i) {
       const int col = 16 * (wave + 8 * i) + li;
       const float d = (expf(lg[i][r] - lse) - (col == row ? 1.f : 0.f)) * inv;
       dl[(4 * kq + r) * LD + col] = d;
-      if (a.logits) a.logits[(size_t)row * B + col] = lg[i][r];
-      if (a.dlogits) a.dlogits[(size_t)row * B + col] = d;
+      if (mat == 0 && a.logits) a.logits[(size_t)row * B + col] = lg[i][r];
+      if (mat == 0 && a.dlogits) a.dlogits[(size_t)row * B + col] = d;
     }
   }
   __syncthreads();
-  // ---- B: dz = dl . wz (waves 0-3), T = dl . z_pos (waves 4-7); a wave multiplies its quarter of k into all four
-  // feature tiles (four independent accumulator chains), the quarters are then added in order through LDS
+  // ---- B: this workgroup's product -- dz = dl . wz (matrix 0) or T = dl . z_pos (matrix 1): a wave multiplies its
+  // eighth of k into all four feature tiles (four independent accumulator chains), the eighths are then added in
+  // order through LDS
   {
     const float* arow = dl + li * LD + cbase;
     f32x4 acc[4];
@@ -946,20 +947,33 @@ __global__ __launch_bounds__(512) void curl_head_kernel(CurlHeadArgs a) {
         }
       }
     }
-    // lane (li, kq) of tile t: rows 4 kq + r, feature 4 li + t.  Quarter partials -> qp[mat][kquart][row][feature]
-    float* qp = pq + ((mat * 4 + kquart) * 16) * 64;
+    // lane (li, kq) of tile t: rows 4 kq + r, feature 4 li + t.  Partial tiles -> pq[wave][row][feature]
+    float* qp = pq + (wave * 16) * 64;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) qp[(4 * kq + r) * 64 + 4 * li + t] = acc[t][r];
   }
   __syncthreads();
-  for (int i = tid; i < 2 * 16 * 64; i += 512) {  // dz tile, T tile: the four k quarters in order
-    const int m = i >> 10, rf = i & 1023;
-    const float* q = pq + (m * 4 * 16) * 64 + rf;
-    t0[i] = ((q[0] + q[16 * 64]) + q[2 * 16 * 64]) + q[3 * 16 * 64];
+  for (int i = tid; i < 16 * 64; i += 512) {  // the product's 16 x 64 tile: the eight k ranges in order
+    float v = pq[i];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) v += pq[w * 16 * 64 + i];
+    t0[i] = v;
   }
   __syncthreads();
+  if (mat == 1) {
+    // ---- C2: this block's 16 rows of dW[i][k] = sum_a z_a[a][i] T[a][k]
+    float* wp = a.w_partial + (size_t)rblk * F * F;
+    for (int idx = tid; idx < F * F; idx += 512) {
+      const int i = idx / F, kk = idx - i * F;
+      float acc = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc += zs[r * 64 + i] * t0[r * 64 + kk];
+      wp[idx] = acc;
+    }
+    return;
+  }
   // ---- C1: LayerNorm backward of rows 2 wave, 2 wave + 1 (lane = feature); partial column sums in row order
   {
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
@@ -981,25 +995,13 @@ __global__ __launch_bounds__(512) void curl_head_kernel(CurlHeadArgs a) {
     }
     pr[(wave * 3 + 0) * 64 + lane] = p0, pr[(wave * 3 + 1) * 64 + lane] = p1, pr[(wave * 3 + 2) * 64 + lane] = p2;
   }
-  // ---- C2: this block's 16 rows of dW[i][k] = sum_a z_a[a][i] T[a][k]
-  {
-    const float* T = t0 + 16 * 64;
-    float* wp = a.w_partial + (size_t)blockIdx.x * F * F;
-    for (int idx = tid; idx < F * F; idx += 512) {
-      const int i = idx / F, k = idx - i * F;
-      float acc = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc += zs[r * 64 + i] * T[r * 64 + k];
-      wp[idx] = acc;
-    }
-  }
   __syncthreads();
   for (int i = tid; i < 3 * F; i += 512) {
     const int q = i / F, f = i - q * F;
     float v = pr[(0 * 3 + q) * 64 + f];
 #pragma unroll
     for (int w = 1; w < 8; ++w) v += pr[(w * 3 + q) * 64 + f];
-    a.ln_partial[(size_t)blockIdx.x * 3 * F + i] = v;
+    a.ln_partial[(size_t)rblk * 3 * F + i] = v;
   }
 }
 
@@ -1669,7 +1671,7 @@ int curla_curl_head(const float* z_a, const float* z_pos, const float* wz, const
 #define CURLA_CURL_HEAD(NTILE)                                                                                  \
   case NTILE:                                                                                                    \
     if (curla_set_dyn_lds(reinterpret_cast<const void*>(curl_head_kernel<NTILE>), lds) != CURLA_OK) return CURLA_ERR_LAUNCH; \
-    hipLaunchKernelGGL(curl_head_kernel<NTILE>, dim3(B / 16), dim3(512), lds, st, a);                          \
+    hipLaunchKernelGGL(curl_head_kernel<NTILE>, dim3(2 * (B / 16)), dim3(512), lds, st, a);                    \
     break
   switch (B / 128) {
     CURLA_CURL_HEAD(1);
