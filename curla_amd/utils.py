@@ -476,7 +476,15 @@ class ReplayBuffer(object):
         aug = self.augmentor
         if isinstance(aug, augmentations.ColorJiggle):
             params, order = aug.draw_params(B * (c // 3))
-            ops.color_jiggle(ring, idx, params.to(self.device), order.to(self.device), B, out)
+            # one pinned staging block, one asynchronous copy: a `.to(device)` of a pageable tensor makes the host wait
+            # until the stream has drained (two of them per call left ~60 us of idle GPU around every jitter launch)
+            n4 = params.numel()
+            cuda = self.device.type == "cuda"
+            stage = torch.empty(n4 + 4, dtype=torch.int32, pin_memory=cuda)
+            stage[:n4] = params.reshape(-1).view(torch.int32)
+            stage[n4:] = order
+            d = stage.to(self.device, non_blocking=True)
+            ops.color_jiggle(ring, idx, d[:n4].view(torch.float32).view(params.shape), d[n4:], B, out)
         elif isinstance(aug, augmentations.NoisyCover):
             colors = aug.draw_colors()
             noise = torch.randn((B, h, w, c), device=self.device) * aug.std
