@@ -289,6 +289,120 @@ def test_full_shape_update_vs_reference_summaries():
         check(f"c1shape cpc grad {k}", summarize(captured["cpc"][kk]), v, 2e-4)
 
 
+def test_multi_step_phases_vs_oracle_on_the_agents_own_parameters():
+    """Five consecutive updates (even, odd, ... : critic every step, actor + alpha and the target soft update every
+    second, CURL every step) with EVERY phase of EVERY step held to 1e-4: the oracle's phase functions are evaluated
+    on the agent's own parameters as they stand when the phase starts (so the chaos of Adam trajectories, SURVEY.md D11,
+    does not enter -- the optimizer steps themselves are compared with torch.optim.Adam in tests/test_gpu_kernels.py),
+    on the same minibatch and noise: losses, and every gradient an optimizer consumes (24 critic tensors, 10 actor
+    tensors + log_alpha, 12 encoder tensors + W), conv gradients along the device's ReLU branches."""
+    import curla_amd
+    from oracle import curla_oracle as O
+    torch.manual_seed(9)
+    np.random.seed(9)
+    in_hw, out_hw, B, hidden, layers = (40, 44), (32, 36), 16, 96, 4
+    agent, aug = make_agent((9,) + out_hw, in_hw, hidden)
+    oracle = O.OracleAgent((9,) + out_hw, (2,), hidden_dim=hidden, **{k: v for k, v in HP.items() if k != "log_interval"})
+    snap = lambda module, like: {k: module.state_dict()[k].detach().cpu().clone() for k in like}  # noqa: E731
+    rb = curla_amd.ReplayBuffer((9,) + in_hw, (2,), 64, B, torch.device("cuda"), aug)
+    rs = np.random.RandomState(4)
+    n = 48
+    obs_all = rs.randint(0, 256, (n, 9) + in_hw, dtype=np.uint8)
+    nxt_all = rs.randint(0, 256, (n, 9) + in_hw, dtype=np.uint8)
+    act_all = rs.uniform(-1, 1, (n, 2)).astype(np.float32)
+    rew_all = rs.randn(n).astype(np.float32)
+    done_all = (np.arange(n) % 7) == 6
+    rb.add_batch(obs_all, act_all, rew_all, nxt_all, done_all)
+    L = NullLogger()
+    kw = dict(num_layers=layers, log_std_min=-10, log_std_max=2)
+    grads = {}
+
+    def keep(name, module, opt, extra=None):
+        real = opt.step
+
+        def step():
+            grads[name] = grads_of(module)
+            if extra is not None:
+                grads[name + ".extra"] = extra()
+            real()
+        opt.step = step
+    keep("critic", agent.critic, agent.critic_optimizer)
+    keep("actor", agent.actor, agent.actor_optimizer, lambda: agent.log_alpha.grad.detach().cpu().clone())
+    keep("encoder", agent.critic.encoder, agent.encoder_optimizer, lambda: agent.CURL.W.grad.detach().cpu().clone())
+
+    def branches_of(ws, ref_enc, tag):
+        out = []
+        for i in range(layers):
+            dev_act = ws.acts_main[i].permute(0, 3, 1, 2).cpu()
+            ref_act = ref_enc[f"conv{i + 1}"]
+            check(f"{tag} activations conv{i + 1}", dev_act, ref_act)
+            differ = (dev_act > 0) != (ref_act > 0)
+            assert int(differ.sum()) <= 4
+            if differ.any():
+                assert float(torch.maximum(dev_act[differ].abs(), ref_act[differ].abs()).max()) <= 1e-5
+            out.append(dev_act > 0)
+        return out
+
+    for step in range(5):
+        idxs, offs = rb.draw_indices()
+        nc, na = torch.randn(B, 2), torch.randn(B, 2)
+        crop = lambda src, j: torch.from_numpy(O.random_crop(src[idxs], offs[2 * j], offs[2 * j + 1], out_hw)).float()  # noqa: E731
+        o_obs, o_nxt, o_pos = crop(obs_all, 0), crop(nxt_all, 1), crop(obs_all, 2)
+        o_act, o_rew = torch.from_numpy(act_all[idxs]), torch.from_numpy(rew_all[idxs])[:, None]
+        o_nd = torch.from_numpy(1.0 - done_all[idxs].astype(np.float32))[:, None]
+        obs, act, rew, nxt, nd, ckw = rb.sample_cpc_refs(indices=(idxs, offs))
+        ws = agent._ws(B)
+        tag = f"own-params step{step}"
+        # ---- critic
+        pre = (snap(agent.actor, oracle.actor), snap(agent.critic, oracle.critic),
+               snap(agent.critic_target, oracle.critic_target), agent.log_alpha.detach().cpu().clone())
+        agent.update_critic(obs, act, rew, nxt, nd, L, step, noise=nc.cuda())
+        ref = O.critic_phase(*pre, o_obs, o_act, o_rew, o_nxt, o_nd, nc, discount=0.99, **kw)
+        br = branches_of(ws, ref["enc"], tag + " critic")
+        ref = O.critic_phase(*pre, o_obs, o_act, o_rew, o_nxt, o_nd, nc, discount=0.99, relu_branches=br, **kw)
+        check(f"{tag} critic loss", L.scalars["train_critic/loss"], ref["loss"])
+        assert len(grads["critic"]) == len(ref["grads"]) == 24
+        for k, v in ref["grads"].items():
+            check(f"{tag} critic grad {k}", grads["critic"][k], v)
+        if step % 2 == 0:
+            # ---- actor / alpha (on the critic as its step left it), then the target soft update
+            ref = O.actor_phase(snap(agent.actor, oracle.actor), snap(agent.critic, oracle.critic),
+                                agent.log_alpha.detach().cpu().clone(), o_obs, na, target_entropy=oracle.target_entropy, **kw)
+            agent.update_actor_and_alpha(obs, L, step, noise=na.cuda())
+            check(f"{tag} actor loss", L.scalars["train_actor/loss"], ref["actor_loss"])
+            check(f"{tag} alpha loss", L.scalars["train_alpha/loss"], ref["alpha_loss"])
+            got = {k: v for k, v in grads["actor"].items() if ".convs." not in k}
+            assert len(got) == len(ref["grads"]) == 10
+            for k, v in ref["grads"].items():
+                check(f"{tag} actor grad {k}", got[k], v)
+            check(f"{tag} log_alpha grad", grads["actor.extra"], ref["log_alpha_grad"])
+            before = {k: v.detach().clone() for k, v in agent.critic_target.state_dict().items()}
+            agent.soft_update_targets()
+            sd, st = agent.critic.state_dict(), agent.critic_target.state_dict()
+            for k in ("encoder.convs.0.weight", "encoder.fc.weight", "Q2.trunk.2.weight"):
+                tau = HP["encoder_tau"] if k.startswith("encoder.") else HP["critic_tau"]
+                check(f"{tag} soft update {k}", st[k], tau * sd[k] + (1 - tau) * before[k], 1e-6)
+        # ---- CURL
+        snap_c, snap_t = snap(agent.critic, oracle.critic), snap(agent.critic_target, oracle.critic_target)
+        snap_w = agent.CURL.W.detach().cpu().clone()
+        ref = O.cpc_phase(snap_c, snap_t, snap_w, o_obs, o_pos, num_layers=layers)
+        agent.update_cpc(ckw["obs_anchor"], ckw["obs_pos"], ckw, L, step)
+        check(f"{tag} curl loss", L.scalars["train/curl_loss"], ref["loss"])
+        check(f"{tag} CURL W grad", grads["encoder.extra"], ref["W_grad"])
+        raw = max(rel_err(grads["encoder"][k[len("encoder."):]], v) for k, v in ref["grads"].items())
+        REPORT.append((f"{tag} CURL encoder grads, raw (own branches on both sides): worst", raw))
+        # (the anchors' activations under the encoder as the CURL phase saw it are still in the workspace: the oracle
+        # differentiates along their branches; values -- the loss -- are untouched by that)
+        br = [ws.acts_main[i].permute(0, 3, 1, 2).cpu() > 0 for i in range(layers)]
+        refb = O.cpc_phase(snap_c, snap_t, snap_w, o_obs, o_pos, num_layers=layers, relu_branches=br)
+        assert float((refb["loss"] - ref["loss"]).abs()) == 0.0
+        assert len(grads["encoder"]) == len(refb["grads"]) == 12
+        for k, v in refb["grads"].items():
+            check(f"{tag} CURL grad {k}", grads["encoder"][k[len("encoder."):]], v)
+    for opt in (agent.critic_optimizer, agent.actor_optimizer, agent.encoder_optimizer):
+        del opt.step
+
+
 def test_update_chain_vs_oracle_agent():
     """3 consecutive update() calls (even, odd, even) from the same init against
     the oracle agent fed the same minibatches and noise: losses per step."""
