@@ -47,6 +47,7 @@ SIGNATURES = {
     "curla_mlp_out_fwd_nested": [vp, c_ll, c_ll, vp, c_ll, c_ll, vp, c_ll, c_ll, vp, c_ll, c_ll, c_int, c_int, c_int, c_int, c_int,
                                  vp],
     "curla_gemm_multi": [c_int, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_ll, vp],
+    "curla_fc_fwd_multi": [c_int, vp, vp, vp, c_int, c_int, c_int, c_int, c_ll, c_int, vp],
     "curla_splitk_reduce": [vp, c_int, c_ll, c_int, c_int, c_int, vp, c_int, vp, c_int, vp],
     "curla_mlp_out_fwd": [vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, c_int, c_int, c_int, c_int, vp],
     "curla_mlp_out_bwd": [vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, c_int, c_int, c_int, c_int, vp],

@@ -710,6 +710,193 @@ __global__ __launch_bounds__(256, 2) void fc_bwd_kernel(FcBwdArgs g, float* dW, 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Encoder fc layer, forward: split-K partial sums  P[s][b][f] = sum over the k of split s of x[b][k] W[f][k]  for up to
+// four (x, W) pairs of one shape in one launch (encoder.py:67,94-101: the fc in front of the LayerNorm; the partials are
+// added up by fc_ln_fwd_kernel).
+//   D[f][b] tiles: A operand = W (rows f), B operand = x (columns b); k is walked in a permuted order -- a lane's quarter
+//   kq of a 32-wide k-slice is 8 CONTIGUOUS floats (k0 + 8 kq + s, s = the MFMA step), so both operands are 16-byte
+//   reads.  A wave owns two b-tiles (32 rows); a 256-thread workgroup covers 128 rows and one K range.  NT full feature
+//   tiles go through the matrix pipe, NTAIL further features (50 = 3 x 16 + 2) are FMAs on the x values the lane holds.
+//   x comes from HBM straight into registers, three slices ahead (four register sets); W -- the same for the four waves --
+//   goes through LDS in chunks of four slices, double-buffered: one barrier per 192 MFMAs of a wave.
+// x layouts: row-major [B][K], or BLOCKED [B / 16][K / 32][16][32] (16 samples' pixel records adjacent; a k-slice = the
+// 32 channels of one pixel): a slice of a b-tile is then 2 KB contiguous and a b-tile's slices follow each other.
+// ---------------------------------------------------------------------------------------------------------------------
+struct FcFwdArgs {
+  const float* x[4];
+  const float* W[4];
+  float* out[4];
+  int nprob, B, F, K, nsplit, nrg;  // nrg = B / 128 row groups
+  int blocked;                      // x layout: 0 row-major, 1 blocked (see above)
+  long long split_stride;           // floats between two splits' partials
+};
+
+constexpr int kFcChunk = 4;            // k-slices per W chunk in LDS
+constexpr int kFcPitch = 32 * kFcChunk + 4;  // floats per feature row of a chunk (16-byte aligned, off the bank stride)
+
+template <int NT, int NTAIL>
+__global__ __launch_bounds__(256, 2) void fc_fwd_kernel(FcFwdArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [2][F][kFcPitch]
+  constexpr int NTL = NTAIL > 0 ? NTAIL : 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  int idx = blockIdx.x;
+  const int split = idx % g.nsplit;
+  idx /= g.nsplit;
+  const int rg = idx % g.nrg, prob = idx / g.nrg;
+  const int nslices = g.K >> 5;
+  const int s0 = (int)((long long)nslices * split / g.nsplit), s1 = (int)((long long)nslices * (split + 1) / g.nsplit);
+  const int t0 = rg * 8 + wave * 2;  // this wave's b-tiles t0, t0 + 1
+  const unsigned rowK = 4u * (unsigned)g.K;
+  auto uniform_rsrc = [](const void* p, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo32 = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi32 = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi32 << 32) | lo32), (short)0,
+                                             (int)__builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rx = uniform_rsrc(g.x[prob], (unsigned)g.B * rowK);
+  const __amdgpu_buffer_rsrc_t rw = uniform_rsrc(g.W[prob], (unsigned)g.F * rowK);
+  const unsigned xslice = g.blocked ? 2048u : 128u;  // bytes from one k-slice of a b-tile to the next
+  unsigned xo[2];
+#pragma unroll
+  for (int bt = 0; bt < 2; ++bt)
+    xo[bt] = g.blocked ? (unsigned)(t0 + bt) * (unsigned)nslices * 2048u + 128u * li + 32u * kq
+                       : (unsigned)(16 * (t0 + bt) + li) * rowK + 32u * kq;
+  struct XS {
+    f32x4 v[2][2];  // [b-tile][half]: x[row][k0 + 8 kq + 4 half + e]
+  };
+  auto load_x = [&](XS& X, int sl) {
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)min(sl, s1 - 1) * xslice);
+#pragma unroll
+    for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) X.v[bt][h] = buf_f32x4(rx, xo[bt] + 16u * h, so);
+  };
+  // W chunk c (slices s0 + 4 c ..): F rows x 128 floats, 16-byte pieces spread over the workgroup
+  constexpr int NPC = 8 * kFcChunk;                 // 16-byte pieces per feature row and chunk
+  const int npieces = g.F * NPC;
+  constexpr int WREG = (64 * NPC + 255) / 256;       // pieces per thread (F <= 64)
+  f32x4 wst[WREG];
+  auto fetch_w = [&](int c) {
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(s0 + kFcChunk * c) * 128u);
+#pragma unroll
+    for (int u = 0; u < WREG; ++u) {
+      const int p = tid + 256 * u;
+      const int f = p / NPC, q = p - f * NPC;
+      // (pieces past the last feature or past the matrix' end: out of range, zeros)
+      const unsigned off = p < npieces ? (unsigned)f * rowK + 16u * q : 0x80000000u;
+      wst[u] = buf_f32x4(rw, off, so);
+    }
+  };
+  auto commit_w = [&](int buf) {
+    float* dst = wl + buf * 64 * kFcPitch;
+#pragma unroll
+    for (int u = 0; u < WREG; ++u) {
+      const int p = tid + 256 * u;
+      const int f = p / NPC, q = p - f * NPC;
+      if (p < npieces) *reinterpret_cast<f32x4*>(dst + f * kFcPitch + 4 * q) = wst[u];
+    }
+  };
+  f32x4 acc[2][NT];
+  float atail[2][NTL];
+#pragma unroll
+  for (int bt = 0; bt < 2; ++bt) {
+#pragma unroll
+    for (int ft = 0; ft < NT; ++ft) acc[bt][ft] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) atail[bt][j] = 0.f;
+  }
+  auto multiply = [&](const XS& X, const float* wc, int sj) {  // slice sj of the chunk at wc
+    f32x4 wv[NT][2], wt[NTL][2];
+#pragma unroll
+    for (int ft = 0; ft < NT; ++ft)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        wv[ft][h] = *reinterpret_cast<const f32x4*>(wc + (16 * ft + li) * kFcPitch + 32 * sj + 8 * kq + 4 * h);
+    if (NTAIL > 0) {
+#pragma unroll
+      for (int j = 0; j < NTAIL; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          wt[j][h] = *reinterpret_cast<const f32x4*>(wc + (16 * NT + j) * kFcPitch + 32 * sj + 8 * kq + 4 * h);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int ft = 0; ft < NT; ++ft)
+#pragma unroll
+          for (int bt = 0; bt < 2; ++bt) acc[bt][ft] = mfma16(wv[ft][h][e], X.v[bt][h][e], acc[bt][ft]);
+    if (NTAIL > 0) {
+#pragma unroll
+      for (int j = 0; j < NTAIL; ++j)
+#pragma unroll
+        for (int bt = 0; bt < 2; ++bt)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atail[bt][j] = fmaf(X.v[bt][h][e], wt[j][h][e], atail[bt][j]);
+    }
+  };
+  const int nchunks = (s1 - s0 + kFcChunk - 1) / kFcChunk;
+  if (nchunks > 0) {
+    XS X0, X1, X2, X3;
+    fetch_w(0);
+    load_x(X0, s0), load_x(X1, s0 + 1), load_x(X2, s0 + 2);
+    commit_w(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+      const float* wc = wl + (c & 1) * 64 * kFcPitch;
+      const int sl = s0 + kFcChunk * c;
+      fetch_w(c + 1);  // (unconditional -- a conditional request makes the compiler wait for ALL loads at the next use;
+                       // past the split's end it reads the neighbour's slices or, past the matrix, zeros: never used)
+      // four slices; x set i mod 4 holds slice i, requested three slices ahead (slices past the split's end are computed
+      // on re-read data with W rows that are zero past the matrix: they are skipped instead)
+      load_x(X3, sl + 3);
+      multiply(X0, wc, 0);
+      load_x(X0, sl + 4);
+      if (sl + 1 < s1) multiply(X1, wc, 1);
+      load_x(X1, sl + 5);
+      if (sl + 2 < s1) multiply(X2, wc, 2);
+      load_x(X2, sl + 6);
+      if (sl + 3 < s1) multiply(X3, wc, 3);
+      commit_w((c + 1) & 1);
+      __syncthreads();
+    }
+  }
+  // partial sums of this split: P[split][b][f]; lane (li, kq) holds features 16 ft + 4 kq + r of row 16 t + li
+  float* out = g.out[prob] + (size_t)split * g.split_stride;
+#pragma unroll
+  for (int bt = 0; bt < 2; ++bt) {
+    const int b = 16 * (t0 + bt) + li;
+    float* row = out + (size_t)b * g.F;
+#pragma unroll
+    for (int ft = 0; ft < NT; ++ft) {
+      const int f = 16 * ft + 4 * kq;
+      if (f + 3 < g.F) {
+        *reinterpret_cast<f32x2*>(row + f) = f32x2{acc[bt][ft][0], acc[bt][ft][1]};
+        *reinterpret_cast<f32x2*>(row + f + 2) = f32x2{acc[bt][ft][2], acc[bt][ft][3]};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (f + r < g.F) row[f + r] = acc[bt][ft][r];
+      }
+    }
+    if (NTAIL > 0) {
+#pragma unroll
+      for (int j = 0; j < NTAIL; ++j) {  // the four quarters of a slice's k sit in the four lane groups: add them in order
+        float v = atail[bt][j];
+        const float q1 = __shfl(v, li + 16), q2 = __shfl(v, li + 32), q3 = __shfl(v, li + 48);
+        if (kq == 0) row[16 * NT + j] = ((v + q1) + q2) + q3;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Products with a SMALL output and a long k: the data gradient of an MLP's first layer ([B x 1024] x [1024 x 54]),
 // its weight gradient ([1024 x 54] over B rows), the CURL bilinear products ([B x B] x [B x 50], [50 x 50] over B
@@ -1013,6 +1200,38 @@ int curla_gemm_multi(int nprob, const float* const* A, const float* const* B, fl
   }
   for (int i = nprob; i < 4; ++i) g.Ap[i] = g.Bp[i] = nullptr, g.Cp[i] = nullptr;
   return gemm_launch(g, 0, 0, static_cast<hipStream_t>(stream));
+}
+
+int curla_fc_fwd_multi(int nprob, const float* const* x, const float* const* W, float* const* partial, int B, int F, int K,
+                       int nsplit, long long split_stride, int x_blocked, void* stream) {
+  CURLA_REQUIRE(nprob > 0 && nprob <= 4 && x && W && partial && B > 0 && F > 0 && K > 0 && nsplit > 0);
+  // the instantiated shapes: 50..64 even features (50: three tiles + two features on FMAs), whole 128-row groups, 32-wide
+  // k-slices, at least one slice per split, 32-bit byte offsets; everything else: CURLA_ERR_UNSUPPORTED (the caller
+  // takes curla_gemm_multi)
+  if (F < 50 || F > 64 || F % 2 != 0 || B % 128 != 0 || K % 32 != 0 || nsplit > K / 32 ||
+      (long long)B * K * 4 >= (1LL << 31) || (long long)F * K * 4 >= (1LL << 31) || split_stride % 2 != 0)
+    return CURLA_ERR_UNSUPPORTED;
+  FcFwdArgs g;
+  for (int i = 0; i < 4; ++i) {
+    g.x[i] = i < nprob ? x[i] : nullptr, g.W[i] = i < nprob ? W[i] : nullptr, g.out[i] = i < nprob ? partial[i] : nullptr;
+    if (i < nprob) {
+      CURLA_REQUIRE(x[i] && W[i] && partial[i]);
+      if (!aligned16(x[i]) || !aligned16(W[i]) || (reinterpret_cast<uintptr_t>(partial[i]) & 7)) return CURLA_ERR_UNSUPPORTED;
+    }
+  }
+  g.nprob = nprob, g.B = B, g.F = F, g.K = K, g.nsplit = nsplit, g.nrg = B / 128, g.split_stride = split_stride;
+  g.blocked = x_blocked ? 1 : 0;
+  const int grid = nprob * g.nrg * nsplit;
+  const size_t lds = (size_t)2 * 64 * kFcPitch * sizeof(float);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (F == 50) {
+    if (curla_set_dyn_lds(reinterpret_cast<const void*>(fc_fwd_kernel<3, 2>), lds) != CURLA_OK) return CURLA_ERR_LAUNCH;
+    hipLaunchKernelGGL((fc_fwd_kernel<3, 2>), dim3(grid), dim3(256), lds, st, g);
+  } else {
+    if (curla_set_dyn_lds(reinterpret_cast<const void*>(fc_fwd_kernel<4, 0>), lds) != CURLA_OK) return CURLA_ERR_LAUNCH;
+    hipLaunchKernelGGL((fc_fwd_kernel<4, 0>), dim3(grid), dim3(256), lds, st, g);
+  }
+  return curla_launch_status();
 }
 
 static int fc_bwd_check(const float* dz, const float* big, const float* out, int B, int F, int K) {

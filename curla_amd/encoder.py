@@ -14,6 +14,8 @@ Differences from the reference, all deliberate:
   ``state_dict()`` / ``load_state_dict()`` convert, so checkpoints are
   reference-compatible in both directions.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -104,6 +106,7 @@ class CNNEncoder(nn.Module):
         self.record_outputs = False  # fill self.outputs (NCHW copies) for histogram/image logging
         self._ws = {}
         self._partial = {}
+        self._nsplit = {}  # batch size -> splits the latest fc_partial of that size wrote
 
     # -- kernel-side helpers ------------------------------------------------
     def workspace(self, B, tag="infer"):
@@ -123,10 +126,20 @@ class CNNEncoder(nn.Module):
         return min(ks, max(1, self.flat_dim // 256))
 
     def partial(self, B):
+        """Split-K partial-sum buffer [splits][B][F]: room for the tiled GEMM's ksplit(B) and for the streaming
+        kernel's choice (ops.fc_fwd_nsplit, which depends on how many encoders share a launch)."""
         if B not in self._partial:
-            self._partial[B] = torch.empty((self.ksplit(B), B, self.feature_dim), device=self.fc.weight.device,
-                                           dtype=torch.float32)
+            ns = max(self.ksplit(B), ops.FC_FWD_MAX_SPLIT if self._streams(B) else 1)
+            self._partial[B] = torch.empty((ns, B, self.feature_dim), device=self.fc.weight.device, dtype=torch.float32)
         return self._partial[B]
+
+    def _streams(self, B):
+        """Does the fc forward of this batch size take the streaming kernel (curla_fc_fwd_multi)?"""
+        return os.environ.get("CURLA_FC_FWD") != "gemm" and ops.fc_fwd_supported(B, self.feature_dim, self.flat_dim)
+
+    def nsplit(self, B):
+        """How many splits the partial buffer holds right now (what the latest fc_partial of this batch size wrote)."""
+        return self._nsplit.get(B, self.ksplit(B))
 
     def conv_forward(self, obs_ref, acts, conv_params=None):
         """relu(conv_l(...)) for l = 1..L (encoder.py:77-88); acts[l-1] receives layer l."""
@@ -176,6 +189,11 @@ class CNNEncoder(nn.Module):
             raise RuntimeError("encoder weights are not in kernel layout; call CNNEncoder.to_kernel_layout() "
                                "(CurlSacAgent does) before running the HIP path")
         F, K = self.feature_dim, self.flat_dim
+        if self._streams(B):
+            ns = self._nsplit[B] = ops.fc_fwd_nsplit(1, B, K)
+            ops.fc_fwd_multi([h], [self.fc.weight], [self.partial(B)], B, F, K, ns, B * F)
+            return
+        self._nsplit[B] = self.ksplit(B)
         ops.gemm(h, 0, K, 0, self.fc.weight, 0, K, 0, self.partial(B), F, 0, B, F, K, 1, ksplit=self.ksplit(B),
                  split_stride=B * F)
 
@@ -190,13 +208,22 @@ class CNNEncoder(nn.Module):
             for e, h in pairs:
                 e.fc_partial(h)
             return
+        if enc0._streams(B):
+            ns = ops.fc_fwd_nsplit(len(pairs), B, K)
+            for e, _ in pairs:
+                e._nsplit[B] = ns
+            ops.fc_fwd_multi([h for _, h in pairs], [e.fc.weight for e, _ in pairs], [e.partial(B) for e, _ in pairs], B, F,
+                             K, ns, B * F)
+            return
+        for e, _ in pairs:
+            e._nsplit[B] = enc0.ksplit(B)
         ops.gemm_multi([h for _, h in pairs], [e.fc.weight for e, _ in pairs], [e.partial(B) for e, _ in pairs], B, F, K,
                        ksplit=enc0.ksplit(B), split_stride=B * F)
 
     def ln_from_partial(self, B, z, fc_out=None, xhat=None, rstd=None, xa=None, act=None):
         """Split-K reduction + bias + LayerNorm (+tanh) of the partial sums left by ``fc_partial``."""
         F = self.feature_dim
-        ops.fc_ln_fwd(self.partial(B), self.ksplit(B), B * F, F, self.fc.bias, self.ln.weight, self.ln.bias, B, F, z,
+        ops.fc_ln_fwd(self.partial(B), self.nsplit(B), B * F, F, self.fc.bias, self.ln.weight, self.ln.bias, B, F, z,
                       fc_out=fc_out, xhat=xhat, rstd=rstd, eps=self.ln.eps, tanh_out=0 if self.output_logits else 1,
                       xa=xa, act=act)
         return z
@@ -207,10 +234,10 @@ class CNNEncoder(nn.Module):
         as ln_from_partial's (an ``xa`` without ``act`` gets only its feature columns written; A = action columns)."""
         enc0 = jobs[0][0]
         F = enc0.feature_dim
-        assert all(e.feature_dim == F and e.ksplit(B) == enc0.ksplit(B) and e.ln.eps == enc0.ln.eps for e, _, _ in jobs)
+        assert all(e.feature_dim == F and e.nsplit(B) == enc0.nsplit(B) and e.ln.eps == enc0.ln.eps for e, _, _ in jobs)
         ops.fc_ln_fwd_multi([dict(partial=e.partial(B), bias=e.fc.bias, gamma=e.ln.weight, beta=e.ln.bias, y=z,
                                   tanh_out=0 if e.output_logits else 1, **kw) for e, z, kw in jobs],
-                            enc0.ksplit(B), B * F, F, B, F, enc0.ln.eps, A)
+                            enc0.nsplit(B), B * F, F, B, F, enc0.ln.eps, A)
 
     def to_kernel_layout(self):
         """Re-order fc.weight's input columns (c,y,x) -> (y,x,c) in place."""

@@ -236,6 +236,46 @@ def gemm_multi(As, Bs, Cs, M, N, K, ksplit=1, split_stride=0):
          split_stride, stream())
 
 
+FC_FWD_MAX_SPLIT = 64
+
+
+def fc_fwd_supported(B, F_, K):
+    """Shapes the streaming encoder-fc forward (curla_fc_fwd_multi) is instantiated for."""
+    return 50 <= F_ <= 64 and F_ % 2 == 0 and B % 128 == 0 and K % 32 == 0 and B * K * 4 < 2 ** 31 and F_ * K * 4 < 2 ** 31
+
+
+def fc_fwd_nsplit(nprob, B, K):
+    """Split-K factor of the streaming fc forward: two 256-thread workgroups fit a CU, and a grid a few workgroups LARGER
+    than that capacity costs a whole extra round (516 workgroups: 72 us, 768: 53 us, 504: 52 us for three [512 x 30752]
+    operands) -- so: 1.5 rounds' worth, never just above a whole number of rounds."""
+    cap = 2 * cu_count()
+    per = nprob * (B // 128)
+    ns = max(1, min(FC_FWD_MAX_SPLIT, (3 * cap // 2) // per, K // 32))
+    while ns > 1 and ns * per > cap and 0 < (ns * per) % cap <= cap // 8:
+        ns -= 1
+    return ns
+
+
+def fc_fwd_multi(xs, Ws, outs, B, F_, K, nsplit, split_stride, blocked=False):
+    """Split-K partial sums outs[i][s] = xs[i] [B, K] @ Ws[i] [F, K]^T over split s, up to 4 pairs of one shape in one
+    launch (fc_fwd_supported shapes only).  ``blocked``: xs are in the [B/16][K/32][16][32] layout."""
+    import ctypes
+    n = len(xs)
+    P = ctypes.c_void_p * n
+    a, b, c = P(*[ptr(t) for t in xs]), P(*[ptr(t) for t in Ws]), P(*[ptr(t) for t in outs])
+    call("curla_fc_fwd_multi", n, ctypes.addressof(a), ctypes.addressof(b), ctypes.addressof(c), B, F_, K, nsplit,
+         split_stride, 1 if blocked else 0, stream())
+
+
+def to_blocked(x, B, K):
+    """Row-major [B, K] -> the blocked layout [B/16][K/32][16][32] (same number of elements, a new tensor)."""
+    return x.reshape(B // 16, 16, K // 32, 32).permute(0, 2, 1, 3).contiguous().view(B, K)
+
+
+def from_blocked(x, B, K):
+    return x.reshape(B // 16, K // 32, 16, 32).permute(0, 2, 1, 3).contiguous().view(B, K)
+
+
 def linear_fwd(x, sx, W, sW, bias, sb, out, so, M, N, K, nb=1, relu=0, outer=None):
     """out[z] = act(x[z] @ W[z]^T + bias[z]);  x [M,K], W [N,K] (nn.Linear layout).
     ``outer`` = (n2, sx2, sW2, so2): a second batch level (item (o, z) at base + z * s + o * s2; bias strides as W's)."""

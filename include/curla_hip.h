@@ -141,6 +141,14 @@ int curla_gemm_nested(const float* A, int a_kmajor, int lda, long long strideA, 
  * critic phase has three, curl_sac.py:350-358).  Each launch less is ~5 us. */
 int curla_gemm_multi(int nprob, const float* const* A, const float* const* B, float* const* C, int lda, int ldb, int ldc,
                      int M, int N, int K, int ksplit, long long split_stride, void* stream);
+/* The encoder fc layer's forward product as split-K partial sums, for up to four (x, W) pairs of one shape:
+ * partial[i][s][b][f] = sum over the k of split s (32-wide slices, nsplit near-equal runs of them) of x[i][b][k] W[i][f][k],
+ * split s at partial[i] + s * split_stride.  W [F][K] row-major; x [B][K] row-major (x_blocked = 0) or BLOCKED
+ * [B / 16][K / 32][16][32] (x_blocked = 1: element (b, k) at ((b / 16) (K / 32) + k / 32) 512 + (b % 16) 32 + k % 32).
+ * 50 <= F <= 64 even, B % 128 == 0, K % 32 == 0; other shapes: CURLA_ERR_UNSUPPORTED (curla_gemm_multi computes the same
+ * sums from a row-major x in another order). */
+int curla_fc_fwd_multi(int nprob, const float* const* x, const float* const* W, float* const* partial, int B, int F, int K,
+                       int nsplit, long long split_stride, int x_blocked, void* stream);
 int curla_splitk_reduce(const float* partial, int nsplit, long long split_stride, int M, int N, int ldp, float* C,
                         int ldc, const float* bias, int relu, void* stream);
 /* Backward of the encoder fc layer z = fc(h) (encoder.py:98; autograd of the reference's nn.Linear), F <= 64 features,

@@ -847,6 +847,39 @@ def test_conv1_fwd_two_problems(ops, u8_impl, B1, B2, C):
     assert torch.equal(o1, outs[0]) and torch.equal(o2, outs[1])
 
 
+@pytest.mark.parametrize("B,Fd,K,nprob,ns,blocked", [(128, 50, 3456, 1, 7, False), (512, 50, 30752, 3, 43, True),
+                                                     (256, 64, 640, 2, 20, False), (128, 58, 96, 4, 3, True),
+                                                     (384, 50, 1184, 2, 37, True), (128, 50, 416, 1, 13, False)])
+def test_fc_forward_streaming_kernel(ops, B, Fd, K, nprob, ns, blocked):
+    """curla_fc_fwd_multi: the encoder fc layer's forward as split-K partial sums (three feature tiles on the matrix pipe
+    + two features on FMAs at F = 50; W through LDS, x straight from memory), up to four (x, W) pairs per launch, x
+    row-major or in the blocked layout: the sum over the splits against x @ W^T in float64, single splits against the k
+    ranges they stand for, nothing written around the outputs, reproducible run to run."""
+    assert ops.fc_fwd_supported(B, Fd, K)
+    xs = [rnd(B, K, seed=101 + i).cuda() for i in range(nprob)]
+    xin = [ops.to_blocked(x, B, K) for x in xs] if blocked else xs
+    if blocked:
+        assert torch.equal(ops.from_blocked(xin[0], B, K), xs[0])
+    Ws = [(rnd(Fd, K, seed=111 + i) * 0.05).cuda() for i in range(nprob)]
+    guard = 64
+    bufs = [torch.full((ns * B * Fd + 2 * guard,), float("nan"), device="cuda") for _ in range(nprob)]
+    outs = [b[guard:guard + ns * B * Fd].view(ns, B, Fd) for b in bufs]
+    ops.fc_fwd_multi(xin, Ws, outs, B, Fd, K, ns, B * Fd, blocked=blocked)
+    nsl = K // 32
+    for i in range(nprob):
+        ref = xs[i].cpu().double() @ Ws[i].cpu().double().t()
+        check(f"fc_fwd_multi sum of splits {B}x{Fd}x{K} problem {i}", outs[i].double().sum(0).cpu(), ref, 2e-6)
+        for s_ in (0, ns // 2, ns - 1):
+            k0, k1 = 32 * (nsl * s_ // ns), 32 * (nsl * (s_ + 1) // ns)
+            ref_s = xs[i][:, k0:k1].cpu().double() @ Ws[i][:, k0:k1].cpu().double().t()
+            check(f"fc_fwd_multi split {s_} of {ns}", outs[i][s_].cpu(), ref_s, 2e-6)
+        assert bool(torch.isnan(bufs[i][:guard]).all()) and bool(torch.isnan(bufs[i][-guard:]).all())
+    again = [torch.empty_like(o) for o in outs]
+    ops.fc_fwd_multi(xin, Ws, again, B, Fd, K, ns, B * Fd, blocked=blocked)
+    for a, o in zip(again, outs):
+        assert torch.equal(a, o)
+
+
 def test_gemm_multi_matches_single_launches(ops):
     """curla_gemm_multi: three unrelated split-K products of one shape, operands by pointer, in one launch --
     bit-identical to three curla_gemm launches."""

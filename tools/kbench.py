@@ -119,6 +119,24 @@ def main():
         if flags != [0]:
             lib.curla_debug_ablate(0)
 
+    if "fcfwd" in args.what:  # the encoder fc forward of three encoders in one launch: tiled GEMM against the streaming kernel
+        Kf, Fd = 30752, 50
+        hs = [torch.relu(r(B, Kf)) for _ in range(3)]
+        hb = [ops.to_blocked(h, B, Kf) for h in hs]
+        Wf = [r(Fd, Kf) * 0.01 for _ in range(3)]
+        fl_ = 2.0 * 3 * B * Kf * Fd
+        for ks in (32,):
+            po = [torch.empty(ks, B, Fd, device=dev) for _ in range(3)]
+            report(f"fc fwd x3 gemm_multi ksplit {ks}", timeit(lambda: ops.gemm_multi(hs, Wf, po, B, Fd, Kf, ksplit=ks, split_stride=B * Fd)), fl_)
+        for blocked, xs_ in ((False, hs), (True, hb)):
+            for ns in (21, 32, 43, 64):
+                po = [torch.empty(ns, B, Fd, device=dev) for _ in range(3)]
+                report(f"fc fwd x3 fc_fwd_multi nsplit {ns} blocked={blocked}",
+                       timeit(lambda: ops.fc_fwd_multi(xs_, Wf, po, B, Fd, Kf, ns, B * Fd, blocked=blocked)), fl_)
+        for ns in (43, 64):
+            po = [torch.empty(ns, B, Fd, device=dev) for _ in range(2)]
+            report(f"fc fwd x2 fc_fwd_multi nsplit {ns} blocked", timeit(lambda: ops.fc_fwd_multi(hb[:2], Wf[:2], po, B, Fd, Kf, ns, B * Fd, blocked=True)), fl_ * 2 / 3)
+
     if "conv" in args.what:
         w, b = r(32, 32, 3, 3) * 0.1, r(32) * 0.1
         for fl in flags:
