@@ -2,6 +2,7 @@
 vectors recorded from the reference and (b) the oracle on fresh inputs.
 Everything runs through the C ABI; integer outputs bit-exact, per-phase losses,
 activations and gradients within 1e-4 (per-tensor max-abs-normalised)."""
+import collections
 import hashlib
 
 import numpy as np
@@ -401,6 +402,105 @@ def test_multi_step_phases_vs_oracle_on_the_agents_own_parameters():
             check(f"{tag} CURL grad {k}", grads["encoder"][k[len("encoder."):]], v)
     for opt in (agent.critic_optimizer, agent.actor_optimizer, agent.encoder_optimizer):
         del opt.step
+
+
+def test_one_update_at_batch_256_takes_the_fused_paths_and_matches_the_oracle():
+    """The smallest batch at which update() takes EVERY fused path at once -- all stride-1 layers of two minibatches in
+    one launch (B a multiple of the CU count), the streaming fc forward and the one-launch CURL head (B a multiple of
+    128), the LayerNorm sums inside the fc backward, the target lerp inside the critic's Adam launch, log_alpha's step
+    inside the actor's -- on small images so that the oracle is quick: a call trace proves the paths were taken, and
+    every phase is compared with the oracle on the agent's own parameters (losses, CURL logits, the gradients the
+    CURL phase hands to its optimizers, the targets after the soft update)."""
+    import curla_amd
+    from curla_amd import _lib
+    from oracle import curla_oracle as O
+    torch.manual_seed(21)
+    np.random.seed(21)
+    in_hw, out_hw, B, hidden, layers = (40, 44), (32, 36), 256, 64, 4
+    agent, aug = make_agent((9,) + out_hw, in_hw, hidden)
+    oracle = O.OracleAgent((9,) + out_hw, (2,), hidden_dim=hidden, **{k: v for k, v in HP.items() if k != "log_interval"})
+    snap = lambda module, like: {k: module.state_dict()[k].detach().cpu().clone() for k in like}  # noqa: E731
+    rb = curla_amd.ReplayBuffer((9,) + in_hw, (2,), 512, B, torch.device("cuda"), aug)
+    rs = np.random.RandomState(6)
+    n = 300
+    obs_all = rs.randint(0, 256, (n, 9) + in_hw, dtype=np.uint8)
+    nxt_all = rs.randint(0, 256, (n, 9) + in_hw, dtype=np.uint8)
+    act_all = rs.uniform(-1, 1, (n, 2)).astype(np.float32)
+    rew_all = rs.randn(n).astype(np.float32)
+    done_all = (np.arange(n) % 7) == 6
+    rb.add_batch(obs_all, act_all, rew_all, nxt_all, done_all)
+    L = NullLogger()
+    kw = dict(num_layers=layers, log_std_min=-10, log_std_max=2)
+    idxs, offs = rb.draw_indices()
+    nc, na = torch.randn(B, 2), torch.randn(B, 2)
+    crop = lambda src, j: torch.from_numpy(O.random_crop(src[idxs], offs[2 * j], offs[2 * j + 1], out_hw)).float()  # noqa: E731
+    o_obs, o_nxt, o_pos = crop(obs_all, 0), crop(nxt_all, 1), crop(obs_all, 2)
+    o_act, o_rew = torch.from_numpy(act_all[idxs]), torch.from_numpy(rew_all[idxs])[:, None]
+    o_nd = torch.from_numpy(1.0 - done_all[idxs].astype(np.float32))[:, None]
+    obs, act, rew, nxt, nd, ckw = rb.sample_cpc_refs(indices=(idxs, offs))
+    ws = agent._ws(B)
+    calls = []
+    real_call = _lib.call
+
+    def traced(name, *a):
+        calls.append(name)
+        return real_call(name, *a)
+    import curla_amd.ops as ops_mod
+    import curla_amd.optim as optim_mod
+    mods = (ops_mod, optim_mod)
+    for m in mods:
+        m.call = traced
+    try:
+        pre = (snap(agent.actor, oracle.actor), snap(agent.critic, oracle.critic),
+               snap(agent.critic_target, oracle.critic_target), agent.log_alpha.detach().cpu().clone())
+        tgt_before = {k: v.detach().clone() for k, v in agent.critic_target.state_dict().items()}
+        agent._soft_update_hint, agent._soft_update_done = True, False  # (what update() does around update_critic)
+        agent.update_critic(obs, act, rew, nxt, nd, L, 0, noise=nc.cuda())
+        agent._soft_update_hint = False
+        assert agent._soft_update_done
+        ref_c = O.critic_phase(*pre, o_obs, o_act, o_rew, o_nxt, o_nd, nc, discount=0.99, **kw)
+        check("B256 critic loss", L.scalars["train_critic/loss"], ref_c["loss"])
+        sd, st = agent.critic.state_dict(), agent.critic_target.state_dict()
+        for k in ("encoder.convs.1.weight", "encoder.ln.bias", "Q1.trunk.0.weight"):
+            tau = HP["encoder_tau"] if k.startswith("encoder.") else HP["critic_tau"]
+            check(f"B256 target after the fused lerp {k}", st[k], tau * sd[k] + (1 - tau) * tgt_before[k], 1e-6)
+        ref_a = O.actor_phase(snap(agent.actor, oracle.actor), snap(agent.critic, oracle.critic),
+                              agent.log_alpha.detach().cpu().clone(), o_obs, na, target_entropy=oracle.target_entropy, **kw)
+        agent._pos_hint = ckw["obs_pos"]  # (update(): the positives' target pass shares the actor phase's conv launches)
+        agent.update_actor_and_alpha(obs, L, 0, noise=na.cuda())
+        agent._pos_hint = None
+        check("B256 actor loss", L.scalars["train_actor/loss"], ref_a["actor_loss"])
+        check("B256 alpha loss", L.scalars["train_alpha/loss"], ref_a["alpha_loss"])
+        snap_c, snap_t = snap(agent.critic, oracle.critic), snap(agent.critic_target, oracle.critic_target)
+        snap_w = agent.CURL.W.detach().cpu().clone()
+        enc_grads = {}
+        real_step = agent.encoder_optimizer.step
+
+        def keep():
+            enc_grads.update(grads_of(agent.critic.encoder))
+            enc_grads["W"] = agent.CURL.W.grad.detach().cpu().clone()
+            real_step()
+        agent.encoder_optimizer.step = keep
+        agent.update_cpc(ckw["obs_anchor"], ckw["obs_pos"], ckw, L, 0)
+        del agent.encoder_optimizer.step
+    finally:
+        for m in mods:
+            m.call = real_call
+    ref_p = O.cpc_phase(snap_c, snap_t, snap_w, o_obs, o_pos, num_layers=layers)
+    check("B256 curl loss", L.scalars["train/curl_loss"], ref_p["loss"])
+    lg = ws.logits.cpu()  # (the kernel keeps the raw logits; the reference subtracts the row maxima, curl_sac.py:221)
+    check("B256 curl logits", lg - lg.max(1)[0][:, None], ref_p["logits"], 2e-5)
+    br = [ws.acts_main[i].permute(0, 3, 1, 2).cpu() > 0 for i in range(layers)]
+    ref_pb = O.cpc_phase(snap_c, snap_t, snap_w, o_obs, o_pos, num_layers=layers, relu_branches=br)
+    check("B256 CURL W grad", enc_grads["W"], ref_pb["W_grad"])
+    for k, v in ref_pb["grads"].items():
+        check(f"B256 CURL grad {k}", enc_grads[k[len("encoder."):]], v)
+    c = collections.Counter(calls)
+    assert c["curla_curl_head"] == 1 and c["curla_curl_ce"] == 0, c
+    assert c["curla_fc_fwd_multi"] == 2 and c["curla_gemm_multi"] == 0, c
+    assert c["curla_conv3x3_s1_fwd_stack"] == 2 and c["curla_conv3x3_s1_fwd2"] == 0 and c["curla_conv3x3_s1_fwd"] == 0, c
+    assert c["curla_fc_bwd_ln"] == 1 and c["curla_fc_bwd_ln2"] == 1 and c["curla_fc_dw_ln"] == 1 and c["curla_ln_bwd_partial"] == 2, c
+    assert c["curla_adam_step_lerp"] == 1 and c["curla_adam_step_scalar64"] == 1 and c["curla_soft_update2"] == 0, c
 
 
 def test_update_chain_vs_oracle_agent():
