@@ -817,6 +817,175 @@ __global__ __launch_bounds__(512) void conv1_fwd_u8_kernel(Conv1Args a) {
 }
 
 // ---------------------------------------------------------------------------
+// The same layer, HYBRID form: the banded kernel's input side (one workgroup per sample, the crop staged as bytes in
+// LDS by one burst of aligned loads -- which is what makes that kernel indifferent to where the ring slots come from)
+// with the row walk's compute loop (conv1_u8_rw.h: a wave owns 16 output columns and walks down; a lane group's
+// E = ceil(3C/4) operand bytes of an input row are CONTIGUOUS, here read from LDS as aligned dwords + v_alignbyte, two
+// new rows per 6 E MFMAs) instead of one byte read + one (row, column) walk per k-step.  The sample's steps (strips x
+// rows, rw::Geom) are split evenly over the 8 waves.  Only for crops that fit one band (nbands == 1).
+// ---------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(512, 2) void conv1_u8_walk_kernel(Conv1Args a, rw::Geom G) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int E = (3 * C + 3) / 4, KR = 4 * E;
+  constexpr int NLD = (E + 3 + 3) / 4;  // aligned dwords that hold a run starting at byte 0..3 of the first
+  constexpr int NWD = (E + 3) / 4;      // dwords of the run once it starts at byte 0
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int RSb = conv1_row_bytes(a.Wc, C);
+  const bool second = (int)blockIdx.x >= a.B;
+  const int b = second ? blockIdx.x - a.B : blockIdx.x;
+  if (second) a.idx = a.idx2, a.h1 = a.h1_2, a.w1 = a.w1_2, a.w = a.w2, a.bias = a.bias2, a.out = a.out2;
+  // the crop's bytes: requested before the weight phase, stored to LDS after it (same region)
+  constexpr int U0 = 7;
+  Conv1StageRegs<U0> rg0;
+  {
+    const int64_t fi = a.idx ? a.idx[b] : b;
+    const int oh0 = a.h1 ? a.h1[b] : 0, ow0 = a.w1 ? a.w1[b] : 0;
+    const uint8_t* frame0 = static_cast<const uint8_t*>(a.src) + (size_t)fi * a.Hs * a.Ws * C;
+    conv1_stage_u8_issue<U0>(rg0, frame0, oh0, ow0, C, a.Ws, a.Wc, 0, 2 * a.Ho + 1, RSb, 0, tid, 512);
+  }
+  for (int i = tid; i < 3 * KR * 32; i += 512) {
+    const int co = i & 31, k = i >> 5;
+    const int dy = k / KR, rr = k - dy * KR;
+    const int dx = rr / C, c = rr - dx * C;
+    lds[i] = rr < 3 * C ? a.w[(co * C + c) * 9 + dy * 3 + dx] * a.scale : 0.f;
+  }
+  __syncthreads();
+  float wr[3][E][2];  // lane (li = cout, kq): W[cout][dy][rr = E kq + e] * scale
+  {
+    const float* wl = lds + (E * kq) * 32 + li;
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) wr[dy][e][mt] = wl[(dy * KR + e) * 32 + mt * 16];
+  }
+  f32x4 bias4[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) bias4[mt] = *reinterpret_cast<const f32x4*>(a.bias + mt * 16 + 4 * kq);
+  __syncthreads();
+  uint8_t* ldsb = reinterpret_cast<uint8_t*>(lds);
+  conv1_stage_u8_commit<U0>(rg0, ldsb);
+  conv1_stage_u8(ldsb, static_cast<const uint8_t*>(a.src), a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Wc, 0, 2 * a.Ho + 1, RSb,
+                 tid, 512, /*first_run=*/U0 * 512);
+  __syncthreads();
+
+  const int lo = G.steps * wave / 8, hi = G.steps * (wave + 1) / 8;
+  const int out_row = a.Wo * 128;
+  const __amdgpu_buffer_rsrc_t rout = rw::uniform_rsrc(a.out + (size_t)b * a.Ho * a.Wo * 32, a.Ho * out_row);
+  for (int g = lo; g < hi;) {
+    int k, sb, n_strip;
+    if (g < G.nfull * G.Ho) {
+      k = g / G.Ho, sb = g - k * G.Ho, n_strip = G.Ho;
+    } else {
+      const int q = (g - G.nfull * G.Ho) / G.nr;
+      k = G.nfull + q, sb = g - G.nfull * G.Ho - q * G.nr, n_strip = G.nr;
+    }
+    const int n = hi - g < n_strip - sb ? hi - g : n_strip - sb;
+    g += n;
+    int x, y0;
+    bool lane_on;
+    if (k < G.nfull) {
+      x = 16 * k + li, y0 = 0, lane_on = true;
+    } else {
+      const int u = (k - G.nfull) * 16 + li;
+      const int col = u / G.nseg, sg = u - col * G.nseg;
+      lane_on = col < G.brem;
+      x = 16 * G.nfull + col, y0 = sg * G.nr;
+    }
+    // (lanes without a column, and rows past the crop, read whatever sits in LDS: finite bytes; nothing of it is stored)
+    const int Y = lane_on ? min(y0 + sb, a.Ho - 1) : 0;
+    const int xx = lane_on ? x : 0;
+    const unsigned run = (unsigned)(2 * Y * RSb + 2 * xx * C + E * kq);
+    const unsigned sh = run & 3u;
+    const uint8_t* rowp = ldsb + (run & ~3u);
+    unsigned vo = lane_on ? (unsigned)(((y0 + sb) * a.Wo + x) * 128 + kq * 16) : 0x80000000u;
+    const int rmax = 2 * a.Ho - 2 * Y;  // last crop row (relative to 2 Y) that exists in LDS
+    struct Raw {
+      uint32_t d[NLD];
+    };
+    struct Row {
+      float v[E];
+    };
+    auto load_row = [&](Raw& R, int r) {  // crop row 2 Y + r (clamped into the staged image)
+      const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + (size_t)min(r, rmax) * RSb);
+#pragma unroll
+      for (int j = 0; j < NLD; ++j) R.d[j] = p[j];
+    };
+    auto convert = [&](Row& F, const Raw& R) {
+      rw::RawBytes<NWD> Wd;
+#pragma unroll
+      for (int j = 0; j < NWD; ++j) Wd.d[j] = __builtin_amdgcn_alignbyte(j + 1 < NLD ? R.d[j + 1 < NLD ? j + 1 : j] : 0u, R.d[j], sh);
+#pragma unroll
+      for (int e = 0; e < E; ++e) F.v[e] = rw::byte_f32<NWD>(Wd, e);
+    };
+    auto mma_row = [&](f32x4 (&acc)[2], const Row& F, const int dy) {
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) acc[mt] = mfma16(wr[dy][e][mt], F.v[e], acc[mt]);
+    };
+    struct Pair {
+      Raw a, b;
+    };
+    auto step = [&](const Row& r0, Row& r1, Row& r2, const Pair& cur, Pair& nxt, const int t) {
+      load_row(nxt.a, 2 * t + 3);
+      load_row(nxt.b, 2 * t + 4);
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 acc[2] = {bias4[0], bias4[1]};
+      mma_row(acc, r0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      convert(r1, cur.a);
+      convert(r2, cur.b);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_row(acc, r1, 1);
+      mma_row(acc, r2, 2);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        f32x4 v = acc[mt];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rw::relu_bits(v[r]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rout,
+                                               vo + mt * 64u, 0, 2);
+      }
+      vo += out_row;
+    };
+    Row S0, S1, S2, S3, S4;
+    Pair P0, P1;
+    {
+      Raw R0;
+      load_row(R0, 0), load_row(P0.a, 1), load_row(P0.b, 2);
+      convert(S0, R0);
+    }
+    for (int t = 0;;) {  // rows of step t sit in sets (2t, 2t+1, 2t+2) mod 5, its bytes in pair t mod 2
+      step(S0, S1, S2, P0, P1, t);
+      if (++t >= n) break;
+      step(S2, S3, S4, P1, P0, t);
+      if (++t >= n) break;
+      step(S4, S0, S1, P0, P1, t);
+      if (++t >= n) break;
+      step(S1, S2, S3, P1, P0, t);
+      if (++t >= n) break;
+      step(S3, S4, S0, P0, P1, t);
+      if (++t >= n) break;
+      step(S0, S1, S2, P1, P0, t);
+      if (++t >= n) break;
+      step(S2, S3, S4, P0, P1, t);
+      if (++t >= n) break;
+      step(S4, S0, S1, P1, P0, t);
+      if (++t >= n) break;
+      step(S1, S2, S3, P0, P1, t);
+      if (++t >= n) break;
+      step(S3, S4, S0, P1, P0, t);
+      if (++t >= n) break;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // weight gradient, stride-1 32->32:  dW[co][ci][tap] = sum_pixels g[p][co] * in[p+tap][ci]
 // GEMM view: D[co][ci] per tap, K = pixels (4 per MFMA).  36 accumulator tiles
 // (2 x 2 x 9) live in registers for the whole persistent workgroup; partial
@@ -1618,10 +1787,11 @@ bool use_rw() {
   return !band;
 }
 // ... and the weight gradient: CURLA_S1_WGRAD=band keeps the banded kernel beside the row-walk forward / data gradient
-// CURLA_C1_U8=rw: the row-walk uint8 first-layer forward (conv1_u8_rw.h) instead of the LDS-banded one.  Measured on
+// CURLA_C1_U8=rw: the LDS-free row-walk uint8 first-layer forward (conv1_u8_rw.h) instead of the default (the hybrid
+// conv1_u8_walk_kernel: crop staged in LDS, row walk out of LDS; CURLA_C1_U8=band: the banded loop).  Measured on
 // 1024 + 512 / 512 + 512 samples of configs[1]: alone, re-reading the same ring slots out of the Infinity Cache, the
-// row walk takes 100 / 66 us against 128 / 86; on slots drawn afresh for every launch from a ring of gigabytes -- what
-// update() does -- 114 us on average against 104 (rocprofv3, same box).  The default is what update() runs fastest.
+// LDS-free walk takes 100 / 66 us against the banded loop's 128 / 86; on slots drawn afresh for every launch from a ring
+// of gigabytes -- what update() does -- 114 us on average against 104 (hybrid: 102).
 bool use_rw_u8() {  // (read at every call -- two per update -- so that one process can run both: the tests do)
   const char* e = getenv("CURLA_C1_U8");
   return use_rw() && e && !strcmp(e, "rw");
@@ -1926,6 +2096,22 @@ static int conv1_fwd_impl(const void* src, int src_kind, const int64_t* idx, con
     rc = set_lds(conv1_fwd_u8_kernel<CC>, lds);                                                             \
     if (rc == CURLA_OK) hipLaunchKernelGGL((conv1_fwd_u8_kernel<CC>), dim3(grid), dim3(512), lds, st, a);   \
   }
+    // one band = the whole crop in LDS: the hybrid form (row walk out of LDS) unless CURLA_C1_U8=band asks for the old loop
+    const char* impl = getenv("CURLA_C1_U8");
+    if (a.nbands == 1 && use_rw() && !(impl && !strcmp(impl, "band"))) {
+      rw::Geom G;
+      G.Hi = Hc, G.Wi = Wc, G.Ho = a.Ho, G.Wo = a.Wo;
+      rw::plan_units(G, a.Ho, a.Wo, 16);
+#define CONV1_U8_WALK(CC)                                                                                     \
+  {                                                                                                           \
+    rc = set_lds(conv1_u8_walk_kernel<CC>, lds);                                                              \
+    if (rc == CURLA_OK) hipLaunchKernelGGL((conv1_u8_walk_kernel<CC>), dim3(grid), dim3(512), lds, st, a, G); \
+  }
+      if (C == 9) CONV1_U8_WALK(9) else if (C == 12) CONV1_U8_WALK(12) else if (C == 6) CONV1_U8_WALK(6) else CONV1_U8_WALK(3)
+#undef CONV1_U8_WALK
+      if (rc != CURLA_OK) return rc;
+      return curla_launch_status();
+    }
     if (C == 9) CONV1_U8_LAUNCH(9) else if (C == 12) CONV1_U8_LAUNCH(12) else if (C == 6) CONV1_U8_LAUNCH(6) else CONV1_U8_LAUNCH(3)
 #undef CONV1_U8_LAUNCH
     if (rc != CURLA_OK) return rc;

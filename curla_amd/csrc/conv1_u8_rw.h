@@ -22,7 +22,8 @@
 // average against 104 under rocprofv3 on the same box (88 against 88 per 1024 samples in the microbenchmark).  More
 // prefetch distance (1 / 2 / 4 steps: 90.6 / 86.4 / 88.4 us), five waves per SIMD instead of four, and pulling a
 // workgroup's crops into the L2 in one coalesced burst first (92 against 82) did not change that; the banded kernel,
-// which reads a crop once in one burst and then works out of LDS, does not see the difference.  DESIGN.md section 6.
+// which reads a crop once in one burst and then works out of LDS, does not see the difference -- and the default is now
+// the hybrid of the two (conv1_u8_walk_kernel in conv.hip: that staging, this loop reading from LDS).  DESIGN.md section 6.
 #pragma once
 
 namespace rw {

@@ -130,15 +130,20 @@ CONV1_CASES = [  # C, Hs, Ws, Hc, Wc, B
 ]
 
 
-@pytest.fixture(params=["band", "rw"])
+@pytest.fixture(params=["hybrid", "band", "rw"])
 def u8_impl(request):
-    """Both uint8 first-layer forwards: the LDS-banded default and the row walk (CURLA_C1_U8=rw, conv1_u8_rw.h)."""
+    """The three uint8 first-layer forwards: the default (crop staged in LDS + row walk out of LDS when the crop fits
+    one band, else the banded loop), the banded loop alone (CURLA_C1_U8=band) and the row walk straight from memory
+    (CURLA_C1_U8=rw, conv1_u8_rw.h)."""
     import os
     old = os.environ.get("CURLA_C1_U8")
-    os.environ["CURLA_C1_U8"] = request.param
+    if request.param == "hybrid":
+        os.environ.pop("CURLA_C1_U8", None)
+    else:
+        os.environ["CURLA_C1_U8"] = request.param
     yield request.param
     if old is None:
-        del os.environ["CURLA_C1_U8"]
+        os.environ.pop("CURLA_C1_U8", None)
     else:
         os.environ["CURLA_C1_U8"] = old
 
