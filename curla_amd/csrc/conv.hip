@@ -911,7 +911,7 @@ __global__ __launch_bounds__(512, 2) void conv1_u8_walk_kernel(Conv1Args a, rw::
       float v[E];
     };
     auto load_row = [&](Raw& R, int r) {  // crop row 2 Y + r (clamped into the staged image)
-      const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + (size_t)min(r, rmax) * RSb);
+      const uint32_t* p = reinterpret_cast<const uint32_t*>(rowp + __mul24(min(r, rmax), RSb));  // (24-bit: no 64-bit mad)
 #pragma unroll
       for (int j = 0; j < NLD; ++j) R.d[j] = p[j];
     };
@@ -1319,6 +1319,7 @@ struct Wgrad1Args {
   int B, C, Hs, Ws, Hc, Wc, Ho, Wo, th, nbands;
   float scale;
   unsigned lds_bytes;  // dynamic LDS of the launch (the uint8 kernel sizes its final cross-wave sum by it)
+  int dbg;
 };
 
 template <int SRC, int C>
@@ -1440,7 +1441,8 @@ __global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
   constexpr int K9 = 9 * C;
   constexpr bool TAIL = (K9 % 16 == 1);
   constexpr int NT = TAIL ? K9 / 16 : (K9 + 15) / 16;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform: the piece bookkeeping below stays scalar)
   const int li = lane & 15, kq = lane >> 4;
   const int RSb = conv1_row_bytes(a.Wc, C);
   f32x4 acc[2][NT];
@@ -1448,8 +1450,8 @@ __global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
-  float bsum[2] = {0.f, 0.f};
-  float atail[2] = {0.f, 0.f};
+  f32x2 bsum = {0.f, 0.f};   // (pairs: one packed add / fma for both halves of the output channels)
+  f32x2 atail = {0.f, 0.f};
   int koff[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -1464,87 +1466,143 @@ __global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
     const int band = item / a.B, b = item - band * a.B;
     const int y0 = band * a.th;
     const int tha = min(a.th, a.Ho - y0);
-    conv1_stage_u8(ldsb, static_cast<const uint8_t*>(a.src), a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Wc, 2 * y0,
-                   2 * tha + 1, RSb, tid, NTHR);
+    if (!ABL(1))
+      conv1_stage_u8(ldsb, static_cast<const uint8_t*>(a.src), a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Wc, 2 * y0,
+                     2 * tha + 1, RSb, tid, NTHR);
     __syncthreads();
     const float* const gband = a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32 + li;  // the band's pixels are contiguous
-    // Row walk: wave w takes output rows w, w + NW, ... of the band; a k-step ("unit") is 4 consecutive pixels of
-    // one row (lane group kq -> pixel 4j + kq), units are processed in chunks of UNR.  Everything a unit needs is then
-    // at a COMPILE-TIME offset from per-chunk bases: the six byte operands at (row base + koff[t]) + 8 C jj, the two
-    // gradient values at chunk base + 128 jj floats -- no per-unit address arithmetic, no (row, column) bookkeeping
-    // (the pixel-order walk spent ~45 VALU instructions per 12 MFMAs on those: matrix pipe busy 46 %).  The bytes are
-    // multiplied unscaled, `scale` is applied once to the accumulated sums.
-    constexpr int UNR = 5;
-    const int upr = (a.Wo + 3) >> 2;         // units per row
-    const int cpr = (upr + UNR - 1) / UNR;   // chunks per row
-    // gradient values of a chunk (from HBM/L2, one chunk ahead of their use; lanes past the row or the band: zero page)
-    auto gload = [&](int ty, int c, float (&av)[UNR][2]) {
-      const int x0 = 4 * c * UNR + kq;
-      const bool full = ty < tha && 4 * (c + 1) * UNR <= a.Wo;  // (wave-uniform)
-      if (full) {
-        const float* gp = gband + (ty * a.Wo + x0) * 32;
-#pragma unroll
-        for (int jj = 0; jj < UNR; ++jj) av[jj][0] = gp[128 * jj], av[jj][1] = gp[128 * jj + 16];
+    // The walk.  A k-step ("unit") is 4 pixels, lane group kq takes one of them; units come in PIECES of UNR, and the
+    // band's pieces are dealt to the waves round-robin (piece w, w + NW, ...).  Two kinds of piece:
+    //   row piece:    UNR consecutive units of one output row (pixels 4u + kq): only the floor(Wo / 4) WHOLE units of
+    //                 a row, so that no unit multiplies fewer than 4 pixels;
+    //   column piece: the Wo % 4 columns a row's whole units leave over, walked DOWN -- a unit is rows 4u + kq of one
+    //                 such column (at Wo = 37: 10 units for column 36 instead of a quarter-filled tenth unit in each
+    //                 of the 37 rows: 343 units per crop, not 370).
+    // In a row piece everything a unit needs sits at a COMPILE-TIME offset from per-piece bases: the byte operands at
+    // (piece base + koff[t]) + 8 C jj, the two gradient values at piece base + 128 jj floats -- no per-unit address
+    // arithmetic (the pixel-order walk spent ~45 VALU instructions per 12 MFMAs on it: matrix pipe busy 46 %).  Pieces
+    // of 3 (not whole rows) so that the waves' shares differ by at most one piece: 115 pieces over 8 waves = 15 each
+    // at most, 45 units, where whole rows gave 5 rows x 10 units.  The bytes are multiplied unscaled, `scale` is
+    // applied once to the accumulated sums.
+    constexpr int UNR = 3;
+    const int fullu = a.Wo >> 2, remc = a.Wo & 3;
+    const int cpr = (fullu + UNR - 1) / UNR;  // row pieces per row
+    const int cpc = (((tha + 3) >> 2) + UNR - 1) / UNR;  // column pieces per left-over column
+    const int nrow = tha * cpr, npieces = nrow + remc * cpc;
+    const int kdiv = NW / max(cpr, 1), kmod = NW - kdiv * cpr;
+    struct Piece {  // (wave-uniform)
+      int q, ty, c;  // row piece: row ty, piece c of the row;  column piece (q >= nrow): left-over column ty, piece c
+    };
+    auto column_of = [&](Piece& p) {
+      const int qq = p.q - nrow;
+      p.ty = qq / cpc, p.c = qq - p.ty * cpc;
+    };
+    auto next_piece = [&](Piece& p) {
+      p.q += NW;
+      if (p.q < nrow) {
+        p.c += kmod, p.ty += kdiv;
+        if (p.c >= cpr) p.c -= cpr, ++p.ty;
       } else {
+        column_of(p);
+      }
+    };
+    // gradient values of a piece (from HBM/L2, one piece ahead of their use; pixels past the band: zero page)
+    auto gload = [&](const Piece& p, f32x2 (&av)[UNR]) {
+      if (p.q < nrow) {
+        const float* gp = gband + (p.ty * a.Wo + 4 * UNR * p.c + kq) * 32;
+        if (UNR * (p.c + 1) <= fullu) {
+#pragma unroll
+          for (int jj = 0; jj < UNR; ++jj) av[jj] = f32x2{gp[128 * jj], gp[128 * jj + 16]};
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < UNR; ++jj) {
+            const float* g1 = UNR * p.c + jj < fullu ? gp + 128 * jj : g_zero_px;
+            av[jj] = f32x2{g1[0], g1[16]};
+          }
+        }
+      } else {
+        const int x = 4 * fullu + p.ty;
 #pragma unroll
         for (int jj = 0; jj < UNR; ++jj) {
-          const int x = x0 + 4 * jj;
-          const float* gp = (ty < tha && x < a.Wo) ? gband + (ty * a.Wo + x) * 32 : g_zero_px;
-          av[jj][0] = gp[0], av[jj][1] = gp[16];
+          const int y = 4 * (UNR * p.c + jj) + kq;
+          const float* g1 = (p.ty < remc && y < tha) ? gband + (y * a.Wo + x) * 32 : g_zero_px;
+          av[jj] = f32x2{g1[0], g1[16]};
         }
       }
     };
-    auto unit = [&](const uint8_t* ub, const float (&avj)[2]) {
-      float bv[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) bv[t] = (float)ub[koff[t]];
-      bsum[0] += avj[0];
-      bsum[1] += avj[1];
-      if (TAIL) {
-        const float bt = (float)ub[koff_tail];
-        atail[0] += avj[0] * bt;
-        atail[1] += avj[1] * bt;
-      }
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        acc[0][t] = mfma16(avj[0], bv[t], acc[0][t]);
-        acc[1][t] = mfma16(avj[1], bv[t], acc[1][t]);
-      }
+    // operand bytes of a piece, LDS -> registers (also one piece ahead: the multiply below never waits for LDS).
+    // Units past the row / the band get an address inside the band: their gradient is the zero page's.
+    constexpr int NB = NT + (TAIL ? 1 : 0);
+    struct Raw {
+      uint32_t b[UNR][NB];
     };
-    auto compute = [&](int ty, int c, const float (&av)[UNR][2]) {
-      const uint8_t* rowy = ldsb + __mul24(2 * ty, RSb);
-      if (4 * (c + 1) * UNR <= a.Wo) {  // (wave-uniform) every unit of the chunk is whole: compile-time offsets
-        const uint8_t* rowb = rowy + 2 * (4 * c * UNR + kq) * C;
+    auto bload_unit = [&](const uint8_t* ub, uint32_t (&b)[NB]) {
 #pragma unroll
-        for (int jj = 0; jj < UNR; ++jj) unit(rowb + 8 * C * jj, av[jj]);
-      } else {  // the row's last chunk: units past the row are skipped, lanes past it multiply a zero gradient and
-                // have their byte address clamped into the row
+      for (int t = 0; t < NT; ++t) b[t] = ub[koff[t]];
+      if (TAIL) b[NT] = ub[koff_tail];
+    };
+    auto bload = [&](const Piece& p, Raw& R) {
+      if (p.q < nrow) {
+        const uint8_t* rowb = ldsb + __mul24(2 * p.ty, RSb) + 2 * (4 * UNR * p.c + kq) * C;
+        if (UNR * (p.c + 1) <= fullu) {  // the usual piece: compile-time offsets
 #pragma unroll
-        for (int jj = 0; jj < UNR; ++jj) {
-          const int xu = 4 * (c * UNR + jj);
-          if (xu < a.Wo) unit(rowy + 2 * min(xu + kq, a.Wo - 1) * C, av[jj]);
+          for (int jj = 0; jj < UNR; ++jj) bload_unit(rowb + 8 * C * jj, R.b[jj]);
+        } else {
+#pragma unroll
+          for (int jj = 0; jj < UNR; ++jj) bload_unit(UNR * p.c + jj < fullu ? rowb + 8 * C * jj : rowb, R.b[jj]);
         }
+      } else {
+        const uint8_t* colb = ldsb + 2 * min(4 * fullu + p.ty, a.Wo - 1) * C;
+#pragma unroll
+        for (int jj = 0; jj < UNR; ++jj)
+          bload_unit(colb + __mul24(2 * min(4 * (UNR * p.c + jj) + kq, tha - 1), RSb), R.b[jj]);
       }
     };
-    float avA[UNR][2], avB[UNR][2];
-    int ty = wave, c = 0;
-    if (ty < tha) gload(ty, c, avA);
-    while (ty < tha) {  // (wave-uniform)
-      int nty = ty, nc = c + 1;
-      if (nc == cpr) nc = 0, nty += NW;
-      gload(nty, nc, avB);
+    auto mma = [&](const Raw& R, const f32x2 (&av)[UNR]) {
+#pragma unroll
+      for (int jj = 0; jj < UNR; ++jj) {
+        float bv[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bv[t] = (float)R.b[jj][t];
+        bsum += av[jj];
+        if (TAIL) {
+          const float bt = (float)R.b[jj][NB - 1];
+          atail += av[jj] * f32x2{bt, bt};
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          acc[0][t] = mfma16(av[jj][0], bv[t], acc[0][t]);
+          acc[1][t] = mfma16(av[jj][1], bv[t], acc[1][t]);
+        }
+#ifndef CURLA_WG1_NOGROUP
+        // a unit's conversions ahead of its MFMAs (a conversion right in front of the MFMA that reads it costs wait states)
+        __builtin_amdgcn_sched_group_barrier(0x002, NB + 3, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT, 0);
+#endif
+      }
+    };
+    f32x2 avA[UNR], avB[UNR];
+    Raw RA, RB;
+    Piece cur;
+    cur.q = ABL(2) ? npieces : wave;
+    if (cur.q < nrow) cur.ty = cur.q / cpr, cur.c = cur.q - cur.ty * cpr;
+    else column_of(cur);
+    gload(cur, avA), bload(cur, RA);
+    while (cur.q < npieces) {  // (wave-uniform)
+      Piece nxt = cur;
+      next_piece(nxt);
+      gload(nxt, avB), bload(nxt, RB);  // (past the last piece: a column piece outside the band -- zero page, clamped bytes)
       __builtin_amdgcn_sched_barrier(0);
-      compute(ty, c, avA);
+      mma(RA, avA);
       __builtin_amdgcn_sched_barrier(0);
-      ty = nty, c = nc;
-      if (ty >= tha) break;
-      nc = c + 1;
-      if (nc == cpr) nc = 0, nty += NW;
-      gload(nty, nc, avA);
+      cur = nxt;
+      if (cur.q >= npieces) break;
+      next_piece(nxt);
+      gload(nxt, avA), bload(nxt, RA);
       __builtin_amdgcn_sched_barrier(0);
-      compute(ty, c, avB);
+      mma(RB, avB);
       __builtin_amdgcn_sched_barrier(0);
-      ty = nty, c = nc;
+      cur = nxt;
     }
     __syncthreads();
   }
@@ -1571,6 +1629,13 @@ __global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
   // straight into the slab -- instead of NW serialised read-modify-write rounds over the output layout.
   const int nw = 32 * C * 9;
   float* slab = a.partial + (size_t)blockIdx.x * (nw + 32);
+  if (ABL(4)) {  // timing only: no cross-wave sum, no slab
+    float t = bsum[0] + bsum[1] + atail[0] + atail[1];
+#pragma unroll
+    for (int q = 0; q < 2 * NT; ++q) t += acc[q / NT][q % NT][0] + acc[q / NT][q % NT][3];
+    if (t == 12345.678f) slab[tid] = t;
+    return;
+  }
   f32x4* l4 = reinterpret_cast<f32x4*>(lds);
   const int TC = max(1, min(2 * NT, (int)(a.lds_bytes / (NW * 1024))));  // tiles per pass (1 KB per tile and wave)
   __syncthreads();
@@ -2372,6 +2437,7 @@ static int launch_wgrad1(const void* src, int src_kind, const int64_t* idx, cons
   a.Ho = (Hc - 3) / 2 + 1, a.Wo = (Wc - 3) / 2 + 1;
   a.scale = scale;
   a.lds_bytes = 0;
+  a.dbg = ABL_HOST;
   const int nw = 32 * C * 9;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int grid;

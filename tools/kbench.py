@@ -119,6 +119,30 @@ def main():
         if flags != [0]:
             lib.curla_debug_ablate(0)
 
+    if "wg1" in args.what:  # the uint8 first-layer weight gradient alone (ablations: 1 no staging, 2 no multiply, 4 no slab)
+        NS = args.slots
+        store = torch.randint(0, 256, (NS * 84 * 84 * 9 + 32,), dtype=torch.uint8, device=dev)
+        ring = store[:NS * 84 * 84 * 9].view(NS, 84, 84, 9)
+        h1 = torch.randint(0, 8, (B,), device=dev, dtype=torch.int32)
+        w1 = torch.randint(0, 8, (B,), device=dev, dtype=torch.int32)
+        sets = [ops.ObsRef.from_ring(ring, torch.randint(0, NS, (B,), device=dev), h1, w1, B, (76, 76)) for _ in range(16)]
+        g = r(B, 37, 37, 32)
+        dw0, db = torch.empty(32, 9, 3, 3, device=dev), torch.empty(32, device=dev)
+        ws0 = torch.empty(ops.wgrad_workspace_floats(9), device=dev)
+        fl_ = 2.0 * B * 37 * 37 * 32 * 9 * 9
+        for fl in flags:
+            if flags != [0]:
+                lib.curla_debug_ablate(fl)
+            it3 = [0]
+
+            def wg_fresh():
+                it3[0] += 1
+                ops.conv1_wgrad_slabs(sets[it3[0] % 16], g, ws0, 32)
+            report(f"[abl {fl}] conv1_wgrad u8 slabs only, same slots", timeit(lambda: ops.conv1_wgrad_slabs(sets[0], g, ws0, 32)), fl_)
+            report(f"[abl {fl}] conv1_wgrad u8 slabs only, fresh slots", timeit(wg_fresh, iters=32), fl_)
+        if flags != [0]:
+            lib.curla_debug_ablate(0)
+
     if "fcfwd" in args.what:  # the encoder fc forward of three encoders in one launch: tiled GEMM against the streaming kernel
         Kf, Fd = 30752, 50
         hs = [torch.relu(r(B, Kf)) for _ in range(3)]
