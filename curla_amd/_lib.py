@@ -57,6 +57,7 @@ SIGNATURES = {
     "curla_gemm_small_shape": [c_int, c_int, c_int, c_int],
     "curla_gemm_colsum": [vp, c_int, c_int, c_ll, vp, c_int, c_int, c_ll, vp, c_int, c_ll, c_int, c_int, c_int, c_int, vp,
                           c_ll, vp],
+    "curla_linear_bwd": [vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, vp, c_ll, c_int, c_int, c_int, c_int, vp],
     "curla_fc_ln_fwd": [vp, c_int, c_ll, c_int, vp, vp, vp, c_int, c_int, c_float, vp, vp, vp, vp, c_int, vp, vp, c_int,
                         vp],
     "curla_critic_td_loss": [vp, vp, c_ll, vp, vp, vp, vp, c_float, c_int, vp, vp, vp, vp],

@@ -2478,6 +2478,12 @@ static int launch_wgrad1(const void* src, int src_kind, const int64_t* idx, cons
     size_t lds = (((size_t)(2 * a.th + 1) * RSb + 15) & ~(size_t)15) + 32;
     if (lds < (size_t)(nw + 32) * sizeof(float)) lds = (size_t)(nw + 32) * sizeof(float);
     if (lds < (size_t)nwaves * 1024) lds = (size_t)nwaves * 1024;  // the final cross-wave sum: one tile of every wave
+    {  // ... and all of a wave's tiles at once (ONE pass of the sum: 48.3 -> 44.8 us at 84x84x9) where two workgroups
+       // of that size still share a CU
+      const int k9 = 9 * C, ntiles = 2 * ((k9 % 16 == 1) ? k9 / 16 : (k9 + 15) / 16);
+      const size_t one_pass = (size_t)ntiles * nwaves * 1024;
+      if (nwaves == 8 && one_pass <= 80 * 1024 && lds < one_pass) lds = one_pass;
+    }
     a.lds_bytes = (unsigned)lds;
     const int nitems = B * a.nbands;
     const int per_cu = nwaves == 4 ? 4 : 2;

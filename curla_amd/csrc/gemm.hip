@@ -11,6 +11,7 @@
 // grid.z enumerates batch x split-K; a split writes its partial product to
 // C + split * split_stride and the caller reduces (deterministic order).
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.h"
 
@@ -145,20 +146,21 @@ __device__ __forceinline__ void frags(const float* __restrict__ S, int row, int 
 // The k loop is double-buffered in LDS (two operand tile pairs, 40 KB): while the waves multiply tile t out of one
 // buffer, tile t+1 goes from registers into the other and tile t+2 is in flight from HBM/L2 -- ONE barrier per k tile,
 // and the LDS write -> barrier -> fragment read latency of the next tile sits under the current tile's MFMAs.
+using GemmLds = float[2][BK * KSTR];
+
+// one TBM x TBN output tile (tile column bx, tile row by, batch x split item z) by the 256 threads of a workgroup
 template <bool AK, bool BKM, int TBM, int TBN, bool FAST>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int z, GemmLds& As,
+                                          GemmLds& Bs) {
   constexpr int MI = TBM / 32;  // 16-row fragments per wave
   constexpr int WM = TBM / 2;   // rows per wave
   constexpr int NJ = TBN / 32;
   constexpr int WN = TBN / 2;  // columns per wave
-  __shared__ __attribute__((aligned(16))) float As[2][BK * KSTR];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * KSTR];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
-  const int z = blockIdx.z;
   const int batch = z / g.ksplit, ks = z - batch * g.ksplit;
-  const int m0 = blockIdx.y * TBM, n0 = blockIdx.x * TBN;
+  const int m0 = by * TBM, n0 = bx * TBN;
   const int bo = batch / g.nb_inner, bi = batch - bo * g.nb_inner;
   const float* A = g.nptr ? g.Ap[batch] : g.A + bi * g.sA + bo * g.sA2;
   const float* B = g.nptr ? g.Bp[batch] : g.B + bi * g.sB + bo * g.sB2;
@@ -289,6 +291,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
         }
       }
     }
+}
+
+template <bool AK, bool BKM, int TBM, int TBN, bool FAST>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) GemmLds As, Bs;
+  gemm_tile<AK, BKM, TBM, TBN, FAST>(g, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+}
+
+// Backward of a linear layer as ONE launch: the weight gradient dW = dy^T x (both operands k-major, k = the batch rows)
+// and the data gradient dx = (dy W) masked (W k-major) are independent products over the same dy -- the first `n1`
+// workgroups take the tiles of the first, the rest the tiles of the second (grids gx x gy x batch each).  Saves a
+// launch's ramp and tail per layer and lets the second product's first workgroups fill the first one's last round.
+template <int TM1, int TN1, int TM2, int TN2>
+__global__ __launch_bounds__(256) void gemm_pair_kernel(GemmArgs g1, GemmArgs g2, int n1, int gx1, int gy1, int gx2,
+                                                        int gy2) {
+  __shared__ __attribute__((aligned(16))) GemmLds As, Bs;
+  int bid = blockIdx.x;
+  if (bid < n1) {
+    const int r = bid / gx1;
+    gemm_tile<true, true, TM1, TN1, true>(g1, bid - r * gx1, r % gy1, r / gy1, As, Bs);
+  } else {
+    bid -= n1;
+    const int r = bid / gx2;
+    gemm_tile<false, true, TM2, TN2, true>(g2, bid - r * gx2, r % gy2, r / gy2, As, Bs);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -908,23 +935,22 @@ __global__ __launch_bounds__(256, 2) void fc_fwd_kernel(FcFwdArgs g) {
 // quarter-lane-group q multiplies k = 16c + 4q + s), so a row-major operand is one float4 per lane and chunk.
 // ---------------------------------------------------------------------------
 template <bool AK, bool BKM, int NW, int U>
-__global__ __launch_bounds__(64 * NW) void gemm_small_kernel(GemmArgs g) {
-  __shared__ f32x4 red[NW][64];
+__device__ __forceinline__ void gemm_small_tile(const GemmArgs& g, const int bx, const int by, const int batch,
+                                                f32x4 (&red)[NW][64], float (&red_cs)[NW][16]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, kq = lane >> 4;
-  const int batch = blockIdx.z;
   const int bo = batch / g.nb_inner, bi = batch - bo * g.nb_inner;
   const float* A = g.A + bi * g.sA + bo * g.sA2;
   const float* B = g.B + bi * g.sB + bo * g.sB2;
   float* C = g.C + bi * g.sC + bo * g.sC2;
-  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+  const int m0 = by * 16, n0 = bx * 16;
   const int mi = min(m0 + li, g.M - 1), ni = min(n0 + li, g.N - 1);  // (edge lanes re-read the last row; never stored)
   // a lane's element (row r, k) of chunk c, step s: k = 16c + 4kq + s
   const float* pa = AK ? A + (size_t)(4 * kq) * g.lda + mi : A + (size_t)mi * g.lda + 4 * kq;
   const float* pb = BKM ? B + (size_t)(4 * kq) * g.ldb + ni : B + (size_t)ni * g.ldb + 4 * kq;
   const size_t ca = AK ? (size_t)16 * g.lda : 16, cb = BKM ? (size_t)16 * g.ldb : 16;
   // colsum: the workgroups of the first column of tiles also add up the A operands they load anyway
-  const bool do_cs = g.colsum && blockIdx.x == 0;  // block-uniform
+  const bool do_cs = g.colsum && bx == 0;  // block-uniform
   float asum = 0.f;
   const int T = (g.K / 16) / NW;  // chunks per wave (the host guarantees K % (16 * NW) == 0)
   struct Frag {
@@ -972,7 +998,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_small_kernel(GemmArgs g) {
 #pragma unroll
     for (int u = 0; u < U; ++u) cur[u] = nxt[u];
   }
-  __shared__ float red_cs[NW][16];
   if (do_cs) {  // the four k-quarters of a row sit in lanes li, li+16, li+32, li+48
     asum += __shfl_xor(asum, 16);
     asum += __shfl_xor(asum, 32);
@@ -1001,6 +1026,30 @@ __global__ __launch_bounds__(64 * NW) void gemm_small_kernel(GemmArgs g) {
   }
 }
 
+template <bool AK, bool BKM, int NW, int U>
+__global__ __launch_bounds__(64 * NW) void gemm_small_kernel(GemmArgs g) {
+  __shared__ f32x4 red[NW][64];
+  __shared__ float red_cs[NW][16];
+  gemm_small_tile<AK, BKM, NW, U>(g, blockIdx.x, blockIdx.y, blockIdx.z, red, red_cs);
+}
+
+// the two small products of a linear layer's backward pass (see gemm_pair_kernel) in one launch
+template <int NW, int U>
+__global__ __launch_bounds__(64 * NW) void gemm_small_pair_kernel(GemmArgs g1, GemmArgs g2, int n1, int gx1, int gy1,
+                                                                  int gx2, int gy2) {
+  __shared__ f32x4 red[NW][64];
+  __shared__ float red_cs[NW][16];
+  int bid = blockIdx.x;
+  if (bid < n1) {
+    const int r = bid / gx1;
+    gemm_small_tile<true, true, NW, U>(g1, bid - r * gx1, r % gy1, r / gy1, red, red_cs);
+  } else {
+    bid -= n1;
+    const int r = bid / gx2;
+    gemm_small_tile<false, true, NW, U>(g2, bid - r * gx2, r % gy2, r / gy2, red, red_cs);
+  }
+}
+
 // sum split-K partials: C[m][n] = sum_s P[s][m][n] (+bias, ReLU)
 __global__ void splitk_reduce_kernel(const float* P, int nsplit, long long sSplit, int M, int N, int ldp, float* C,
                                      int ldc, const float* bias, int relu) {
@@ -1025,33 +1074,21 @@ static bool small_shape(int M, int N, int K, int nbatch) {
   return small_on && K >= 256 && K % 64 == 0 && t32 <= 128 && nbatch <= 65535;
 }
 
-static int gemm_launch(GemmArgs& g, int a_kmajor, int b_kmajor, hipStream_t st) {
+// which kernel a product takes: the small-output kernel (16 or 4 waves per tile) or the tiled one with its tile shape
+struct GemmPlan {
+  bool small, wide, fast;
+  int tbm, tbn;
+};
+
+static int gemm_plan(GemmArgs& g, int a_kmajor, int b_kmajor, GemmPlan& p) {
   const int M = g.M, N = g.N, K = g.K, nbatch = g.nbatch, ksplit = g.ksplit;
-  {
+  p.small = ksplit == 1 && !g.bias && !g.mask && !g.relu && g.nptr == 0 && small_shape(M, N, K, nbatch);
+  p.wide = false, p.fast = false, p.tbm = p.tbn = 16;
+  if (g.colsum && !p.small) return CURLA_ERR_UNSUPPORTED;
+  if (p.small) {
     const long long t16 = (long long)((M + 15) / 16) * ((N + 15) / 16) * nbatch;
-    const bool small = ksplit == 1 && !g.bias && !g.mask && !g.relu && g.nptr == 0 && small_shape(M, N, K, nbatch);
-    if (g.colsum && !small) return CURLA_ERR_UNSUPPORTED;
-    if (small) {
-      const bool wide = t16 < 64 && K % 256 == 0;  // a handful of tiles: 16 waves each
-      const dim3 grid((N + 15) / 16, (M + 15) / 16, nbatch);
-#define CURLA_GEMM_SMALL(AKM, BKMAJ)                                                              \
-  do {                                                                                            \
-    if (wide)                                                                                     \
-      hipLaunchKernelGGL((gemm_small_kernel<AKM, BKMAJ, 16, 2>), grid, dim3(1024), 0, st, g);     \
-    else                                                                                          \
-      hipLaunchKernelGGL((gemm_small_kernel<AKM, BKMAJ, 4, 8>), grid, dim3(256), 0, st, g);       \
-  } while (0)
-      if (a_kmajor && b_kmajor)
-        CURLA_GEMM_SMALL(true, true);
-      else if (a_kmajor)
-        CURLA_GEMM_SMALL(true, false);
-      else if (b_kmajor)
-        CURLA_GEMM_SMALL(false, true);
-      else
-        CURLA_GEMM_SMALL(false, false);
-#undef CURLA_GEMM_SMALL
-      return curla_launch_status();
-    }
+    p.wide = t16 < 64 && K % 256 == 0;  // a handful of tiles: 16 waves each
+    return CURLA_OK;
   }
   int kc = (K + ksplit - 1) / ksplit;
   kc = (kc + BK - 1) / BK * BK;  // chunk boundaries stay float4-aligned
@@ -1082,10 +1119,42 @@ static int gemm_launch(GemmArgs& g, int a_kmajor, int b_kmajor, hipStream_t st) 
       if (v == 3232) tbm = 32, tbn = 32;
     }
   }
+  p.tbm = tbm, p.tbn = tbn;
   // interior + aligned everywhere: the k loop runs without bounds / alignment tests
   // (a k-major operand still needs whole tiles: its float4 runs along the rows)
-  const bool fast = g.vecA && g.vecB && (K % BK == 0) && (g.kchunk % BK == 0) && (!a_kmajor || M % tbm == 0) &&
-                    (!b_kmajor || N % tbn == 0);
+  p.fast = g.vecA && g.vecB && (K % BK == 0) && (g.kchunk % BK == 0) && (!a_kmajor || M % tbm == 0) &&
+           (!b_kmajor || N % tbn == 0);
+  return CURLA_OK;
+}
+
+static int gemm_launch(GemmArgs& g, int a_kmajor, int b_kmajor, hipStream_t st) {
+  const int M = g.M, N = g.N, nbatch = g.nbatch, ksplit = g.ksplit;
+  GemmPlan p;
+  const int prc = gemm_plan(g, a_kmajor, b_kmajor, p);
+  if (prc != CURLA_OK) return prc;
+  if (p.small) {
+    const bool wide = p.wide;
+    const dim3 grid((N + 15) / 16, (M + 15) / 16, nbatch);
+#define CURLA_GEMM_SMALL(AKM, BKMAJ)                                                              \
+  do {                                                                                            \
+    if (wide)                                                                                     \
+      hipLaunchKernelGGL((gemm_small_kernel<AKM, BKMAJ, 16, 2>), grid, dim3(1024), 0, st, g);     \
+    else                                                                                          \
+      hipLaunchKernelGGL((gemm_small_kernel<AKM, BKMAJ, 4, 8>), grid, dim3(256), 0, st, g);       \
+  } while (0)
+    if (a_kmajor && b_kmajor)
+      CURLA_GEMM_SMALL(true, true);
+    else if (a_kmajor)
+      CURLA_GEMM_SMALL(true, false);
+    else if (b_kmajor)
+      CURLA_GEMM_SMALL(false, true);
+    else
+      CURLA_GEMM_SMALL(false, false);
+#undef CURLA_GEMM_SMALL
+    return curla_launch_status();
+  }
+  const int tbm = p.tbm, tbn = p.tbn;
+  const bool fast = p.fast;
 #define CURLA_GEMM_LAUNCH3(AKM, BKMAJ, TM, TN, FS)                                                          \
   hipLaunchKernelGGL((gemm_kernel<AKM, BKMAJ, TM, TN, FS>), dim3((N + TN - 1) / TN, (M + TM - 1) / TM, nbatch * ksplit), \
                      dim3(256), 0, st, g)
@@ -1157,6 +1226,69 @@ int curla_gemm_colsum(const float* A, int a_kmajor, int lda, long long strideA, 
   g.nb_inner = nbatch, g.sA2 = g.sB2 = g.sC2 = g.sBias2 = g.sMask2 = 0;
   g.colsum = colsum, g.sColsum = strideColsum, g.sColsum2 = 0;
   return gemm_launch(g, a_kmajor, b_kmajor, static_cast<hipStream_t>(stream));
+}
+
+static void gemm_args_plain(GemmArgs& g, const float* A, int lda, long long sA, const float* B, int ldb, long long sB,
+                            float* C, int ldc, long long sC, int M, int N, int K, int nbatch) {
+  g.A = A, g.B = B, g.C = C, g.bias = nullptr, g.mask = nullptr;
+  g.M = M, g.N = N, g.K = K, g.lda = lda, g.ldb = ldb, g.ldc = ldc, g.ldmask = 0;
+  g.sA = sA, g.sB = sB, g.sC = sC, g.sBias = 0, g.sMask = 0, g.sSplit = 0;
+  g.nbatch = nbatch, g.ksplit = 1, g.kchunk = 0;
+  g.alpha = 1.f, g.relu = 0, g.stream_c = 0;
+  g.vecA = (lda % 4 == 0) && (sA % 4 == 0) && aligned16(A);
+  g.vecB = (ldb % 4 == 0) && (sB % 4 == 0) && aligned16(B);
+  g.nptr = 0;
+  g.nb_inner = nbatch, g.sA2 = g.sB2 = g.sC2 = g.sBias2 = g.sMask2 = 0;
+  g.colsum = nullptr, g.sColsum = g.sColsum2 = 0;
+}
+
+int curla_linear_bwd(const float* dy, long long stride_dy, const float* x, long long stride_x, const float* W,
+                     long long stride_W, const float* mask, long long stride_mask, float* dW, long long stride_dW,
+                     float* db, long long stride_db, float* dx, long long stride_dx, int B, int N, int K, int nbatch,
+                     void* stream) {
+  CURLA_REQUIRE(dy && x && W && dW && dx && B > 0 && N > 0 && K > 0 && nbatch > 0);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  GemmArgs g1, g2;
+  // dW[n][k] = sum_b dy[b][n] x[b][k]: both operands k-major (k = batch row)
+  gemm_args_plain(g1, dy, N, stride_dy, x, K, stride_x, dW, K, stride_dW, N, K, B, nbatch);
+  g1.colsum = db, g1.sColsum = stride_db;
+  // dx[b][k] = sum_n dy[b][n] W[n][k], zero where mask <= 0: W k-major
+  gemm_args_plain(g2, dy, N, stride_dy, W, K, stride_W, dx, K, stride_dx, B, K, N, nbatch);
+  g2.mask = mask, g2.ldmask = K, g2.sMask = stride_mask;
+  GemmPlan p1, p2;
+  int rc = gemm_plan(g1, 1, 1, p1);
+  if (rc != CURLA_OK) return rc;
+  rc = gemm_plan(g2, 0, 1, p2);
+  if (rc != CURLA_OK) return rc;
+  static const bool split = getenv("CURLA_LINEAR_BWD") && !strcmp(getenv("CURLA_LINEAR_BWD"), "split");
+  const int T1 = p1.small ? 16 : 0, T2 = p2.small ? 16 : 0;
+  const int gx1 = (g1.N + (T1 ? T1 : p1.tbn) - 1) / (T1 ? T1 : p1.tbn), gy1 = (g1.M + (T1 ? T1 : p1.tbm) - 1) / (T1 ? T1 : p1.tbm);
+  const int gx2 = (g2.N + (T2 ? T2 : p2.tbn) - 1) / (T2 ? T2 : p2.tbn), gy2 = (g2.M + (T2 ? T2 : p2.tbm) - 1) / (T2 ? T2 : p2.tbm);
+  const long long n1 = (long long)gx1 * gy1 * nbatch, n2 = (long long)gx2 * gy2 * nbatch;
+  if (!split && n1 + n2 < (1LL << 30)) {
+    if (p1.small && p2.small && !p1.wide && !p2.wide) {
+      hipLaunchKernelGGL((gemm_small_pair_kernel<4, 8>), dim3((unsigned)(n1 + n2)), dim3(256), 0, st, g1, g2, (int)n1, gx1,
+                         gy1, gx2, gy2);
+      return curla_launch_status();
+    }
+    if (!p1.small && !p2.small && p1.fast && p2.fast) {
+#define CURLA_PAIR(TM1, TN1, TM2, TN2)                                                                                   \
+  if (p1.tbm == TM1 && p1.tbn == TN1 && p2.tbm == TM2 && p2.tbn == TN2) {                                               \
+    hipLaunchKernelGGL((gemm_pair_kernel<TM1, TN1, TM2, TN2>), dim3((unsigned)(n1 + n2)), dim3(256), 0, st, g1, g2,      \
+                       (int)n1, gx1, gy1, gx2, gy2);                                                                     \
+    return curla_launch_status();                                                                                        \
+  }
+      // (the shapes the twin-Q and the actor MLPs produce at batch 512 and 1024, hidden 1024)
+      CURLA_PAIR(64, 64, 64, 32)
+      CURLA_PAIR(64, 32, 32, 32)
+      CURLA_PAIR(64, 64, 64, 64)
+      CURLA_PAIR(64, 32, 64, 32)
+#undef CURLA_PAIR
+    }
+  }
+  rc = gemm_launch(g1, 1, 1, st);
+  if (rc != CURLA_OK) return rc;
+  return gemm_launch(g2, 0, 1, st);
 }
 
 int curla_gemm_nested(const float* A, int a_kmajor, int lda, long long strideA, long long strideA2, const float* B,

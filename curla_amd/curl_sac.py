@@ -119,15 +119,20 @@ def _mlp_bwd(x, sx, P, G, nb, B, din, H, dout, h1, h2, dy, dh2, dh1, dx, loss=No
         if G is not None:
             ops.linear_dw(dy, B * dout, h2, B * H, G.W[2], s, B, dout, H, nb)
         ops.linear_dx(dy, B * dout, P.W[2], s, dh2, B * H, B, dout, H, nb, mask=h2, smask=B * H)
+    # a layer's weight and data gradient are independent products over the same dy: one launch for the pair
     if G is not None:
-        ops.linear_dw(dh2, B * H, h1, B * H, G.W[1], s, B, H, H, nb)
-    ops.linear_dx(dh2, B * H, P.W[1], s, dh1, B * H, B, H, H, nb, mask=h1, smask=B * H)
-    if G is not None:
+        ops.linear_bwd(dh2, B * H, h1, B * H, P.W[1], s, G.W[1], s, dh1, B * H, B, H, H, nb, mask=h1, smask=B * H)
+    else:
+        ops.linear_dx(dh2, B * H, P.W[1], s, dh1, B * H, B, H, H, nb, mask=h1, smask=B * H)
+    if G is not None and dx is not None:
+        ops.linear_bwd(dh1, B * H, x, sx, P.W[0], s, G.W[0], s, dx, B * din, B, H, din, nb,
+                       db=G.b[0] if fold else None, sdb=s)
+    elif G is not None:
         ops.linear_dw(dh1, B * H, x, sx, G.W[0], s, B, H, din, nb, colsum=G.b[0] if fold else None, s_colsum=s)
-        if not fold:
-            ops.colsum3(dy, dout, dh2, H, dh1, H, B, G.b[2], G.b[1], G.b[0], s, nb)
-    if dx is not None:
+    elif dx is not None:
         ops.linear_dx(dh1, B * H, P.W[0], s, dx, B * din, B, H, din, nb)
+    if G is not None and not fold:
+        ops.colsum3(dy, dout, dh2, H, dh1, H, B, G.b[2], G.b[1], G.b[0], s, nb)
 
 
 class Actor(nn.Module):

@@ -303,6 +303,13 @@ def linear_dw(dy, sdy, x, sx, out, so, M, N, K, nb=1, colsum=None, s_colsum=0):
              s_colsum, stream())
 
 
+def linear_bwd(dy, sdy, x, sx, W, sW, dW, sdW, dx, sdx, M, N, K, nb=1, mask=None, smask=0, db=None, sdb=0):
+    """linear_dw + linear_dx of one layer over the same dy [M,N] in ONE launch where both products take the same kernel
+    family (two launches otherwise): dW [N,K] = dy^T x, dx [M,K] = (dy W) masked; ``db`` [N] as linear_dw's colsum."""
+    call("curla_linear_bwd", ptr(dy), sdy, ptr(x), sx, ptr(W), sW, ptr(mask), smask, ptr(dW), sdW, ptr(db), sdb, ptr(dx),
+         sdx, M, N, K, nb, stream())
+
+
 _small_shape_cache = {}
 
 

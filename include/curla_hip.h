@@ -128,6 +128,16 @@ int curla_gemm_small_shape(int M, int N, int K, int nbatch);
 int curla_gemm_colsum(const float* A, int a_kmajor, int lda, long long strideA, const float* B, int b_kmajor, int ldb,
                       long long strideB, float* C, int ldc, long long strideC, int M, int N, int K, int nbatch,
                       float* colsum, long long strideColsum, void* stream);
+/* Backward of a batched linear layer y = x W^T (curl_sac.py:70-74, 129-133: the hidden and first layers of the actor
+ * trunk and of the twin Q functions) in ONE launch where the two products take the same kernel family, two otherwise:
+ *   dW[z][n][k] = sum_b dy[z][b][n] x[z][b][k]          (db[z][n] = sum_b dy[z][b][n] when db != NULL: needs
+ *                                                        curla_gemm_small_shape(N, K, B, nbatch), else UNSUPPORTED)
+ *   dx[z][b][k] = sum_n dy[z][b][n] W[z][n][k], zeroed where mask[z][b][k] <= 0 (mask may be NULL)
+ * dy [B][N], x / mask / dx [B][K], W / dW [N][K] row-major, batch strides in floats (0 = shared). */
+int curla_linear_bwd(const float* dy, long long stride_dy, const float* x, long long stride_x, const float* W,
+                     long long stride_W, const float* mask, long long stride_mask, float* dW, long long stride_dW,
+                     float* db, long long stride_db, float* dx, long long stride_dx, int B, int N, int K, int nbatch,
+                     void* stream);
 /* curla_gemm with a two-level batch: item (outer, inner) at base + inner * stride + outer * stride2 (no split-K).  The
  * twin Q functions of the target critic and of the critic are one such batch of four: the twins a block apart inside a
  * flat parameter buffer, the two flat buffers wherever the allocator put them (curl_sac.py:353-358). */

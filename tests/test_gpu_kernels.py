@@ -264,6 +264,48 @@ def test_gemm_small_output_long_k(ops, M, N, K, ak, bk, nb):
         assert torch.isnan(cs[:, M:]).all()
 
 
+# B, N (out features), K (in features), nbatch, shared x, bias gradient
+LINEAR_BWD_CASES = [(512, 1024, 1024, 2, False, False),  # twin-Q hidden layer: tiled pair 64x64 + 64x32
+                    (512, 1024, 1024, 1, False, False),  # actor hidden layer: tiled pair 64x32 + 32x32
+                    (1024, 1024, 1024, 2, False, False),  # batch 1024: 64x64 + 64x64
+                    (1024, 1024, 1024, 1, False, False),  # 64x32 + 64x32
+                    (512, 1024, 54, 2, True, True),      # twin-Q first layer: the small-output pair, x shared, db folded
+                    (512, 1024, 50, 1, False, True),     # actor first layer
+                    (96, 40, 24, 1, False, False),       # neither family fits both: two launches
+                    (256, 1024, 1024, 2, False, False)]
+
+
+@pytest.mark.parametrize("B,N,K,nb,shared_x,with_db", LINEAR_BWD_CASES)
+def test_linear_bwd_pair_launch(ops, B, N, K, nb, shared_x, with_db):
+    """curla_linear_bwd: dW = dy^T x (+ db) and dx = (dy W) masked from one launch, against float64 and against the
+    two separate products bit for bit (same kernels, same tiles, same order of summation)."""
+    dy, W = rnd(nb, B, N, seed=71), rnd(nb, N, K, seed=72) * 0.1
+    x = rnd(1 if shared_x else nb, B, K, seed=73)
+    mask = rnd(nb, B, K, seed=74)
+    xe = x.expand(nb, B, K)
+    dyd, Wd, xd, md = dev(dy), dev(W), dev(x), dev(mask)
+    sx = 0 if shared_x else B * K
+    dW = torch.full((nb, N, K), float("nan"), device="cuda")
+    dx = torch.full((nb, B, K), float("nan"), device="cuda")
+    db = torch.full((nb, N), float("nan"), device="cuda") if with_db else None
+    if with_db:
+        assert ops.linear_dw_folds_bias(B, N, K, nb)
+    ops.linear_bwd(dyd, B * N, xd, sx, Wd, N * K, dW, N * K, dx, B * K, B, N, K, nb, mask=md, smask=B * K, db=db, sdb=N)
+    tol = 3e-5
+    check(f"linear_bwd dW {B}x{N}x{K} nb{nb}", dW.cpu(), torch.einsum("zbn,zbk->znk", dy.double(), xe.double()).float(), tol)
+    check(f"linear_bwd dx {B}x{N}x{K} nb{nb}", dx.cpu(),
+          (torch.einsum("zbn,znk->zbk", dy.double(), W.double()) * (mask > 0)).float(), tol)
+    if with_db:
+        check(f"linear_bwd db {B}x{N}x{K} nb{nb}", db.cpu(), dy.double().sum(1).float(), tol)
+    dW2, dx2 = torch.full_like(dW, float("nan")), torch.full_like(dx, float("nan"))
+    db2 = torch.full_like(db, float("nan")) if with_db else None
+    ops.linear_dw(dyd, B * N, xd, sx, dW2, N * K, B, N, K, nb, colsum=db2, s_colsum=N)
+    ops.linear_dx(dyd, B * N, Wd, N * K, dx2, B * K, B, N, K, nb, mask=md, smask=B * K)
+    assert torch.equal(dW, dW2) and torch.equal(dx, dx2)
+    if with_db:
+        assert torch.equal(db, db2)
+
+
 @pytest.mark.parametrize("B,Fd,K", [(24, 50, 3456), (9, 130, 800), (5, 64, 288), (3, 256, 512), (515, 50, 64)])
 def test_gemm_splitk_and_fc_ln(ops, B, Fd, K):
     h, W, bias = rnd(B, K, seed=31), rnd(Fd, K, seed=32, scale=0.05), rnd(Fd, seed=33)

@@ -218,7 +218,7 @@ def test_update_schedule_launch_counts():
     assert even["curla_soft_update2"] == 1 and odd["curla_soft_update2"] == 0   # critic_target_update_freq = 2
     # launches that are neither convolutions nor dense layers (GEMMs / last-layer kernels): LayerNorm pieces, policy
     # head, losses, bias-gradient sums, the scalar gather, the target lerp -- kept to about twenty per even update
-    dense = ("curla_conv", "curla_gemm", "curla_mlp_out", "curla_fc_")
+    dense = ("curla_conv", "curla_gemm", "curla_mlp_out", "curla_fc_", "curla_linear_bwd")
     small = {k: v for k, v in even.items() if not k.startswith(dense)}
     assert sum(small.values()) <= 13, small
     # what used to be launches of their own and now rides in another: the LayerNorms of the encoders of a phase (one
@@ -228,6 +228,9 @@ def test_update_schedule_launch_counts():
     assert even["curla_mlp_out_head_fwd"] == 2 and odd["curla_mlp_out_head_fwd"] == 1 and even["curla_actor_head_fwd"] == 0
     assert even["curla_gemm_nested"] == 2 and even["curla_mlp_out_fwd_nested"] == 1
     assert sum(even.values()) <= 65 and sum(odd.values()) <= 46
+    # a linear layer's weight and data gradient share a launch: hidden + first layer of the twin Q functions (critic
+    # phase) and of the actor trunk (actor phase; the Q functions there only pass the gradient down: curla_gemm)
+    assert even["curla_linear_bwd"] == 4 and odd["curla_linear_bwd"] == 2
     # fc backward: data + weight gradient in one launch where the conv stack gets a gradient (critic, CURL), the
     # weight gradient alone in the actor phase (encoder detached)
     # -- and each of them finishes the LayerNorm / fc-bias gradients its LayerNorm backward left as partial sums

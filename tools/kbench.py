@@ -256,6 +256,23 @@ def main():
             report(f"linear_fwd {B}x{H}x{H} nb{nb}", timeit(lambda: ops.linear_fwd(x, B * H, W, H * H, bb, H, out, B * H, B, H, H, nb, relu=1)), fl_)
             report(f"linear_dx  {B}x{H}x{H} nb{nb}", timeit(lambda: ops.linear_dx(x, B * H, W, H * H, out, B * H, B, H, H, nb, mask=x, smask=B * H)), fl_)
             report(f"linear_dw  {B}x{H}x{H} nb{nb}", timeit(lambda: ops.linear_dw(x, B * H, out, B * H, W, H * H, B, H, H, nb)), fl_)
+            dWp, dxp = torch.empty(nb, H, H, device=dev), torch.empty(nb, B, H, device=dev)
+
+            def two():
+                ops.linear_dw(x, B * H, out, B * H, dWp, H * H, B, H, H, nb)
+                ops.linear_dx(x, B * H, W, H * H, dxp, B * H, B, H, H, nb, mask=out, smask=B * H)
+            report(f"linear_dw + linear_dx {B}x{H}x{H} nb{nb}", timeit(two), 2 * fl_)
+            report(f"linear_bwd (pair)     {B}x{H}x{H} nb{nb}",
+                   timeit(lambda: ops.linear_bwd(x, B * H, out, B * H, W, H * H, dWp, H * H, dxp, B * H, B, H, H, nb, mask=out, smask=B * H)), 2 * fl_)
+            k1 = 54 if nb == 2 else 50
+            x1, W1, dW1, dx1, db1 = r(nb, B, k1), r(nb, H, k1), torch.empty(nb, H, k1, device=dev), torch.empty(nb, B, k1, device=dev), torch.empty(nb, H, device=dev)
+
+            def two1():
+                ops.linear_dw(x, B * H, x1, B * k1, dW1, H * k1, B, H, k1, nb, colsum=db1, s_colsum=H)
+                ops.linear_dx(x, B * H, W1, H * k1, dx1, B * k1, B, H, k1, nb)
+            report(f"first layer dw + dx   {B}x{H}x{k1} nb{nb}", timeit(two1), 4.0 * nb * B * H * k1)
+            report(f"first layer pair      {B}x{H}x{k1} nb{nb}",
+                   timeit(lambda: ops.linear_bwd(x, B * H, x1, B * k1, W1, H * k1, dW1, H * k1, dx1, B * k1, B, H, k1, nb, db=db1, sdb=H)), 4.0 * nb * B * H * k1)
         h, Wf = r(B, K), r(F, K)
         for ks in (16, 32, 64):
             part = torch.empty(ks, B, F, device=dev)
