@@ -685,6 +685,63 @@ __device__ __forceinline__ void conv1_stage_u8(uint8_t* lds, const uint8_t* fram
   }
 }
 
+// The same byte staging dealt out BY ROW: wave w of NW takes crop rows w, w + NW, ..., lane g the row's g-th 16-byte
+// run (lanes past the row idle).  A row's address, its misalignment and its LDS offset are then wave-uniform -- scalar
+// registers and scalar arithmetic -- and a run costs a lane one address add instead of an integer division by the run
+// count and 64-bit pointer arithmetic (the element-per-thread form above: ~40 VALU instructions per run, ~3800 wave
+// instructions per 76x76x9 crop against the 2700 of the multiply loop that follows).  UR rows per wave and call.
+template <int UR>
+struct Conv1RowRegs {
+  uint32_t dw[UR][5];
+  uint32_t sh[UR];  // (wave-uniform)
+  int dst[UR];      // (wave-uniform row offset; < 0: no row)
+};
+
+template <int UR>
+__device__ __forceinline__ void conv1_stage_rows_issue(Conv1RowRegs<UR>& rg, const uint8_t* crop, int pitch, int nbytes,
+                                                       int rows, int RSb, int r_first, int wave, int nwaves, int lane) {
+  const bool lane_on = 16 * lane < nbytes;
+#pragma unroll
+  for (int k = 0; k < UR; ++k) {
+    const int r = r_first + wave + k * nwaves;  // (uniform)
+    rg.dst[k] = r < rows ? r * RSb : -1;
+    const uint8_t* p = crop + (size_t)min(r, rows - 1) * pitch;
+    rg.sh[k] = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 3);
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p - rg.sh[k]) + 4 * lane;
+    // (registers of rows / lanes that load nothing stay undefined: the commit never stores them)
+    if (r < rows && lane_on) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rg.dw[k][e] = q[e];
+      if (rg.sh[k]) rg.dw[k][4] = q[4];  // only touch the fifth dword when the run straddles it
+    }
+  }
+}
+
+template <int UR>
+__device__ __forceinline__ void conv1_stage_rows_commit(const Conv1RowRegs<UR>& rg, uint8_t* lds, int nbytes, int lane) {
+  const bool lane_on = 16 * lane < nbytes;
+#pragma unroll
+  for (int k = 0; k < UR; ++k) {
+    uint4 o;
+    o.x = __builtin_amdgcn_alignbyte(rg.dw[k][1], rg.dw[k][0], rg.sh[k]);
+    o.y = __builtin_amdgcn_alignbyte(rg.dw[k][2], rg.dw[k][1], rg.sh[k]);
+    o.z = __builtin_amdgcn_alignbyte(rg.dw[k][3], rg.dw[k][2], rg.sh[k]);
+    o.w = __builtin_amdgcn_alignbyte(rg.dw[k][4], rg.dw[k][3], rg.sh[k]);
+    if (rg.dst[k] >= 0 && lane_on) *reinterpret_cast<uint4*>(lds + rg.dst[k] + 16 * lane) = o;
+  }
+}
+
+// all rows [r_first, rows) of a crop, UR per wave and pass
+template <int UR>
+__device__ __forceinline__ void conv1_stage_rows(uint8_t* lds, const uint8_t* crop, int pitch, int nbytes, int rows,
+                                                 int RSb, int r_first, int wave, int nwaves, int lane) {
+  for (int r0 = r_first; r0 < rows; r0 += UR * nwaves) {
+    Conv1RowRegs<UR> rg;
+    conv1_stage_rows_issue<UR>(rg, crop, pitch, nbytes, rows, RSb, r0, wave, nwaves, lane);
+    conv1_stage_rows_commit<UR>(rg, lds, nbytes, lane);
+  }
+}
+
 // float4 copy of `n4` contiguous float4 from HBM into the pixel-padded LDS band layout (8 float4 per pixel ->
 // stride kLdsPix floats), U loads in flight per thread per pass
 __device__ __forceinline__ void stage_band_f32(float* lds_band, const float* src, int n4, int tid, int nthreads) {
@@ -838,14 +895,16 @@ __global__ __launch_bounds__(512, 2) void conv1_u8_walk_kernel(Conv1Args a, rw::
   const int b = second ? blockIdx.x - a.B : blockIdx.x;
   if (second) a.idx = a.idx2, a.h1 = a.h1_2, a.w1 = a.w1_2, a.w = a.w2, a.bias = a.bias2, a.out = a.out2;
   // the crop's bytes: requested before the weight phase, stored to LDS after it (same region)
-  constexpr int U0 = 7;
-  Conv1StageRegs<U0> rg0;
+  constexpr int U0 = 10;  // rows per wave in flight across the weight phase (8 waves x 10 >= the 77 rows of a 76x76 crop)
+  Conv1RowRegs<U0> rg0;
+  const int crop_rows = 2 * a.Ho + 1, crop_bytes = a.Wc * C;
+  const uint8_t* crop0;
   {
-    const int64_t fi = a.idx ? a.idx[b] : b;
-    const int oh0 = a.h1 ? a.h1[b] : 0, ow0 = a.w1 ? a.w1[b] : 0;
-    const uint8_t* frame0 = static_cast<const uint8_t*>(a.src) + (size_t)fi * a.Hs * a.Ws * C;
-    conv1_stage_u8_issue<U0>(rg0, frame0, oh0, ow0, C, a.Ws, a.Wc, 0, 2 * a.Ho + 1, RSb, 0, tid, 512);
+    const int64_t fi = a.idx ? rw::const_load(a.idx, b) : (int64_t)b;  // (scalar loads: b is wave-uniform)
+    const int oh0 = a.h1 ? rw::const_load(a.h1, b) : 0, ow0 = a.w1 ? rw::const_load(a.w1, b) : 0;
+    crop0 = static_cast<const uint8_t*>(a.src) + ((size_t)fi * a.Hs + oh0) * a.Ws * C + (size_t)ow0 * C;
   }
+  conv1_stage_rows_issue<U0>(rg0, crop0, a.Ws * C, crop_bytes, crop_rows, RSb, 0, wave, 8, lane);  // (host: <= 64 runs per row)
   for (int i = tid; i < 3 * KR * 32; i += 512) {
     const int co = i & 31, k = i >> 5;
     const int dy = k / KR, rr = k - dy * KR;
@@ -868,9 +927,8 @@ __global__ __launch_bounds__(512, 2) void conv1_u8_walk_kernel(Conv1Args a, rw::
   for (int mt = 0; mt < 2; ++mt) bias4[mt] = *reinterpret_cast<const f32x4*>(a.bias + mt * 16 + 4 * kq);
   __syncthreads();
   uint8_t* ldsb = reinterpret_cast<uint8_t*>(lds);
-  conv1_stage_u8_commit<U0>(rg0, ldsb);
-  conv1_stage_u8(ldsb, static_cast<const uint8_t*>(a.src), a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Wc, 0, 2 * a.Ho + 1, RSb,
-                 tid, 512, /*first_run=*/U0 * 512);
+  conv1_stage_rows_commit<U0>(rg0, ldsb, crop_bytes, lane);
+  conv1_stage_rows<4>(ldsb, crop0, a.Ws * C, crop_bytes, crop_rows, RSb, /*r_first=*/U0 * 8, wave, 8, lane);
   __syncthreads();
 
   const int lo = G.steps * wave / 8, hi = G.steps * (wave + 1) / 8;
@@ -1466,9 +1524,16 @@ __global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
     const int band = item / a.B, b = item - band * a.B;
     const int y0 = band * a.th;
     const int tha = min(a.th, a.Ho - y0);
-    if (!ABL(1))
-      conv1_stage_u8(ldsb, static_cast<const uint8_t*>(a.src), a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Wc, 2 * y0,
-                     2 * tha + 1, RSb, tid, NTHR);
+    if (!ABL(1)) {
+      const int64_t fi = a.idx ? rw::const_load(a.idx, b) : (int64_t)b;  // (scalar loads: b is wave-uniform)
+      const int oh = a.h1 ? rw::const_load(a.h1, b) : 0, ow = a.w1 ? rw::const_load(a.w1, b) : 0;
+      const uint8_t* crop = static_cast<const uint8_t*>(a.src) + ((size_t)fi * a.Hs + oh + 2 * y0) * a.Ws * C + (size_t)ow * C;
+      if (a.Wc * C <= 64 * 16)  // a lane per 16-byte run of a row
+        conv1_stage_rows<10>(ldsb, crop, a.Ws * C, a.Wc * C, 2 * tha + 1, RSb, 0, wave, NW, lane);
+      else
+        conv1_stage_u8(ldsb, static_cast<const uint8_t*>(a.src), a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Wc, 2 * y0,
+                       2 * tha + 1, RSb, tid, NTHR);
+    }
     __syncthreads();
     const float* const gband = a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32 + li;  // the band's pixels are contiguous
     // The walk.  A k-step ("unit") is 4 pixels, lane group kq takes one of them; units come in PIECES of UNR, and the
@@ -2163,7 +2228,8 @@ static int conv1_fwd_impl(const void* src, int src_kind, const int64_t* idx, con
   }
     // one band = the whole crop in LDS: the hybrid form (row walk out of LDS) unless CURLA_C1_U8=band asks for the old loop
     const char* impl = getenv("CURLA_C1_U8");
-    if (a.nbands == 1 && use_rw() && !(impl && !strcmp(impl, "band"))) {
+    // (its staging gives a lane one 16-byte run of a crop row: rows of at most 64 runs)
+    if (a.nbands == 1 && Wc * C <= 64 * 16 && use_rw() && !(impl && !strcmp(impl, "band"))) {
       rw::Geom G;
       G.Hi = Hc, G.Wi = Wc, G.Ho = a.Ho, G.Wo = a.Wo;
       rw::plan_units(G, a.Ho, a.Wo, 16);

@@ -47,6 +47,7 @@ def main():
     ap.add_argument("--what", type=str, default="conv,gemm,misc")
     ap.add_argument("--slots", type=int, default=2048, help="c1only: ring slots (2048 = 130 MB: Infinity-Cache resident)")
     ap.add_argument("--outs", type=int, default=1, help="c1only: rotate over this many output buffers")
+    ap.add_argument("--lib", type=str, default="", help="measure this build of the library instead (A/B against an older commit)")
     args = ap.parse_args()
     if args.build_ablate:
         print(build_ablate())
@@ -56,6 +57,9 @@ def main():
     if flags != [0]:
         _lib.LIB_PATH = os.path.join(ROOT, "tools", "_build", "libcurla_ablate.so")
         _lib.SIGNATURES["curla_debug_ablate"] = [ctypes.c_int]
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
+        os.environ["CURLA_SKIP_SRCHASH"] = "1"
     lib = _lib.load()
     B = args.B
     dev = "cuda"
