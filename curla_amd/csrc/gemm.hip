@@ -828,13 +828,13 @@ __global__ __launch_bounds__(256, 2) void fc_fwd_kernel(FcFwdArgs g) {
     }
   };
   f32x4 acc[2][NT];
-  float atail[2][NTL];
+  f32x2 atail[2][NTL];  // (even / odd k of the lane's values apart: one packed FMA per register pair, added at the end)
 #pragma unroll
   for (int bt = 0; bt < 2; ++bt) {
 #pragma unroll
     for (int ft = 0; ft < NT; ++ft) acc[bt][ft] = f32x4{0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < NTL; ++j) atail[bt][j] = 0.f;
+    for (int j = 0; j < NTL; ++j) atail[bt][j] = f32x2{0.f, 0.f};
   }
   auto multiply = [&](const XS& X, const float* wc, int sj) {  // slice sj of the chunk at wc
     f32x4 wv[NT][2], wt[NTL][2];
@@ -864,9 +864,10 @@ __global__ __launch_bounds__(256, 2) void fc_fwd_kernel(FcFwdArgs g) {
 #pragma unroll
         for (int bt = 0; bt < 2; ++bt)
 #pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) atail[bt][j] = fmaf(X.v[bt][h][e], wt[j][h][e], atail[bt][j]);
+          for (int h = 0; h < 2; ++h) {
+            atail[bt][j] += f32x2{X.v[bt][h][0], X.v[bt][h][1]} * f32x2{wt[j][h][0], wt[j][h][1]};
+            atail[bt][j] += f32x2{X.v[bt][h][2], X.v[bt][h][3]} * f32x2{wt[j][h][2], wt[j][h][3]};
+          }
     }
   };
   const int nchunks = (s1 - s0 + kFcChunk - 1) / kFcChunk;
@@ -916,7 +917,7 @@ __global__ __launch_bounds__(256, 2) void fc_fwd_kernel(FcFwdArgs g) {
     if (NTAIL > 0) {
 #pragma unroll
       for (int j = 0; j < NTAIL; ++j) {  // the four quarters of a slice's k sit in the four lane groups: add them in order
-        float v = atail[bt][j];
+        float v = atail[bt][j][0] + atail[bt][j][1];
         const float q1 = __shfl(v, li + 16), q2 = __shfl(v, li + 32), q3 = __shfl(v, li + 48);
         if (kq == 0) row[16 * NT + j] = ((v + q1) + q2) + q3;
       }
