@@ -19,7 +19,15 @@ namespace {
 
 constexpr int BM = 64, BN = 64, BK = 32;
 constexpr int RSTR = BK + 8;   // LDS stride, row-major tile [64][BK]: 40 floats -> 16-B aligned rows, ds_read_b128 of 16 rows x 4 k-quarters conflict-free
-constexpr int KSTR = BM + 16;  // LDS stride, k-major tile [BK][64]  (80 = 16 mod 32: the two lane groups of a half are disjoint)
+#ifndef CURLA_GEMM_KSTR
+#define CURLA_GEMM_KSTR (BM + 4)
+#endif
+// LDS stride, k-major tile [BK][64].  A fragment read is k = 16j + 4kq + e of row li: bank = (k * KSTR + li) mod 32, and
+// with KSTR = 68 (= 4 mod 32) that is (16 kq + 4 e + li) mod 32 -- the two lane groups of a half-wave (kq, kq + 1) take
+// disjoint halves of the banks.  (80, the stride of rounds 1-2, put both on the same 16 banks: SQ_LDS_BANK_CONFLICT 0.3-0.4
+// of the LDS cycles of the kernels with a k-major operand.)
+constexpr int KSTR = CURLA_GEMM_KSTR;
+constexpr int kGemmTileFloats = (BK * KSTR > BM * RSTR) ? BK * KSTR : BM * RSTR;
 
 struct GemmArgs {
   const float* A;
@@ -146,7 +154,7 @@ __device__ __forceinline__ void frags(const float* __restrict__ S, int row, int 
 // The k loop is double-buffered in LDS (two operand tile pairs, 40 KB): while the waves multiply tile t out of one
 // buffer, tile t+1 goes from registers into the other and tile t+2 is in flight from HBM/L2 -- ONE barrier per k tile,
 // and the LDS write -> barrier -> fragment read latency of the next tile sits under the current tile's MFMAs.
-using GemmLds = float[2][BK * KSTR];
+using GemmLds = float[2][kGemmTileFloats];
 
 // one TBM x TBN output tile (tile column bx, tile row by, batch x split item z) by the 256 threads of a workgroup
 template <bool AK, bool BKM, int TBM, int TBN, bool FAST>
