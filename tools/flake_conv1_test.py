@@ -5,10 +5,16 @@ from tests import test_gpu_kernels as T
 from curla_amd import ops
 n_bad = 0
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 10):
-    for case in T.CONV1_CASES:
-        try:
-            T.test_crop_and_conv1_u8(ops, *case)
-        except AssertionError as e:
-            n_bad += 1
-            print("rep", rep, case, "->", str(e)[:200], flush=True)
+    for impl in ("hybrid", "band", "rw"):  # (what the u8_impl fixture does)
+        if impl == "hybrid":
+            os.environ.pop("CURLA_C1_U8", None)
+        else:
+            os.environ["CURLA_C1_U8"] = impl
+        for case in T.CONV1_CASES:
+            try:
+                T.test_crop_and_conv1_u8(ops, impl, *case)
+            except AssertionError as e:
+                n_bad += 1
+                print("rep", rep, impl, case, "->", str(e)[:200], flush=True)
+os.environ.pop("CURLA_C1_U8", None)
 print("failures:", n_bad)
