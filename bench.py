@@ -20,6 +20,17 @@ measures c3 and c5 as well (the c2 ring is freed first) and reports them under `
 measures one configuration only.  At N > 1 only c2 is measured unless ``--others`` asks for all three (a failure in a
 secondary configuration of a multi-GPU job would take the headline line down with it).
 
+At N > 1 BOTH data-parallel schedules are measured (``--schedule auto``, the default): the blocking one (one all-reduce
+per gradient bucket in front of its optimizer step) and the overlapped one (each bucket in two asynchronous pieces under
+the conv backward); the line's ``value`` is the faster one's K timed steps, ``schedule`` names it and ``allreduce`` holds
+both (``blocking`` / ``overlapped``: value, ms_per_step, communication exposed per step) next to the per-bucket
+all-reduce times and bus bandwidths.  ``--schedule blocking|overlapped`` measures one.
+
+``--sweep``: ONE job of N ranks measures the sub-groups 1, 2, 4, ... N in turn (ranks 0 .. n-1 compute, the others wait
+on a CPU barrier), both schedules each, and prints one JSON line per n plus a summary line with the scaling efficiency
+per n and the schedule the measurement picks -- the whole multi-GPU decision from one command on one node:
+    python bench.py --gpus 8 --sweep [--others]
+
 ``--dry-run`` walks the same host path -- launcher respawn, ring shards, rank seeds, data-parallel setup, the
 update loop, the all-reduce report, the one JSON line -- with gloo on the CPU and the kernel calls routed to the
 launch-trace hook (nothing is computed, no GPU is touched): the N>1 plumbing can be rehearsed without a node
@@ -218,16 +229,25 @@ class Job:
                 dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
             else:
                 dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.dev)
+        self.ctl = None  # (sweep: a gloo group for the barriers the idle ranks wait at -- no kernel spins on their GPUs)
 
     def sync(self):
         if not self.dry:
             torch.cuda.synchronize()
 
-    def barrier(self):
-        if self.distributed:
+    def barrier(self, pg=None, n=None):
+        """Barrier over the ranks of ``pg`` (default: all) + device sync.  ``n == 1``: nobody to wait for."""
+        if self.distributed and (n is None or n > 1 or pg is not None):
             import torch.distributed as dist
-            dist.barrier()
+            dist.barrier(group=pg)
         self.sync()
+
+    def host_barrier(self):
+        """All ranks, on the CPU (the sweep's idle ranks wait here while a sub-group measures)."""
+        self.sync()
+        if self.ctl is not None:
+            import torch.distributed as dist
+            dist.barrier(group=self.ctl)
 
     def cu_count(self):
         return 256 if self.dry else torch.cuda.get_device_properties(self.dev).multi_processor_count
@@ -254,12 +274,17 @@ class Job:
             _lib.set_trace_hook(None)
 
 
-def measure(job, name, steps, warmup, with_cpu_baseline):
+def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overlap=None):
     """One configuration: build agent + ring shard, prime, warm up, time ``steps`` updates between barriers.
-    Returns the result object on rank 0 (None elsewhere).  Everything it allocated is released on return."""
+    Returns the result object on rank 0 (None elsewhere).  Everything it allocated is released on return.
+    ``pg`` / ``n``: the process group and the number of ranks this measurement runs on (default: all of the job's;
+    the sweep passes ranks 0 .. n-1 -- only they call); ``overlap``: the data-parallel schedule (None: the agent's
+    default, CURLA_DP_OVERLAP)."""
     import curla_amd
     from curla_amd import ops
-    args, cfg, dev, rank, world = job.args, CONFIGS[name], job.dev, job.rank, job.world
+    args, cfg, dev, rank = job.args, CONFIGS[name], job.dev, job.rank
+    world = job.world if n is None else n
+    distributed = job.distributed and (world > 1 or os.environ.get("CURLA_BENCH_FORCE_DIST") == "1")
     launches0 = job.launches if job.dry else 0
 
     C, (H, W), B = cfg["obs"][0], cfg["obs"][1:], cfg["batch"]
@@ -272,8 +297,9 @@ def measure(job, name, steps, warmup, with_cpu_baseline):
         alpha_lr=1e-4, alpha_beta=0.5, actor_lr=1e-3, actor_beta=0.9, critic_lr=1e-3, critic_beta=0.9, critic_tau=0.01,
         encoder_feature_dim=50, encoder_lr=1e-3, encoder_tau=0.05, num_layers=cfg["layers"], num_filters=32,
         pixel_sac=cfg["pixel_sac"], log_interval=10 ** 9)
-    if job.distributed:
-        agent.enable_data_parallel(single_rank_collectives=(world == 1))  # rank 0's parameters are broadcast
+    if distributed:
+        # rank 0's parameters are broadcast
+        agent.enable_data_parallel(process_group=pg, single_rank_collectives=(world == 1), overlap=overlap)
     seed = 1 + rank
     curla_amd.set_seed_everywhere(seed)  # rank-specific sampling / policy-noise streams
 
@@ -371,7 +397,7 @@ def measure(job, name, steps, warmup, with_cpu_baseline):
         for _ in range(warmup):
             agent.update(rb, L, step)
             step += 1
-        job.barrier()
+        job.barrier(pg, world)
         # event pairs are taken on a sample of the timed steps spread over the whole region (<= 32 steps): thousands
         # of pending HIP events slow the runtime itself and would perturb the measurement
         rec_stride = max(4, steps // 32)  # (an instrumented step is ~3 % slower: at most every 4th one)
@@ -382,7 +408,7 @@ def measure(job, name, steps, warmup, with_cpu_baseline):
             agent.update(rb, L, step)
             step += 1
         recording[0] = False
-        job.barrier()
+        job.barrier(pg, world)
         dt = time.perf_counter() - t0
     finally:
         ops.conv_s1_fwd, ops.conv_s1_fwd2, ops.conv_s1_fwd_stack = real
@@ -393,10 +419,10 @@ def measure(job, name, steps, warmup, with_cpu_baseline):
             "non-finite state"
 
     allreduce = None
-    if job.distributed:
+    if distributed:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=pg)
         dt = float(t.item())
         # outside the timed region: cost of the gradient all-reduces of one update, each bucket timed alone
         # (SURVEY.md 8e reporting: all-reduce time per phase and the bus bandwidth it reaches)
@@ -404,26 +430,30 @@ def measure(job, name, steps, warmup, with_cpu_baseline):
         buckets = {"critic": agent._critic_gflat[lay["enc"][0]:lay["total"]], "actor": agent._actor_gflat}
         if not cfg["pixel_sac"]:
             buckets["cpc"] = agent._critic_gflat[0:lay["enc"][1]]
-        allreduce = {"overlapped_with_backward": bool(agent._dp_overlap)}
+        allreduce = {"overlapped_with_backward": bool(agent._dp_overlap), "buckets": {}}
         reps = 2 if job.dry else 10
         for bname, buf in buckets.items():
             scratch = torch.zeros_like(buf)
             for _ in range(1 if job.dry else 3):
-                dist.all_reduce(scratch)
+                dist.all_reduce(scratch, group=pg)
             job.sync()
             start, stop = job.timer()
             start()
             for _ in range(reps):
-                dist.all_reduce(scratch)
+                dist.all_reduce(scratch, group=pg)
             ms = stop() / reps
             nbytes = scratch.numel() * 4
-            allreduce[bname] = {"bytes": nbytes, "ms": ms,
-                                "bus_GBps": 2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9}
+            allreduce["buckets"][bname] = {"bytes": nbytes, "ms": ms,
+                                           "bus_GBps": 2.0 * (world - 1) / world * nbytes / (ms * 1e-3) / 1e9}
         # every rank's shard size and sampling seed, for the line (rank 0 reports what the ranks actually used)
         mine = torch.tensor([rank, cap, seed, rb.capacity], dtype=torch.int64, device=dev)
         everyone = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(everyone, mine)
+        dist.all_gather(everyone, mine, group=pg)
         shards = [dict(rank=int(v[0]), capacity=int(v[1]), seed=int(v[2])) for v in everyone]
+        # what the communicator itself says it spans (RCCL at N > 1; gloo in a dry run)
+        allreduce["communicator"] = {"backend": dist.get_backend(pg), "ranks": dist.get_world_size(pg),
+                                     "rccl_version": (".".join(map(str, torch.cuda.nccl.version()))
+                                                      if not job.dry else None)}
     else:
         shards = [dict(rank=0, capacity=cap, seed=seed)]
 
@@ -462,13 +492,15 @@ def measure(job, name, steps, warmup, with_cpu_baseline):
                                    if stacked else
                                    "conv_rw_fwd_kernel (row-walk Winograd F(2,3): one 3x3 s1 32->32 + bias + ReLU layer per "
                                    "launch, f32 MFMA 16x16x4; FLOPs counted as direct-conv FLOPs)",
-                         "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_F32_TFLOPS, "traffic": traffic,
-                         # `achieved` counts the ALGORITHMIC (direct-convolution) FLOPs of SURVEY.md 8(d); the kernel is
-                         # Winograd F(2,3) along x and executes 2/3 of them, so `frac` can exceed 1.  What the matrix
-                         # pipe really does is `executed`: compare THAT with the peak, and `mfma_busy_frac_pmc` with 1.
-                         "executed": achieved / 1.5, "executed_frac": achieved / 1.5 / PEAK_F32_TFLOPS,
-                         "executed_note": "MFMA FLOPs issued = algorithmic / 1.5 (Winograd F(2,3) in one dimension)",
+                         # The kernel is Winograd F(2,3) along x: it issues 2/3 of the direct-convolution FLOPs of
+                         # SURVEY.md 8(d).  `achieved` / `frac` are what the matrix pipe really executes (compare with
+                         # 1.0 and with `mfma_busy_frac_pmc`); the SURVEY 8(d) accounting in direct-conv FLOPs, which can
+                         # exceed 1 because the algorithm skips work, is under `direct_equiv_*`.
+                         "achieved": achieved / 1.5, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / 1.5 / PEAK_F32_TFLOPS, "traffic": traffic,
+                         "achieved_note": "MFMA FLOPs issued = algorithmic direct-conv FLOPs / 1.5 (Winograd F(2,3) in one "
+                                          "dimension; strip padding not counted)",
+                         "direct_equiv_achieved": achieved, "direct_equiv_frac": achieved / PEAK_F32_TFLOPS,
                          "traffic_unit": "HBM bytes per launch; " + pmc_note,
                          "algorithmic_bytes_per_launch": kbytes / n_launch,
                          "launches": len(ev_pairs), "avg_launch_ms": avg_ms,
@@ -506,6 +538,11 @@ def main():
     ap.add_argument("--prefill", choices=("device", "host"), default="device")
     ap.add_argument("--clock-warmup-s", type=float, default=0.6,
                     help="seconds of scratch conv launches before the warm-up steps (0 for counter-collection runs)")
+    ap.add_argument("--schedule", choices=("auto", "blocking", "overlapped"), default="auto",
+                    help="data-parallel schedule at N > 1 (auto: measure both, report the faster, disclose both)")
+    ap.add_argument("--sweep", action="store_true",
+                    help="one job measures the sub-groups of 1, 2, 4, ... N ranks, both schedules each: a JSON line "
+                         "per n and a summary line")
     ap.add_argument("--dry-run", action="store_true",
                     help="gloo + launch-trace hook on the CPU: the host path of an N-rank run without a GPU")
     args = ap.parse_args()
@@ -525,12 +562,15 @@ def main():
     if "RANK" not in os.environ and args.gpus > 1:
         respawn_under_torchrun(args)
     job = Job(args)
-    cpu_bl = not args.no_cpu_baseline and job.world == 1 and not job.dry
+    cpu_bl = not args.no_cpu_baseline and job.world == 1 and not job.dry and not args.sweep
     try:
-        out = measure(job, main_cfg, *budget(main_cfg), cpu_bl)
+        if args.sweep:
+            sweep(job, main_cfg, others, budget)
+            return
+        out = measure_schedules(job, main_cfg, *budget(main_cfg), cpu_bl)
         extra = {}
         for name in others:
-            r = measure(job, name, *budget(name), cpu_bl)
+            r = measure_schedules(job, name, *budget(name), cpu_bl)
             if r is not None:
                 extra[name] = r
         if job.rank == 0:
@@ -539,6 +579,104 @@ def main():
             print(json.dumps(out), flush=True)
     finally:
         job.close()
+
+
+def measure_schedules(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, single_gpu_ms=None):
+    """measure() under the data-parallel schedule(s) ``--schedule`` asks for.  One rank (or a world of one): there is no
+    schedule to choose.  ``auto`` measures blocking then overlapped -- each its own agent, ring and K timed steps -- and
+    returns the faster one's line with both under ``allreduce``; an error in the second one is reported, not raised
+    (the first result stands).  ``single_gpu_ms``: this job's own N = 1 time per step, when it has one (the sweep), for
+    the communication each schedule leaves exposed."""
+    world = job.world if n is None else n
+    if not (job.distributed and (world > 1 or os.environ.get("CURLA_BENCH_FORCE_DIST") == "1")):
+        return measure(job, name, steps, warmup, with_cpu_baseline, pg, n)
+    want = job.args.schedule
+    scheds = ["blocking", "overlapped"] if want == "auto" else [want]
+    res = {}
+    for i, sc in enumerate(scheds):
+        try:
+            res[sc] = measure(job, name, steps, warmup, with_cpu_baseline and i == 0, pg, n, overlap=(sc == "overlapped"))
+        except Exception as e:  # noqa: BLE001
+            if i == 0:
+                raise
+            res[sc] = {"error": f"{type(e).__name__}: {e}"}
+    if job.rank != 0:
+        return None
+    ok = {sc: r for sc, r in res.items() if r is not None and "error" not in r}
+    best = max(ok, key=lambda sc: ok[sc]["value"])
+    out = ok[best]
+    raw = out.pop("allreduce")
+
+    def brief(r):
+        if r is None:
+            return None
+        if "error" in r:
+            return r
+        b = {"value": r["value"], "ms_per_step": r["ms_per_step"]}
+        if single_gpu_ms is not None:
+            b["exposed_comm_ms_per_step"] = r["ms_per_step"] - single_gpu_ms
+        return b
+    out["schedule"] = best
+    out["allreduce"] = {"schedule": best, "schedule_chosen_by": ("measurement (--schedule auto: both timed, the faster "
+                                                                 "one's K steps are this line's value)"
+                                                                 if want == "auto" else f"--schedule {want}"),
+                        "blocking": brief(res.get("blocking")), "overlapped": brief(res.get("overlapped")),
+                        "buckets": raw["buckets"], "communicator": raw["communicator"]}
+    return out
+
+
+def sweep(job, main_cfg, others, budget):
+    """--sweep: sub-groups of 1, 2, 4, ... ranks of ONE job, both schedules each; one JSON line per n, then a summary."""
+    import torch.distributed as dist
+    world = job.world
+    sizes = [n for n in (1, 2, 4, 8, 16, 32, 64) if n < world] + [world]
+    groups = {}
+    if job.distributed:
+        # every rank creates every group (members or not), in the same order
+        job.ctl = dist.new_group(backend="gloo")
+        for n in sizes:
+            if 1 < n < world:
+                groups[n] = dist.new_group(ranks=list(range(n)))
+    lines = {}
+    for name in [main_cfg] + list(others):
+        single_ms = None
+        for n in sizes:
+            r = None
+            if job.rank < n:
+                r = measure_schedules(job, name, *budget(name), False, groups.get(n), n, single_ms)
+            job.host_barrier()
+            if job.distributed:  # every rank learns the N = 1 time (rank 0 has it)
+                t = torch.tensor([r["ms_per_step"] if (job.rank == 0 and n == 1) else 0.0], dtype=torch.float64)
+                if n == 1:
+                    dist.broadcast(t, src=0, group=job.ctl)
+                    single_ms = float(t.item())
+            elif n == 1:
+                single_ms = r["ms_per_step"]
+            if job.rank == 0:
+                r["sweep"] = {"job_ranks": world, "ranks_measuring": list(range(n)),
+                              "single_gpu_ms_per_step": single_ms}
+                if n > 1:
+                    one = lines[(name, 1)]
+                    r["sweep"]["scaling_efficiency_vs_this_jobs_n1"] = r["value"] / (n * one["value"])
+                lines[(name, n)] = r
+                print(json.dumps(r), flush=True)
+    if job.rank == 0:
+        summary = {"sweep_summary": True, "job_ranks": world, "dry_run": bool(job.dry), "configs": {}}
+        for name in [main_cfg] + list(others):
+            per = {}
+            for n in sizes:
+                r = lines[(name, n)]
+                per[str(n)] = {"value": r["value"], "ms_per_step": r["ms_per_step"], "schedule": r.get("schedule"),
+                               "scaling_efficiency": r["value"] / (n * lines[(name, 1)]["value"]),
+                               "allreduce": r.get("allreduce")}
+            chosen = lines[(name, sizes[-1])].get("schedule")
+            summary["configs"][name] = {
+                "metric": lines[(name, 1)]["metric"], "unit": lines[(name, 1)]["unit"], "per_n": per,
+                "default_schedule": chosen,
+                "how_to_apply": (None if chosen is None else
+                                 ("CURLA_DP_OVERLAP=1 / enable_data_parallel(overlap=True)" if chosen == "overlapped"
+                                  else "the default (CURLA_DP_OVERLAP unset / overlap=False)"))}
+        print(json.dumps(summary), flush=True)
 
 
 if __name__ == "__main__":

@@ -102,8 +102,11 @@ SIGNATURES = {
     "curla_color_jiggle_nchw": [vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp],
     "curla_noisy_cover_nchw": [vp, vp, c_float, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp],
     "curla_version": [],
+    "curla_set_option": [ctypes.c_char_p, ctypes.c_char_p],
+    "curla_get_option": [ctypes.c_char_p],
 }
-_RESTYPES = {"curla_conv_wgrad_workspace_floats": c_size_t, "curla_version": ctypes.c_char_p}
+_RESTYPES = {"curla_conv_wgrad_workspace_floats": c_size_t, "curla_version": ctypes.c_char_p,
+             "curla_get_option": ctypes.c_char_p}
 _ERRORS = {-1: "CURLA_ERR_ARG (bad pointer/size/alignment)", -2: "CURLA_ERR_LAUNCH (HIP launch failed)",
            -3: "CURLA_ERR_UNSUPPORTED (shape not supported by the gfx950 kernels)"}
 
@@ -165,6 +168,40 @@ def call(name, *args):
     rc = getattr(load(), name)(*args)
     if rc != 0:
         raise CurlaHipError(f"{name} failed: {_ERRORS.get(rc, rc)}")
+
+
+OPTIONS = ("conv1_u8", "conv1_f32", "bwd_split", "gemm_small", "gemm_tile", "linear_bwd")  # curla_amd/csrc/options.h
+
+
+def set_option(name, value):
+    """curla_set_option: choose a kernel variant at run time (include/curla_hip.h lists names and values).  Runs on
+    the host only (no GPU needed); raises on an unknown name or value."""
+    rc = load().curla_set_option(str(name).encode(), str(value).encode())
+    if rc != 0:
+        raise CurlaHipError(f"curla_set_option({name!r}, {value!r}): unknown option or value")
+
+
+def get_option(name):
+    v = load().curla_get_option(str(name).encode())
+    if v is None:
+        raise CurlaHipError(f"curla_get_option({name!r}): unknown option")
+    return v.decode()
+
+
+class option:
+    """``with _lib.option("conv1_u8", "rw"): ...`` -- a variant for the duration of a block (tests, A/B timing)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
 
 
 def ptr(t):

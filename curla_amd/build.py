@@ -14,7 +14,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcurla_hip.so")
 STAMP = LIB + ".srchash"
 HEADER = os.path.join(HERE, "..", "include", "curla_hip.h")
-SOURCES = ["conv.hip", "gemm.hip", "heads.hip", "augment.hip"]
+SOURCES = ["conv.hip", "gemm.hip", "heads.hip", "augment.hip", "options.hip"]
 ARCH = "gfx950"  # MI355X only
 FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC"]
 

@@ -6,28 +6,26 @@
 //
 // Layout: activations are NHWC fp32 in HBM ([B][H][W][32]); conv weights stay
 // in the reference OIHW layout (they are nn.Parameters shared with Adam) and
-// are re-gathered into MFMA operand registers at kernel start.  Every inner
+// are re-gathered into MFMA operand images at kernel start.  Every inner
 // product runs on the exact-f32 matrix pipe (v_mfma_f32_16x16x4_f32), which has
 // the same 157 TFLOP/s roof as the fp32 vector pipe but needs one operand VGPR
-// per lane instead of 2 per FMA.  GEMM view of the forward:
-//   D[cout (16 per wave)][pixel pair (16 per tile)] += U[cout][k] * V[k][pixel pair],  k = (row tap, cin),
-// with the x direction in 1-D Winograd F(2,3) form (4 products per two outputs).  A 256-thread workgroup
-// stages a band of input rows in LDS (pixel stride padded 32 -> 36 floats); its 4 waves are 2 output-channel
-// halves x 2 tile slots.  Two such workgroups share a CU (<= 80 KB LDS, <= 256 VGPRs each): while one stages
-// or stores, the other's waves keep the matrix pipe fed.  What bounds the tile loops is VALU issue time (a VALU
-// instruction and an MFMA cannot issue in the same cycle), so everything in them is counted in instructions:
-// packed fp32 adds for the Winograd transform, division-free pixel walks, epilogues deferred into the next tile.
+// per lane instead of 2 per FMA.  The stride-1 layers (forward, data gradient, weight gradient) are the row-walk
+// kernels of conv_rw.h / conv_rw_wgrad.h: 1-D Winograd F(2,3) along x, a wave walks down a strip of pixel-pair
+// columns with the transformed filter streamed from LDS; the first layer has a banded form (crop staged in LDS) and
+// row-walk forms (conv1_rw.h, conv1_u8_rw.h).  What bounds the loops is VALU issue time (a VALU instruction and an
+// f32 MFMA cannot issue in the same cycle), so everything in them is counted in instructions.  (Rounds 1-3 also
+// carried a banded LDS-tiled form of the stride-1 kernels; it was removed in round 4 once the row walk covered
+// every shape -- DESIGN.md section 3.)
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 
 #include "common.h"
+#include "options.h"
 
 namespace {
 
 constexpr int kLdsPix = 36;   // floats per pixel in LDS (32 channels + 4 pad: conflict-free b128 reads)
-constexpr int kWStride = 289; // LDS row stride while re-gathering the OIHW weights
-constexpr int kMaxPf = 18;    // float4 staging registers per thread (band <= 256*18/8 = 576 pixels, 81 KB of LDS)
 
 enum { MODE_FWD = 0, MODE_DGRAD = 1 };
 
@@ -44,327 +42,6 @@ int g_ablate = 0;
 #define ABL(bit) 0
 #define ABL_HOST 0
 #endif
-
-struct ConvS1Args {
-  const float* in;   // [B][Hs][Ws][32]
-  const float* w;    // OIHW [32][32][3][3]
-  const float* aux;  // FWD: bias[32]; DGRAD: activation below, [B][Ho][Wo][32] (ReLU mask)
-  float* out;        // [B][Ho][Wo][32]
-  int B, Hs, Ws, Ho, Wo, pad, th, nbands;
-  int h1;  // height of band 0 (>= th; the other bands are th rows, the last one what is left)
-  int qstep, rstep;  // 32 = qstep * PW + rstep, PW = pixel pairs per output row
-  int dbg;
-  // forward only: a second problem of the same geometry with its own weights (B2 samples; 0 = none).  Its items
-  // follow the first problem's, so a workgroup re-builds its weight registers at most once.
-  const float* in2;
-  const float* w2;
-  const float* aux2;
-  float* out2;
-  int B2;
-};
-
-// ---------------------------------------------------------------------------
-// stride-1 32->32 conv: forward (bias+ReLU) and data-gradient (full correlation
-// with the flipped/transposed filter, ReLU mask of the layer below fused in).
-// The x direction uses Winograd F(2,3) (4 MFMA products per two outputs instead of 6): the input
-// transform is 4 vector adds on the LDS window right before the MFMAs, the output transform 4 adds
-// per pair; the y direction and the channel sums are the plain accumulation.
-// ---------------------------------------------------------------------------
-// (the kernel body as a device function of (block id, block count): conv_s1_kernel runs it over the whole grid,
-// bwd_s1_kernel over the second part of a grid whose first part is the weight-gradient kernel's)
-template <int MODE>
-__device__ __forceinline__ void conv_s1_body(const ConvS1Args& a, const int bid, const int nblk) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, kq = lane >> 4;
-  const int WT = a.Wo + 2;
-
-  // ---- weights -> registers (A operand).  A wave owns ONE 16-channel output
-  // tile (mt) for all its pixel tiles, so it keeps 72 weight registers, not 144;
-  // wave pairs (2p, 2p+1) share pixel tiles.  k-step (q,e) of tap t covers
-  // cin = 16q + 4kq' + e over the four lane groups kq'.
-  const int mt = wave & 1, tslot = wave >> 1;
-  float wu[3][4][8];
-  f32x4 bias4 = {0, 0, 0, 0};
-  auto load_weights = [&](const float* wsrc, const float* aux) {
-    {
-      // 9216 weights = 2304 float4, 9 per thread, all in flight at once (OIHW rows are 288 floats = 72 float4)
-      f32x4 wv[9];
-#pragma unroll
-      for (int u = 0; u < 9; ++u) wv[u] = reinterpret_cast<const f32x4*>(wsrc)[tid + u * 256];
-#pragma unroll
-      for (int u = 0; u < 9; ++u) {
-        const int i4 = tid + u * 256;
-        const int r = i4 / 72, c = (i4 - r * 72) * 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) lds[r * kWStride + c + e] = wv[u][e];
-      }
-    }
-    __syncthreads();
-    // 1-D Winograd F(2,3) along x: two adjacent outputs share one 4-pixel window and need 4 products
-    // per (row tap, cin) instead of 6.  Filter transform per row tap dy (g0,g1,g2 = the three x taps):
-    //   U0 = g0, U1 = (g0+g1+g2)/2, U2 = (g0-g1+g2)/2, U3 = g2
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const int co = mt * 16 + li;
-        const int ci = 16 * (s >> 2) + 4 * kq + (s & 3);
-        float gx[3];
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const int t = dy * 3 + dx;
-          gx[dx] = (MODE == MODE_FWD) ? lds[co * kWStride + ci * 9 + t] : lds[ci * kWStride + co * 9 + (8 - t)];
-        }
-        wu[dy][0][s] = gx[0];
-        wu[dy][1][s] = 0.5f * (gx[0] + gx[1] + gx[2]);
-        wu[dy][2][s] = 0.5f * (gx[0] - gx[1] + gx[2]);
-        wu[dy][3][s] = gx[2];
-      }
-    if (MODE == MODE_FWD) bias4 = *reinterpret_cast<const f32x4*>(aux + mt * 16 + 4 * kq);
-    __syncthreads();
-  };
-  load_weights(a.w, a.aux);
-
-  f32x2 wt = {0, 0};  // winograd_bt_pk's temporary, live for the whole kernel (see common.h)
-  // The items of one problem, as a lambda so that the forward's optional second problem (its own weights) is a second
-  // loop after a weight reload, not a branch inside the loop (which costs the forward kernel 34 spilled registers).
-  auto run = [&](const float* in_base, const float* aux_base, float* out_base, int Bc, int item, int item_end,
-                 int item0) {
-  for (; item < item_end; item += nblk) {
-    const int local = item - item0;
-    const int band = local / Bc, b = local - band * Bc;  // band-major: every workgroup sees every band size
-    const int y0 = band == 0 ? 0 : a.h1 + (band - 1) * a.th;
-    const int tha = band == 0 ? a.h1 : min(a.th, a.Ho - y0);
-    // ---- stage the band: all loads in flight at once, then the LDS writes.  The
-    // exposed latency is covered by the CU's second workgroup, whose phases are
-    // not synchronised with this one's.
-    {
-      const int n4 = (tha + 2) * WT * 8;
-      f32x4 pf[kMaxPf];
-      if (MODE == MODE_FWD) {
-        // the band (tha+2 full rows) is one contiguous run of HBM: no index arithmetic
-        const f32x4* src = reinterpret_cast<const f32x4*>(in_base + ((size_t)(b * a.Hs + y0) * a.Ws) * 32);
-#pragma unroll
-        for (int u = 0; u < kMaxPf; ++u) {
-          const int f = tid + u * 256;
-          f32x4 v = {0, 0, 0, 0};
-          if (f < n4 && !(ABL(1) && item != bid)) v = src[f];
-          pf[u] = v;
-        }
-      } else {
-        // zero-padded band: walk (row, col) incrementally (32 pixels per step), no divisions.  Buffer loads whose
-        // descriptor spans exactly this sample's image: rows above / below it are out of range and read zeros by
-        // themselves (a negative offset is a huge unsigned one); columns left / right of it would land in a
-        // neighbouring row, so their lanes are pointed past the buffer.  No bounds branches, no 64-bit lane addresses.
-        const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(in_base + (size_t)b * a.Hs * a.Ws * 32), (short)0, a.Hs * a.Ws * 128, 0x00020000);
-        int r = (tid >> 3) / WT, c = (tid >> 3) - r * WT;
-        const int ch = tid & 7;
-#pragma unroll
-        for (int u = 0; u < kMaxPf; ++u) {
-          const int f = tid + u * 256;
-          const int sy = y0 + r - a.pad, sx = c - a.pad;
-          const bool ok = f < n4 && (unsigned)sx < (unsigned)a.Ws && !(ABL(1) && item != bid);
-          const unsigned voff = ok ? (unsigned)(((sy * a.Ws + sx) * 32 + ch * 4) * 4) : 0x80000000u;
-          pf[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, voff, 0, 0));
-          c += 32;
-          if (WT >= 32) {  // wave-uniform: at most one row wrap per 32-pixel step
-            const bool wrap = c >= WT;
-            c = wrap ? c - WT : c;
-            r = wrap ? r + 1 : r;
-          } else {
-            while (c >= WT) c -= WT, ++r;
-          }
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < kMaxPf; ++u) {
-        const int f = tid + u * 256;
-        if (f < n4 && !(ABL(2) && item != bid))
-          *reinterpret_cast<f32x4*>(lds + (f >> 3) * kLdsPix + (f & 7) * 4) = pf[u];
-      }
-    }
-    __syncthreads();
-
-    // a lane owns a horizontal PAIR of output pixels (x0 = 2j, 2j+1); a tile is 16 pairs
-    const int PW = (a.Wo + 1) >> 1;            // pairs per output row (the last one is half valid when Wo is odd)
-    const int npairs = tha * PW;
-    const int ntiles = (npairs + 15) >> 4;
-    int ty = (tslot * 16 + li) / PW, j = (tslot * 16 + li) - ty * PW;
-    // The output transform + bias/ReLU (mask) + stores of a tile are deferred into the second half-step of the
-    // NEXT tile: there they issue between that tile's MFMAs instead of waiting for the matrix pipe to drain
-    // with nothing else to do (the epilogue at the tile's own end cost 17 % of the kernel).
-    // Two accumulator sets alternate between consecutive tiles, so the deferred epilogue reads registers no
-    // MFMA of the current tile writes (a copy would wait for the pipe all the same).
-    f32x4 accA[4], accB[4], pma = {0, 0, 0, 0}, pmb = {0, 0, 0, 0};
-    // per-item (wave-uniform) base pointers: a tile only adds a 32-bit element offset
-    float* const out_item = out_base + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
-    const float* const aux_item = aux_base + ((size_t)(b * a.Ho + y0) * a.Wo) * 32;
-    const __amdgpu_buffer_rsrc_t raux = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)aux_item, (short)0, MODE == MODE_DGRAD ? tha * a.Wo * 128 : 0, 0x00020000);
-    int pg = 0;
-    bool ppv = false, psecond = false;
-    auto epilogue = [&](const f32x4 (&pacc)[4]) {
-      if (ppv && !ABL(4)) {
-        // output transform A^T m: y(x0) = m0+m1+m2, y(x0+1) = m1-m2-m3
-        f32x4 ya = pacc[0] + pacc[1] + pacc[2];
-        f32x4 yb = pacc[1] - pacc[2] - pacc[3];
-        if (MODE == MODE_FWD) {  // (the bias came in through the accumulators' initial values)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ya[r] = fmaxf(ya[r], 0.f), yb[r] = fmaxf(yb[r], 0.f);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) ya[r] = pma[r] > 0.f ? ya[r] : 0.f, yb[r] = pmb[r] > 0.f ? yb[r] : 0.f;
-        }
-        if (ABL(8) && ya[0] != 12345.678f) return;  // timing only: transforms without the stores
-        if (ABL(16)) {  // timing only: each wave writes whole 128-B lines (wrong placement)
-          float* q = out_item + pg - mt * 16 - 4 * kq + mt * 32 + 4 * kq;
-          *reinterpret_cast<f32x4*>(q) = ya;
-          *reinterpret_cast<f32x4*>(q + 16) = yb;
-          return;
-        }
-        // streaming stores: the 64-B half lines a wave writes are not read again by this kernel; keeping them
-        // out of the L2's way is worth 6-9 % of the kernel
-        if (ABL(32)) {  // timing only: ordinary (L2 write-back) stores
-          *reinterpret_cast<f32x4*>(out_item + pg) = ya;
-          if (psecond) *reinterpret_cast<f32x4*>(out_item + pg + 32) = yb;
-          return;
-        }
-        __builtin_nontemporal_store(ya, reinterpret_cast<f32x4*>(out_item + pg));
-        if (psecond) __builtin_nontemporal_store(yb, reinterpret_cast<f32x4*>(out_item + pg + 32));
-      }
-    };
-    auto tile = [&](f32x4 (&acc)[4], const f32x4 (&pacc)[4], int t, bool have_prev) {
-      const bool pv = t * 16 + li < npairs;
-      if (!pv) ty = 0, j = 0;
-      // (24-bit multiplies: full-rate v_mad_u32_u24 instead of the quarter-rate 32-bit forms; every index here is
-      // far below 2^24)
-      const float* base = lds + __mul24(__mul24(ty, WT) + 2 * j, kLdsPix) + 4 * kq;
-      const int x0 = 2 * j;
-      const int g = (__mul24(ty, a.Wo) + x0) * 32 + mt * 16 + 4 * kq;  // element offset inside the item's output band
-      const bool second = x0 + 1 < a.Wo;
-      f32x4 ma = {0, 0, 0, 0}, mb = {0, 0, 0, 0};
-      if (MODE == MODE_DGRAD && !ABL(4)) {  // ReLU mask of the layer below: in flight for a whole tile
-        // (buffer loads, no branch: lanes without a pixel point past the item's range and read zeros)
-        ma = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(raux, pv ? (unsigned)g * 4u : 0x80000000u, 0, 0));
-        mb = __builtin_bit_cast(
-            f32x4, __builtin_amdgcn_raw_buffer_load_b128(raux, (pv && second) ? (unsigned)(g + 32) * 4u : 0x80000000u, 0, 0));
-      }
-      // y(x0) = m0+m1+m2 and y(x0+1) = m1-m2-m3: starting m0 at +bias and m3 at -bias adds the bias to both
-      acc[0] = bias4, acc[1] = f32x4{0, 0, 0, 0}, acc[2] = f32x4{0, 0, 0, 0}, acc[3] = -bias4;
-      // 6 half-steps (3 row taps x 2 cin halves); the 4 window reads of the next half-step are issued
-      // before the 16 MFMAs of the current one
-      f32x4 d[2][4];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) d[0][c] = *reinterpret_cast<const f32x4*>(base + c * kLdsPix);
-#pragma unroll
-      for (int h = 0; h < 6; ++h) {
-        const int dy = h >> 1, q = h & 1;
-        if (h < 5) {
-          const int ndy = (h + 1) >> 1, nq = (h + 1) & 1;
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            d[(h + 1) & 1][c] = *reinterpret_cast<const f32x4*>(base + (ndy * WT + c) * kLdsPix + 16 * nq);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const f32x4 d0 = d[h & 1][0], d1 = d[h & 1][1], d2 = d[h & 1][2], d3 = d[h & 1][3];
-        // input transform B^T d = (d0-d2, d1+d2, d2-d1, d1-d3), two channels per packed VALU op
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          f32x2 v0 = {d0[2 * p], d0[2 * p + 1]}, e1 = {d1[2 * p], d1[2 * p + 1]};
-          f32x2 v2 = {d2[2 * p], d2[2 * p + 1]}, v3 = {d3[2 * p], d3[2 * p + 1]};
-          winograd_bt_pk(v0, e1, v2, v3, wt);
-#pragma unroll
-          for (int r = 0; r < 2; ++r) {
-            const int e = 2 * p + r;
-            acc[0] = mfma16(wu[dy][0][4 * q + e], v0[r], acc[0]);
-            acc[1] = mfma16(wu[dy][1][4 * q + e], wt[r], acc[1]);
-            acc[2] = mfma16(wu[dy][2][4 * q + e], v2[r], acc[2]);
-            acc[3] = mfma16(wu[dy][3][4 * q + e], v3[r], acc[3]);
-          }
-        }
-        if (h == 1 && have_prev) epilogue(pacc);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      pma = ma, pmb = mb, pg = g, ppv = pv, psecond = second;
-      // the lane's pair index advances by 32 per tile step = a.qstep whole rows + a.rstep pairs (host-computed), plus
-      // at most one more wrap: five VALU instructions, no branch, whatever the row length
-      j += a.rstep, ty += a.qstep;
-      const bool wrap = j >= PW;
-      j = wrap ? j - PW : j;
-      ty = wrap ? ty + 1 : ty;
-    };
-    int t = tslot, done = 0;
-    for (; t < ntiles; t += 4) {
-      tile(accA, accB, t, done > 0);
-      ++done;
-      if (t + 2 < ntiles) {
-        tile(accB, accA, t + 2, true);
-        ++done;
-      }
-    }
-    if (done & 1)
-      epilogue(accA);
-    else if (done)
-      epilogue(accB);
-    __syncthreads();
-  }
-  };
-  const int nitems1 = a.B * a.nbands;
-  run(a.in, a.aux, a.out, a.B, bid, nitems1, 0);
-  if (MODE == MODE_FWD && a.B2 > 0) {
-    // this workgroup's walk k, k+G, k+2G, ... over the concatenated item list continues in the second problem
-    const int G = nblk;
-    const int first2 = bid + G * ((nitems1 - bid + G - 1) / G);
-    load_weights(a.w2, a.aux2);
-    run(a.in2, a.aux2, a.out2, a.B2, first2, nitems1 + a.B2 * a.nbands, nitems1);
-  }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(256, 2) void conv_s1_kernel(ConvS1Args a) {
-  conv_s1_body<MODE>(a, blockIdx.x, gridDim.x);
-}
-
-// The whole stack of stride-1 layers (layers 2..L of the encoder) of up to two minibatches in ONE launch.  With the
-// batch sizes multiples of the grid size, workgroup k of the persistent grid processes samples k, k+G, ... of every
-// layer (the item walk is band-major over `item % B`), i.e. it OWNS its samples: layer l+1 only reads what the same
-// workgroup wrote for layer l, so no other workgroup has to be waited for -- a workgroup-scope fence and a barrier
-// between layers make its own stores visible to its own loads, which then come out of the L2 instead of HBM.  Each
-// launch saved is 4-9 us at these sizes.
-constexpr int kMaxStack = 6;
-struct ConvS1StackArgs {
-  int nlayers, B, B2, Hs0, Ws0;
-  const float* in0;
-  const float* in0_2;
-  const float* w[kMaxStack];
-  const float* bias[kMaxStack];
-  float* out[kMaxStack];
-  const float* w2[kMaxStack];
-  const float* bias2[kMaxStack];
-  float* out2[kMaxStack];
-  int th[kMaxStack], h1[kMaxStack], nbands[kMaxStack];
-};
-
-__global__ __launch_bounds__(256, 2) void conv_s1_stack_kernel(ConvS1StackArgs S) {
-  for (int l = 0; l < S.nlayers; ++l) {
-    ConvS1Args a;
-    a.in = l == 0 ? S.in0 : S.out[l - 1], a.w = S.w[l], a.aux = S.bias[l], a.out = S.out[l];
-    a.in2 = l == 0 ? S.in0_2 : S.out2[l - 1], a.w2 = S.w2[l], a.aux2 = S.bias2[l], a.out2 = S.out2[l];
-    a.B = S.B, a.B2 = S.B2;
-    a.Hs = S.Hs0 - 2 * l, a.Ws = S.Ws0 - 2 * l, a.pad = 0, a.Ho = a.Hs - 2, a.Wo = a.Ws - 2;
-    a.th = S.th[l], a.h1 = S.h1[l], a.nbands = S.nbands[l];
-    const int PW = (a.Wo + 1) >> 1;
-    a.qstep = 32 / PW, a.rstep = 32 - a.qstep * PW;
-    a.dbg = 0;
-    conv_s1_body<MODE_FWD>(a, blockIdx.x, gridDim.x);
-    // this workgroup's outputs of layer l are (only) its own inputs of layer l + 1
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-  }
-}
 
 #include "conv_rw.h"
 
@@ -1044,305 +721,11 @@ __global__ __launch_bounds__(512, 2) void conv1_u8_walk_kernel(Conv1Args a, rw::
 }
 
 // ---------------------------------------------------------------------------
-// weight gradient, stride-1 32->32:  dW[co][ci][tap] = sum_pixels g[p][co] * in[p+tap][ci]
-// GEMM view: D[co][ci] per tap, K = pixels (4 per MFMA).  36 accumulator tiles
-// (2 x 2 x 9) live in registers for the whole persistent workgroup; partial
-// sums leave through one slab per workgroup and a deterministic second pass.
+// weight gradient, stride-1 32->32:  dW[co][ci][tap] = sum_pixels g[p][co] * in[p+tap][ci]  (conv_rw_wgrad.h).
+// Partial sums leave through one slab of kPartialS1 floats per workgroup and a deterministic second pass
+// (wgrad_reduce_multi_kernel below).
 // ---------------------------------------------------------------------------
-struct WgradS1Args {
-  const float* in;  // [B][Hi][Wi][32]
-  const float* g;   // [B][Ho][Wo][32]
-  float* partial;   // [grid][kPartial]
-  int B, Hi, Wi, Ho, Wo, th, nbands;
-};
 constexpr int kPartialS1 = 32 * 288 + 32;
-
-// WALK: how a lane finds the pixel pair of its k-step.  0: per-lane (row, column) counters, any size.  1 / 2 (even / odd
-// Wo, rows of at least 8 pairs): the k-step's first pair is walked in SCALAR registers and a lane is a constant offset
-// from it (+ one conditional row-wrap correction); the gradient comes through buffer loads whose descriptor ends at the
-// band's end, so pairs past the band read zeros.  The per-lane walk cost ~30 VALU instructions per 24 MFMAs -- and
-// a VALU instruction holds the SIMD's issue port for its 4 cycles while the matrix pipe waits.
-template <int WALK>
-__device__ __forceinline__ void wgrad_s1_body(const WgradS1Args& a, const int bid, const int nblk) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = WALK ? __builtin_amdgcn_readfirstlane(tid >> 6) : (tid >> 6);
-  const int li = lane & 15, kq = lane >> 4;
-  // a wave owns the 16 output channels mt*16.. of dW; wave pairs share pixels.
-  // Winograd F(3,2) along x (the transpose of the forward's F(2,3)): for a horizontal pair of
-  // gradient pixels (g0,g1) and its 4-pixel input window (d0..d3), the three x taps need 4 products
-  //   M0 += g0 (d0-d2), M1 += (g0+g1)(d1+d2), M2 += (g0-g1)(d2-d1), M3 += -g1 (d1-d3)
-  // summed over all pairs; dW(dx=0,1,2) = M0+(M1+M2)/2, (M1-M2)/2, (M1+M2)/2+M3 once at the end.
-  const int mt = wave & 1, uslot = wave >> 1;
-  f32x4 acc[3][4][2];  // [dy][k][cin tile]
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) acc[dy][k][ct] = f32x4{0, 0, 0, 0};
-  float bsum = 0.f;
-  f32x2 wt = {0, 0};  // winograd_bt_pk's temporary, live for the whole kernel (see common.h)
-
-  const int PW = (a.Wo + 1) >> 1;  // pixel pairs per gradient row
-  const int qstep = 8 / PW, rstep = 8 - qstep * PW;
-  const int nitems = a.B * a.nbands;
-  for (int item = bid; item < nitems; item += nblk) {
-    const int band = item / a.B, b = item - band * a.B;  // band-major: every workgroup sees every band size
-    const int y0 = band * a.th;
-    const int tha = min(a.th, a.Ho - y0);
-    // band = (tha+2) input rows, contiguous in HBM.  The gradient rows are NOT staged: a lane's gradient operand is
-    // channel mt*16+li of the two pixels of its pair, every value is needed by exactly one wave, and the 16 lanes
-    // of a group read 64 contiguous bytes -- each wave loads them from HBM/L2 itself, three k-steps ahead.  The
-    // LDS then holds input rows only: bands of 13 rows instead of 6 at 37x37 (half the items, 12 % less halo).
-    const int nin = (tha + 2) * a.Wi * 8;
-    {
-      const float* pin = a.in + ((size_t)(b * a.Hi + y0) * a.Wi) * 32;
-      f32x4 pf[kMaxPf];
-#pragma unroll
-      for (int u = 0; u < kMaxPf; ++u) {
-        const int f = tid + u * 256;
-        f32x4 v = {0, 0, 0, 0};
-        if (f < nin) v = *reinterpret_cast<const f32x4*>(pin + (size_t)f * 4);
-        pf[u] = v;
-      }
-#pragma unroll
-      for (int u = 0; u < kMaxPf; ++u) {
-        const int f = tid + u * 256;
-        if (f < nin) *reinterpret_cast<f32x4*>(lds + (f >> 3) * kLdsPix + (f & 7) * 4) = pf[u];
-      }
-      // the pixel behind the band: with an odd row length the last pair's window reaches one pixel past the last
-      // row; its product has a zero gradient factor, but 0 x (whatever LDS held) must not be NaN
-      if (tid < kLdsPix / 4) *reinterpret_cast<f32x4*>(lds + (tha + 2) * a.Wi * kLdsPix + tid * 4) = f32x4{0, 0, 0, 0};
-    }
-    __syncthreads();
-
-    const int npairs = tha * PW;
-    const float* const gband = a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32 + mt * 16 + li;
-    const int nunits = ((npairs + 7) >> 3) << 1;  // 4 pairs per MFMA k-step, 2 k-steps per group of 8 pairs
-    // This wave's k-steps are units u = uslot, uslot+2, ...; the lane's pair of unit u is q(u) = (u>>1)*8 + (u&1) + 2*kq
-    // (pairs of a k-step are 2 apart = 4 pixels: the two lane groups of an LDS half hit disjoint banks).  Both
-    // fetchers are called for consecutive k-steps in order and keep their pair's (row, column) incrementally
-    // (+8 pairs per call), each with its own copy because the gradient fetch runs ahead of the window fetch.
-    int gy = ((uslot & 1) + 2 * kq) / PW, gj = ((uslot & 1) + 2 * kq) - gy * PW;
-    int fy = gy, fj = gj;
-    auto advance = [&](int& y, int& j) {  // 8 pairs further = qstep rows + rstep pairs, at most one more wrap
-      j += rstep, y += qstep;
-      const bool wrap = j >= PW;
-      j = wrap ? j - PW : j;
-      y = wrap ? y + 1 : y;
-    };
-    auto gfetch = [&](int u, float (&gv)[2]) {
-      const int q = (u >> 1) * 8 + (u & 1) + 2 * kq;
-      const bool pv = (u < nunits) && (q < npairs);
-      const int x0 = 2 * gj;
-      const float* gp = gband + (gy * a.Wo + x0) * 32;
-      const bool second = pv && x0 + 1 < a.Wo;
-      gv[0] = *(pv ? gp : g_zero_px + li);  // (lanes past the band load a zero: no select on the loaded value)
-      gv[1] = *(second ? gp + 32 : g_zero_px + li);
-      advance(gy, gj);
-    };
-    auto dfetch = [&](int u, f32x2 (&dv)[3][4]) {
-      const int q = (u >> 1) * 8 + (u & 1) + 2 * kq;
-      const bool pv = (u < nunits) && (q < npairs);
-      const int ty = pv ? fy : 0, x0 = pv ? 2 * fj : 0;
-      const float* ip = lds + (ty * a.Wi + x0) * kLdsPix + li;
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float* qd = ip + (dy * a.Wi + c) * kLdsPix;
-          dv[dy][c] = f32x2{qd[0], qd[16]};  // the two cin tiles of one window pixel (one ds_read2_b32)
-        }
-      advance(fy, fj);
-    };
-    auto mma = [&](const float (&gv)[2], f32x2 (&dv)[3][4]) {
-      bsum += gv[0] + gv[1];
-      const float g0 = gv[0], g1 = gv[0] + gv[1], g2 = gv[0] - gv[1], g3 = -gv[1];
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        // (d0-d2, d1+d2, d2-d1, d1-d3) for both cin tiles with 4 packed adds
-        winograd_bt_pk(dv[dy][0], dv[dy][1], dv[dy][2], dv[dy][3], wt);
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          acc[dy][0][ct] = mfma16(g0, dv[dy][0][ct], acc[dy][0][ct]);
-          acc[dy][1][ct] = mfma16(g1, wt[ct], acc[dy][1][ct]);
-          acc[dy][2][ct] = mfma16(g2, dv[dy][2][ct], acc[dy][2][ct]);
-          acc[dy][3][ct] = mfma16(g3, dv[dy][3][ct], acc[dy][3][ct]);
-        }
-      }
-    };
-    // ---- WALK 1 / 2: the same two fetchers on a scalar walk ----
-    // k-step of unit u: first pair q0 = (u >> 1) * 8 + uslot at (row sy, pair sj), scalar; lane kq's pair is 2 kq
-    // further, wrapped into the next row when sj + 2 kq >= PW (PW >= 8 > 6: at most once).
-    //   gradient floats from the band start: (sy Wo + 2 sj) 32  [scalar]  +  4 kq 32 + mt 16 + li  [lane]
-    //                                        + (Wo - 2 PW) 32 if wrapped (0 / -32 for even / odd Wo)
-    //   window floats in LDS:                (sy Wi + 2 sj) 36  [scalar]  +  4 kq 36 + li          [lane]
-    //                                        + (Wi - 2 PW) 36 if wrapped
-    // A pair past the band end reads gradient zeros (buffer range) and, in LDS, the last valid pair's window (its
-    // address is clamped: 0 x finite).  Odd Wo: the second pixel of a row's last pair is the next row's first in
-    // memory -- those lanes load from past the buffer instead.
-    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)(a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32), (short)0, WALK ? tha * a.Wo * 128 : 0, 0x00020000);
-    const unsigned g_lane = (unsigned)(4 * kq * 32 + mt * 16 + li) * 4u;
-    const unsigned g_lane_w = g_lane + (unsigned)((a.Wo - 2 * PW) * 128);
-    const unsigned d_lane = (unsigned)(4 * kq * kLdsPix + li) * 4u;
-    const unsigned d_lane_w = d_lane + (unsigned)((a.Wi - 2 * PW) * kLdsPix * 4);
-    const unsigned d_max = (unsigned)(((tha - 1) * a.Wi + 2 * (PW - 1)) * kLdsPix + 15) * 4u;
-    const unsigned d_row = (unsigned)(a.Wi * kLdsPix * 4);
-    int sgy = 0, sgj = uslot, sfy = 0, sfj = uslot;  // (uslot < 2 <= PW)
-    auto sadvance = [&](int& y, int& j) {
-      j += rstep, y += qstep;
-      if (j >= PW) j -= PW, y += 1;
-    };
-    auto gfetch_s = [&](float (&gv)[2]) {
-      const unsigned soff = (unsigned)((sgy * a.Wo + 2 * sgj) * 128);
-      const int jl = sgj + 2 * kq;
-      const bool wrapped = jl >= PW;
-      if (WALK == 1) {  // even Wo: rows of pairs are contiguous, nothing depends on the wrap
-        gv[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, g_lane, soff, 0));
-        gv[1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, g_lane, soff + 128u, 0));
-      } else {
-        const unsigned v0 = wrapped ? g_lane_w : g_lane;
-        const bool last = (jl == PW - 1) || (jl == 2 * PW - 1);
-        const unsigned v1 = last ? 0x80000000u : v0;
-        gv[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, v0, soff, 0));
-        gv[1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, v1, soff + 128u, 0));
-      }
-      sadvance(sgy, sgj);
-    };
-    auto dfetch_s = [&](f32x2 (&dv)[3][4]) {
-      const unsigned sbase = (unsigned)((sfy * a.Wi + 2 * sfj) * kLdsPix * 4);
-      const bool wrapped = sfj + 2 * kq >= PW;
-      const unsigned off = min((wrapped ? d_lane_w : d_lane) + sbase, d_max);
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy) {
-        const float* row = reinterpret_cast<const float*>(reinterpret_cast<const char*>(lds) + off + dy * d_row);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) dv[dy][c] = f32x2{row[c * kLdsPix], row[c * kLdsPix + 16]};
-      }
-      sadvance(sfy, sfj);
-    };
-    // software pipeline over this wave's k-steps: window reads (LDS) one step ahead in two register sets, gradient
-    // values (HBM/L2) three steps ahead in four; a k-step past the band multiplies zeros and is skipped
-    float g0[2], g1[2], g2[2], g3[2];
-    f32x2 dA[3][4], dB[3][4];
-    if (WALK) {
-      gfetch_s(g0), gfetch_s(g1), gfetch_s(g2);
-      dfetch_s(dA);
-      for (int u = uslot; u < nunits; u += 8) {
-        gfetch_s(g3);
-        dfetch_s(dB);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(g0, dA);
-        __builtin_amdgcn_sched_barrier(0);
-        gfetch_s(g0);
-        dfetch_s(dA);
-        __builtin_amdgcn_sched_barrier(0);
-        if (u + 2 < nunits) mma(g1, dB);
-        __builtin_amdgcn_sched_barrier(0);
-        gfetch_s(g1);
-        dfetch_s(dB);
-        __builtin_amdgcn_sched_barrier(0);
-        if (u + 4 < nunits) mma(g2, dA);
-        __builtin_amdgcn_sched_barrier(0);
-        gfetch_s(g2);
-        dfetch_s(dA);
-        __builtin_amdgcn_sched_barrier(0);
-        if (u + 6 < nunits) mma(g3, dB);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-      gfetch(uslot, g0), gfetch(uslot + 2, g1), gfetch(uslot + 4, g2);
-      dfetch(uslot, dA);
-      for (int u = uslot; u < nunits; u += 8) {
-        gfetch(u + 6, g3);
-        dfetch(u + 2, dB);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(g0, dA);
-        __builtin_amdgcn_sched_barrier(0);
-        gfetch(u + 8, g0);
-        dfetch(u + 4, dA);
-        __builtin_amdgcn_sched_barrier(0);
-        if (u + 2 < nunits) mma(g1, dB);
-        __builtin_amdgcn_sched_barrier(0);
-        gfetch(u + 10, g1);
-        dfetch(u + 6, dB);
-        __builtin_amdgcn_sched_barrier(0);
-        if (u + 4 < nunits) mma(g2, dA);
-        __builtin_amdgcn_sched_barrier(0);
-        gfetch(u + 12, g2);
-        dfetch(u + 8, dA);
-        __builtin_amdgcn_sched_barrier(0);
-        if (u + 6 < nunits) mma(g3, dB);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    __syncthreads();
-  }
-
-  // output transform (linear, so applied once to the accumulated products), then the cross-wave
-  // sum in a fixed order (deterministic) and one slab per workgroup
-  bsum += __shfl_xor(bsum, 16);
-  bsum += __shfl_xor(bsum, 32);
-  for (int w = 0; w < 2; ++w) {
-    if (uslot == w) {
-#pragma unroll
-      for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          const f32x4 hs = 0.5f * (acc[dy][1][ct] + acc[dy][2][ct]);
-          const f32x4 hd = 0.5f * (acc[dy][1][ct] - acc[dy][2][ct]);
-          const f32x4 dw[3] = {acc[dy][0][ct] + hs, hd, hs + acc[dy][3][ct]};
-#pragma unroll
-          for (int dx = 0; dx < 3; ++dx)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int co = mt * 16 + 4 * kq + r, ci = ct * 16 + li;
-              float* d = lds + co * 288 + ci * 9 + dy * 3 + dx;
-              *d = (w == 0) ? dw[dx][r] : *d + dw[dx][r];
-            }
-        }
-      if (kq == 0) {
-        float* d = lds + 32 * 288 + mt * 16 + li;
-        *d = (w == 0) ? bsum : *d + bsum;
-      }
-    }
-    __syncthreads();
-  }
-  float* slab = a.partial + (size_t)bid * kPartialS1;
-  for (int i = tid; i < kPartialS1; i += 256) slab[i] = lds[i];
-}
-
-template <int WALK>
-__global__ __launch_bounds__(256, 2) void wgrad_s1_kernel(WgradS1Args a) {
-  wgrad_s1_body<WALK>(a, blockIdx.x, gridDim.x);
-}
-
-// Weight gradient and data gradient of one layer in ONE launch: both only read the layer's output gradient, so they
-// need not wait for each other.  The first nw workgroups run the weight-gradient body, the rest the data-gradient
-// body; the hardware starts the second set as the first one's workgroups retire, so the tail of one kernel and the
-// ramp of the next overlap instead of being separated by a kernel boundary (4-9 us per launch at these sizes).
-template <int WALK>
-__global__ __launch_bounds__(256, 2) void bwd_s1_kernel(WgradS1Args wa, ConvS1Args da, int nw) {
-  if ((int)blockIdx.x < nw)
-    wgrad_s1_body<WALK>(wa, blockIdx.x, nw);
-  else
-    conv_s1_body<MODE_DGRAD>(da, (int)blockIdx.x - nw, (int)gridDim.x - nw);
-}
-
-// the same launch with the data gradient in its row-walk form (conv_rw.h)
-template <int WALK>
-__global__ __launch_bounds__(256, 2) void bwd_rw_kernel(WgradS1Args wa, rw::Args da, int nw) {
-  if ((int)blockIdx.x < nw) {
-    wgrad_s1_body<WALK>(wa, blockIdx.x, nw);
-  } else {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    rw::build_filter<MODE_DGRAD, 256>(lds, da.p[0][0].w, nullptr, threadIdx.x);
-    __syncthreads();
-    rw::run_layer<MODE_DGRAD, 4>(da.g[0], da.p[0][0], da.p[0][1], lds, (int)blockIdx.x - nw, (int)gridDim.x - nw);
-  }
-}
 
 #include "conv_rw_wgrad.h"
 
@@ -1828,80 +1211,6 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(ReduceJobs J) 
 
 // ------------------------------ host-side planning ------------------------------
 constexpr int kMaxLds = 160 * 1024;
-constexpr int kBandPx = 567;  // pixels a band may hold: (567 + 1 slack) * 144 B = 79.9 KB of LDS -> 2 workgroups per CU
-static_assert(kBandPx * 8 <= 256 * kMaxPf, "band must fit the staging registers");
-
-// Rows per band for the stride-1 kernels.  The band (th+2 input rows, plus th
-// gradient rows for wgrad) must fit kBandPx pixels.  Candidates split Ho into
-// nb near-equal bands; the score is the fraction of useful 16-pixel tile slots
-// (tiles are dealt to `nslots` wave groups) times the halo re-read factor.
-int plan_band_s1(int Ho, int Wo, int px_per_row_extra, int budget_px, int unit_px, int nslots, bool pairs = false) {
-  int th_max = 0;
-  for (int th = 1; th <= Ho; ++th)
-    if ((th + 2) * (Wo + 2) + px_per_row_extra * th <= budget_px) th_max = th;
-  if (th_max == 0) return 1;
-  int best = th_max;
-  double best_eff = -1.0;
-  const int nb0 = (Ho + th_max - 1) / th_max;
-  for (int nb = nb0; nb <= nb0 + 3 && nb <= Ho; ++nb) {
-    const int th = (Ho + nb - 1) / nb;
-    if (th > th_max) continue;
-    const int nbands = (Ho + th - 1) / th;
-    double work = 0, slots = 0;
-    for (int bnd = 0; bnd < nbands; ++bnd) {
-      const int tha = (bnd == nbands - 1) ? Ho - bnd * th : th;
-      const int units = pairs ? tha * ((Wo + 1) / 2) : tha * Wo;  // work items per band (pixel pairs or pixels)
-      const int tiles = (units + unit_px - 1) / unit_px;
-      work += (pairs ? tha * Wo / 2.0 : tha * Wo) / (double)unit_px;
-      slots += ((tiles + nslots - 1) / nslots) * nslots;
-    }
-    const double eff = work / slots * (double)th / (th + 2) * (1.0 - 0.01 * nbands);  // small per-band fixed cost
-    if (eff > best_eff) best_eff = eff, best = th;
-  }
-  return best;
-}
-
-// Bands of the forward / data-gradient kernel: band 0 has h1 rows, the others th (the last what is left), all
-// within the LDS budget.  A band's 16-pair tiles are dealt to two wave pairs, so an odd tile count idles one of
-// them for a tile; letting band 0 differ (31 rows = 11 + 10 + 10 instead of 11 + 11 + 9) buys even counts.
-// Score = useful tile slots / dealt tile slots x rows / staged rows (halo), minus a small per-band cost.
-void plan_bands_conv_s1(int Ho, int Wo, int budget_px, int* th_out, int* h1_out, int* nb_out) {
-  const int PW = (Wo + 1) / 2;
-  int th_max = 0;
-  for (int th = 1; th <= Ho; ++th)
-    if ((th + 2) * (Wo + 2) <= budget_px) th_max = th;
-  if (th_max == 0) {
-    *th_out = 1, *h1_out = 1, *nb_out = Ho;
-    return;
-  }
-  double best = -1.0;
-  auto slots = [&](int rows) {
-    const int tiles = (rows * PW + 15) / 16;
-    return (double)((tiles + 1) / 2 * 2);
-  };
-  for (int th = 1; th <= th_max; ++th)
-    for (int variant = 0; variant < 2; ++variant) {
-      int h1, nb;
-      if (variant == 0) {
-        h1 = th, nb = (Ho + th - 1) / th;  // uniform, last band short
-      } else {
-        nb = (Ho - th) / th + 1;  // first band takes the remainder: th <= h1 < 2 th
-        h1 = Ho - (nb - 1) * th;
-        if (nb < 2 || h1 > th_max) continue;
-      }
-      if (h1 >= Ho) h1 = Ho, nb = 1;
-      double s = slots(h1);
-      int rows_left = Ho - h1;
-      for (int b = 1; b < nb; ++b) {
-        const int r = rows_left < th ? rows_left : th;
-        s += slots(r);
-        rows_left -= r;
-      }
-      const double eff = (Ho * Wo / 32.0) / s * (double)Ho / (Ho + 2.0 * nb) * (1.0 - 0.01 * nb);
-      if (eff > best) best = eff, *th_out = th, *h1_out = h1, *nb_out = nb;
-    }
-}
-
 // Dynamic LDS limit of a kernel: raised once per (kernel, device) to the largest size this library ever asks for --
 // never lowered, never set per launch (curla_set_dyn_lds, common.h).
 template <typename K>
@@ -1910,27 +1219,13 @@ int set_lds(K kernel, size_t bytes) {
   return curla_set_dyn_lds(reinterpret_cast<const void*>(kernel), kMaxLds);
 }
 
-// Which stride-1 forward / data-gradient kernels run: the row-walk form (conv_rw.h) unless CURLA_S1_IMPL=band asks for
-// the banded one (kept for A/B timing; both pass the same tests).
-bool use_rw() {
-  static const bool band = getenv("CURLA_S1_IMPL") && !strcmp(getenv("CURLA_S1_IMPL"), "band");
-  return !band;
-}
-// ... and the weight gradient: CURLA_S1_WGRAD=band keeps the banded kernel beside the row-walk forward / data gradient
-// CURLA_C1_U8=rw: the LDS-free row-walk uint8 first-layer forward (conv1_u8_rw.h) instead of the default (the hybrid
-// conv1_u8_walk_kernel: crop staged in LDS, row walk out of LDS; CURLA_C1_U8=band: the banded loop).  Measured on
-// 1024 + 512 / 512 + 512 samples of configs[1]: alone, re-reading the same ring slots out of the Infinity Cache, the
-// LDS-free walk takes 100 / 66 us against the banded loop's 128 / 86; on slots drawn afresh for every launch from a ring
-// of gigabytes -- what update() does -- 114 us on average against 104 (hybrid: 102).
-bool use_rw_u8() {  // (read at every call -- two per update -- so that one process can run both: the tests do)
-  const char* e = getenv("CURLA_C1_U8");
-  return use_rw() && e && !strcmp(e, "rw");
-}
-
-bool use_rw_wgrad() {
-  static const bool band = getenv("CURLA_S1_WGRAD") && !strcmp(getenv("CURLA_S1_WGRAD"), "band");
-  return use_rw() && !band;
-}
+// Which uint8 first-layer forward runs (option conv1_u8, options.h): the default is the hybrid conv1_u8_walk_kernel
+// (crop staged in LDS as bytes, row walk out of LDS) whenever the crop fits one band of LDS, else the banded loop;
+// "band" forces the banded loop, "rw" the LDS-free row walk (conv1_u8_rw.h).  Measured on 1024 + 512 / 512 + 512 samples
+// of configs[1]: alone, re-reading the same ring slots out of the Infinity Cache, the LDS-free walk takes 100 / 66 us
+// against the banded loop's 128 / 86; on slots drawn afresh for every launch from a ring of gigabytes -- what update()
+// does -- 114 us on average against 104 (hybrid: 102).
+bool use_rw_u8() { return curla_opt(kOptConv1U8) == 2; }
 
 // The row-walk forward keeps (pixel pair, 32 channels) of a whole row in flight per wave; any width works, the strips
 // only get more numerous.  Limits: byte offsets inside one sample must fit 31 bits.
@@ -1973,42 +1268,14 @@ rw::Args rw_dgrad_args(const float* g, const float* w, const float* act_below, f
 int launch_conv_s1(int mode, const float* in, const float* w, const float* aux, float* out, int B, int Hs, int Ws,
                    hipStream_t st, const float* in2 = nullptr, const float* w2 = nullptr, const float* aux2 = nullptr,
                    float* out2 = nullptr, int B2 = 0) {
-  if (use_rw() && rw_supported(Hs, Ws)) {
-    if (mode == MODE_FWD)
-      return launch_rw_fwd(1, in, &w, &aux, &out, B, in2, &w2, &aux2, &out2, B2, Hs, Ws, false, st);
-    const rw::Args A = rw_dgrad_args(in, w, aux, out, B, Hs, Ws);
-    const int cap = 2 * curla_cu_count();
-    const size_t lds = rw::kWFloats * sizeof(float);
-    int rc = set_lds(conv_rw_dgrad_kernel, lds);
-    if (rc != CURLA_OK) return rc;
-    hipLaunchKernelGGL(conv_rw_dgrad_kernel, dim3(B < cap ? B : cap), dim3(256), lds, st, A);
-    return curla_launch_status();
-  }
-  ConvS1Args a;
-  a.in = in, a.w = w, a.aux = aux, a.out = out;
-  a.in2 = in2, a.w2 = w2, a.aux2 = aux2, a.out2 = out2, a.B2 = B2;
-  a.B = B, a.Hs = Hs, a.Ws = Ws;
-  a.pad = mode == MODE_FWD ? 0 : 2;
-  a.Ho = mode == MODE_FWD ? Hs - 2 : Hs + 2;
-  a.Wo = mode == MODE_FWD ? Ws - 2 : Ws + 2;
-  if (a.Ho <= 0 || a.Wo <= 0 || (a.Wo + 2) * 3 > kBandPx) return CURLA_ERR_UNSUPPORTED;
-  plan_bands_conv_s1(a.Ho, a.Wo, kBandPx, &a.th, &a.h1, &a.nbands);
-  const int PW = (a.Wo + 1) / 2;
-  a.qstep = 32 / PW, a.rstep = 32 - a.qstep * PW;
-  a.dbg = ABL_HOST;
-  size_t lds = ((size_t)(a.h1 + 2) * (a.Wo + 2) + 1) * kLdsPix * sizeof(float);  // +1 pixel: 4th window pixel of the last pair
-  const size_t wl = (size_t)32 * kWStride * sizeof(float);
-  if (lds < wl) lds = wl;
-  const int nitems = (B + B2) * a.nbands;
-  const int grid = nitems < 2 * curla_cu_count() ? nitems : 2 * curla_cu_count();
-  int rc;
-  if (mode == MODE_FWD) {
-    if ((rc = set_lds(conv_s1_kernel<MODE_FWD>, lds)) != CURLA_OK) return rc;
-    hipLaunchKernelGGL(conv_s1_kernel<MODE_FWD>, dim3(grid), dim3(256), lds, st, a);
-  } else {
-    if ((rc = set_lds(conv_s1_kernel<MODE_DGRAD>, lds)) != CURLA_OK) return rc;
-    hipLaunchKernelGGL(conv_s1_kernel<MODE_DGRAD>, dim3(grid), dim3(256), lds, st, a);
-  }
+  if (!rw_supported(Hs, Ws)) return CURLA_ERR_UNSUPPORTED;
+  if (mode == MODE_FWD) return launch_rw_fwd(1, in, &w, &aux, &out, B, in2, &w2, &aux2, &out2, B2, Hs, Ws, false, st);
+  const rw::Args A = rw_dgrad_args(in, w, aux, out, B, Hs, Ws);
+  const int cap = 2 * curla_cu_count();
+  const size_t lds = rw::kWFloats * sizeof(float);
+  int rc = set_lds(conv_rw_dgrad_kernel, lds);
+  if (rc != CURLA_OK) return rc;
+  hipLaunchKernelGGL(conv_rw_dgrad_kernel, dim3(B < cap ? B : cap), dim3(256), lds, st, A);
   return curla_launch_status();
 }
 
@@ -2064,51 +1331,23 @@ int curla_conv3x3_s1_fwd_stack(int nlayers, const float* in, const float* const*
                                float* const* out, int B, const float* in2, const float* const* w2,
                                const float* const* bias2, float* const* out2, int B2, int Hi, int Wi, int channels,
                                void* stream) {
-  CURLA_REQUIRE(nlayers > 0 && nlayers <= kMaxStack && in && w && bias && out && B > 0 && Hi >= 3 && Wi >= 3);
+  CURLA_REQUIRE(nlayers > 0 && nlayers <= rw::kMaxLayers && in && w && bias && out && B > 0 && Hi >= 3 && Wi >= 3);
   CURLA_REQUIRE(B2 == 0 || (in2 && w2 && bias2 && out2));
   if (channels != 32) return CURLA_ERR_UNSUPPORTED;
-  if (use_rw()) {
-    // ownership of samples by workgroups needs whole rounds of the grid (one workgroup per CU) over each minibatch
-    const int G1 = curla_cu_count();
-    if (B % G1 != 0 || B2 % G1 != 0) return CURLA_ERR_UNSUPPORTED;
-    CURLA_REQUIRE(aligned16(in) && (!B2 || aligned16(in2)));
-    for (int l = 0; l < nlayers; ++l) {
-      CURLA_REQUIRE(w[l] && bias[l] && out[l] && aligned16(w[l]) && aligned16(bias[l]) && aligned16(out[l]));
-      CURLA_REQUIRE(!B2 || (w2[l] && bias2[l] && out2[l] && aligned16(w2[l]) && aligned16(bias2[l]) && aligned16(out2[l])));
-    }
-    if (Hi - 2 * nlayers < 1 || Wi - 2 * nlayers < 1) return CURLA_ERR_UNSUPPORTED;
-    return launch_rw_fwd(nlayers, in, w, bias, out, B, in2, w2, bias2, out2, B2, Hi, Wi, true,
-                         static_cast<hipStream_t>(stream));
-  }
-  const int G = 2 * curla_cu_count();
-  // ownership of samples by workgroups needs whole rounds of the grid over each minibatch
-  if (B % G != 0 || B2 % G != 0) return CURLA_ERR_UNSUPPORTED;
-  ConvS1StackArgs S;
-  S.nlayers = nlayers, S.B = B, S.B2 = B2, S.Hs0 = Hi, S.Ws0 = Wi;
-  S.in0 = in, S.in0_2 = in2;
+  // ownership of samples by workgroups needs whole rounds of the grid (one workgroup per CU) over each minibatch
+  const int G1 = curla_cu_count();
+  if (B % G1 != 0 || B2 % G1 != 0) return CURLA_ERR_UNSUPPORTED;
   CURLA_REQUIRE(aligned16(in) && (!B2 || aligned16(in2)));
-  size_t lds = (size_t)32 * kWStride * sizeof(float);
-  for (int l = 0; l < kMaxStack; ++l) {
-    const bool on = l < nlayers;
-    S.w[l] = on ? w[l] : nullptr, S.bias[l] = on ? bias[l] : nullptr, S.out[l] = on ? out[l] : nullptr;
-    S.w2[l] = on && B2 ? w2[l] : nullptr, S.bias2[l] = on && B2 ? bias2[l] : nullptr, S.out2[l] = on && B2 ? out2[l] : nullptr;
-    S.th[l] = S.h1[l] = S.nbands[l] = 1;
-    if (!on) continue;
-    CURLA_REQUIRE(S.w[l] && S.bias[l] && S.out[l] && aligned16(S.w[l]) && aligned16(S.bias[l]) && aligned16(S.out[l]));
-    CURLA_REQUIRE(!B2 || (S.w2[l] && S.bias2[l] && S.out2[l] && aligned16(S.w2[l]) && aligned16(S.bias2[l]) && aligned16(S.out2[l])));
-    const int Ho = Hi - 2 * l - 2, Wo = Wi - 2 * l - 2;
-    if (Ho <= 0 || Wo <= 0 || (Wo + 2) * 3 > kBandPx) return CURLA_ERR_UNSUPPORTED;
-    plan_bands_conv_s1(Ho, Wo, kBandPx, &S.th[l], &S.h1[l], &S.nbands[l]);
-    const size_t need = ((size_t)(S.h1[l] + 2) * (Wo + 2) + 1) * kLdsPix * sizeof(float);
-    if (need > lds) lds = need;
+  for (int l = 0; l < nlayers; ++l) {
+    CURLA_REQUIRE(w[l] && bias[l] && out[l] && aligned16(w[l]) && aligned16(bias[l]) && aligned16(out[l]));
+    CURLA_REQUIRE(!B2 || (w2[l] && bias2[l] && out2[l] && aligned16(w2[l]) && aligned16(bias2[l]) && aligned16(out2[l])));
   }
-  int rc = set_lds(conv_s1_stack_kernel, lds);
-  if (rc != CURLA_OK) return rc;
-  hipLaunchKernelGGL(conv_s1_stack_kernel, dim3(G), dim3(256), lds, static_cast<hipStream_t>(stream), S);
-  return curla_launch_status();
+  if (Hi - 2 * nlayers < 1 || Wi - 2 * nlayers < 1) return CURLA_ERR_UNSUPPORTED;
+  return launch_rw_fwd(nlayers, in, w, bias, out, B, in2, w2, bias2, out2, B2, Hi, Wi, true,
+                       static_cast<hipStream_t>(stream));
 }
 
-int curla_conv3x3_s1_stack_granule(void) { return use_rw() ? curla_cu_count() : 2 * curla_cu_count(); }
+int curla_conv3x3_s1_stack_granule(void) { return curla_cu_count(); }
 
 int curla_conv3x3_s1_dgrad(const float* g, const float* w, const float* act_below, float* gin, int B, int Ho, int Wo,
                            int channels, void* stream) {
@@ -2226,10 +1465,9 @@ static int conv1_fwd_impl(const void* src, int src_kind, const int64_t* idx, con
     rc = set_lds(conv1_fwd_u8_kernel<CC>, lds);                                                             \
     if (rc == CURLA_OK) hipLaunchKernelGGL((conv1_fwd_u8_kernel<CC>), dim3(grid), dim3(512), lds, st, a);   \
   }
-    // one band = the whole crop in LDS: the hybrid form (row walk out of LDS) unless CURLA_C1_U8=band asks for the old loop
-    const char* impl = getenv("CURLA_C1_U8");
-    // (its staging gives a lane one 16-byte run of a crop row: rows of at most 64 runs)
-    if (a.nbands == 1 && Wc * C <= 64 * 16 && use_rw() && !(impl && !strcmp(impl, "band"))) {
+    // one band = the whole crop in LDS: the hybrid form (row walk out of LDS) unless option conv1_u8 = band asks for the
+    // banded loop (its staging gives a lane one 16-byte run of a crop row: rows of at most 64 runs)
+    if (a.nbands == 1 && Wc * C <= 64 * 16 && curla_opt(kOptConv1U8) != 1) {
       rw::Geom G;
       G.Hi = Hc, G.Wi = Wc, G.Ho = a.Ho, G.Wo = a.Wo;
       rw::plan_units(G, a.Ho, a.Wo, 16);
@@ -2248,7 +1486,7 @@ static int conv1_fwd_impl(const void* src, int src_kind, const int64_t* idx, con
     if (rc != CURLA_OK) return rc;
     return curla_launch_status();
   }
-  if (src_kind == 2 && use_rw() && (long long)Hc * Wc * C * 4 < (1LL << 30)) {
+  if (src_kind == 2 && curla_opt(kOptConv1F32) == 0 && (long long)Hc * Wc * C * 4 < (1LL << 30)) {
     // float NHWC minibatch: row walk, nothing staged (conv1_rw.h)
     rw::Conv1Args ra;
     ra.src = static_cast<const float*>(src), ra.w = w, ra.bias = bias, ra.out = out;
@@ -2295,53 +1533,18 @@ size_t curla_conv_wgrad_workspace_floats(int cin) {
   return (size_t)4 * curla_cu_count() * ((size_t)32 * cin * 9 + 32);  // at most four workgroups (slabs) per CU
 }
 
-// which pair walk the weight-gradient body uses (see wgrad_s1_body): scalar for rows of at least 8 pairs
-static int wgrad_walk(int Wo) {
-  static const bool off = getenv("CURLA_WGRAD_WALK") && atoi(getenv("CURLA_WGRAD_WALK")) == 0;  // tuning aid
-  if (off || (Wo + 1) / 2 < 8) return 0;
-  return (Wo & 1) ? 2 : 1;
-}
-
 static int launch_wgrad_s1(const float* in, const float* g, float* workspace, int B, int Hi, int Wi, int channels,
                            hipStream_t st, int* nslabs) {
   CURLA_REQUIRE(in && g && workspace && B > 0 && Hi >= 3 && Wi >= 3);
-  if (channels != 32) return CURLA_ERR_UNSUPPORTED;
+  if (channels != 32 || !rw_supported(Hi, Wi)) return CURLA_ERR_UNSUPPORTED;
   CURLA_REQUIRE(aligned16(in) && aligned16(g));
-  if (use_rw_wgrad() && rw_supported(Hi, Wi)) {
-    rw::WgradArgs ra{in, g, workspace, B, Hi, Wi, Hi - 2, Wi - 2, rw::plan4(Hi, Wi, Hi - 2, Wi - 2)};
-    const int cap = 2 * curla_cu_count();
-    const int grid = B < cap ? B : cap;
-    const size_t lds = kPartialS1 * sizeof(float);
-    int rc = set_lds(wgrad_rw_kernel, lds);
-    if (rc != CURLA_OK) return rc;
-    hipLaunchKernelGGL(wgrad_rw_kernel, dim3(grid), dim3(256), lds, st, ra);
-    *nslabs = grid;
-    return curla_launch_status();
-  }
-  WgradS1Args a;
-  a.in = in, a.g = g, a.partial = workspace;
-  a.B = B, a.Hi = Hi, a.Wi = Wi, a.Ho = Hi - 2, a.Wo = Wi - 2;
-  if ((a.Wo + 2) * 3 > kBandPx) return CURLA_ERR_UNSUPPORTED;
-  a.th = plan_band_s1(a.Ho, a.Wo, 0, kBandPx, 8, 1, /*pairs=*/true);
-  a.nbands = (a.Ho + a.th - 1) / a.th;
-  size_t lds = (size_t)((a.th + 2) * Wi + 1) * kLdsPix * sizeof(float);  // +1 pixel: 4th window pixel of the last pair
-  if (lds < kPartialS1 * sizeof(float)) lds = kPartialS1 * sizeof(float);
-  const int nitems = B * a.nbands;
-  const int grid = nitems < 2 * curla_cu_count() ? nitems : 2 * curla_cu_count();
-  int rc;
-  switch (wgrad_walk(a.Wo)) {
-    case 1:
-      if ((rc = set_lds(wgrad_s1_kernel<1>, lds)) != CURLA_OK) return rc;
-      hipLaunchKernelGGL(wgrad_s1_kernel<1>, dim3(grid), dim3(256), lds, st, a);
-      break;
-    case 2:
-      if ((rc = set_lds(wgrad_s1_kernel<2>, lds)) != CURLA_OK) return rc;
-      hipLaunchKernelGGL(wgrad_s1_kernel<2>, dim3(grid), dim3(256), lds, st, a);
-      break;
-    default:
-      if ((rc = set_lds(wgrad_s1_kernel<0>, lds)) != CURLA_OK) return rc;
-      hipLaunchKernelGGL(wgrad_s1_kernel<0>, dim3(grid), dim3(256), lds, st, a);
-  }
+  rw::WgradArgs ra{in, g, workspace, B, Hi, Wi, Hi - 2, Wi - 2, rw::plan4(Hi, Wi, Hi - 2, Wi - 2)};
+  const int cap = 2 * curla_cu_count();
+  const int grid = B < cap ? B : cap;
+  const size_t lds = kPartialS1 * sizeof(float);
+  int rc = set_lds(wgrad_rw_kernel, lds);
+  if (rc != CURLA_OK) return rc;
+  hipLaunchKernelGGL(wgrad_rw_kernel, dim3(grid), dim3(256), lds, st, ra);
   *nslabs = grid;
   return curla_launch_status();
 }
@@ -2370,99 +1573,27 @@ int curla_conv3x3_s1_bwd_slabs(const float* in, const float* g, const float* w, 
   if (channels != 32) return CURLA_ERR_UNSUPPORTED;
   CURLA_REQUIRE(aligned16(in) && aligned16(g) && aligned16(w) && aligned16(gin));
   const int Ho = Hi - 2, Wo = Wi - 2;
-  if (use_rw_wgrad() && rw_supported(Hi, Wi)) {
-    // both halves in their row-walk forms: equal numbers of workgroups of each kind (the two do about the same
-    // number of MFMAs per sample), each owning samples k, k + n, ...
-    static const int split_rw = getenv("CURLA_BWD_SPLIT") ? atoi(getenv("CURLA_BWD_SPLIT")) : -1;
-    const bool split2 = split_rw >= 0 ? split_rw != 0 : (long long)B * Ho * Wo <= (1LL << 20);
-    const int cap2 = split2 ? curla_cu_count() : 2 * curla_cu_count();
-    const int n2 = B < cap2 ? B : cap2;
-    rw::WgradArgs wr{in, g, workspace, B, Hi, Wi, Ho, Wo, rw::plan4(Hi, Wi, Ho, Wo)};
-    const rw::Args dr = rw_dgrad_args(g, w, in, gin, B, Ho, Wo);
-    size_t lds2 = rw::kWFloats * sizeof(float);
-    if (lds2 < kPartialS1 * sizeof(float)) lds2 = kPartialS1 * sizeof(float);
-    int rc2 = set_lds(bwd_rw2_kernel, lds2);
-    if (rc2 != CURLA_OK) return rc2;
-    hipLaunchKernelGGL(bwd_rw2_kernel, dim3(2 * n2), dim3(256), lds2, static_cast<hipStream_t>(stream), wr, dr, n2);
-    *nslabs = n2;
-    return curla_launch_status();
-  }
-  // weight-gradient part (as launch_wgrad_s1)
-  WgradS1Args wa;
-  wa.in = in, wa.g = g, wa.partial = workspace;
-  wa.B = B, wa.Hi = Hi, wa.Wi = Wi, wa.Ho = Ho, wa.Wo = Wo;
-  if ((Wo + 2) * 3 > kBandPx) return CURLA_ERR_UNSUPPORTED;
-  wa.th = plan_band_s1(Ho, Wo, 0, kBandPx, 8, 1, /*pairs=*/true);
-  wa.nbands = (Ho + wa.th - 1) / wa.th;
-  size_t lds_w = (size_t)((wa.th + 2) * Wi + 1) * kLdsPix * sizeof(float);
-  if (lds_w < kPartialS1 * sizeof(float)) lds_w = kPartialS1 * sizeof(float);
-  // grid: 2 x CUs workgroups of each kind, run one kind after the other -- or, for short launches, ONE workgroup of
-  // each kind per CU side by side (blocks 0..CUs-1 and CUs..2 CUs-1; both persistent over their kind's items).  Side
-  // by side the layer takes as long (143 / 161 / 182 us at B = 512: a CU shared between the two kinds is no busier
-  // than one shared by two of a kind), but the weight gradient leaves half as many slabs for the reduction to read
-  // (14 -> 10 us per backward pass).  Long launches keep the 2 + 2 form: there a few percent of imbalance between the
-  // kinds (the tail runs at one workgroup per CU) costs more than the slabs (B = 1024 at 81 x 81: +0.3 ms per update).
-  static const int split_env = getenv("CURLA_BWD_SPLIT") ? atoi(getenv("CURLA_BWD_SPLIT")) : -1;  // tuning aid: 0 / 1
-  const bool split = split_env >= 0 ? split_env != 0 : (long long)B * Ho * Wo <= (1LL << 20);
-  const int cap = split ? curla_cu_count() : 2 * curla_cu_count();
-  const int items_w = B * wa.nbands;
-  const int nw = items_w < cap ? items_w : cap;
-  if (use_rw() && rw_supported(Hi, Wi)) {
-    // data gradient in its row-walk form: workgroup k of its block range owns samples k, k + nd, ...
-    const rw::Args ra = rw_dgrad_args(g, w, in, gin, B, Ho, Wo);
-    const int nd_rw = B < cap ? B : cap;
-    size_t lds_rw = rw::kWFloats * sizeof(float);
-    if (lds_rw < lds_w) lds_rw = lds_w;
-    int rc_rw;
-    hipStream_t st_rw = static_cast<hipStream_t>(stream);
-    switch (wgrad_walk(Wo)) {
-      case 1:
-        if ((rc_rw = set_lds(bwd_rw_kernel<1>, lds_rw)) != CURLA_OK) return rc_rw;
-        hipLaunchKernelGGL(bwd_rw_kernel<1>, dim3(nw + nd_rw), dim3(256), lds_rw, st_rw, wa, ra, nw);
-        break;
-      case 2:
-        if ((rc_rw = set_lds(bwd_rw_kernel<2>, lds_rw)) != CURLA_OK) return rc_rw;
-        hipLaunchKernelGGL(bwd_rw_kernel<2>, dim3(nw + nd_rw), dim3(256), lds_rw, st_rw, wa, ra, nw);
-        break;
-      default:
-        if ((rc_rw = set_lds(bwd_rw_kernel<0>, lds_rw)) != CURLA_OK) return rc_rw;
-        hipLaunchKernelGGL(bwd_rw_kernel<0>, dim3(nw + nd_rw), dim3(256), lds_rw, st_rw, wa, ra, nw);
-    }
-    *nslabs = nw;
-    return curla_launch_status();
-  }
-  // data-gradient part (as launch_conv_s1 in MODE_DGRAD: input = the output gradient [B][Ho][Wo], output [B][Hi][Wi])
-  ConvS1Args da;
-  da.in = g, da.w = w, da.aux = in, da.out = gin;
-  da.in2 = nullptr, da.w2 = nullptr, da.aux2 = nullptr, da.out2 = nullptr, da.B2 = 0;
-  da.B = B, da.Hs = Ho, da.Ws = Wo, da.pad = 2, da.Ho = Hi, da.Wo = Wi;
-  if ((da.Wo + 2) * 3 > kBandPx) return CURLA_ERR_UNSUPPORTED;
-  plan_bands_conv_s1(da.Ho, da.Wo, kBandPx, &da.th, &da.h1, &da.nbands);
-  const int PW = (da.Wo + 1) / 2;
-  da.qstep = 32 / PW, da.rstep = 32 - da.qstep * PW;
-  da.dbg = 0;
-  size_t lds_d = ((size_t)(da.h1 + 2) * (da.Wo + 2) + 1) * kLdsPix * sizeof(float);
-  const size_t wl = (size_t)32 * kWStride * sizeof(float);
-  if (lds_d < wl) lds_d = wl;
-  const int items_d = B * da.nbands;
-  const int nd = items_d < cap ? items_d : cap;
-  const size_t lds = lds_w > lds_d ? lds_w : lds_d;
-  int rc;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (wgrad_walk(Wo)) {
-    case 1:
-      if ((rc = set_lds(bwd_s1_kernel<1>, lds)) != CURLA_OK) return rc;
-      hipLaunchKernelGGL(bwd_s1_kernel<1>, dim3(nw + nd), dim3(256), lds, st, wa, da, nw);
-      break;
-    case 2:
-      if ((rc = set_lds(bwd_s1_kernel<2>, lds)) != CURLA_OK) return rc;
-      hipLaunchKernelGGL(bwd_s1_kernel<2>, dim3(nw + nd), dim3(256), lds, st, wa, da, nw);
-      break;
-    default:
-      if ((rc = set_lds(bwd_s1_kernel<0>, lds)) != CURLA_OK) return rc;
-      hipLaunchKernelGGL(bwd_s1_kernel<0>, dim3(nw + nd), dim3(256), lds, st, wa, da, nw);
-  }
-  *nslabs = nw;
+  if (!rw_supported(Hi, Wi)) return CURLA_ERR_UNSUPPORTED;
+  // Weight gradient and data gradient of the layer in ONE launch (both only read the layer's output gradient): the
+  // first n workgroups run the weight-gradient body, the next n the data-gradient body, each owning samples k, k + n,
+  // ... (the two do about the same number of MFMAs per sample).  Grid: 2 x CUs workgroups of each kind, run one kind
+  // after the other -- or, for short launches, ONE workgroup of each kind per CU side by side: the layer takes as long
+  // (a CU shared between the two kinds is no busier than one shared by two of a kind), but the weight gradient leaves
+  // half as many slabs for the reduction to read.  Long launches keep the 2 + 2 form: there a few percent of imbalance
+  // between the kinds (the tail runs at one workgroup per CU) costs more than the slabs (B = 1024 at 81 x 81: +0.3 ms
+  // per update).  Option bwd_split (options.h) forces either form.
+  const int split_opt = curla_opt(kOptBwdSplit);
+  const bool split2 = split_opt ? split_opt == 2 : (long long)B * Ho * Wo <= (1LL << 20);
+  const int cap2 = split2 ? curla_cu_count() : 2 * curla_cu_count();
+  const int n2 = B < cap2 ? B : cap2;
+  rw::WgradArgs wr{in, g, workspace, B, Hi, Wi, Ho, Wo, rw::plan4(Hi, Wi, Ho, Wo)};
+  const rw::Args dr = rw_dgrad_args(g, w, in, gin, B, Ho, Wo);
+  size_t lds2 = rw::kWFloats * sizeof(float);
+  if (lds2 < kPartialS1 * sizeof(float)) lds2 = kPartialS1 * sizeof(float);
+  int rc2 = set_lds(bwd_rw2_kernel, lds2);
+  if (rc2 != CURLA_OK) return rc2;
+  hipLaunchKernelGGL(bwd_rw2_kernel, dim3(2 * n2), dim3(256), lds2, static_cast<hipStream_t>(stream), wr, dr, n2);
+  *nslabs = n2;
   return curla_launch_status();
 }
 
@@ -2507,7 +1638,7 @@ static int launch_wgrad1(const void* src, int src_kind, const int64_t* idx, cons
   const int nw = 32 * C * 9;
   hipStream_t st = static_cast<hipStream_t>(stream);
   int grid;
-  if (src_kind == 2 && use_rw() && (long long)Hc * Wc * C * 4 < (1LL << 30)) {
+  if (src_kind == 2 && curla_opt(kOptConv1F32) == 0 && (long long)Hc * Wc * C * 4 < (1LL << 30)) {
     // float NHWC minibatch: row walk, nothing staged (conv1_rw.h)
     rw::Wgrad1Args ra;
     ra.src = static_cast<const float*>(src), ra.g = g, ra.partial = workspace;

@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include "common.h"
+#include "options.h"
 
 namespace {
 
@@ -1078,7 +1079,7 @@ extern "C" {
 
 // small output, long k: one workgroup per 16 x 16 tile, k split over its waves (gemm_small_kernel)
 static bool small_shape(int M, int N, int K, int nbatch) {
-  static const bool small_on = !(getenv("CURLA_GEMM_SMALL") && atoi(getenv("CURLA_GEMM_SMALL")) == 0);
+  const bool small_on = curla_opt(kOptGemmSmall) == 0;  // (option gemm_small, options.h)
   const long long t32 = (long long)((M + 31) / 32) * ((N + 31) / 32) * nbatch;
   return small_on && K >= 256 && K % 64 == 0 && t32 <= 128 && nbatch <= 65535;
 }
@@ -1119,14 +1120,11 @@ static int gemm_plan(GemmArgs& g, int a_kmajor, int b_kmajor, GemmPlan& p) {
   // instead of 128-B pieces of each HBM row and is faster even at one workgroup per CU
   if (tbn == 32 && M <= 64 && a_kmajor && b_kmajor && 2 * wgs64 >= cu2) tbn = 64;
   if (tbn == 32 && wgs6432 < cu2 && M > 32) tbm = 32;
-  {  // tuning aid (tools/gemm_shapes.py): CURLA_GEMM_TILE=6464|6432|3232 forces a tile shape
-    static const char* force = getenv("CURLA_GEMM_TILE");
-    if (force) {
-      const int v = atoi(force);
-      if (v == 6464) tbm = 64, tbn = 64;
-      if (v == 6432) tbm = 64, tbn = 32;
-      if (v == 3232) tbm = 32, tbn = 32;
-    }
+  switch (curla_opt(kOptGemmTile)) {  // option gemm_tile (options.h; tools/gemm_shapes.py): a forced tile shape
+    case 1: tbm = 64, tbn = 64; break;
+    case 2: tbm = 64, tbn = 32; break;
+    case 3: tbm = 32, tbn = 32; break;
+    default: break;
   }
   p.tbm = tbm, p.tbn = tbn;
   // interior + aligned everywhere: the k loop runs without bounds / alignment tests
@@ -1269,7 +1267,7 @@ int curla_linear_bwd(const float* dy, long long stride_dy, const float* x, long 
   if (rc != CURLA_OK) return rc;
   rc = gemm_plan(g2, 0, 1, p2);
   if (rc != CURLA_OK) return rc;
-  static const bool split = getenv("CURLA_LINEAR_BWD") && !strcmp(getenv("CURLA_LINEAR_BWD"), "split");
+  const bool split = curla_opt(kOptLinearBwd) == 1;  // (option linear_bwd, options.h)
   const int T1 = p1.small ? 16 : 0, T2 = p2.small ? 16 : 0;
   const int gx1 = (g1.N + (T1 ? T1 : p1.tbn) - 1) / (T1 ? T1 : p1.tbn), gy1 = (g1.M + (T1 ? T1 : p1.tbm) - 1) / (T1 ? T1 : p1.tbm);
   const int gx2 = (g2.N + (T2 ? T2 : p2.tbn) - 1) / (T2 ? T2 : p2.tbn), gy2 = (g2.M + (T2 ? T2 : p2.tbm) - 1) / (T2 ? T2 : p2.tbm);

@@ -932,13 +932,17 @@ __global__ __launch_bounds__(512) void curl_head_kernel(CurlHeadArgs a) {
           for (int t = 0; t < 4; ++t) acc[t] = mfma16(av[u], bv[c0 + u][t], acc[t]);
       }
     } else {
-      for (int c0 = 0; c0 < KW; c0 += 8) {
+      // runs of CH k-steps: 8 where KW = 4 NTILE divides by 8, else 4 (NTILE 5, 7: a run of 8 would walk into the next
+      // lane group's columns and, in the last wave, past the operand's last row)
+      constexpr int CH = (KW % 8 == 0) ? 8 : 4;
+      static_assert(KW % CH == 0, "phase B walks whole runs");
+      for (int c0 = 0; c0 < KW; c0 += CH) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) load_bv(bv[u], c0 + u);
+        for (int u = 0; u < CH; ++u) load_bv(bv[u], c0 + u);
 #pragma unroll
-        for (int u = 0; u < 8; ++u) fix_bv(bv[u]);
+        for (int u = 0; u < CH; ++u) fix_bv(bv[u]);
 #pragma unroll
-        for (int u4 = 0; u4 < 8; u4 += 4) {
+        for (int u4 = 0; u4 < CH; u4 += 4) {
           const f32x4 av = *reinterpret_cast<const f32x4*>(arow + c0 + u4);
 #pragma unroll
           for (int u = 0; u < 4; ++u)

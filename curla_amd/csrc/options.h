@@ -1,0 +1,18 @@
+// Run-time kernel-selection options of the library (curla_set_option / curla_get_option in include/curla_hip.h).
+// Every option has a default that is the measured-best path; the alternatives are kept because they are the fallback
+// for shapes the default does not take, or the A/B partner a measurement needs -- and every value of every option runs
+// under the whole-update parity test of tests/test_gpu_switches.py.  The environment variable of the same name
+// (CURLA_<NAME>) only sets the INITIAL value, read once when the library is first used.
+#pragma once
+
+enum CurlaOpt {
+  kOptConv1U8 = 0,  // first layer from the uint8 ring: 0 hybrid (crop in LDS, row walk out of LDS), 1 band, 2 rw (no LDS)
+  kOptConv1F32,     // first layer (and its weight gradient) from a float NHWC minibatch: 0 rw (conv1_rw.h), 1 band
+  kOptBwdSplit,     // stride-1 backward launch: 0 auto, 1 two + two workgroups per CU, 2 one + one side by side
+  kOptGemmSmall,    // small-output / long-k products on gemm_small_kernel: 0 on, 1 off (tiled kernel)
+  kOptGemmTile,     // tile shape of the tiled GEMM: 0 auto, 1 64x64, 2 64x32, 3 32x32
+  kOptLinearBwd,    // backward of a linear layer: 0 one launch for dW and dx, 1 two launches
+  kOptCount
+};
+
+int curla_opt(int id);  // current value (options.hip)

@@ -20,6 +20,7 @@ the reference's autograd cannot do:
 => 5 conv-stack forwards + 2 backwards per update instead of the reference's 7 + 2.
 """
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -706,9 +707,12 @@ class CurlSacAgent(object):
     def _noise(self, ws, noise):
         """(noise buffer, rng): explicit ``noise`` is copied into the buffer (rng None).  Without it
         (``torch.randn_like``, curl_sac.py:97) the policy-head launch draws the numbers itself and writes them into the
-        buffer: rng = (seed, offset) of the device's default torch generator, whose Philox offset is advanced here as a
-        ``normal_()`` would advance it -- so torch.manual_seed, get_rng_state / set_rng_state (checkpoints) and the
-        per-rank seeds keep their meaning.  Where the generator does not expose its offset: a ``normal_()`` launch."""
+        buffer: rng = (seed, Philox counter) taken from the device's default torch generator, whose offset is moved on
+        here by the numbers drawn (rounded up to 4) -- consecutive draws use NON-OVERLAPPING counters and
+        torch.manual_seed, get_rng_state / set_rng_state (checkpoints) and the per-rank seeds keep their meaning.  The
+        offset trajectory is this build's own: it is NOT the one a ``normal_()`` launch would leave behind (torch's
+        increment depends on its grid), so a generator state saved by the ``normal_()`` path continues with different
+        numbers.  Where the generator does not expose its offset this agent warns once and draws with ``normal_()``."""
         if noise is not None:
             ws.noise.copy_(noise)
             return ws.noise, None
@@ -719,8 +723,10 @@ class CurlSacAgent(object):
                 off = gen.get_offset()
                 gen.set_offset(off + 4 * ((ws.noise.numel() + 3) // 4))
                 return ws.noise, (gen.initial_seed(), off // 4)
-            except (AttributeError, RuntimeError):
-                type(self)._noise_launch = True
+            except (AttributeError, RuntimeError) as e:
+                self._noise_launch = True  # (this agent only)
+                warnings.warn(f"curla_amd: the torch generator exposes no Philox offset ({e!r}); policy noise falls "
+                              "back to a separate normal_() launch per phase", RuntimeWarning, stacklevel=2)
         ws.noise.normal_()
         return ws.noise, None
 
@@ -1047,12 +1053,9 @@ class CurlSacAgent(object):
     def load(self, model_dir, augmentation, step):
         """curl_sac.py:458-465."""
         self.CURL.load_state_dict(torch.load('%s/%s_curl_%s.pt' % (model_dir, augmentation, step)))
-        print('Loaded model %s/%s_curl_%s.pt' % (model_dir, augmentation, step))
         self.actor.load_state_dict(torch.load('%s/%s_actor_%s.pt' % (model_dir, augmentation, step)))
-        print('Loaded model %s/%s_actor_%s.pt' % (model_dir, augmentation, step))
         self.critic.load_state_dict(torch.load('%s/%s_critic_%s.pt' % (model_dir, augmentation, step)))
         self.critic_target.load_state_dict(self.critic.state_dict())
-        print('Loaded model %s/%s_critic_%s.pt' % (model_dir, augmentation, step))
 
     # -- full training state (SURVEY.md 8f rank 2: the reference only writes the three state_dicts above and
     #    cannot resume; this adds log_alpha, the target critic, the five Adam states, the RNG streams and the step)

@@ -34,6 +34,20 @@ extern "C" {
 
 const char* curla_version(void);
 
+/* Run-time kernel-selection options (curla_amd/csrc/options.h).  Every option's default is the measured-best path;
+ * the other values are fallbacks for shapes the default does not take or A/B partners for measurements, and every
+ * value runs under the whole-update parity test (tests/test_gpu_switches.py).  The environment variable
+ * CURLA_<NAME> sets the initial value (read once, at first use); afterwards only these calls change it.
+ *   conv1_u8    hybrid | band | rw     first layer from the uint8 ring (utils.py:151-166 + encoder.py:78-81)
+ *   conv1_f32   rw | band              first layer and its weight gradient from a float NHWC minibatch
+ *   bwd_split   auto | 0 | 1           stride-1 backward: 2 + 2 workgroups per CU, or 1 + 1 side by side
+ *   gemm_small  1 | 0                  small-output / long-k products on their own kernel
+ *   gemm_tile   auto | 6464 | 6432 | 3232
+ *   linear_bwd  pair | split           dW and dx of a linear layer in one launch or two
+ * curla_set_option returns CURLA_ERR_ARG for an unknown name or value; curla_get_option NULL for an unknown name. */
+int curla_set_option(const char* name, const char* value);
+const char* curla_get_option(const char* name);
+
 /* ---- encoder convolutions (encoder.py:54-63 construction, :77-90 forward) ---- */
 
 /* First layer: 3x3 stride 2, C -> 32, + bias + ReLU, with the minibatch assembly

@@ -173,32 +173,83 @@ class _ReluGivenBranch(torch.autograd.Function):
     another (1-2 elements out of 20 million per layer at B=512), and since a conv weight gradient is a sum of
     ~600k signed, largely cancelling terms, ONE such element moves it by ~1e-4 .. 1e-3 of its size.  Comparing two
     evaluations element by element is meaningful only when both took the same branch at those elements; the tests
-    assert separately that the disagreeing elements are few and all within rounding of 0."""
+    assert separately that the disagreeing elements are few and all within rounding of 0.
+
+    The branch is looked up at BACKWARD time in ``plan[key]`` (None / missing: the ReLU's own x > 0), so one forward
+    pass can be differentiated several times under different branch decisions (``regrad`` of the phase functions)."""
 
     @staticmethod
-    def forward(ctx, x, positive):
-        ctx.save_for_backward(positive)
+    def forward(ctx, x, plan, key):
+        ctx.plan, ctx.key = plan, key
+        ctx.save_for_backward(x > 0)
         return x.clamp_min(0)
 
     @staticmethod
     def backward(ctx, g):
-        (positive,) = ctx.saved_tensors
-        return g * positive.to(g.dtype), None
+        positive = ctx.plan.get(ctx.key)
+        if positive is None:
+            (positive,) = ctx.saved_tensors
+        return g * positive.to(g.dtype), None, None
+
+
+def _relu(x, plan, key):
+    """torch.relu, or -- when the caller differentiates along given branches (``plan`` is a dict) -- the same values
+    with the derivative's branch taken from ``plan[key]``."""
+    return torch.relu(x) if plan is None else _ReluGivenBranch.apply(x, plan, key)
+
+
+def _branch_plan(relu_branches=None, q_branches=None, trunk_branches=None, force=False):
+    """The dict _ReluGivenBranch reads: ("conv", i) -> [B, C, H, W] booleans, ("Q1." | "Q2." | "trunk.", j) ->
+    [B, hidden] booleans.  None when no branch is given (plain torch.relu everywhere) unless ``force``."""
+    if relu_branches is None and q_branches is None and trunk_branches is None and not force:
+        return None
+    plan = {}
+    for i, m in enumerate(relu_branches or []):
+        plan[("conv", i)] = m
+    for name, pair in zip(("Q1.trunk.", "Q2.trunk."), q_branches or []):
+        for j, m in enumerate(pair or []):
+            plan[(name, j)] = m
+    for j, m in enumerate(trunk_branches or []):
+        plan[("trunk.", j)] = m
+    return plan
+
+
+def _conv2d(x, w, b, stride):
+    """F.conv2d (encoder.py:80,85).  float64 inputs (the arbiter passes of tests/test_gpu_fullsize.py) go through
+    PyTorch's im2col path, whose column buffer covers the whole batch (15 GB for one layer of configs[4]): those are
+    evaluated 64 samples at a time -- a sample's result does not depend on its batch."""
+    if x.dtype != torch.float64 or x.shape[0] <= 64:
+        return F.conv2d(x, w, b, stride=stride)
+    return torch.cat([F.conv2d(xc, w, b, stride=stride) for xc in x.split(64)])
+
+
+def as_dtype(x, dtype):
+    """Tensors / dicts / lists of tensors cast to ``dtype`` (detached copies; None and non-float tensors pass
+    through): the float64 evaluation of a phase is the same function on ``as_dtype(..., torch.float64)`` arguments."""
+    if x is None:
+        return None
+    if isinstance(x, dict):
+        return {k: as_dtype(v, dtype) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(as_dtype(v, dtype) for v in x)
+    if torch.is_tensor(x) and x.is_floating_point():
+        return x.detach().to(dtype)
+    return x
 
 
 def encoder_forward(p: Params, prefix: str, obs: torch.Tensor, num_layers: int,
                     detach: bool = False, output_logits: bool = True,
                     conv_prefix: Optional[str] = None, outputs: Optional[dict] = None,
-                    relu_branches: Optional[list] = None) -> torch.Tensor:
+                    plan: Optional[dict] = None) -> torch.Tensor:
     """CNNEncoder.forward (encoder.py:77-110).  obs: float NCHW in [0,255].
     ``conv_prefix`` lets the actor use the critic's conv tensors (weight tying,
-    encoder.py:112-116 / curl_sac.py:290).  ``relu_branches`` (tests only): one boolean NCHW tensor per conv
-    layer, the branch each ReLU's derivative takes (see _ReluGivenBranch); None = the plain ``torch.relu``."""
+    encoder.py:112-116 / curl_sac.py:290).  ``plan`` (tests only, see _branch_plan): the branch each conv ReLU's
+    derivative takes; None = the plain ``torch.relu``."""
     cp = conv_prefix if conv_prefix is not None else prefix
     x = obs / 255.0
     for i in range(num_layers):
-        x = F.conv2d(x, p[f"{cp}convs.{i}.weight"], p[f"{cp}convs.{i}.bias"], stride=2 if i == 0 else 1)
-        x = torch.relu(x) if relu_branches is None else _ReluGivenBranch.apply(x, relu_branches[i])
+        x = _conv2d(x, p[f"{cp}convs.{i}.weight"], p[f"{cp}convs.{i}.bias"], 2 if i == 0 else 1)
+        x = _relu(x, plan, ("conv", i))
         if outputs is not None:
             outputs[f"conv{i + 1}"] = x
     h = x.reshape(x.size(0), -1)
@@ -212,20 +263,23 @@ def encoder_forward(p: Params, prefix: str, obs: torch.Tensor, num_layers: int,
     return h_norm if output_logits else torch.tanh(h_norm)
 
 
-def mlp3(p: Params, prefix: str, x: torch.Tensor, relu_branches: Optional[list] = None) -> torch.Tensor:
-    """Linear-ReLU-Linear-ReLU-Linear trunk (curl_sac.py:70-74,129-133).  ``relu_branches`` (tests only): the
-    branch each of the two ReLUs' derivatives takes, as two boolean [B, hidden] tensors (see _ReluGivenBranch: a hidden
-    unit within rounding of 0 moves a trunk weight gradient by ~1/sqrt(B) of a row's size)."""
-    act = (lambda h, i: torch.relu(h)) if relu_branches is None else (lambda h, i: _ReluGivenBranch.apply(h, relu_branches[i]))
-    x = act(F.linear(x, p[f"{prefix}0.weight"], p[f"{prefix}0.bias"]), 0)
-    x = act(F.linear(x, p[f"{prefix}2.weight"], p[f"{prefix}2.bias"]), 1)
-    return F.linear(x, p[f"{prefix}4.weight"], p[f"{prefix}4.bias"])
+def mlp3(p: Params, prefix: str, x: torch.Tensor, plan: Optional[dict] = None,
+         hidden: Optional[list] = None) -> torch.Tensor:
+    """Linear-ReLU-Linear-ReLU-Linear trunk (curl_sac.py:70-74,129-133).  ``plan`` (tests only, see _branch_plan):
+    the branch each of the two ReLUs' derivatives takes (a hidden unit within rounding of 0 moves a trunk weight
+    gradient by ~1/sqrt(B) of a row's size).  ``hidden`` (tests only): a list that receives the two PRE-activations
+    [B, hidden] (detached)."""
+    h1 = F.linear(x, p[f"{prefix}0.weight"], p[f"{prefix}0.bias"])
+    h2 = F.linear(_relu(h1, plan, (prefix, 0)), p[f"{prefix}2.weight"], p[f"{prefix}2.bias"])
+    if hidden is not None:
+        hidden += [h1.detach(), h2.detach()]
+    return F.linear(_relu(h2, plan, (prefix, 1)), p[f"{prefix}4.weight"], p[f"{prefix}4.bias"])
 
 
 def actor_forward(actor: Params, critic: Params, obs: torch.Tensor, noise: Optional[torch.Tensor],
                   num_layers: int, log_std_min: float, log_std_max: float,
                   detach_encoder: bool = False, compute_pi: bool = True, compute_log_pi: bool = True,
-                  trunk_branches: Optional[list] = None):
+                  plan: Optional[dict] = None, hidden: Optional[list] = None):
     """Actor.forward + gaussian_logprob + squash (curl_sac.py:20-35,79-110).
     The conv tensors come from ``critic`` (tied); fc/ln/trunk from ``actor``.
     ``noise`` replaces ``torch.randn_like(mu)`` (curl_sac.py:97)."""
@@ -234,7 +288,7 @@ def actor_forward(actor: Params, critic: Params, obs: torch.Tensor, noise: Optio
         if k.startswith("encoder.convs."):
             merged[k] = v
     z = encoder_forward(merged, "encoder.", obs, num_layers, detach=detach_encoder)
-    mu, log_std = mlp3(merged, "trunk.", z, trunk_branches).chunk(2, dim=-1)
+    mu, log_std = mlp3(merged, "trunk.", z, plan, hidden).chunk(2, dim=-1)
     log_std = torch.tanh(log_std)
     log_std = log_std_min + 0.5 * (log_std_max - log_std_min) * (log_std + 1)
     pi = log_pi = None
@@ -252,15 +306,13 @@ def actor_forward(actor: Params, critic: Params, obs: torch.Tensor, noise: Optio
 
 
 def critic_forward(critic: Params, obs: torch.Tensor, action: torch.Tensor, num_layers: int,
-                   detach_encoder: bool = False, outputs: Optional[dict] = None, relu_branches: Optional[list] = None,
-                   q_branches: Optional[list] = None):
-    """Critic.forward / QFunction.forward (curl_sac.py:135-169).  ``q_branches`` (tests only): [Q1's, Q2's] pair of
-    mlp3 ``relu_branches``."""
-    z = encoder_forward(critic, "encoder.", obs, num_layers, detach=detach_encoder, outputs=outputs,
-                        relu_branches=relu_branches)
+                   detach_encoder: bool = False, outputs: Optional[dict] = None, plan: Optional[dict] = None,
+                   hidden: Optional[list] = None):
+    """Critic.forward / QFunction.forward (curl_sac.py:135-169).  ``plan`` (tests only): see _branch_plan;
+    ``hidden`` (tests only) receives Q1's then Q2's two hidden pre-activations."""
+    z = encoder_forward(critic, "encoder.", obs, num_layers, detach=detach_encoder, outputs=outputs, plan=plan)
     za = torch.cat([z, action], dim=1)
-    qb = q_branches if q_branches is not None else (None, None)
-    return mlp3(critic, "Q1.trunk.", za, qb[0]), mlp3(critic, "Q2.trunk.", za, qb[1])
+    return mlp3(critic, "Q1.trunk.", za, plan, hidden), mlp3(critic, "Q2.trunk.", za, plan, hidden)
 
 
 def curl_logits(W: torch.Tensor, z_a: torch.Tensor, z_pos: torch.Tensor) -> torch.Tensor:
@@ -281,13 +333,29 @@ def _grads(p: Params) -> Dict[str, Optional[torch.Tensor]]:
     return {k: (None if v.grad is None else v.grad.detach().clone()) for k, v in p.items()}
 
 
+def _regrad_fn(plan: dict, leaves, backward, collect):
+    """``regrad(relu_branches=None, q_branches=None, trunk_branches=None)`` of a phase evaluated with ``regrad=True``:
+    differentiates the SAME forward pass again with the ReLU derivatives along the given branches (None: every ReLU's
+    own) and returns what ``collect()`` gathers.  Values are untouched by construction: only backward passes rerun."""
+    def regrad(relu_branches=None, q_branches=None, trunk_branches=None):
+        plan.clear()
+        plan.update(_branch_plan(relu_branches, q_branches, trunk_branches, force=True))
+        for v in leaves:
+            v.grad = None
+        backward(True)
+        return collect()
+    return regrad
+
+
 def critic_phase(actor: Params, critic: Params, critic_target: Params, log_alpha: torch.Tensor,
                  obs, action, reward, next_obs, not_done, noise, *, num_layers: int, discount: float,
                  log_std_min: float, log_std_max: float, detach_encoder: bool = False,
-                 relu_branches: Optional[list] = None, q_branches: Optional[list] = None):
+                 relu_branches: Optional[list] = None, q_branches: Optional[list] = None, regrad: bool = False):
     """CurlSacAgent.update_critic up to and including backward
     (curl_sac.py:349-367).  Returns dict(loss, target_Q, q1, q2, grads, enc).
-    ``relu_branches``: see encoder_forward (applies to the critic's differentiated pass over ``obs``)."""
+    ``relu_branches`` / ``q_branches`` (tests only): the derivative branches of the conv ReLUs (one boolean NCHW tensor
+    per layer) and of the twin-Q hidden units ([Q1's pair, Q2's pair] of [B, hidden] booleans) in the critic's
+    differentiated pass over ``obs``; ``regrad=True`` adds ``regrad(...)`` to the result (see _regrad_fn) -> grads."""
     with torch.no_grad():
         _, policy_action, log_pi, _ = actor_forward(actor, critic, next_obs, noise, num_layers,
                                                     log_std_min, log_std_max)
@@ -295,58 +363,75 @@ def critic_phase(actor: Params, critic: Params, critic_target: Params, log_alpha
         alpha = log_alpha.detach().exp()
         target_V = torch.min(tq1, tq2) - alpha * log_pi
         target_Q = reward + (not_done * discount * target_V)
-        target_Q = target_Q.to(torch.float32)
+        target_Q = target_Q.to(reward.dtype)  # (curl_sac.py:355 `.to(torch.float32)`: the float64 log_alpha promotes it)
     c = _leafify(critic)
-    enc = {}
-    q1, q2 = critic_forward(c, obs, action, num_layers, detach_encoder=detach_encoder, outputs=enc,
-                            relu_branches=relu_branches, q_branches=q_branches)
+    enc, qh = {}, []
+    plan = _branch_plan(relu_branches, q_branches, force=regrad)
+    q1, q2 = critic_forward(c, obs, action, num_layers, detach_encoder=detach_encoder, outputs=enc, plan=plan, hidden=qh)
     loss = F.mse_loss(q1, target_Q) + F.mse_loss(q2, target_Q)
-    loss.backward()
-    return dict(loss=loss.detach(), target_Q=target_Q, q1=q1.detach(), q2=q2.detach(),
-                policy_action=policy_action, next_log_pi=log_pi,
-                grads=_grads(c), enc={k: v.detach() for k, v in enc.items()})
+    loss.backward(retain_graph=regrad)
+    out = dict(loss=loss.detach(), target_Q=target_Q, q1=q1.detach(), q2=q2.detach(),
+               policy_action=policy_action, next_log_pi=log_pi,
+               grads=_grads(c), enc={k: v.detach() for k, v in enc.items()}, q_hidden=qh)
+    if regrad:
+        out["regrad"] = _regrad_fn(plan, list(c.values()), lambda keep: loss.backward(retain_graph=keep), lambda: _grads(c))
+    return out
 
 
 def actor_phase(actor: Params, critic: Params, log_alpha: torch.Tensor, obs, noise, *,
                 num_layers: int, log_std_min: float, log_std_max: float, target_entropy: float,
-                trunk_branches: Optional[list] = None, q_branches: Optional[list] = None):
+                trunk_branches: Optional[list] = None, q_branches: Optional[list] = None, regrad: bool = False):
     """CurlSacAgent.update_actor_and_alpha up to the two backward calls
     (curl_sac.py:373-403).  Live gradients: the actor's own fc/ln/trunk and
     log_alpha; gradients deposited on critic tensors are dead in the reference
-    (cleared before any step reads them) and are not returned."""
+    (cleared before any step reads them) and are not returned.  ``trunk_branches`` / ``q_branches`` / ``regrad``
+    (tests only): as in critic_phase; ``regrad(...)`` returns the actor's live gradients."""
     a = _leafify(actor)
     la = log_alpha.detach().clone().requires_grad_(True)
+    th, qh = [], []
+    plan = _branch_plan(None, q_branches, trunk_branches, force=regrad)
     _, pi, log_pi, log_std = actor_forward(a, critic, obs, noise, num_layers, log_std_min, log_std_max,
-                                           detach_encoder=True, trunk_branches=trunk_branches)
-    q1, q2 = critic_forward(critic, obs, pi, num_layers, detach_encoder=True, q_branches=q_branches)
+                                           detach_encoder=True, plan=plan, hidden=th)
+    q1, q2 = critic_forward(critic, obs, pi, num_layers, detach_encoder=True, plan=plan, hidden=qh)
     actor_Q = torch.min(q1, q2)
     actor_loss = (la.exp().detach() * log_pi - actor_Q).mean()
     entropy = 0.5 * log_std.shape[1] * (1.0 + np.log(2 * np.pi)) + log_std.sum(dim=-1)
-    actor_loss.backward()
+    actor_loss.backward(retain_graph=regrad)
     alpha_loss = (la.exp() * (-log_pi - target_entropy).detach()).mean()
     alpha_loss.backward()
-    grads = {k: g for k, g in _grads(a).items() if g is not None}
-    return dict(actor_loss=actor_loss.detach(), alpha_loss=alpha_loss.detach(), entropy=entropy.mean().detach(),
-                alpha=la.exp().detach(), pi=pi.detach(), log_pi=log_pi.detach(), log_std=log_std.detach(),
-                q1=q1.detach(), q2=q2.detach(), grads=grads, log_alpha_grad=la.grad.detach().clone())
+    live = lambda: {k: g for k, g in _grads(a).items() if g is not None}  # noqa: E731
+    out = dict(actor_loss=actor_loss.detach(), alpha_loss=alpha_loss.detach(), entropy=entropy.mean().detach(),
+               alpha=la.exp().detach(), pi=pi.detach(), log_pi=log_pi.detach(), log_std=log_std.detach(),
+               q1=q1.detach(), q2=q2.detach(), grads=live(), log_alpha_grad=la.grad.detach().clone(),
+               trunk_hidden=th, q_hidden=qh)
+    if regrad:
+        out["regrad"] = _regrad_fn(plan, list(a.values()), lambda keep: actor_loss.backward(retain_graph=keep), live)
+    return out
 
 
 def cpc_phase(critic: Params, critic_target: Params, W: torch.Tensor, obs_anchor, obs_pos, *, num_layers: int,
-              relu_branches: Optional[list] = None):
+              relu_branches: Optional[list] = None, regrad: bool = False):
     """CurlSacAgent.update_cpc up to backward (curl_sac.py:406-417): anchors
     through the online encoder, positives through the target encoder under
-    no_grad, bilinear logits, cross-entropy against arange(B)."""
+    no_grad, bilinear logits, cross-entropy against arange(B).  ``relu_branches`` / ``regrad`` (tests only): as in
+    critic_phase; ``regrad(...)`` returns (encoder grads, W grad)."""
     enc = _leafify({k: v for k, v in critic.items() if k.startswith("encoder.")})
     Wl = W.detach().clone().requires_grad_(True)
-    z_a = encoder_forward(enc, "encoder.", obs_anchor, num_layers, relu_branches=relu_branches)
+    plan = _branch_plan(relu_branches, force=regrad)
+    acts = {}
+    z_a = encoder_forward(enc, "encoder.", obs_anchor, num_layers, plan=plan, outputs=acts)
     with torch.no_grad():
         z_pos = encoder_forward(critic_target, "encoder.", obs_pos, num_layers)
     logits = curl_logits(Wl, z_a, z_pos)
     labels = torch.arange(logits.shape[0]).long()
     loss = F.cross_entropy(logits, labels)
-    loss.backward()
-    return dict(loss=loss.detach(), z_a=z_a.detach(), z_pos=z_pos, logits=logits.detach(),
-                grads=_grads(enc), W_grad=Wl.grad.detach().clone())
+    loss.backward(retain_graph=regrad)
+    out = dict(loss=loss.detach(), z_a=z_a.detach(), z_pos=z_pos, logits=logits.detach(),
+               grads=_grads(enc), W_grad=Wl.grad.detach().clone(), enc={k: v.detach() for k, v in acts.items()})
+    if regrad:
+        out["regrad"] = _regrad_fn(plan, list(enc.values()) + [Wl], lambda keep: loss.backward(retain_graph=keep),
+                                   lambda: (_grads(enc), Wl.grad.detach().clone()))
+    return out
 
 
 def soft_update(net: Params, target: Params, tau: float, prefix: str) -> None:

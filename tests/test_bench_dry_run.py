@@ -4,7 +4,9 @@ The driver starts the multi-GPU bench as ``python -m torch.distributed.run ... b
 ``python bench.py --gpus N`` respawns itself that way.  What must hold at any N is checked here at N = 4 (all three
 configurations, through the self-respawn) and N = 8 (configs[1] only, through the driver's own launcher command):
 N ranks came up, the ring is sharded ``capacity // N`` per rank, every rank samples from its own seed, exactly one
-JSON line is printed, it says ``n_gpus: N`` / ``dpN`` and carries an all-reduce entry per gradient bucket."""
+JSON line is printed, it says ``n_gpus: N`` / ``dpN``, carries an all-reduce entry per gradient bucket and BOTH
+data-parallel schedules (``--schedule auto``).  ``--sweep`` (sub-groups of 1, 2, 4, 8 ranks of one 8-rank job, both
+schedules each, one line per n + a summary) is rehearsed the same way."""
 import json
 import os
 import socket
@@ -20,7 +22,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(cmd):
+def _run(cmd, n_lines=1):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -33,8 +35,8 @@ def _run(cmd):
     # (a library's report can also land on the same line as another rank's: what must hold is ONE JSON object, and
     # nothing on stdout that is not a Gloo connection report)
     objs = [ln for ln in lines if ln.lstrip().startswith("{")]
-    assert len(objs) == 1 and len(lines) == 1, lines
-    return json.loads(objs[0])
+    assert len(objs) == n_lines and len(lines) == n_lines, lines
+    return json.loads(objs[0]) if n_lines == 1 else [json.loads(o) for o in objs]
 
 
 def _check_line(d, n, capacity, buckets):
@@ -48,9 +50,16 @@ def _check_line(d, n, capacity, buckets):
     assert sorted({s["seed"] for s in shards}) == [1 + r for r in range(n)]  # rank r samples from seed 1 + r
     assert d["config"]["replay_capacity"] == (capacity // n) * n
     ar = d["allreduce"]
-    assert set(ar) == {"overlapped_with_backward"} | set(buckets)
+    assert set(ar) == {"schedule", "schedule_chosen_by", "blocking", "overlapped", "buckets", "communicator"}
+    assert set(ar["buckets"]) == set(buckets)
     for b in buckets:
-        assert ar[b]["bytes"] > 0 and ar[b]["ms"] > 0 and ar[b]["bus_GBps"] > 0
+        assert ar["buckets"][b]["bytes"] > 0 and ar["buckets"][b]["ms"] > 0 and ar["buckets"][b]["bus_GBps"] > 0
+    # both schedules were timed; the line is the faster one's
+    assert ar["schedule"] == d["schedule"] and ar["schedule"] in ("blocking", "overlapped")
+    for sc in ("blocking", "overlapped"):
+        assert ar[sc]["value"] > 0 and ar[sc]["ms_per_step"] > 0
+    assert d["value"] == max(ar["blocking"]["value"], ar["overlapped"]["value"]) == ar[ar["schedule"]]["value"]
+    assert ar["communicator"] == {"backend": "gloo", "ranks": n, "rccl_version": None}
     assert "cpu_baseline" not in d  # rank 0 at N = 1 only
     assert d["kernel_calls_traced"] > 50 * (d["steps"] + d["warmup"] + 1) // 2
 
@@ -64,7 +73,8 @@ def test_four_ranks_through_the_self_respawn_all_configs():
     # bucket sizes of SURVEY.md 8e at hidden 1024: critic [encoder|Q1|Q2], actor [fc, ln | trunk], cpc [W | encoder]
     # (+ the 16-byte slot padding of the flat buffers: a few floats per tensor)
     for bucket, floats in (("critic", 3_777_912), ("actor", 2_643_674), ("cpc", 1_570_618)):
-        assert d["allreduce"][bucket]["bytes"] // 4 in range(floats, floats + 96), (bucket, d["allreduce"][bucket])
+        got = d["allreduce"]["buckets"][bucket]
+        assert got["bytes"] // 4 in range(floats, floats + 96), (bucket, got)
     others = d["other_configs"]
     assert sorted(others) == ["c3", "c5"]
     _check_line(others["c3"], 4, 512, ("critic", "actor"))   # pixel_sac: no cpc bucket
@@ -80,6 +90,41 @@ def test_eight_ranks_through_the_drivers_launcher_command():
     d = _run(cmd)
     _check_line(d, 8, 1000, ("critic", "actor", "cpc"))
     assert "other_configs" not in d
+
+
+def test_one_schedule_on_request():
+    d = _run([sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run", "--capacity", "256",
+              "--schedule", "overlapped"])
+    assert d["n_gpus"] == 2 and d["schedule"] == "overlapped"
+    assert d["allreduce"]["blocking"] is None and d["allreduce"]["overlapped"]["value"] == d["value"]
+
+
+def test_sweep_of_an_eight_rank_job_decides_the_schedule_in_one_command():
+    """``bench.py --gpus 8 --sweep``: n = 1, 2, 4, 8 sub-groups of ONE job, both schedules each, per-bucket all-reduce
+    times, what the communicator says it spans, efficiency against the job's own n = 1 -- one line per n + a summary."""
+    out = _run([sys.executable, "bench.py", "--gpus", "8", "--sweep", "--steps", "2", "--warmup", "1", "--dry-run",
+                "--capacity", "1000"], n_lines=5)
+    lines, summary = out[:4], out[4]
+    assert [d["n_gpus"] for d in lines] == [1, 2, 4, 8]
+    one = lines[0]
+    assert "allreduce" not in one and one["sweep"]["ranks_measuring"] == [0] and one["config"]["parallelism"] == "dp1"
+    assert one["config"]["shards"] == [dict(rank=0, capacity=1000, seed=1)]
+    for d in lines[1:]:
+        n = d["n_gpus"]
+        _check_line(d, n, 1000, ("critic", "actor", "cpc"))
+        sw = d["sweep"]
+        assert sw["job_ranks"] == 8 and sw["ranks_measuring"] == list(range(n))
+        assert sw["single_gpu_ms_per_step"] == one["ms_per_step"]
+        assert abs(sw["scaling_efficiency_vs_this_jobs_n1"] - d["value"] / (n * one["value"])) < 1e-9
+        for sc in ("blocking", "overlapped"):
+            exposed = d["allreduce"][sc]["exposed_comm_ms_per_step"]
+            assert abs(exposed - (d["allreduce"][sc]["ms_per_step"] - one["ms_per_step"])) < 1e-9
+    assert summary["sweep_summary"] is True and summary["job_ranks"] == 8 and summary["dry_run"] is True
+    c2 = summary["configs"]["c2"]
+    assert sorted(c2["per_n"], key=int) == ["1", "2", "4", "8"]
+    assert c2["per_n"]["1"]["scaling_efficiency"] == 1.0 and c2["per_n"]["1"]["schedule"] is None
+    assert c2["default_schedule"] == lines[3]["schedule"] == c2["per_n"]["8"]["schedule"]
+    assert ("CURLA_DP_OVERLAP=1" in c2["how_to_apply"]) == (c2["default_schedule"] == "overlapped")
 
 
 def test_world_size_mismatch_is_refused():

@@ -1,4 +1,4 @@
-"""BASELINE.json's configurations at their FULL sizes, compared with the oracle directly.
+"""BASELINE.json's configurations at their FULL sizes, compared with the oracle directly, float64 as the arbiter.
 
 One even-step ``agent.update(replay_buffer, L, 0)`` -- critic phase, target soft update, actor / alpha phase, CURL
 phase -- per configuration, on the MI355X, against the oracle's phases evaluated on the CPU from the same weights,
@@ -9,24 +9,42 @@ the same minibatch (the bytes the ring hands the kernels) and the same policy no
   c5  configs[4] per GPU: B = 1024, 168x168x12, 6 conv layers, colour-jittered float observations -- the oracle is
       given the identical post-augmentation tensors (the jitter arithmetic itself is kornia's: parity unpinned)
 
-ReLU branches.  A conv weight gradient at these sizes is a sum of ~600k (c2) to ~7M (c5) signed, largely cancelling
-terms, so ONE activation whose pre-activation is within fp32 rounding of 0 -- positive in one evaluation of the network,
-not in the other; 0-2 elements out of 20 million per layer -- moves it by 1e-4 .. 1e-3 of its size (the reference does
-the same to itself: its own fp32 and fp64 evaluations differ by 2e-4 .. 3e-4 on these tensors).  The same holds
-for the hidden units of the 1024-wide MLPs: one unit of one sample flipping moves a row of a trunk weight gradient by
-~1/sqrt(B) of its size, and through d(loss)/dz everything below it.  The gradients are therefore compared with the
-oracle evaluated under the SAME branch decisions (the derivative of each ReLU -- conv layers, Q trunks, actor trunk --
-takes its branch from the device's activations: ``relu_branches`` / ``q_branches`` / ``trunk_branches`` in
-oracle/curla_oracle.py; values are untouched), and the test asserts separately that the two sides disagree on at most a
-few conv branches per layer, all at activations within 1e-5 of 0.  The un-aligned errors are written to the report as
-well ("raw").
+Three evaluations of every phase are compared: the DEVICE (fp32, HIP kernels), the oracle in fp32 (the reference's own
+arithmetic: PyTorch CPU fp32, pinned by the golden vectors) and the oracle in FLOAT64 (same function, parameters / inputs
+/ noise cast to double): the arbiter.
+
+Values -- losses, conv activations, z_a, z_pos, logits -- are held to 1e-4 against the fp32 oracle and, per tensor, to
+``e_hip <= max(1e-4, 2 e_ref)`` where e_hip = err(device, fp64) and e_ref = err(fp32 oracle, fp64).
+
+Gradients need one more notion.  A conv weight gradient at these sizes is a sum of ~600k (c2) to ~7M (c5) signed,
+largely cancelling terms, so ONE activation whose pre-activation is within fp32 rounding of 0 -- positive in one fp32
+evaluation of the network, not in another -- moves it by 1e-4 .. 1e-3 of its size, and so does one hidden unit of the
+1024-wide MLPs for the layers below it.  These events are DISCRETE and few (0-6 per layer at B = 512, ~60 per evaluation
+at configs[4]), so the un-aligned error of any fp32 evaluation -- the reference's own included -- is a Poisson draw: in
+this test's first run e_hip / e_ref ranged from 0.8 to 13 over the conv gradients and reached 9000 on an MLP tensor where
+the device had one such unit and the reference none.  What IS a property of the kernels, and is asserted, per tensor:
+
+  (A) the device is exact up to its branch decisions:  err(device, fp64 differentiated along the DEVICE's ReLU
+      branches) <= 1e-4 for every gradient an optimizer consumes (the fp64 forward pass is differentiated again with
+      each ReLU derivative taking its branch from the device's activations; values are untouched);
+  (B) the device's branch decisions are legitimate: wherever the device's branch differs from float64's, the
+      activation is within 1e-5 of zero on both sides; there are at most 2 n_ref + 8 such places per configuration,
+      n_ref being the number of places where the fp32 ORACLE differs from float64;
+  (C) the reference does the same to itself: (A) and (B) hold for the fp32 oracle in the device's place --
+      err(fp32 oracle, fp64 along the fp32 oracle's branches) <= 1e-4, its disagreements with float64 all within
+      1e-5 of zero -- so its un-aligned error e_ref (1.6e-4 .. 8e-4 on the conv gradients) is branch decisions too;
+  (D) un-aligned, where the statistics carry it (the maximum over all tensors of a configuration):
+      max e_hip <= max(1e-4, 4 max e_ref).
+Both un-aligned columns (e_hip, e_ref) and both aligned ones are written per tensor to gpurun_out/fullsize_arbiter.txt
+(committed as profiles/r04_fullsize_parity.txt).  The device's branches are also counted against the fp32 oracle's,
+conv layers and MLP hidden units alike (at most 64 per conv layer, 32 per MLP layer, all within 1e-5 of zero).
 
 All learning rates are zero, so the four Adam steps inside the update leave the parameters where they were and every
 phase of both sides is evaluated at identical weights (multi-step parameter trajectories are chaotic under fp32
 reassociation, SURVEY.md D11 -- they are not what 1e-4 is about); the soft update runs with train.py's rates on both
-sides.  Compared, each per tensor with max|a-b| / max|b| <= 1e-4 (curl_sac.py:349-423): the logged losses, z_a, z_pos
-and the logits of the CURL phase, and EVERY gradient an optimizer consumes -- 24 critic tensors, 10 actor tensors,
-log_alpha, 12 encoder tensors + W of the CURL phase."""
+sides.  Compared, each per tensor with max|a-b| / max|b| (curl_sac.py:349-423): the logged losses, z_a, z_pos and the
+logits of the CURL phase, and EVERY gradient an optimizer consumes -- 24 critic tensors, 10 actor tensors, log_alpha,
+12 encoder tensors + W of the CURL phase."""
 import os
 import time
 
@@ -39,7 +57,9 @@ from tests.test_gpu_agent import HP, NullLogger, _copy_agent_into_oracle, grads_
 
 pytestmark = pytest.mark.gpu
 
-REPORT = []
+REPORT = []   # (name, number): values against the fp32 oracle, branch counts, timings
+ARBITER = []  # (name, e_hip, e_ref, a_hip, a_ref): errors against the float64 evaluation (a_*: along own branches)
+NEAR_ZERO = 1e-5
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -48,13 +68,63 @@ def _report():
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/fullsize_parity.txt", "a") as f:
         for n, e in REPORT:
-            f.write(f"{n:78s} {e:.3e}\n")
+            f.write(f"{n:86s} {e:.3e}\n")
+    with open("gpurun_out/fullsize_arbiter.txt", "a") as f:
+        f.write("# errors against the oracle's FLOAT64 evaluation of the same phase (max|a-b| / max|b| per tensor)\n"
+                "#   e_hip / e_ref: device / fp32 oracle against float64, NO branch alignment\n"
+                "#   a_hip / a_ref: device / fp32 oracle against float64 differentiated along THEIR OWN ReLU branches\n"
+                "# asserted: a_hip <= 1e-4, a_ref <= 1e-4 per tensor; values: e_hip <= max(1e-4, 2 e_ref) per tensor;\n"
+                "#           per configuration max e_hip <= max(1e-4, 4 max e_ref)\n")
+        f.write(f"# {'tensor':70s} {'e_hip':>10s} {'e_ref':>10s} {'a_hip':>10s} {'a_ref':>10s}\n")
+        for n, eh, er, ah, ar in ARBITER:
+            cols = " ".join(f"{v:10.3e}" if v is not None else f"{'-':>10s}" for v in (eh, er, ah, ar))
+            f.write(f"{n:72s} {cols}\n")
 
 
 def check(name, got, ref, tol=RTOL):
     e = rel_err(got, ref)
     REPORT.append((name, e))
     return (name, e, tol) if not (np.isfinite(e) and e <= tol) else None
+
+
+def value_arbiter(name, got, ref32, ref64):
+    """A value (loss, activation, feature, logit): e_hip = err(device, fp64), e_ref = err(fp32 oracle, fp64); fails
+    when the device is further from the exact result than 1e-4 AND than twice the reference's own fp32 evaluation."""
+    e_hip, e_ref = rel_err(got, ref64), rel_err(ref32, ref64)
+    ARBITER.append((name, e_hip, e_ref, None, None))
+    ok = np.isfinite(e_hip) and e_hip <= max(RTOL, 2.0 * e_ref)
+    return None if ok else (name + " [fp64 arbiter]", e_hip, max(RTOL, 2.0 * e_ref))
+
+
+def grad_arbiter(name, got, ref32, g64_own, g64_along_hip, g64_along_ref, worst):
+    """A gradient: un-aligned errors reported (and folded into the configuration's maxima), aligned ones asserted:
+    (A) the device against float64 along the device's branches, (C) the fp32 oracle against float64 along its own."""
+    e_hip, e_ref = rel_err(got, g64_own), rel_err(ref32, g64_own)
+    a_hip, a_ref = rel_err(got, g64_along_hip), rel_err(ref32, g64_along_ref)
+    ARBITER.append((name, e_hip, e_ref, a_hip, a_ref))
+    worst[0], worst[1] = max(worst[0], e_hip), max(worst[1], e_ref)
+    bad = []
+    if not (np.isfinite(a_hip) and a_hip <= RTOL):
+        bad.append((name + " [device vs fp64 along the device's branches]", a_hip, RTOL))
+    if not (np.isfinite(a_ref) and a_ref <= RTOL):
+        bad.append((name + " [fp32 oracle vs fp64 along the fp32 oracle's branches]", a_ref, RTOL))
+    return bad
+
+
+def branch_flips(tag, what, a, b, limit=None):
+    """Units whose ReLU branch differs between two evaluations (pre- or post-activation values, any float dtype):
+    how many; every one of them must be within NEAR_ZERO of zero on both sides."""
+    a, b = a.cpu(), b.cpu()
+    differ = (a > 0) != (b > 0)
+    k = int(differ.sum())
+    worst = float(torch.maximum(a[differ].abs().double(), b[differ].abs().double()).max()) if k else 0.0
+    REPORT.append((f"{tag} {what}: ReLU branches that differ (of {differ.numel()})", float(k)))
+    if k:
+        REPORT.append((f"{tag} {what}: largest |activation| at a differing branch", worst))
+    assert worst <= NEAR_ZERO, (what, worst)
+    if limit is not None:
+        assert k <= limit, (what, k, limit)
+    return k
 
 
 def _move_off_init(agent, oracle, layers, seed=5):
@@ -87,7 +157,7 @@ def _run(tag, obs_shape, in_hw, aug_name, layers, B, pixel_sac, capacity):
     from oracle import curla_oracle as O
     torch.manual_seed(31)
     np.random.seed(31)
-    torch.set_num_threads(min(16, os.cpu_count() or 1))  # (the oracle's CPU convs get slower beyond a few dozen threads)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))  # (the oracle's CPU convs get no faster beyond 16 threads here)
     dev = torch.device("cuda")
     C = obs_shape[0]
     out_hw = tuple(obs_shape[1:])
@@ -140,20 +210,6 @@ def _run(tag, obs_shape, in_hw, aug_name, layers, B, pixel_sac, capacity):
     o_act, o_rew, o_nd = act.cpu().clone(), rew.cpu().clone(), nd.cpu().clone()
     noise_c, noise_a = torch.randn(B, 2), torch.randn(B, 2)
 
-    # ---- oracle: the phases of OracleAgent.update() at step 0, learning rates zero (curl_sac.py:426-451)
-    t0 = time.perf_counter()
-    kwc = dict(num_layers=layers, log_std_min=-10, log_std_max=2)
-    rc = O.critic_phase(oracle.actor, oracle.critic, oracle.critic_target, oracle.log_alpha, o_obs, o_act, o_rew, o_nxt,
-                        o_nd, noise_c, discount=0.99, **kwc)
-    ra = O.actor_phase(oracle.actor, oracle.critic, oracle.log_alpha, o_obs, noise_a,
-                       target_entropy=oracle.target_entropy, **kwc)
-    saved_target = {k: v.detach().clone() for k, v in oracle.critic_target.items()}  # (for the second critic pass)
-    with torch.no_grad():
-        for prefix, tau in (("Q1.", hp["critic_tau"]), ("Q2.", hp["critic_tau"]), ("encoder.", hp["encoder_tau"])):
-            O.soft_update(oracle.critic, oracle.critic_target, tau, prefix)
-    rp = None if pixel_sac else O.cpc_phase(oracle.critic, oracle.critic_target, oracle.W, o_obs, o_pos, num_layers=layers)
-    t_oracle = time.perf_counter() - t0
-
     # ---- the device: ONE update() call on that minibatch and that noise
     rb.sample_cpc_refs = lambda: (obs, act, rew, nxt, nd, kw)
     noises = iter([noise_c.to(dev), noise_a.to(dev)])
@@ -161,20 +217,18 @@ def _run(tag, obs_shape, in_hw, aug_name, layers, B, pixel_sac, capacity):
     captured = {}
     real_step = agent.critic_optimizer.step
 
-    def hidden(*ts):  # post-ReLU hidden activations of the MLPs -> the branches their derivatives took
-        return [(t > 0).cpu() for t in ts]
-
-    def critic_step():
+    def critic_step():  # (post-ReLU hidden activations of the twin-Q MLPs: their signs are the device's branches)
         captured["critic"] = grads_of(agent.critic)
         w_ = agent._ws(B)
-        captured["critic_q"] = hidden(w_.q_h1[0], w_.q_h2[0], w_.q_h1[1], w_.q_h2[1])
+        captured["critic_qh"] = [t.detach().cpu().clone() for t in (w_.q_h1[0], w_.q_h2[0], w_.q_h1[1], w_.q_h2[1])]
         real_step()
     agent.critic_optimizer.step = critic_step
     real_actor_step = agent.actor_optimizer.step
 
     def actor_step():
         w_ = agent._ws(B)
-        captured["actor_mlp"] = hidden(w_.a_h1, w_.a_h2, w_.q_h1[0], w_.q_h2[0], w_.q_h1[1], w_.q_h2[1])
+        hs = (w_.a_h1, w_.a_h2, w_.q_h1[0], w_.q_h2[0], w_.q_h1[1], w_.q_h2[1])
+        captured["actor_mlph"] = [t.detach().cpu().clone() for t in hs]
         real_actor_step()
     agent.actor_optimizer.step = actor_step
     before = agent._critic_flat.clone()
@@ -184,74 +238,140 @@ def _run(tag, obs_shape, in_hw, aug_name, layers, B, pixel_sac, capacity):
     assert _lib._lib is not None
     assert torch.equal(before, agent._critic_flat), "learning rate 0: the parameters must not have moved"
     ws = agent._ws(B)
+    # the device's activations of obs under the (unmoved) online weights are still in the workspace (the actor phase
+    # recomputed them from the same weights; the CURL phase of an even step reuses them)
+    dev_acts = [ws.acts_main[i].permute(0, 3, 1, 2).cpu() for i in range(layers)]  # NHWC -> NCHW
+    hip_conv = [a > 0 for a in dev_acts]
+    cqh, amh = captured["critic_qh"], captured["actor_mlph"]
+    pos_of = lambda ts: [t > 0 for t in ts]  # noqa: E731
 
-    bad = []
+    # ---- the fp32 oracle: the phases of OracleAgent.update() at step 0, learning rates zero (curl_sac.py:426-451)
+    t0 = time.perf_counter()
+    kwc = dict(num_layers=layers, log_std_min=-10, log_std_max=2)
+    rc = O.critic_phase(oracle.actor, oracle.critic, oracle.critic_target, oracle.log_alpha, o_obs, o_act, o_rew, o_nxt,
+                        o_nd, noise_c, discount=0.99, **kwc)
+    ra = O.actor_phase(oracle.actor, oracle.critic, oracle.log_alpha, o_obs, noise_a,
+                       target_entropy=oracle.target_entropy, **kwc)
+    d = lambda x: O.as_dtype(x, torch.float64)  # noqa: E731
+    target64 = d(oracle.critic_target)  # (before the soft update)
+    with torch.no_grad():
+        for prefix, tau in (("Q1.", hp["critic_tau"]), ("Q2.", hp["critic_tau"]), ("encoder.", hp["encoder_tau"])):
+            O.soft_update(oracle.critic, oracle.critic_target, tau, prefix)
+    rp = None if pixel_sac else O.cpc_phase(oracle.critic, oracle.critic_target, oracle.W, o_obs, o_pos, num_layers=layers)
+    t_oracle = time.perf_counter() - t0
+    ref_conv = [rc["enc"][f"conv{i + 1}"] > 0 for i in range(layers)]
+
+    bad, worst = [], [0.0, 0.0]   # worst: the configuration's largest un-aligned gradient errors (device, fp32 oracle)
+    n_hip64 = n_ref64 = 0         # branch disagreements with float64, all ReLUs of the configuration
+
+    # ---- critic phase (curl_sac.py:349-371): float64, differentiated three times from one forward pass
+    t0 = time.perf_counter()
+    d_obs = d(o_obs)
+    rc64 = O.critic_phase(d(oracle.actor), d(oracle.critic), target64, oracle.log_alpha, d_obs, d(o_act), d(o_rew),
+                          d(o_nxt), d(o_nd), d(noise_c), discount=0.99, regrad=True, **kwc)
+    g64 = rc64["grads"]
+    g64_hip = rc64["regrad"](relu_branches=hip_conv, q_branches=[pos_of(cqh[0:2]), pos_of(cqh[2:4])])
+    g64_ref = rc64["regrad"](relu_branches=ref_conv, q_branches=[pos_of(rc["q_hidden"][0:2]), pos_of(rc["q_hidden"][2:4])])
+    del rc64["regrad"]
+    t_oracle64 = time.perf_counter() - t0
     bad.append(check(f"{tag} critic loss", L.scalars["train_critic/loss"], rc["loss"]))
-    bad.append(check(f"{tag} actor loss", L.scalars["train_actor/loss"], ra["actor_loss"]))
-    bad.append(check(f"{tag} alpha loss", L.scalars["train_alpha/loss"], ra["alpha_loss"]))
-    bad.append(check(f"{tag} entropy", L.scalars["train_actor/entropy"], ra["entropy"]))
-    assert len(captured["critic"]) == 8 + 2 * layers + 8 == len(rc["grads"])
-    # ---- ReLU branches: the device's activations of obs under the (unmoved) online weights are still in the workspace
-    # (the actor phase recomputed them from the same weights)
-    branches, n_differ = [], 0
+    bad.append(value_arbiter(f"{tag} critic loss", L.scalars["train_critic/loss"], rc["loss"], rc64["loss"]))
+    n_differ = 0
     for i in range(layers):
-        dev_act = ws.acts_main[i].permute(0, 3, 1, 2).cpu()          # NHWC -> NCHW
-        ref_act = rc["enc"][f"conv{i + 1}"]
-        assert dev_act.shape == ref_act.shape
-        bad.append(check(f"{tag} activations conv{i + 1}", dev_act, ref_act))
-        pos = dev_act > 0
-        differ = pos != (ref_act > 0)
-        k = int(differ.sum())
-        n_differ += k
-        REPORT.append((f"{tag} conv{i + 1}: ReLU branches that differ (of {differ.numel()})", float(k)))
-        assert k <= 4 + 2e-6 * differ.numel(), (i, k)
-        if k:  # only where both sides are within rounding of zero
-            assert float(torch.maximum(dev_act[differ].abs(), ref_act[differ].abs()).max()) <= 1e-5
-        branches.append(pos)
-        del dev_act, differ
-    cq = captured["critic_q"]
-    rcb = O.critic_phase(oracle.actor, oracle.critic, saved_target, oracle.log_alpha, o_obs, o_act, o_rew, o_nxt, o_nd,
-                         noise_c, discount=0.99, relu_branches=branches, q_branches=[cq[0:2], cq[2:4]], **kwc)
-    assert float((rcb["loss"] - rc["loss"]).abs()) == 0.0  # values are untouched, only derivative branches
-    for k, v in rcb["grads"].items():
-        check(f"{tag} critic grad {k} (raw: own branches on both sides)", captured["critic"][k], rc["grads"][k])
-        bad.append(check(f"{tag} critic grad {k}", captured["critic"][k], v))
+        name = f"conv{i + 1}"
+        a32, a64 = rc["enc"][name], rc64["enc"][name]
+        assert dev_acts[i].shape == a32.shape
+        bad.append(check(f"{tag} activations {name}", dev_acts[i], a32))
+        bad.append(value_arbiter(f"{tag} activations {name}", dev_acts[i], a32, a64))
+        # few, and only where both sides are within rounding of zero (observed: <= 6 per layer at B = 512, <= 30 at
+        # configs[4]'s 2e8 activations per layer)
+        n_differ += branch_flips(tag, f"{name}, device vs fp32 oracle", dev_acts[i], a32, 64)
+        n_hip64 += branch_flips(tag, f"{name}, device vs float64", dev_acts[i], a64)
+        n_ref64 += branch_flips(tag, f"{name}, fp32 oracle vs float64", a32, a64)
+        rc64["enc"][name] = None
+    n_mlp = 0
+    for j, nm in enumerate(("Q1 hidden 1", "Q1 hidden 2", "Q2 hidden 1", "Q2 hidden 2")):
+        n_mlp += branch_flips(tag, f"critic phase {nm}, device vs fp32 oracle", cqh[j], rc["q_hidden"][j], 32)
+        n_hip64 += branch_flips(tag, f"critic phase {nm}, device vs float64", cqh[j], rc64["q_hidden"][j])
+        n_ref64 += branch_flips(tag, f"critic phase {nm}, fp32 oracle vs float64", rc["q_hidden"][j], rc64["q_hidden"][j])
+    assert len(captured["critic"]) == 8 + 2 * layers + 8 == len(rc["grads"])
+    for k in rc["grads"]:
+        bad += grad_arbiter(f"{tag} critic grad {k}", captured["critic"][k], rc["grads"][k], g64[k], g64_hip[k],
+                            g64_ref[k], worst)
+    del rc64, g64, g64_hip, g64_ref
+
+    # ---- actor / alpha phase (curl_sac.py:373-404): no conv gradients; the branches are the MLPs' hidden units
+    t0 = time.perf_counter()
+    ra64 = O.actor_phase(d(oracle.actor), d(oracle.critic), oracle.log_alpha, d_obs, d(noise_a),
+                         target_entropy=oracle.target_entropy, regrad=True, **kwc)
+    g64 = ra64["grads"]
+    g64_hip = ra64["regrad"](trunk_branches=pos_of(amh[0:2]), q_branches=[pos_of(amh[2:4]), pos_of(amh[4:6])])
+    ref_h = ra["trunk_hidden"] + ra["q_hidden"]
+    g64_ref = ra64["regrad"](trunk_branches=pos_of(ref_h[0:2]), q_branches=[pos_of(ref_h[2:4]), pos_of(ref_h[4:6])])
+    del ra64["regrad"]
+    t_oracle64 += time.perf_counter() - t0
+    for nm, key, rk in (("actor loss", "train_actor/loss", "actor_loss"), ("alpha loss", "train_alpha/loss", "alpha_loss"),
+                        ("entropy", "train_actor/entropy", "entropy")):
+        bad.append(check(f"{tag} {nm}", L.scalars[key], ra[rk]))
+        bad.append(value_arbiter(f"{tag} {nm}", L.scalars[key], ra[rk], ra64[rk]))
+    h64 = ra64["trunk_hidden"] + ra64["q_hidden"]
+    for j, nm in enumerate(("trunk hidden 1", "trunk hidden 2", "Q1 hidden 1", "Q1 hidden 2", "Q2 hidden 1", "Q2 hidden 2")):
+        n_mlp += branch_flips(tag, f"actor phase {nm}, device vs fp32 oracle", amh[j], ref_h[j], 32)
+        n_hip64 += branch_flips(tag, f"actor phase {nm}, device vs float64", amh[j], h64[j])
+        n_ref64 += branch_flips(tag, f"actor phase {nm}, fp32 oracle vs float64", ref_h[j], h64[j])
+    REPORT.append((f"{tag} MLP hidden units whose ReLU branch differs, device vs fp32 oracle (of "
+                   f"{sum(int(t.numel()) for t in cqh + amh)})", float(n_mlp)))
     actor_grads = {k: v for k, v in grads_of(agent.actor).items() if ".convs." not in k}
     assert len(actor_grads) == 10 == len(ra["grads"])
-    am = captured["actor_mlp"]
-    rab = O.actor_phase(oracle.actor, oracle.critic, oracle.log_alpha, o_obs, noise_a, target_entropy=oracle.target_entropy,
-                        trunk_branches=am[0:2], q_branches=[am[2:4], am[4:6]], **kwc)
-    assert float((rab["actor_loss"] - ra["actor_loss"]).abs()) == 0.0
-    n_mlp = 0
-    for nm, dev_b, ref_h in (("actor trunk", am[0:2], None), ("critic Q", cq, None)):
-        n_mlp += sum(int(b.numel()) for b in dev_b)
-    REPORT.append((f"{tag} MLP hidden units whose ReLU branch is taken from the device", float(n_mlp)))
-    for k, v in rab["grads"].items():
-        check(f"{tag} actor grad {k} (raw: own branches on both sides)", actor_grads[k], ra["grads"][k])
-        bad.append(check(f"{tag} actor grad {k}", actor_grads[k], v))
-    bad.append(check(f"{tag} log_alpha grad", agent.log_alpha.grad.detach().cpu().reshape(1),
-                     rab["log_alpha_grad"].reshape(1)))
-    # the target after the soft update (utils.py:37-41)
+    for k in ra["grads"]:
+        bad += grad_arbiter(f"{tag} actor grad {k}", actor_grads[k], ra["grads"][k], g64[k], g64_hip[k], g64_ref[k], worst)
+    la_grad = agent.log_alpha.grad.detach().cpu().reshape(1)
+    bad.append(check(f"{tag} log_alpha grad", la_grad, ra["log_alpha_grad"].reshape(1)))
+    bad.append(value_arbiter(f"{tag} log_alpha grad", la_grad, ra["log_alpha_grad"].reshape(1),
+                             ra64["log_alpha_grad"].reshape(1)))
+    del ra64, g64, g64_hip, g64_ref
+
+    # ---- the target after the soft update (utils.py:37-41)
     tsd = agent.critic_target.state_dict()
     for k in ("encoder.convs.0.weight", f"encoder.convs.{layers - 1}.weight", "encoder.fc.weight", "Q1.trunk.2.weight"):
         bad.append(check(f"{tag} target after soft update {k}", tsd[k].cpu(), oracle.critic_target[k].detach(), 1e-6))
+
+    # ---- CURL phase (curl_sac.py:406-423)
     if rp is not None:
-        bad.append(check(f"{tag} curl loss", L.scalars["train/curl_loss"], rp["loss"]))
-        bad.append(check(f"{tag} cpc z_a", ws.z_c.cpu(), rp["z_a"]))
-        bad.append(check(f"{tag} cpc z_pos", ws.z_pos.cpu(), rp["z_pos"]))
+        t0 = time.perf_counter()
+        rp64 = O.cpc_phase(d(oracle.critic), d(oracle.critic_target), d(oracle.W), d_obs, d(o_pos), num_layers=layers,
+                           regrad=True)
+        g64, w64 = rp64["grads"], rp64["W_grad"]
+        g64_hip, w64_hip = rp64["regrad"](relu_branches=hip_conv)
+        g64_ref, w64_ref = rp64["regrad"](relu_branches=[rp["enc"][f"conv{i + 1}"] > 0 for i in range(layers)])
+        del rp64["regrad"], rp64["enc"]
+        t_oracle64 += time.perf_counter() - t0
         lg = ws.logits.cpu()
-        bad.append(check(f"{tag} cpc logits (minus row max)", lg - lg.max(1, keepdim=True)[0], rp["logits"]))
+        lg = lg - lg.max(1, keepdim=True)[0]
+        for nm, got, key in (("curl loss", L.scalars["train/curl_loss"], "loss"), ("cpc z_a", ws.z_c.cpu(), "z_a"),
+                             ("cpc z_pos", ws.z_pos.cpu(), "z_pos"), ("cpc logits (minus row max)", lg, "logits")):
+            bad.append(check(f"{tag} {nm}", got, rp[key]))
+            bad.append(value_arbiter(f"{tag} {nm}", got, rp[key], rp64[key]))
         cpc = {k: v for k, v in grads_of(agent.critic).items() if k.startswith("encoder.")}
         assert len(cpc) == 4 + 2 * layers == len(rp["grads"])
-        rpb = O.cpc_phase(oracle.critic, oracle.critic_target, oracle.W, o_obs, o_pos, num_layers=layers,
-                          relu_branches=branches)
-        for k, v in rpb["grads"].items():
-            if ".convs." in k:
-                check(f"{tag} cpc grad {k} (raw: own branches on both sides)", cpc[k], rp["grads"][k])
-            bad.append(check(f"{tag} cpc grad {k}", cpc[k], v))
-        bad.append(check(f"{tag} cpc grad W", agent.CURL.W.grad.detach().cpu(), rp["W_grad"]))
-    REPORT.append((f"{tag} (oracle seconds on {torch.get_num_threads()} host threads, one pass)", t_oracle))
-    REPORT.append((f"{tag} ReLU branches that differ, all layers", float(n_differ)))
+        for k in rp["grads"]:
+            bad += grad_arbiter(f"{tag} cpc grad {k}", cpc[k], rp["grads"][k], g64[k], g64_hip[k], g64_ref[k], worst)
+        bad += grad_arbiter(f"{tag} cpc grad W", agent.CURL.W.grad.detach().cpu(), rp["W_grad"], w64, w64_hip, w64_ref, worst)
+        del rp64, g64, g64_hip, g64_ref
+    del d_obs
+
+    # ---- (B) the device disagrees with float64 about as often as the reference's own fp32 evaluation does,
+    #      (D) and its worst un-aligned error is of the size of the reference's own
+    REPORT.append((f"{tag} ReLU branches that differ from float64's, all ReLUs: device", float(n_hip64)))
+    REPORT.append((f"{tag} ReLU branches that differ from float64's, all ReLUs: fp32 oracle", float(n_ref64)))
+    REPORT.append((f"{tag} conv ReLU branches that differ, device vs fp32 oracle, all layers", float(n_differ)))
+    REPORT.append((f"{tag} largest un-aligned gradient error against float64: device", worst[0]))
+    REPORT.append((f"{tag} largest un-aligned gradient error against float64: fp32 oracle", worst[1]))
+    REPORT.append((f"{tag} (fp32 oracle seconds on {torch.get_num_threads()} host threads)", t_oracle))
+    REPORT.append((f"{tag} (float64 arbiter seconds on {torch.get_num_threads()} host threads)", t_oracle64))
+    assert n_hip64 <= 2 * n_ref64 + 8, (n_hip64, n_ref64)
+    if not worst[0] <= max(RTOL, 4.0 * worst[1]):
+        bad.append((f"{tag} largest un-aligned gradient error [device vs 4 x fp32 oracle]", worst[0], 4.0 * worst[1]))
     bad = [b for b in bad if b is not None]
     assert not bad, bad
 

@@ -105,9 +105,8 @@ def _poison_lds(ops):
     """Leave NaN bit patterns (0xFF bytes) in the LDS of every CU: the banded uint8 forward keeps its crops as bytes in
     LDS, so a ring full of 255s does it.  A kernel that reads LDS it has not written (and multiplies it by a zero
     weight) then produces NaNs deterministically instead of once in a few hundred runs."""
-    import os
-    old = os.environ.pop("CURLA_C1_U8", None)
-    try:
+    from curla_amd import _lib
+    with _lib.option("conv1_u8", "hybrid"):
         store = torch.full((84 * 84 * 9 + 32,), 255, dtype=torch.uint8, device="cuda")
         ring = store[:84 * 84 * 9].view(1, 84, 84, 9)
         B = 1024
@@ -116,9 +115,6 @@ def _poison_lds(ops):
         out = torch.empty(B, 41, 41, 32, device="cuda")
         ops.conv1_fwd(obs, torch.zeros(32, 9, 3, 3, device="cuda"), torch.zeros(32, device="cuda"), out)
         torch.cuda.synchronize()
-    finally:
-        if old is not None:
-            os.environ["CURLA_C1_U8"] = old
 
 
 CONV1_CASES = [  # C, Hs, Ws, Hc, Wc, B
@@ -133,19 +129,11 @@ CONV1_CASES = [  # C, Hs, Ws, Hc, Wc, B
 @pytest.fixture(params=["hybrid", "band", "rw"])
 def u8_impl(request):
     """The three uint8 first-layer forwards: the default (crop staged in LDS + row walk out of LDS when the crop fits
-    one band, else the banded loop), the banded loop alone (CURLA_C1_U8=band) and the row walk straight from memory
-    (CURLA_C1_U8=rw, conv1_u8_rw.h)."""
-    import os
-    old = os.environ.get("CURLA_C1_U8")
-    if request.param == "hybrid":
-        os.environ.pop("CURLA_C1_U8", None)
-    else:
-        os.environ["CURLA_C1_U8"] = request.param
-    yield request.param
-    if old is None:
-        os.environ.pop("CURLA_C1_U8", None)
-    else:
-        os.environ["CURLA_C1_U8"] = old
+    one band, else the banded loop), the banded loop alone (option conv1_u8 = band) and the row walk straight from
+    memory (conv1_u8 = rw, conv1_u8_rw.h)."""
+    from curla_amd import _lib
+    with _lib.option("conv1_u8", request.param):
+        yield request.param
 
 
 @pytest.mark.parametrize("C,Hs,Ws,Hc,Wc,B", CONV1_CASES)
@@ -181,25 +169,28 @@ def test_crop_and_conv1_u8(ops, u8_impl, C, Hs, Ws, Hc, Wc, B):
     out2 = torch.full((B, Ho, Wo, 32), float("nan"), device="cuda")
     ops.conv1_fwd(ops.ObsRef.from_tensor(out_f), dev(w), dev(b), out2)
     check(f"conv1_fwd f32 C{C} {Hc}x{Wc}", nchw(out2), ref)
-    # float NHWC source (the augmented minibatches), banded form
-    if u8_impl == "band":
-        os_env = __import__("os").environ
-        keep = os_env.get("CURLA_S1_IMPL")
-        _poison_lds(ops)
-        out3 = torch.full((B, Ho, Wo, 32), float("nan"), device="cuda")
-        ops.conv1_fwd(ops.ObsRef.from_nhwc(out_f.permute(0, 2, 3, 1).contiguous()), dev(w), dev(b), out3)
-        check(f"conv1_fwd f32 NHWC C{C} {Hc}x{Wc}", nchw(out3), ref)
-        assert keep == os_env.get("CURLA_S1_IMPL")
+    # float NHWC source (the augmented minibatches): the row walk (conv1_rw.h, the default) and the banded form
+    from curla_amd import _lib
+    obs_nhwc = ops.ObsRef.from_nhwc(out_f.permute(0, 2, 3, 1).contiguous())
+    f32_impls = ("rw", "band") if u8_impl == "band" else ("rw",)
+    for f32_impl in f32_impls:
+        with _lib.option("conv1_f32", f32_impl):
+            _poison_lds(ops)
+            out3 = torch.full((B, Ho, Wo, 32), float("nan"), device="cuda")
+            ops.conv1_fwd(obs_nhwc, dev(w), dev(b), out3)
+            check(f"conv1_fwd f32 NHWC [{f32_impl}] C{C} {Hc}x{Wc}", nchw(out3), ref)
     # weight gradient, both sources
     g = rnd(B, 32, Ho, Wo, seed=13) * (ref > 0)
     wl = w.clone().requires_grad_(True)
     bl = b.clone().requires_grad_(True)
     F.conv2d(x / 255.0, wl, bl, stride=2).backward(g)
     ws = torch.empty(ops.wgrad_workspace_floats(C), device="cuda")
-    for name, o in (("u8", obs), ("f32", ops.ObsRef.from_tensor(out_f))):
-        dw = torch.full((32, C, 3, 3), float("nan"), device="cuda")
-        db = torch.full((32,), float("nan"), device="cuda")
-        ops.conv1_wgrad(o, nhwc(g), dw, db, ws)
+    for name, o, impl in [("u8", obs, "rw"), ("f32", ops.ObsRef.from_tensor(out_f), "rw")] + \
+                         [(f"f32 NHWC [{i}]", obs_nhwc, i) for i in f32_impls]:
+        with _lib.option("conv1_f32", impl):
+            dw = torch.full((32, C, 3, 3), float("nan"), device="cuda")
+            db = torch.full((32,), float("nan"), device="cuda")
+            ops.conv1_wgrad(o, nhwc(g), dw, db, ws)
         check(f"conv1_wgrad dW {name} C{C} {Hc}x{Wc}", dw.cpu(), wl.grad)
         check(f"conv1_wgrad db {name} C{C} {Hc}x{Wc}", db.cpu(), bl.grad)
 
@@ -513,7 +504,9 @@ def test_curl_ce(ops, B):
     check(f"curl_ce dlogits B{B}", dl.cpu(), logits.grad)
 
 
-@pytest.mark.parametrize("B,Fd,K", [(128, 50, 64), (512, 50, 196), (256, 49, 128), (1024, 52, 64), (384, 51, 64)])
+@pytest.mark.parametrize("B,Fd,K", [(128, 50, 64), (512, 50, 196), (256, 49, 128), (1024, 52, 64), (384, 51, 64),
+                                    # every B / 128 from 1 to 8: 5 and 7 walk phase B in runs of 4 k-steps (B / 32 = 20, 28)
+                                    (640, 50, 64), (768, 50, 64), (896, 52, 64)])
 def test_curl_head_one_launch(ops, B, Fd, K):
     """curla_curl_head + curla_fc_bwd_ln2: the CURL phase from (z_a, z_pos, W) to the loss, d(loss)/d(fc output) of the
     anchor encoder, the LayerNorm / fc-bias gradients and dW -- against autograd through the reference's formulas

@@ -127,6 +127,77 @@ def test_cpc_phase_matches_reference():
         assert_close(got, v, 2e-5, "cpc grad " + k)
 
 
+def test_float64_mode_matches_reference_and_reports_hidden_units():
+    """The arbiter of tests/test_gpu_fullsize.py: every phase evaluated on float64 casts of the same arguments is the
+    same function (the reference's fp32 numbers to 1e-4 -- fp32's own distance from the exact result --, results in
+    float64), and the phases hand out the MLPs'
+    hidden pre-activations, whose signs are the ReLU branches."""
+    g = load("tiny.npz")
+    actor, critic, target, W, la = _state(g)
+    d = lambda x: O.as_dtype(x, torch.float64)  # noqa: E731
+    b = lambda k: d(_f(g[k]))  # noqa: E731
+    r = O.critic_phase(d(actor), d(critic), d(target), la, b("batch/obs"), b("batch/action"), b("batch/reward"),
+                       b("batch/next_obs"), b("batch/not_done"), b("noise/critic"), discount=0.99, **HP)
+    assert r["loss"].dtype == torch.float64 and r["target_Q"].dtype == torch.float64
+    assert_close(r["loss"], g["scalar/train_critic/loss"], 1e-4, "critic loss (f64)")
+    for k, v in sub(g, "critic/grad/").items():
+        assert r["grads"][k].dtype == torch.float64
+        assert_close(r["grads"][k], v, 1e-4, "critic grad (f64) " + k)
+    B = g["batch/obs"].shape[0]
+    assert [tuple(h.shape) for h in r["q_hidden"]] == [(B, critic["Q1.trunk.0.weight"].shape[0])] * 4
+    r32 = O.critic_phase(actor, critic, target, la, _f(g["batch/obs"]), _f(g["batch/action"]), _f(g["batch/reward"]),
+                         _f(g["batch/next_obs"]), _f(g["batch/not_done"]), _f(g["noise/critic"]), discount=0.99, **HP)
+    za = torch.cat([r32["enc"]["ln"], _f(g["batch/action"])], 1)
+    want = torch.nn.functional.linear(za, critic["Q2.trunk.0.weight"], critic["Q2.trunk.0.bias"])
+    assert_close(r32["q_hidden"][2], want, 1e-6, "Q2 hidden 1 pre-activation")
+    critic_after = sub(g, "critic_after/")
+    ra = O.actor_phase(d(actor), d(critic_after), la, b("batch/obs"), b("noise/actor"), target_entropy=-2.0, **HP)
+    assert_close(ra["actor_loss"], g["scalar/train_actor/loss"], 1e-4, "actor loss (f64)")
+    for k, v in sub(g, "actor/grad/").items():
+        assert_close(ra["grads"][k], v, 1e-4, "actor grad (f64) " + k)
+    assert len(ra["trunk_hidden"]) == 2 and len(ra["q_hidden"]) == 4
+    rp = O.cpc_phase(d(critic_after), d(sub(g, "target_after/")), d(W), b("batch/obs"), b("batch/pos"), num_layers=4)
+    assert_close(rp["loss"], g["scalar/train/curl_loss"], 1e-4, "curl loss (f64)")
+    for k, v in sub(g, "cpc/grad/").items():
+        assert_close(rp["W_grad"] if k == "W" else rp["grads"][k], v, 1e-4, "cpc grad (f64) " + k)
+    # one forward pass, differentiated again: own branches = the plain gradients, given branches = the phase evaluated
+    # along them (values untouched either way)
+    args = (actor, critic, target, la, _f(g["batch/obs"]), _f(g["batch/action"]), _f(g["batch/reward"]),
+            _f(g["batch/next_obs"]), _f(g["batch/not_done"]), _f(g["noise/critic"]))
+    rr = O.critic_phase(*args, discount=0.99, regrad=True, **HP)
+    for k, v in r32["grads"].items():
+        assert torch.equal(rr["grads"][k], v), k
+    again = rr["regrad"]()
+    assert all(torch.equal(again[k], v) for k, v in r32["grads"].items())
+    gen = torch.Generator().manual_seed(3)
+    flip = lambda t: (t > 0) ^ (torch.rand(t.shape, generator=gen) < 0.01)  # noqa: E731
+    conv_b = [flip(r32["enc"][f"conv{i + 1}"]) for i in range(4)]
+    q_b = [[flip(h) for h in r32["q_hidden"][0:2]], [flip(h) for h in r32["q_hidden"][2:4]]]
+    direct = O.critic_phase(*args, discount=0.99, relu_branches=conv_b, q_branches=q_b, **HP)
+    swapped = rr["regrad"](relu_branches=conv_b, q_branches=q_b)
+    assert float(direct["loss"]) == float(r32["loss"])
+    moved = 0
+    for k, v in direct["grads"].items():
+        assert torch.equal(swapped[k], v), k
+        moved += int(not torch.equal(v, r32["grads"][k]))
+    assert moved >= 20  # (1 % of the branches flipped: every gradient below the Q heads' last layer moves)
+    back = rr["regrad"]()
+    assert all(torch.equal(back[k], v) for k, v in r32["grads"].items())
+    rp32 = O.cpc_phase(critic_after, sub(g, "target_after/"), W, _f(g["batch/obs"]), _f(g["batch/pos"]), num_layers=4, regrad=True)
+    eg, wg = rp32["regrad"]()
+    assert torch.equal(wg, rp32["W_grad"]) and all(torch.equal(eg[k], v) for k, v in rp32["grads"].items())
+    ra32 = O.actor_phase(actor, critic_after, la, _f(g["batch/obs"]), _f(g["noise/actor"]), target_entropy=-2.0, regrad=True, **HP)
+    tb = [flip(h) for h in ra32["trunk_hidden"]]
+    direct = O.actor_phase(actor, critic_after, la, _f(g["batch/obs"]), _f(g["noise/actor"]), target_entropy=-2.0,
+                           trunk_branches=tb, **HP)
+    swapped = ra32["regrad"](trunk_branches=tb)
+    assert set(swapped) == set(direct["grads"]) and all(torch.equal(swapped[k], v) for k, v in direct["grads"].items())
+    # the batch-chunked float64 conv is the plain one
+    x = torch.randn(130, 3, 9, 11, dtype=torch.float64)
+    w, bias = torch.randn(4, 3, 3, 3, dtype=torch.float64), torch.randn(4, dtype=torch.float64)
+    assert torch.equal(O._conv2d(x, w, bias, 2), torch.nn.functional.conv2d(x, w, bias, stride=2))
+
+
 def test_acting_path_matches_reference():
     g = load("tiny.npz")
     actor, critic, _, _, _ = _state(g)
