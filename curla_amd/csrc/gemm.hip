@@ -1079,9 +1079,8 @@ extern "C" {
 
 // small output, long k: one workgroup per 16 x 16 tile, k split over its waves (gemm_small_kernel)
 static bool small_shape(int M, int N, int K, int nbatch) {
-  const bool small_on = curla_opt(kOptGemmSmall) == 0;  // (option gemm_small, options.h)
   const long long t32 = (long long)((M + 31) / 32) * ((N + 31) / 32) * nbatch;
-  return small_on && K >= 256 && K % 64 == 0 && t32 <= 128 && nbatch <= 65535;
+  return K >= 256 && K % 64 == 0 && t32 <= 128 && nbatch <= 65535;
 }
 
 // which kernel a product takes: the small-output kernel (16 or 4 waves per tile) or the tiled one with its tile shape

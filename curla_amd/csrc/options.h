@@ -9,7 +9,6 @@ enum CurlaOpt {
   kOptConv1U8 = 0,  // first layer from the uint8 ring: 0 hybrid (crop in LDS, row walk out of LDS), 1 band, 2 rw (no LDS)
   kOptConv1F32,     // first layer (and its weight gradient) from a float NHWC minibatch: 0 rw (conv1_rw.h), 1 band
   kOptBwdSplit,     // stride-1 backward launch: 0 auto, 1 two + two workgroups per CU, 2 one + one side by side
-  kOptGemmSmall,    // small-output / long-k products on gemm_small_kernel: 0 on, 1 off (tiled kernel)
   kOptGemmTile,     // tile shape of the tiled GEMM: 0 auto, 1 64x64, 2 64x32, 3 32x32
   kOptLinearBwd,    // backward of a linear layer: 0 one launch for dW and dx, 1 two launches
   kOptCount

@@ -23,7 +23,6 @@ const OptDef kDefs[kOptCount] = {
     {"conv1_u8", {"hybrid", "band", "rw", nullptr}, {nullptr, nullptr, nullptr, nullptr}},
     {"conv1_f32", {"rw", "band", nullptr}, {nullptr, nullptr, nullptr}},
     {"bwd_split", {"auto", "0", "1", nullptr}, {nullptr, "off", "on", nullptr}},
-    {"gemm_small", {"1", "0", nullptr}, {"on", "off", nullptr}},
     {"gemm_tile", {"auto", "6464", "6432", "3232", nullptr}, {nullptr, "64x64", "64x32", "32x32", nullptr}},
     {"linear_bwd", {"pair", "split", nullptr}, {nullptr, nullptr, nullptr}},
 };

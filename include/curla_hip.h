@@ -41,7 +41,6 @@ const char* curla_version(void);
  *   conv1_u8    hybrid | band | rw     first layer from the uint8 ring (utils.py:151-166 + encoder.py:78-81)
  *   conv1_f32   rw | band              first layer and its weight gradient from a float NHWC minibatch
  *   bwd_split   auto | 0 | 1           stride-1 backward: 2 + 2 workgroups per CU, or 1 + 1 side by side
- *   gemm_small  1 | 0                  small-output / long-k products on their own kernel
  *   gemm_tile   auto | 6464 | 6432 | 3232
  *   linear_bwd  pair | split           dW and dx of a linear layer in one launch or two
  * curla_set_option returns CURLA_ERR_ARG for an unknown name or value; curla_get_option NULL for an unknown name. */

@@ -156,7 +156,6 @@ SWITCHES = [
     ("conv1_f32=band", {"conv1_f32": "band"}, {}, "color_jiggle", (), ()),
     ("bwd_split=0", {"bwd_split": "0"}, {}, "random_crop", (), ()),
     ("bwd_split=1", {"bwd_split": "1"}, {}, "random_crop", (), ()),
-    ("gemm_small=0", {"gemm_small": "0"}, {}, "random_crop", (), ()),
     ("gemm_tile=6464", {"gemm_tile": "6464"}, {}, "random_crop", (), ()),
     ("gemm_tile=6432", {"gemm_tile": "6432"}, {}, "random_crop", (), ()),
     ("gemm_tile=3232", {"gemm_tile": "3232"}, {}, "random_crop", (), ()),
@@ -171,7 +170,9 @@ SWITCHES = [
 
 def test_default_path_calls_what_the_switches_replace():
     _, _, calls, _ = _default("random_crop")
-    for name in ("curla_curl_head", "curla_fc_fwd_multi", "curla_gemm_nested", "curla_adam_step_lerp", "curla_linear_bwd",
+    # (the fused Adam + target lerp launch is not in the list: this test's hooks replace optimizer.step, which makes the
+    # agent take the plain step -- test_one_update_at_batch_256_... asserts it on an un-hooked agent)
+    for name in ("curla_curl_head", "curla_fc_fwd_multi", "curla_gemm_nested", "curla_adam_step", "curla_linear_bwd",
                  "curla_conv3x3_s1_fwd_stack", "curla_conv3x3_s1_bwd_slabs", "curla_conv1_fwd2"):
         assert calls[name] >= 1, (name, dict(calls))
     assert calls["curla_curl_ce"] == 0 and calls["curla_gemm_multi"] == 0
