@@ -64,6 +64,24 @@ __global__ __launch_bounds__(512, 2) void conv_rw_fwd_kernel(rw::Args A) {
   }
 }
 
+#include "conv_rw43.h"
+
+// The forward with Winograd F(4,3) along x (conv_rw43.h): 0.75 x the MFMAs; 256-thread workgroups, ONE wave per SIMD
+// (the 144 accumulator + 96 window registers of a wave do not fit twice), 144 KB of LDS for the two filters.
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_rw43_fwd_kernel(rw::Args A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  for (int l = 0; l < A.nlayers; ++l) {
+    rw43::build_filter<MODE_FWD, 256>(lds, A.p[l][0].w, A.p[l][1].B > 0 ? A.p[l][1].w : nullptr, threadIdx.x);
+    __syncthreads();
+    rw43::run_layer<MODE_FWD, 4>(A.g[l], A.p[l][0], A.p[l][1], lds, blockIdx.x, gridDim.x);
+    if (l + 1 < A.nlayers) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+  }
+}
+
 // data gradient alone (256-thread workgroups: the form that shares a launch with the weight gradient below)
 __global__ __launch_bounds__(256, 2) void conv_rw_dgrad_kernel(rw::Args A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1234,12 +1252,20 @@ bool rw_supported(int Hi, int Wi) { return (long long)(Hi + 2) * (Wi + 2) * 128 
 int launch_rw_fwd(int nlayers, const float* in, const float* const* w, const float* const* bias, float* const* out, int B,
                   const float* in2, const float* const* w2, const float* const* bias2, float* const* out2, int B2, int Hi,
                   int Wi, bool owned, hipStream_t st) {
+  // Winograd F(4,3) (conv_rw43.h) or F(2,3) (conv_rw.h) along x.  F(4,3) issues 0.78 x the MFMAs but ~0.9 VALU
+  // instructions per MFMA instead of 0.4 (input / output transforms, accumulator reads) at one wave per SIMD: measured
+  // on the stacks update() launches (tools/s1_bench.py), it wins 15 % where rows hold at least one full strip of 16 pixel
+  // quads (configs[4]: 83 -> 73 wide, 8.68 -> 7.42 ms and 5.86 -> 4.95 ms) and 5-7 % on configs[1]'s 35-wide rows
+  // (9 quads: every strip is a 5-row segment with 2 halo rows), where it is not worth its 2.5 x rounding noise
+  // (tools/micro/wino_error.py).  auto = F(4,3) when the narrowest layer of the launch has >= 16 quads per row.
+  const int opt43 = curla_opt(kOptS1Fwd);
+  const bool f43 = opt43 == 2 || (opt43 == 0 && (Wi - 2 * nlayers + 3) / 4 >= 16);
   rw::Args A;
   A.nlayers = nlayers;
   for (int l = 0; l < rw::kMaxLayers; ++l) {
     const bool on = l < nlayers;
     const int hi = Hi - 2 * l, wi = Wi - 2 * l;
-    A.g[l] = on ? rw::plan(hi, wi, hi - 2, wi - 2) : rw::Geom{};
+    A.g[l] = on ? (f43 ? rw43::plan(hi, wi, hi - 2, wi - 2) : rw::plan(hi, wi, hi - 2, wi - 2)) : rw::Geom{};
     A.p[l][0] = on ? rw::Problem{l == 0 ? in : out[l - 1], w[l], bias[l], out[l], B} : rw::Problem{};
     A.p[l][1] = (on && B2 > 0) ? rw::Problem{l == 0 ? in2 : out2[l - 1], w2[l], bias2[l], out2[l], B2} : rw::Problem{};
     if (on && (hi < 3 || wi < 3)) return CURLA_ERR_UNSUPPORTED;
@@ -1248,6 +1274,13 @@ int launch_rw_fwd(int nlayers, const float* in, const float* const* w, const flo
   const int cus = curla_cu_count();
   const int bmax = B > B2 ? B : B2;
   const int grid = owned ? cus : (bmax < cus ? bmax : cus);
+  if (f43) {
+    const size_t lds43 = (size_t)(B2 > 0 ? 2 : 1) * rw43::kWFloats * sizeof(float);
+    int rc43 = set_lds(conv_rw43_fwd_kernel, lds43);
+    if (rc43 != CURLA_OK) return rc43;
+    hipLaunchKernelGGL(conv_rw43_fwd_kernel, dim3(grid), dim3(256), lds43, st, A);
+    return curla_launch_status();
+  }
   const size_t lds = (size_t)(B2 > 0 ? 2 : 1) * rw::kWFloats * sizeof(float);
   int rc = set_lds(conv_rw_fwd_kernel, lds);
   if (rc != CURLA_OK) return rc;

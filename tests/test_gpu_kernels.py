@@ -54,13 +54,22 @@ def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
-@pytest.mark.parametrize("B,H,W", [(3, 13, 16), (2, 37, 37), (5, 35, 35), (1, 83, 83), (2, 5, 41), (9, 17, 15)])
-def test_conv_s1_fwd(ops, B, H, W):
+@pytest.fixture(params=["f23", "f43"])
+def s1_impl(request):
+    """The two stride-1 forwards: Winograd F(2,3) (conv_rw.h) and F(4,3) (conv_rw43.h), option s1_fwd."""
+    from curla_amd import _lib
+    with _lib.option("s1_fwd", request.param):
+        yield request.param
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 13, 16), (2, 37, 37), (5, 35, 35), (1, 83, 83), (2, 5, 41), (9, 17, 15), (3, 6, 7),
+                                   (2, 3, 3), (1, 21, 130)])
+def test_conv_s1_fwd(ops, s1_impl, B, H, W):
     x, w, b = rnd(B, 32, H, W, seed=1), rnd(32, 32, 3, 3, seed=2, scale=0.1), rnd(32, seed=3, scale=0.1)
     ref = torch.relu(F.conv2d(x, w, b))
     out = torch.full((B, H - 2, W - 2, 32), float("nan"), device="cuda")
     ops.conv_s1_fwd(nhwc(x), dev(w), dev(b), out)
-    check(f"conv_s1_fwd B{B} {H}x{W}", nchw(out), ref)
+    check(f"conv_s1_fwd [{s1_impl}] B{B} {H}x{W}", nchw(out), ref)
 
 
 @pytest.mark.parametrize("B,H,W", [(3, 11, 14), (2, 35, 35), (1, 81, 81), (4, 3, 39), (7, 13, 13)])
@@ -849,7 +858,7 @@ def test_fc_backward_streaming(ops, B, Fd, K):
 
 
 @pytest.mark.parametrize("B1,B2,H,W", [(5, 3, 13, 16), (2, 7, 37, 37), (600, 300, 9, 9), (1, 1, 35, 35)])
-def test_conv_s1_fwd_two_problems(ops, B1, B2, H, W):
+def test_conv_s1_fwd_two_problems(ops, s1_impl, B1, B2, H, W):
     """curla_conv3x3_s1_fwd2: two minibatches, each with its own weights, in one launch -- bit-identical to the two
     single launches (a workgroup walks into the second problem and re-builds its weight registers there)."""
     x1, x2 = rnd(B1, H, W, 32, seed=61).cuda(), rnd(B2, H, W, 32, seed=62).cuda()
@@ -1208,7 +1217,7 @@ def test_flat_adam_step_with_float64_scalar():
 
 
 @pytest.mark.parametrize("two", [False, True])
-def test_conv_s1_forward_stack_one_launch(ops, two):
+def test_conv_s1_forward_stack_one_launch(ops, s1_impl, two):
     """curla_conv3x3_s1_fwd_stack: three stride-1 layers of one or two minibatches in ONE launch (a workgroup owns its
     samples through the layers) -- every layer's activations bit-identical to the per-layer launches.  Batch sizes
     must be multiples of the persistent grid (ops.stack_granule()); anything else is refused."""
@@ -1235,7 +1244,7 @@ def test_conv_s1_forward_stack_one_launch(ops, two):
     assert not ops.conv_s1_fwd_stack(x1[:G + 1], w1, b1, [t[:G + 1] for t in o1])
 
 
-def test_conv_s1_forward_stack_full_size(ops):
+def test_conv_s1_forward_stack_full_size(ops, s1_impl):
     """The stack launch at BASELINE configs[1] size (the critic phase's [obs | next_obs] online pass of 1024 samples
     + the target pass of 512, 37x37 -> 35 -> 33 -> 31): every layer bit-identical to per-layer launches, twice in
     a row into the same buffers (a workgroup reads back its own stores of the previous layer: a stale or late line

@@ -58,6 +58,9 @@ def _one_update(aug_name, options=None, env=None, lr=0.0, steps=1):
         if aug_name == "random_crop":
             C, in_hw, out_hw = 9, (40, 44), (32, 36)
             aug = curla_amd.RandomCrop(in_hw, out_hw)
+        elif aug_name == "wide":  # rows of >= 16 pixel quads after three stride-1 layers: the F(4,3) forward by default
+            C, in_hw, out_hw, layers = 9, (20, 150), (16, 141), 4
+            aug = curla_amd.RandomCrop(in_hw, out_hw)
         else:  # float NHWC minibatches: the colour-jittered observations of configs[4]
             C, in_hw, out_hw = 12, (36, 40), (36, 40)
             aug = curla_amd.ColorJiggle(in_hw)
@@ -154,6 +157,8 @@ SWITCHES = [
     ("conv1_u8=band", {"conv1_u8": "band"}, {}, "random_crop", (), ()),
     ("conv1_u8=rw", {"conv1_u8": "rw"}, {}, "random_crop", (), ()),
     ("conv1_f32=band", {"conv1_f32": "band"}, {}, "color_jiggle", (), ()),
+    ("s1_fwd=f43", {"s1_fwd": "f43"}, {}, "random_crop", (), ()),
+    ("s1_fwd=f23 (wide rows)", {"s1_fwd": "f23"}, {}, "wide", (), ()),
     ("bwd_split=0", {"bwd_split": "0"}, {}, "random_crop", (), ()),
     ("bwd_split=1", {"bwd_split": "1"}, {}, "random_crop", (), ()),
     ("gemm_tile=6464", {"gemm_tile": "6464"}, {}, "random_crop", (), ()),

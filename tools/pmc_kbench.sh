@@ -1,18 +1,23 @@
 #!/bin/bash
 # Shader-core counters of single kernels under tools/kbench.py (four rocprofv3 --pmc passes).
-# Usage (on the GPU box): tools/pmc_kbench.sh <out-prefix> <kbench args...>
-set -e
-OUT=$1; shift
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+# Usage (on the GPU box): [SCRIPT=tools/s1_bench.py] tools/pmc_kbench.sh <out-prefix> <script args...>
+set -euo pipefail
+OUT="${1:?usage: tools/pmc_kbench.sh <out-prefix> <args...>}"; shift
+SCRIPT="${SCRIPT:-tools/kbench.py}"
+export TMPDIR=/tmp
+cd "${GRAFT_REPO_ROOT:?run this on the GPU box}"
+PY="$(python -c 'import sys; print(sys.executable)')"  # (the program after -- must be the interpreter itself, not a shim)
 i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS" \
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU" \
            "SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU"; do
   i=$((i+1))
-  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/g$i -- python tools/kbench.py "$@" > $OUT.g$i.log 2>&1 || echo "group $i failed"
+  # shellcheck disable=SC2086
+  rocprofv3 --pmc $grp --kernel-trace --output-format csv -d "$OUT/g$i" -- "$PY" "$SCRIPT" "$@" > "$OUT.g$i.log" 2>&1 \
+    || { echo "group $i failed (see $OUT.g$i.log)" >&2; exit 1; }
 done
-python - <<PY
+"$PY" - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/g*/*/*counter_collection.csv"):
