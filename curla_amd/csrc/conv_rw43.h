@@ -15,6 +15,10 @@
 //   * VALU: the input transform is 12 packed FMAs / adds per channel pair (F(2,3): 4 adds), the output transform 10
 //     per 4 outputs (F(2,3): 2 x 2) -- ~150 VALU per 288 MFMAs against 64 per 192;
 //   * LDS: the transformed filter has 6 x-positions: 72 KB per problem, 144 KB for the two problems of a launch;
+//   * a variant with TWO waves per SIMD, each computing one output-channel half of the same pieces (72 accumulator
+//     registers in plain VGPRs, no v_accvgpr_read, a second wave to issue from) was built and measured in round 4: it does
+//     the input transform and the loads twice and is no faster than F(2,3) (505 against 504 us on configs[1]'s critic-phase
+//     stack, 8.42 against 8.81 ms on configs[4]'s) -- not kept;
 //   * rounding: the transforms' coefficients (4, 5, 2, 8; 1/4, 1/6, 1/12, 1/24) cost accuracy: rms error of a
 //     pre-activation 3.2e-7 against 1.3e-7 for F(2,3) and 1.0e-7 for the direct sum (tools/micro/wino_error.py) --
 //     2.5 x as many activations within rounding of zero land on the other side of a ReLU (tests/test_gpu_fullsize.py
@@ -104,7 +108,8 @@ __device__ __forceinline__ void build_filter(float* lds_w, const float* __restri
 
 // B^T d for two channels (see the header): 12 packed VALU issues for 12 results.  Inline asm, invisible to the compiler's
 // hazard recogniser: a VALU write needs 2 wait states before an MFMA reads it (the trailing s_nop); none of the registers
-// written here is ever an MFMA accumulator.  c4 / c2 / c5 hold the constants (4, 4), (2, 2), (5, 5).
+// written here is ever an MFMA accumulator.  c4 / c2 / c5 hold the constants (4, 4), (2, 2), (5, 5) in SGPR pairs (one
+// scalar operand per instruction: within the constant-bus limit).
 __device__ __forceinline__ void bt_pk(f32x2& v0, f32x2& v1, f32x2& v2, f32x2& v3, f32x2& v4, f32x2& v5, const f32x2 d0,
                                       const f32x2 d1, const f32x2 d2, const f32x2 d3, const f32x2 d4, const f32x2 d5,
                                       const f32x2 c4, const f32x2 c2, const f32x2 c5) {
@@ -123,7 +128,7 @@ __device__ __forceinline__ void bt_pk(f32x2& v0, f32x2& v1, f32x2& v2, f32x2& v3
       "v_pk_fma_f32 %5, %11, %16, %5\n\t"                                  // v5 += 4 d1
       "s_nop 1"
       : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3), "=&v"(v4), "=&v"(v5), "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(e)
-      : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(d4), "v"(d5), "v"(c4), "v"(c2), "v"(c5));
+      : "v"(d0), "v"(d1), "v"(d2), "v"(d3), "v"(d4), "v"(d5), "s"(c4), "s"(c2), "s"(c5));
 }
 
 struct Acc {

@@ -50,9 +50,9 @@ def main():
                 print(f"s1_fwd={impl}  {B1}+{B2} x {L} layers from {H}x{H}: {us:8.1f} us  "
                       f"{flop / us / 1e6:6.1f} TF direct-equiv  {flop / us * 1e6 / PEAK * 100:5.1f} % of the f32 peak", flush=True)
         ks = list(outs)
-        if len(ks) == 2:
-            worst = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(outs[ks[0]], outs[ks[1]]))
-            print(f"   max |{ks[0]} - {ks[1]}| / max |.| over all layers: {worst:.2e}")
+        for k in ks[1:]:
+            worst = max(float((a - b).abs().max() / b.abs().max()) for a, b in zip(outs[ks[0]], outs[k]))
+            print(f"   max |{ks[0]} - {k}| / max |.| over all layers: {worst:.2e}")
 
 
 if __name__ == "__main__":
