@@ -394,6 +394,12 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
                     ops.conv1_fwd(bx, bw, bb, bo)
                 torch.cuda.synchronize()
             del bx, bw, bb, bo
+        graphed = bool(args.graphs and not distributed and not job.dry and rb.graph_supported())
+        if graphed:
+            agent.enable_update_graphs(rb)
+            for _ in range(6):  # one eager warm-up + two captures per kind, outside the W warm-up steps
+                agent.update(rb, L, step)
+                step += 1
         for _ in range(warmup):
             agent.update(rb, L, step)
             step += 1
@@ -410,6 +416,14 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
         recording[0] = False
         job.barrier(pg, world)
         dt = time.perf_counter() - t0
+        if graphed:  # a replayed update makes no host-side launch to put events around: time the kernel on eager updates
+            agent.disable_update_graphs()
+            recording[0] = True
+            for _ in range(8):
+                agent.update(rb, L, step)
+                step += 1
+            recording[0] = False
+            job.sync()
     finally:
         ops.conv_s1_fwd, ops.conv_s1_fwd2, ops.conv_s1_fwd_stack = real
     # the timed updates must have produced finite numbers (a NaN run would be meaningless)
@@ -482,7 +496,8 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": cfg["workload"], "baseline_config": f"configs[{cfg['baseline_index']}]",
                        "replay_capacity": cap * world, "shards": shards, "prefill": prefill,
-                       "parallelism": f"dp{world}", "priming_updates": 1, "clock_warmup_s": args.clock_warmup_s},
+                       "parallelism": f"dp{world}", "priming_updates": 1, "clock_warmup_s": args.clock_warmup_s,
+                       "update_graphs": graphed},
             "transitions_per_s": updates_per_s * B,
             "conv_algorithmic_gflop_per_update": per_update / 1e9,
             "conv_roofline_frac_whole_update": per_update * (steps / dt) / (PEAK_F32_TFLOPS * 1e12),
@@ -504,6 +519,9 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
                          "traffic_unit": "HBM bytes per launch; " + pmc_note,
                          "algorithmic_bytes_per_launch": kbytes / n_launch,
                          "launches": len(ev_pairs), "avg_launch_ms": avg_ms,
+                         "launch_timing": ("HIP events around the kernel's launches in 8 eager updates right after the "
+                                           "timed region (the timed updates are graph replays)" if graphed else
+                                           "HIP events around the kernel's launches inside the timed region"),
                          "hbm_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
                          "hbm_peak_GBps": 8000.0,
                          "mfma_busy_frac_pmc": mfma_busy},
@@ -538,6 +556,10 @@ def main():
     ap.add_argument("--prefill", choices=("device", "host"), default="device")
     ap.add_argument("--clock-warmup-s", type=float, default=0.6,
                     help="seconds of scratch conv launches before the warm-up steps (0 for counter-collection runs)")
+    ap.add_argument("--graphs", action="store_true",
+                    help="replay update() from captured hipGraphs (CurlSacAgent.enable_update_graphs; one rank, uint8-ring "
+                         "configurations c2 / c3); the dominant kernel's HIP-event timing then comes from 8 eager updates "
+                         "right after the timed region")
     ap.add_argument("--schedule", choices=("auto", "blocking", "overlapped"), default="auto",
                     help="data-parallel schedule at N > 1 (auto: measure both, report the faster, disclose both)")
     ap.add_argument("--sweep", action="store_true",

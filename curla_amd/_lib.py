@@ -62,13 +62,13 @@ SIGNATURES = {
                         vp],
     "curla_critic_td_loss": [vp, vp, c_ll, vp, vp, vp, vp, c_float, c_int, vp, vp, vp, vp],
     "curla_soft_update2": [vp, vp, c_size_t, c_size_t, c_float, c_float, c_float, c_float, vp],
-    "curla_adam_step": [vp, vp, vp, vp, c_size_t, c_double, c_double, c_double, c_double, c_ll, vp],
-    "curla_adam_step_lerp": [vp, vp, vp, vp, c_size_t, c_double, c_double, c_double, c_double, c_ll, vp, c_size_t,
+    "curla_adam_step": [vp, vp, vp, vp, c_size_t, c_double, c_double, c_double, c_double, c_ll, vp, vp],
+    "curla_adam_step_lerp": [vp, vp, vp, vp, c_size_t, c_double, c_double, c_double, c_double, c_ll, vp, vp, c_size_t,
                              c_float, c_float, c_float, c_float, vp],
-    "curla_adam_step_scalar64": [vp, vp, vp, vp, c_size_t, c_double, c_double, c_double, c_double, c_ll, vp, vp, vp, vp,
-                                 c_double, c_double, c_double, c_double, c_ll, vp],
+    "curla_adam_step_scalar64": [vp, vp, vp, vp, c_size_t, c_double, c_double, c_double, c_double, c_ll, vp, vp, vp, vp, vp,
+                                 c_double, c_double, c_double, c_double, c_ll, vp, vp],
     "curla_adam_step2": [vp, vp, vp, vp, vp, vp, c_size_t, c_size_t, c_double, c_double, c_double, c_double, c_ll, c_double,
-                         c_double, c_double, c_double, c_ll, vp],
+                         c_double, c_double, c_double, c_ll, vp, vp],
     "curla_gather_transition_scalars": [vp, vp, c_int, c_int, vp, vp, vp, vp],
     "curla_sample_stage": [vp, vp, c_ll, vp, c_int, c_int, vp, vp, vp, vp],
     "curla_host_device_pointer": [vp, vp],
@@ -79,9 +79,9 @@ SIGNATURES = {
     "curla_colsum3": [vp, c_int, vp, c_int, vp, c_int, c_int, vp, vp, vp, c_ll, c_int, vp],
     "curla_actor_head_fwd": [vp, vp, c_int, c_int, c_float, c_float, vp, vp, vp, vp, vp, vp, c_int, vp],
     "curla_mlp_out_head_fwd": [vp, vp, vp, vp, c_int, c_int, c_int, vp, c_float, c_float, vp, vp, vp, vp, vp, vp, c_int, vp],
-    "curla_actor_head_fwd_rng": [vp, vp, c_u64, c_u64, c_int, c_int, c_float, c_float, vp, vp, vp, vp, vp, vp, c_int, vp],
-    "curla_mlp_out_head_fwd_rng": [vp, vp, vp, vp, c_int, c_int, c_int, vp, c_u64, c_u64, c_float, c_float, vp, vp, vp, vp,
-                                   vp, vp, c_int, vp],
+    "curla_actor_head_fwd_rng": [vp, vp, c_u64, c_u64, vp, c_int, c_int, c_float, c_float, vp, vp, vp, vp, vp, vp, c_int, vp],
+    "curla_mlp_out_head_fwd_rng": [vp, vp, vp, vp, c_int, c_int, c_int, vp, c_u64, c_u64, vp, c_float, c_float, vp, vp, vp,
+                                   vp, vp, vp, c_int, vp],
     "curla_fc_ln_fwd_multi": [c_int, vp, c_int, c_ll, c_int, c_int, c_int, c_float, c_int, vp],
     "curla_actor_head_bwd": [vp, vp, c_int, vp, vp, c_float, vp, vp, vp, vp, c_int, c_int, c_float, c_float, vp, vp],
     "curla_concat": [vp, vp, c_int, c_int, c_int, vp, vp],

@@ -278,6 +278,9 @@ struct HeadArgs {
   // Box-Muller -- and stored to noise_gen[i] for the backward pass, instead of by a launch of their own
   float* noise_gen;
   unsigned long long rng_seed, rng_offset;
+  // rng_dev != nullptr: (seed, offset) are read from device memory when the kernel RUNS (rng_dev[0], rng_dev[1]) -- a
+  // captured graph is replayed with new stream positions
+  const unsigned long long* rng_dev;
 };
 
 __device__ __forceinline__ void philox4x32_10(unsigned long long seed, unsigned long long ctr, unsigned (&out)[4]) {
@@ -315,7 +318,9 @@ __device__ __forceinline__ void actor_head_one(float mu, float raw, int b, int a
   if (hd.noise || hd.noise_gen) {
     float n;
     if (hd.noise_gen) {
-      n = philox_normal(hd.rng_seed, hd.rng_offset, (unsigned)(b * A + a));
+      const unsigned long long seed = hd.rng_dev ? hd.rng_dev[0] : hd.rng_seed;
+      const unsigned long long offs = hd.rng_dev ? hd.rng_dev[1] : hd.rng_offset;
+      n = philox_normal(seed, offs, (unsigned)(b * A + a));
       hd.noise_gen[(size_t)b * A + a] = n;
     } else {
       n = hd.noise[(size_t)b * A + a];
@@ -1064,6 +1069,7 @@ struct AdamScalar64 {
   double *p, *m, *v;
   const double* g;
   double w1, b2, w2, step_size, bc2_sqrt, eps;
+  const double* dyn;  // != nullptr: step_size = dyn[0], bc2_sqrt = dyn[1], read when the kernel runs
 };
 
 // The target network's soft update in the same pass: target <- tau p + (1 - tau) target with the parameter this launch
@@ -1082,9 +1088,15 @@ __device__ __forceinline__ float lerp_one(float p, float t, float tau, float omt
 __global__ void __launch_bounds__(256) adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v, size_t n,
                                                         int vec, float w1, float b2, float w2, float step_size,
-                                                        float bc2_sqrt, float eps, AdamScalar64 sc, AdamLerp lp) {
+                                                        float bc2_sqrt, float eps, AdamScalar64 sc, AdamLerp lp,
+                                                        const float* __restrict__ dyn) {
+  // dyn != nullptr: the two step-dependent factors lr / (1 - b1^t) and sqrt(1 - b2^t) come from device memory, written
+  // there (by the host, through the update's pinned control block) before the kernel runs: a captured graph is
+  // replayed with new step counts.  The same two floats the host would have passed by value.
+  if (dyn) step_size = dyn[0], bc2_sqrt = dyn[1];
   if (sc.p && blockIdx.x == 0 && threadIdx.x == 0) {  // torch's single-tensor Adam, in double
 #pragma clang fp contract(off)
+    if (sc.dyn) sc.step_size = sc.dyn[0], sc.bc2_sqrt = sc.dyn[1];
     const double gs = *sc.g;
     double ms = *sc.m, vs = *sc.v;
     ms = (sc.w1 < 0.5) ? ms + sc.w1 * (gs - ms) : gs - (gs - ms) * (1.0 - sc.w1);
@@ -1135,7 +1147,9 @@ struct AdamHyper {
 __global__ void __launch_bounds__(256) adam_step2_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                          float* __restrict__ m1, float* __restrict__ v1,
                                                          float* __restrict__ m2, float* __restrict__ v2, size_t n,
-                                                         size_t n_pre, int vec, AdamHyper h1, AdamHyper h2) {
+                                                         size_t n_pre, int vec, AdamHyper h1, AdamHyper h2,
+                                                         const float* __restrict__ dyn) {
+  if (dyn) h1.step_size = dyn[0], h1.bc2_sqrt = dyn[1], h2.step_size = dyn[2], h2.bc2_sqrt = dyn[3];  // (adam_step_kernel)
   const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
   size_t done = 0;
   if (vec) {  // everything 16-byte aligned and n_pre a multiple of 4: a float4 lies on one side of n_pre
@@ -1508,18 +1522,18 @@ static int head_args(const float* noise, int B, int A, float log_std_min, float 
   CURLA_REQUIRE(!pi_xa || (noise && xa_ld >= A));
   hd->noise = noise, hd->mu_t = mu, hd->pi_t = pi, hd->log_pi = log_pi, hd->log_std = log_std, hd->tanh_ls = tanh_ls;
   hd->pi_xa = pi_xa, hd->A = A, hd->xa_ld = xa_ld, hd->lo = log_std_min, hd->hi = log_std_max;
-  hd->noise_gen = nullptr, hd->rng_seed = 0, hd->rng_offset = 0;
+  hd->noise_gen = nullptr, hd->rng_seed = 0, hd->rng_offset = 0, hd->rng_dev = nullptr;
   return CURLA_OK;
 }
 
 // the same with the noise drawn inside the kernel (written to noise_out [B][A])
-static int head_args_rng(float* noise_out, unsigned long long seed, unsigned long long offset, int B, int A,
-                         float log_std_min, float log_std_max, float* mu, float* pi, float* log_pi, float* log_std,
-                         float* tanh_ls, float* pi_xa, int xa_ld, HeadArgs* hd) {
-  CURLA_REQUIRE(noise_out);
+static int head_args_rng(float* noise_out, unsigned long long seed, unsigned long long offset,
+                         const unsigned long long* rng_dev, int B, int A, float log_std_min, float log_std_max, float* mu,
+                         float* pi, float* log_pi, float* log_std, float* tanh_ls, float* pi_xa, int xa_ld, HeadArgs* hd) {
+  CURLA_REQUIRE(noise_out && (reinterpret_cast<uintptr_t>(rng_dev) & 7) == 0);
   const int rc = head_args(noise_out, B, A, log_std_min, log_std_max, mu, pi, log_pi, log_std, tanh_ls, pi_xa, xa_ld, hd);
   if (rc != CURLA_OK) return rc;
-  hd->noise = nullptr, hd->noise_gen = noise_out, hd->rng_seed = seed, hd->rng_offset = offset;
+  hd->noise = nullptr, hd->noise_gen = noise_out, hd->rng_seed = seed, hd->rng_offset = offset, hd->rng_dev = rng_dev;
   return CURLA_OK;
 }
 
@@ -1536,12 +1550,12 @@ int curla_actor_head_fwd(const float* trunk_out, const float* noise, int B, int 
 }
 
 int curla_actor_head_fwd_rng(const float* trunk_out, float* noise_out, unsigned long long seed,
-                             unsigned long long offset, int B, int A, float log_std_min, float log_std_max, float* mu,
-                             float* pi, float* log_pi, float* log_std, float* tanh_ls, float* pi_xa, int xa_ld,
-                             void* stream) {
+                             unsigned long long offset, const unsigned long long* rng_dev, int B, int A,
+                             float log_std_min, float log_std_max, float* mu, float* pi, float* log_pi, float* log_std,
+                             float* tanh_ls, float* pi_xa, int xa_ld, void* stream) {
   CURLA_REQUIRE(trunk_out);
   HeadArgs hd;
-  const int rc = head_args_rng(noise_out, seed, offset, B, A, log_std_min, log_std_max, mu, pi, log_pi, log_std, tanh_ls,
+  const int rc = head_args_rng(noise_out, seed, offset, rng_dev, B, A, log_std_min, log_std_max, mu, pi, log_pi, log_std, tanh_ls,
                                pi_xa, xa_ld, &hd);
   if (rc != CURLA_OK) return rc;
   hipLaunchKernelGGL(actor_head_fwd_kernel, dim3((B + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
@@ -1553,12 +1567,13 @@ static int mlp_out_head_launch(const float* h, const float* W, const float* bias
                                const HeadArgs& hd, void* stream);
 
 int curla_mlp_out_head_fwd_rng(const float* h, const float* W, const float* bias, float* trunk_out, int B, int A, int K,
-                               float* noise_out, unsigned long long seed, unsigned long long offset, float log_std_min,
-                               float log_std_max, float* mu, float* pi, float* log_pi, float* log_std, float* tanh_ls,
-                               float* pi_xa, int xa_ld, void* stream) {
+                               float* noise_out, unsigned long long seed, unsigned long long offset,
+                               const unsigned long long* rng_dev, float log_std_min, float log_std_max, float* mu,
+                               float* pi, float* log_pi, float* log_std, float* tanh_ls, float* pi_xa, int xa_ld,
+                               void* stream) {
   CURLA_REQUIRE(h && W && trunk_out && K > 0);
   HeadArgs hd;
-  const int rc = head_args_rng(noise_out, seed, offset, B, A, log_std_min, log_std_max, mu, pi, log_pi, log_std, tanh_ls,
+  const int rc = head_args_rng(noise_out, seed, offset, rng_dev, B, A, log_std_min, log_std_max, mu, pi, log_pi, log_std, tanh_ls,
                                pi_xa, xa_ld, &hd);
   if (rc != CURLA_OK) return rc;
   return mlp_out_head_launch(h, W, bias, trunk_out, B, A, K, hd, stream);
@@ -1715,47 +1730,48 @@ int curla_soft_update2(const float* param, float* target, size_t n, size_t split
 }
 
 static int adam_step_launch(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
-                            double beta1, double beta2, double eps, long long step, const AdamScalar64& sc,
-                            void* stream, const AdamLerp& lp = AdamLerp{}) {
+                            double beta1, double beta2, double eps, long long step, const float* dyn,
+                            const AdamScalar64& sc, void* stream, const AdamLerp& lp = AdamLerp{}) {
   CURLA_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1 && beta1 >= 0. && beta1 < 1. &&
-                beta2 >= 0. && beta2 < 1.);
+                beta2 >= 0. && beta2 < 1. && (reinterpret_cast<uintptr_t>(dyn) & 3) == 0);
   const double b1 = beta1, b2 = beta2;
   const double bc1 = 1.0 - pow(b1, (double)step), bc2 = 1.0 - pow(b2, (double)step);
   const int vec = aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq) &&
                   (!lp.tgt || (aligned16(lp.tgt) && lp.split % 4 == 0));
   hipLaunchKernelGGL(adam_step_kernel, dim3(nblocks((n + 3) / 4, 256, 8192)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), param, grad, exp_avg, exp_avg_sq, n, vec, (float)(1.0 - b1),
-                     (float)b2, (float)(1.0 - b2), (float)(lr / bc1), (float)sqrt(bc2), (float)eps, sc, lp);
+                     (float)b2, (float)(1.0 - b2), (float)(lr / bc1), (float)sqrt(bc2), (float)eps, sc, lp, dyn);
   return curla_launch_status();
 }
 
 int curla_adam_step_lerp(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
-                         double beta1, double beta2, double eps, long long step, float* target, size_t split, float tau_a,
-                         float one_minus_tau_a, float tau_b, float one_minus_tau_b, void* stream) {
+                         double beta1, double beta2, double eps, long long step, const float* dyn, float* target,
+                         size_t split, float tau_a, float one_minus_tau_a, float tau_b, float one_minus_tau_b,
+                         void* stream) {
   CURLA_REQUIRE(target && split <= n);
   AdamScalar64 none = {};
   AdamLerp lp{target, split, tau_a, one_minus_tau_a, tau_b, one_minus_tau_b};
-  return adam_step_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, none, stream, lp);
+  return adam_step_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, dyn, none, stream, lp);
 }
 
 int curla_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
-                    double beta1, double beta2, double eps, long long step, void* stream) {
+                    double beta1, double beta2, double eps, long long step, const float* dyn, void* stream) {
   AdamScalar64 none = {};
-  return adam_step_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, none, stream);
+  return adam_step_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, dyn, none, stream);
 }
 
 int curla_adam_step_scalar64(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
-                             double beta1, double beta2, double eps, long long step, double* param64,
+                             double beta1, double beta2, double eps, long long step, const float* dyn, double* param64,
                              const double* grad64, double* exp_avg64, double* exp_avg_sq64, double lr64, double beta1_64,
-                             double beta2_64, double eps64, long long step64, void* stream) {
+                             double beta2_64, double eps64, long long step64, const double* dyn64, void* stream) {
   CURLA_REQUIRE(param64 && grad64 && exp_avg64 && exp_avg_sq64 && step64 >= 1 && beta1_64 >= 0. && beta1_64 < 1. &&
-                beta2_64 >= 0. && beta2_64 < 1.);
+                beta2_64 >= 0. && beta2_64 < 1. && (reinterpret_cast<uintptr_t>(dyn64) & 7) == 0);
   AdamScalar64 sc;
   sc.p = param64, sc.g = grad64, sc.m = exp_avg64, sc.v = exp_avg_sq64;
   sc.w1 = 1.0 - beta1_64, sc.b2 = beta2_64, sc.w2 = 1.0 - beta2_64;
   sc.step_size = lr64 / (1.0 - pow(beta1_64, (double)step64));
-  sc.bc2_sqrt = sqrt(1.0 - pow(beta2_64, (double)step64)), sc.eps = eps64;
-  return adam_step_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, sc, stream);
+  sc.bc2_sqrt = sqrt(1.0 - pow(beta2_64, (double)step64)), sc.eps = eps64, sc.dyn = dyn64;
+  return adam_step_launch(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, dyn, sc, stream);
 }
 
 static AdamHyper adam_hyper(double lr, double beta1, double beta2, double eps, long long step) {
@@ -1769,16 +1785,16 @@ static AdamHyper adam_hyper(double lr, double beta1, double beta2, double eps, l
 int curla_adam_step2(float* param, const float* grad, float* exp_avg1, float* exp_avg_sq1, float* exp_avg2,
                      float* exp_avg_sq2, size_t n, size_t n_pre, double lr1, double beta1_1, double beta2_1, double eps1,
                      long long step1, double lr2, double beta1_2, double beta2_2, double eps2, long long step2,
-                     void* stream) {
+                     const float* dyn, void* stream) {
   CURLA_REQUIRE(param && grad && exp_avg1 && exp_avg_sq1 && exp_avg2 && exp_avg_sq2 && n > 0 && n_pre <= n &&
-                step1 >= 1 && step2 >= 1);
+                step1 >= 1 && step2 >= 1 && (reinterpret_cast<uintptr_t>(dyn) & 3) == 0);
   CURLA_REQUIRE(beta1_1 >= 0. && beta1_1 < 1. && beta2_1 >= 0. && beta2_1 < 1. && beta1_2 >= 0. && beta1_2 < 1. &&
                 beta2_2 >= 0. && beta2_2 < 1.);
   const int vec = (n_pre % 4 == 0) && aligned16(param) && aligned16(grad) && aligned16(exp_avg1) &&
                   aligned16(exp_avg_sq1) && aligned16(exp_avg2) && aligned16(exp_avg_sq2);
   hipLaunchKernelGGL(adam_step2_kernel, dim3(nblocks((n + 3) / 4, 256, 8192)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), param, grad, exp_avg1, exp_avg_sq1, exp_avg2, exp_avg_sq2, n, n_pre, vec,
-                     adam_hyper(lr1, beta1_1, beta2_1, eps1, step1), adam_hyper(lr2, beta1_2, beta2_2, eps2, step2));
+                     adam_hyper(lr1, beta1_1, beta2_1, eps1, step1), adam_hyper(lr2, beta1_2, beta2_2, eps2, step2), dyn);
   return curla_launch_status();
 }
 

@@ -322,6 +322,15 @@ class _Workspace:
         self.logits, self.dlogits, self.row_loss = f(B, B), f(B, B), f(B)
 
 
+class _NullLog:
+    """What a captured update logs to: nothing (logging steps are never captured)."""
+
+    def log(self, *a, **k):
+        pass
+
+    log_histogram = log_param = log_image = log
+
+
 class CurlSacAgent(object):
     """CURL representation learning with SAC (curl_sac.py:224-465)."""
 
@@ -429,6 +438,9 @@ class CurlSacAgent(object):
         self._dp_overlap = False
         self._dp_check_every = 0
         self._dp_pending = []
+        self._graphs = None      # captured update graphs: None (off) or {kind: state} (enable_update_graphs)
+        self._graph_cap = None   # while a graph is being captured: the device addresses its kernels read their
+        #                          per-update values from
         self.train()
         self.critic_target.train()
 
@@ -718,6 +730,13 @@ class CurlSacAgent(object):
         if noise is not None:
             ws.noise.copy_(noise)
             return ws.noise, None
+        if self._graph_cap is not None:
+            # captured update graph: (seed, counter) are read by the kernel from the update's control block; the host
+            # side of the draw (the generator's offset) is advanced by the graph manager once per replay
+            cap = self._graph_cap
+            addr = cap["rng"][cap["n_noise"]]
+            cap["n_noise"] += 1
+            return ws.noise, (0, 0, addr)
         if ws.noise.is_cuda and not self._noise_launch:
             try:
                 gen = torch.cuda.default_generators[ws.noise.device.index if ws.noise.device.index is not None
@@ -1008,14 +1027,20 @@ class CurlSacAgent(object):
         """curl_sac.py:426-451.  A curla_amd ReplayBuffer hands over references
         into its HBM ring (gather + crop fused into the first conv); any other
         buffer is used through the reference's ``sample_cpc()`` tensors."""
+        if self._graphs is not None and self._graph_usable(replay_buffer, step, only_cpc):
+            return self._update_graphed(replay_buffer, L, step)
         if hasattr(replay_buffer, "sample_cpc_refs"):
-            obs, action, reward, next_obs, not_done, cpc_kwargs = replay_buffer.sample_cpc_refs()
+            sample = replay_buffer.sample_cpc_refs()
         else:
-            obs, action, reward, next_obs, not_done, cpc_kwargs = replay_buffer.sample_cpc()
+            sample = replay_buffer.sample_cpc()
 
         if self._dp_active and self._dp_check_every > 0 and step % self._dp_check_every == 0:
             self.check_replicas()
+        self._update_phases(sample, L, step, only_cpc)
 
+    def _update_phases(self, sample, L, step, only_cpc=False):
+        """The phases of one update on a drawn minibatch (curl_sac.py:431-451)."""
+        obs, action, reward, next_obs, not_done, cpc_kwargs = sample
         if step % self.log_interval == 0:
             ws = self._ws(action.shape[0])
             ops.mean(reward.contiguous(), reward.numel(), ws.scalars[6:7])
@@ -1045,6 +1070,124 @@ class CurlSacAgent(object):
         if do_cpc:
             obs_anchor, obs_pos = cpc_kwargs["obs_anchor"], cpc_kwargs["obs_pos"]
             self.update_cpc(obs_anchor, obs_pos, cpc_kwargs, L, step)
+
+    # ---------------------------------------------------------------- captured update graphs
+    def enable_update_graphs(self, replay_buffer, warm=1, depth=2):
+        """Replay ``update()`` from captured hipGraphs (kernels only enqueue, take no host syncs and
+        allocate nothing, so a whole update can be captured).  One graph per KIND of step -- (actor phase?, target soft
+        update?, CURL phase?): with train.py's frequencies that is "even" and "odd" -- is captured the first time the
+        kind comes up after ``warm`` eager updates of it, and replayed from then on: the host's work per update shrinks
+        to drawing the indices (NumPy, the reference's stream and order), writing them and ~80 bytes of per-update
+        control values into a pinned block, and one graph launch.  What changes from update to update is DATA the
+        captured kernels read on the device: the minibatch's indices / crop offsets (as before), the Philox stream
+        position of each policy-noise draw and every optimizer's two step-dependent Adam factors (curla_hip.h: the
+        ``rng_dev`` / ``dyn`` arguments); the block's staging kernel is the first node of the graph.
+        ``depth`` graphs are captured per kind, each with its own pinned block, and used in rotation: the host may then
+        prepare update n + 2 depth - 1 while the GPU still reads the block of update n (with one graph per kind it would
+        wait for the replay two updates back before every update).
+        Results are bit-identical to the eager path (tests/test_gpu_graph.py).  Steps the graphs do not cover run
+        eagerly, in any mix: logging steps (``step % log_interval == 0``: they compute extra scalars), histogram /
+        image recording steps, ``only_cpc``, data-parallel runs, float augmentations (ColorJiggle / NoisyCover stage
+        their parameters per call), other replay buffers."""
+        if self.device.type != "cuda":
+            raise RuntimeError("update graphs need the HIP device")
+        if not getattr(replay_buffer, "graph_supported", lambda: False)():
+            raise ValueError("enable_update_graphs: this replay buffer / augmentation is not graph-replayable "
+                             "(uint8-ring minibatches only: RandomCrop or identity, plain storage)")
+        opts = (self.critic_optimizer, self.actor_optimizer, self.encoder_optimizer, self.cpc_optimizer)
+        if not all(isinstance(o, FlatAdam) and "step" not in vars(o) for o in opts) or \
+                type(self.log_alpha_optimizer) is not torch.optim.Adam or self._noise_launch:
+            raise ValueError("enable_update_graphs needs the FlatAdam optimizers and the in-kernel policy noise")
+        self._graphs = {}
+        self._graph_rb = replay_buffer
+        self._graph_warm = int(warm)
+        self._graph_depth = max(1, int(depth))
+        self._graph_seen = {}
+
+    def disable_update_graphs(self):
+        self._graphs = None
+
+    def _graph_kind(self, step):
+        return (step % self.actor_update_freq == 0, step % self.critic_target_update_freq == 0,
+                (not self.pixel_sac) and step % self.cpc_update_freq == 0)
+
+    def _graph_usable(self, replay_buffer, step, only_cpc):
+        return (replay_buffer is self._graph_rb and not only_cpc and not self._dp_active and not self._records(step)
+                and step % self.log_interval != 0 and self.training)
+
+    def _graph_tail(self, kind, B):
+        """The 80 control bytes of one graphed update (ReplayBuffer.GRAPH_TAIL) -- and the host-side bookkeeping of
+        everything they stand for: the torch generator's offset moves on as _noise() would move it, every optimizer that
+        steps in this kind of update counts its step."""
+        do_actor, _, do_cpc = kind
+        u64 = np.zeros(4, dtype=np.uint64)
+        gen = torch.cuda.default_generators[self.device.index if self.device.index is not None
+                                            else torch.cuda.current_device()]
+        n = B * self.action_dim
+        for j in range(2 if do_actor else 1):  # critic-phase draw, then the actor phase's (curl_sac.py:352, 378)
+            off = gen.get_offset()
+            gen.set_offset(off + 4 * ((n + 3) // 4))
+            u64[2 * j], u64[2 * j + 1] = np.uint64(gen.initial_seed() & (2 ** 64 - 1)), np.uint64(off // 4)
+        f64 = np.zeros(2, dtype=np.float64)
+        f32 = np.zeros(8, dtype=np.float32)
+        steps = [(0, self.critic_optimizer)]
+        if do_actor:
+            steps.append((1, self.actor_optimizer))
+            lo = self.log_alpha_optimizer
+            g, p = lo.param_groups[0], lo.param_groups[0]["params"][0]
+            st = lo.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
+            t64 = int(round(float(st["step"]))) + 1
+            b1, b2 = float(g["betas"][0]), float(g["betas"][1])
+            f64[0], f64[1] = float(g["lr"]) / (1.0 - b1 ** float(t64)), (1.0 - b2 ** float(t64)) ** 0.5
+            st["step"] = torch.tensor(float(t64), dtype=torch.float32)
+        if do_cpc:
+            steps += [(2, self.encoder_optimizer), (3, self.cpc_optimizer)]
+        for slot, opt in steps:
+            f32[2 * slot], f32[2 * slot + 1] = opt.hyper_floats(opt.next_step())
+            opt.advance()
+        return u64.tobytes() + f64.tobytes() + f32.tobytes()
+
+    def _update_graphed(self, rb, L, step):
+        kind = self._graph_kind(step)
+        seen = self._graph_seen.get(kind, 0)
+        self._graph_seen[kind] = seen + 1
+        if seen < self._graph_warm:  # (first uses allocate workspaces and set kernel attributes: not capturable)
+            return self._update_phases(rb.sample_cpc_refs(), L, step)
+        ring = self._graphs.setdefault(kind, [])
+        turn = (seen - self._graph_warm) % self._graph_depth
+        if turn >= len(ring):
+            ring.append(dict(slot=sum(len(r) for r in self._graphs.values()), graph=None))
+        st = ring[turn]
+        B = rb.batch_size
+        idxs, offs = rb.draw_indices()
+        blk = rb.graph_write(st["slot"], idxs, offs, self._graph_tail(kind, B))
+        if st["graph"] is None:
+            base = blk["dev"].data_ptr() + blk["tail"]
+            dyn = {self.critic_optimizer: base + 48, self.actor_optimizer: base + 56, self.encoder_optimizer: base + 64,
+                   self.cpc_optimizer: base + 72}
+            self._graph_cap = dict(rng=(base, base + 16), n_noise=0)
+            for opt, addr in dyn.items():
+                opt._dyn = addr
+            self.log_alpha_optimizer._curla_dyn64 = base + 32
+            null = _NullLog()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(graph):
+                    self._update_phases(rb.graph_refs(st["slot"]), null, step)
+            finally:
+                self._graph_cap = None
+                for opt in dyn:
+                    opt._dyn = None
+                self.log_alpha_optimizer._curla_dyn64 = None
+            st["graph"] = graph
+        st["graph"].replay()
+        if blk["event"] is None:
+            blk["event"] = torch.cuda.Event()
+        blk["event"].record()
 
     def save(self, model_dir, augmentation, step):
         """curl_sac.py:453-456 (same three files, reference tensor layouts)."""

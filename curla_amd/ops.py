@@ -467,12 +467,14 @@ def colsum3(X0, N0, X1, N1, X2, N2, M, out0, out1, out2, sOut, nb=1):
 def actor_head_fwd(trunk_out, noise, B, A, lo, hi, mu=None, pi=None, log_pi=None, log_std=None, tanh_ls=None, xa=None,
                    rng=None):
     """``xa`` [B, F + A]: pi is also written into its last A columns (the Q functions' input rows).
-    ``rng`` = (seed, offset): the noise is drawn inside the launch (Philox stream, see curla_hip.h) and WRITTEN to
-    ``noise``; the caller owns the offset bookkeeping (ceil(B A / 4) counters per call)."""
+    ``rng`` = (seed, offset[, device address]): the noise is drawn inside the launch (Philox stream, see curla_hip.h) and
+    WRITTEN to ``noise``; the caller owns the offset bookkeeping (ceil(B A / 4) counters per call).  With a device
+    address the kernel reads (seed, offset) from there when it runs (captured update graphs)."""
     pi_xa, ld = (None, 0) if xa is None else (xa.data_ptr() + 4 * (xa.shape[1] - A), xa.shape[1])
     if rng is not None:
-        call("curla_actor_head_fwd_rng", ptr(trunk_out), ptr(noise), int(rng[0]) & (2 ** 64 - 1), int(rng[1]), B, A, lo, hi,
-             ptr(mu), ptr(pi), ptr(log_pi), ptr(log_std), ptr(tanh_ls), pi_xa, ld, stream())
+        call("curla_actor_head_fwd_rng", ptr(trunk_out), ptr(noise), int(rng[0]) & (2 ** 64 - 1), int(rng[1]),
+             rng[2] if len(rng) > 2 else None, B, A, lo, hi, ptr(mu), ptr(pi), ptr(log_pi), ptr(log_std), ptr(tanh_ls),
+             pi_xa, ld, stream())
         return
     call("curla_actor_head_fwd", ptr(trunk_out), ptr(noise), B, A, lo, hi, ptr(mu), ptr(pi), ptr(log_pi), ptr(log_std),
          ptr(tanh_ls), pi_xa, ld, stream())
@@ -485,8 +487,8 @@ def mlp_out_head_fwd(h, W, bias, trunk_out, noise, B, A, K, lo, hi, mu=None, pi=
     pi_xa, ld = (None, 0) if xa is None else (xa.data_ptr() + 4 * (xa.shape[1] - A), xa.shape[1])
     if rng is not None:
         call("curla_mlp_out_head_fwd_rng", ptr(h), ptr(W), ptr(bias), ptr(trunk_out), B, A, K, ptr(noise),
-             int(rng[0]) & (2 ** 64 - 1), int(rng[1]), lo, hi, ptr(mu), ptr(pi), ptr(log_pi), ptr(log_std), ptr(tanh_ls),
-             pi_xa, ld, stream())
+             int(rng[0]) & (2 ** 64 - 1), int(rng[1]), rng[2] if len(rng) > 2 else None, lo, hi, ptr(mu), ptr(pi),
+             ptr(log_pi), ptr(log_std), ptr(tanh_ls), pi_xa, ld, stream())
         return
     call("curla_mlp_out_head_fwd", ptr(h), ptr(W), ptr(bias), ptr(trunk_out), B, A, K, ptr(noise), lo, hi, ptr(mu),
          ptr(pi), ptr(log_pi), ptr(log_std), ptr(tanh_ls), pi_xa, ld, stream())

@@ -35,6 +35,11 @@ class FlatAdam(torch.optim.Adam):
         self._v = torch.zeros_like(self._m)
         self._steps = [0] * len(self._plist)
         self._plans = {}
+        # Captured update graphs (CurlSacAgent.enable_update_graphs).  While a graph is being captured, ``_dyn`` is the
+        # device address of this optimizer's two step-dependent floats (hyper_floats): the launch reads them from there
+        # when it runs, and the step counts are NOT advanced by the launching code (the graph manager advances them
+        # once per replay: advance()).
+        self._dyn = None
 
     # -- state kept in torch's format ------------------------------------------------------------------------
     def _views(self, i):
@@ -71,6 +76,25 @@ class FlatAdam(torch.optim.Adam):
                 st["exp_avg"], st["exp_avg_sq"] = m, v
                 self._steps[i] = int(round(float(st["step"])))
                 st["step"] = torch.tensor(float(self._steps[i]), dtype=torch.float32)
+
+    # -- captured graphs: the step-dependent factors as data ------------------------------------------------------
+    def next_step(self):
+        """The 1-based count of the step the next ``step()`` takes (all parameters share it in graph mode)."""
+        return self._steps[0] + 1
+
+    def hyper_floats(self, t):
+        """(lr / (1 - beta1^t), sqrt(1 - beta2^t)) as the two float32 values curla_adam_step evaluates from ``step`` on
+        the host: the same double arithmetic (libm pow), rounded to float once."""
+        import numpy as np
+        g = self.param_groups[0]
+        b1, b2 = float(g["betas"][0]), float(g["betas"][1])
+        return np.float32(float(g["lr"]) / (1.0 - b1 ** float(t))), np.float32((1.0 - b2 ** float(t)) ** 0.5)
+
+    def advance(self):
+        """One step's worth of host bookkeeping (what step() does besides launching)."""
+        for i in range(len(self._plist)):
+            self._ensure_state(i)
+            self._steps[i] += 1
 
     # -- the step --------------------------------------------------------------------------------------------
     def _plan(self, gi, group, live):
@@ -117,12 +141,15 @@ class FlatAdam(torch.optim.Adam):
                         e += 1
                     lo = a if k == 0 else self._span[members[k]][0]
                     hi = b if e == len(members) - 1 else self._span[members[e]][1]
-                    for i in members[k:e + 1]:
-                        self._ensure_state(i)
-                        self._steps[i] = t + 1
+                    if self._dyn is None:
+                        for i in members[k:e + 1]:
+                            self._ensure_state(i)
+                            self._steps[i] = t + 1
+                    elif len(plans) != 1 or len(runs) != 1 or e != len(members) - 1 or k != 0:
+                        raise RuntimeError("FlatAdam: a captured step must be ONE run with one step count")
                     call("curla_adam_step", self._flat.data_ptr() + 4 * lo, self._gflat.data_ptr() + 4 * lo,
                          self._m.data_ptr() + 4 * (lo - self._lo), self._v.data_ptr() + 4 * (lo - self._lo), hi - lo,
-                         float(lr), float(b1), float(b2), float(eps), t + 1, s)
+                         float(lr), float(b1), float(b2), float(eps), t + 1, self._dyn, s)
                     k = e + 1
         return loss
 
@@ -160,16 +187,19 @@ class FlatAdam(torch.optim.Adam):
             second.step()
             return
         (a0, a1, ta, ga), (b0, b1, tb, gb) = ra, rb
-        for opt in (first, second):
-            for i in range(len(opt._plist)):
-                opt._ensure_state(i)
-                opt._steps[i] += 1
+        if first._dyn is None:
+            for opt in (first, second):
+                for i in range(len(opt._plist)):
+                    opt._ensure_state(i)
+                    opt._steps[i] += 1
+        elif second._dyn != first._dyn + 8:
+            raise RuntimeError("FlatAdam.step_pair: the second optimizer's captured factors must follow the first's")
         flat, gflat = first._flat, first._gflat
         call("curla_adam_step2", flat.data_ptr() + 4 * b0, gflat.data_ptr() + 4 * b0,
              first._m.data_ptr() + 4 * (a0 - first._lo), first._v.data_ptr() + 4 * (a0 - first._lo),
              second._m.data_ptr() + 4 * (b0 - second._lo), second._v.data_ptr() + 4 * (b0 - second._lo), b1 - b0, a0 - b0,
              float(ga["lr"]), float(ga["betas"][0]), float(ga["betas"][1]), float(ga["eps"]), ta + 1,
-             float(gb["lr"]), float(gb["betas"][0]), float(gb["betas"][1]), float(gb["eps"]), tb + 1, stream())
+             float(gb["lr"]), float(gb["betas"][0]), float(gb["betas"][1]), float(gb["eps"]), tb + 1, first._dyn, stream())
 
 
     # -- this optimizer's step and the target copy's soft update, one launch ---------------------------------------
@@ -188,12 +218,14 @@ class FlatAdam(torch.optim.Adam):
         if run is None or run[0] != lo or not (run[1] <= hi <= run[1] + 3):
             return False
         _, hi, t, g = run
-        for i in range(len(opt._plist)):
-            opt._ensure_state(i)
-            opt._steps[i] = t + 1
+        if opt._dyn is None:
+            for i in range(len(opt._plist)):
+                opt._ensure_state(i)
+                opt._steps[i] = t + 1
         call("curla_adam_step_lerp", opt._flat.data_ptr() + 4 * lo, opt._gflat.data_ptr() + 4 * lo,
              opt._m.data_ptr() + 4 * (lo - opt._lo), opt._v.data_ptr() + 4 * (lo - opt._lo), hi - lo, float(g["lr"]),
-             float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), t + 1, target_flat.data_ptr() + 4 * lo, split,
+             float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), t + 1, opt._dyn, target_flat.data_ptr() + 4 * lo,
+             split,
              float(tau_a), float(1.0 - tau_a), float(tau_b), float(1.0 - tau_b), stream())
         return True
 
@@ -225,15 +257,19 @@ class FlatAdam(torch.optim.Adam):
             st["step"] = st["step"].cpu()
         t64 = int(round(float(st["step"]))) + 1
         lo, hi, t, grp = run
-        for i in range(len(first._plist)):
-            first._ensure_state(i)
-            first._steps[i] = t + 1
+        frozen = first._dyn is not None  # (captured graph: the manager advances both step counts per replay)
+        if not frozen:
+            for i in range(len(first._plist)):
+                first._ensure_state(i)
+                first._steps[i] = t + 1
         call("curla_adam_step_scalar64", first._flat.data_ptr() + 4 * lo, first._gflat.data_ptr() + 4 * lo,
              first._m.data_ptr() + 4 * (lo - first._lo), first._v.data_ptr() + 4 * (lo - first._lo), hi - lo,
-             float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]), t + 1,
+             float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]), t + 1, first._dyn,
              p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), float(g["lr"]),
-             float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), t64, stream())
-        st["step"] = torch.tensor(float(t64), dtype=torch.float32)
+             float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), t64, getattr(scalar_opt, "_curla_dyn64", None),
+             stream())
+        if not frozen:
+            st["step"] = torch.tensor(float(t64), dtype=torch.float32)
 
 
 __all__ = ["FlatAdam"]

@@ -496,6 +496,28 @@ class ReplayBuffer(object):
     def _is_float_aug(self):
         return isinstance(self.augmentor, (augmentations.ColorJiggle, augmentations.NoisyCover))
 
+    def _fill_index_block(self, host, idxs, offs):
+        """A minibatch's indices and crop offsets in the layout the kernels read:
+        idx [B] | idx + capacity [B] (the same transitions in the next_obs half of the double ring) | h1 of obs,
+        next_obs, pos | w1 of obs, next_obs, pos -- so that (obs, next_obs) is ONE run of 2B frame indices, 2B row
+        offsets and 2B column offsets."""
+        B = self.batch_size
+        i64 = host[:2 * B * 8].view(torch.int64)
+        i64[:B].copy_(torch.from_numpy(np.ascontiguousarray(idxs, dtype=np.int64)))
+        i64[B:].copy_(i64[:B] + self.capacity)
+        o32 = host[2 * B * 8:2 * B * 8 + 6 * B * 4].view(torch.int32).view(6, B)
+        offs = np.ascontiguousarray(offs, dtype=np.int32)
+        o32.copy_(torch.from_numpy(np.ascontiguousarray(offs[[0, 2, 4, 1, 3, 5]])))
+
+    def _index_views(self, dst):
+        """(idx [B] int64, the six offset rows, the 2B-long (idx, h1, w1) views) of a device index block."""
+        B = self.batch_size
+        d64 = dst[:2 * B * 8].view(torch.int64)
+        d32 = dst[2 * B * 8:2 * B * 8 + 6 * B * 4].view(torch.int32)
+        # off[2j] / off[2j+1] = h1 / w1 of tensor j (obs, next_obs, pos); pair = the 2B-long views
+        off = [d32[(j // 2 + 3 * (j % 2)) * B:(j // 2 + 3 * (j % 2) + 1) * B] for j in range(6)]
+        return d64[:B], off, (d64, d32[:2 * B], d32[3 * B:5 * B])
+
     def _upload_indices(self, idxs, offs):
         """Copy a minibatch's indices and crop offsets into the next device sample slot; returns the slot's
         (guard, idx view [B] int64, offsets view [6, B] int32)."""
@@ -511,15 +533,7 @@ class ReplayBuffer(object):
             for old in [i for i in self._slot_events if i < e]:
                 del self._slot_events[old]
         host = self._h_index[k]
-        # device layout: idx [B] | idx + capacity [B] (the same transitions in the next_obs half of the double ring)
-        # | h1 of obs, next_obs, pos | w1 of obs, next_obs, pos -- so that (obs, next_obs) is ONE run of 2B frame
-        # indices, 2B row offsets and 2B column offsets
-        i64 = host[:2 * B * 8].view(torch.int64)
-        i64[:B].copy_(torch.from_numpy(np.ascontiguousarray(idxs, dtype=np.int64)))
-        i64[B:].copy_(i64[:B] + self.capacity)
-        o32 = host[2 * B * 8:].view(torch.int32).view(6, B)
-        offs = np.ascontiguousarray(offs, dtype=np.int32)
-        o32.copy_(torch.from_numpy(np.ascontiguousarray(offs[[0, 2, 4, 1, 3, 5]])))
+        self._fill_index_block(host, idxs, offs)
         s = self._sample_slot = (self._sample_slot + 1) % self.N_SAMPLE_SLOTS
         self._sample_gen[s] += 1
         dst = self._d_index[s]
@@ -536,12 +550,8 @@ class ReplayBuffer(object):
             ev.record()
             self._slot_events[u // every] = ev
         guard = (self._sample_gen, s, self._sample_gen[s])
-        d64 = dst[:2 * B * 8].view(torch.int64)
-        d32 = dst[2 * B * 8:].view(torch.int32)
-        # off[2j] / off[2j+1] = h1 / w1 of tensor j (obs, next_obs, pos) as before; pair = the 2B-long views
-        off = [d32[(j // 2 + 3 * (j % 2)) * B:(j // 2 + 3 * (j % 2) + 1) * B] for j in range(6)]
-        self._pair_views = (d64, d32[:2 * B], d32[3 * B:5 * B])
-        return guard, d64[:B], off
+        d_idx, off, self._pair_views = self._index_views(dst)
+        return guard, d_idx, off
 
     def _scalars(self, d_idx):
         """actions [B, ...], rewards [B, 1], not_dones [B, 1] of the sampled transitions (utils.py:159-166): one
@@ -576,6 +586,62 @@ class ReplayBuffer(object):
             ops.gather_stacks(self.frames, self._fid[:, j, :], d_idx, B, views[j])
         self._mb_both = both
         return views[0], views[1], None
+
+    # ---- dedicated sample slots of captured update graphs (CurlSacAgent.enable_update_graphs) ---------------------
+    # A captured graph replays the SAME pointers: its minibatch block lives in its own pinned host slot and its own
+    # device block, never in the rotating ones above.  Behind the indices the block carries GRAPH_TAIL bytes of per-update
+    # control values (RNG stream positions, Adam step factors) that the graph's kernels read from the device copy.
+    GRAPH_TAIL = 80  # u64[4] (seed, critic-noise offset, actor-noise offset, -) | f64[2] log_alpha | f32[8] four Adams
+
+    def graph_supported(self):
+        """Graph replay covers the uint8-ring minibatches (RandomCrop / identity, plain storage, one allocation for both
+        rings, pinned index slots read in place); the float augmentations stage their parameters through per-call
+        pinned blocks and stay eager."""
+        return (self.device.type == "cuda" and not self._is_float_aug() and not self.dedup_frames
+                and self._both is not None and self._h_index_dev is not None)
+
+    def graph_block(self, slot):
+        if not hasattr(self, "_graph_blocks"):
+            self._graph_blocks = {}
+        g = self._graph_blocks.get(slot)
+        if g is None:
+            B, A = self.batch_size, self._n_act
+            nb = self._h_index.shape[1] + self.GRAPH_TAIL
+            host = torch.zeros(nb, dtype=torch.uint8, pin_memory=True)
+            g = dict(host=host, host_dev=ops.host_device_pointer(host), dev=torch.zeros(nb, dtype=torch.uint8, device=self.device),
+                     scal=torch.empty(B * (A + 2), dtype=torch.float32, device=self.device), event=None,
+                     tail=self._h_index.shape[1])
+            self._graph_blocks[slot] = g
+        return g
+
+    def graph_write(self, slot, idxs, offs, tail):
+        """Host side of one graphed update: the minibatch's indices / offsets and the control tail (80 bytes) into the
+        slot's pinned block -- after the previous replay that reads this block has finished."""
+        g = self.graph_block(slot)
+        if g["event"] is not None:
+            g["event"].synchronize()
+        self._fill_index_block(g["host"], idxs, offs)
+        g["host"][g["tail"]:].copy_(torch.from_numpy(np.frombuffer(bytearray(tail), dtype=np.uint8)))
+        return g
+
+    def graph_refs(self, slot):
+        """Device side, called while the graph is being captured: the staging launch (pinned block -> device block +
+        the transitions' scalars) and the sample_cpc 6-tuple with handles into the slot's device block."""
+        g = self.graph_block(slot)
+        B, A = self.batch_size, self._n_act
+        buf = g["scal"]
+        ops.sample_stage(g["host_dev"], g["dev"], g["host"].numel(), self._sc, B, A, buf[:B * A], buf[B * A:B * A + B],
+                         buf[B * A + B:])
+        d_idx, off, (idx2, h2, w2) = self._index_views(g["dev"])
+        crop = tuple(self.augmentor.output_shape)
+        both = self._both
+        obses = ops.ObsRef.from_ring(both, idx2[:B], off[0], off[1], B, crop, None)
+        next_obses = ops.ObsRef.from_ring(both, idx2[B:], off[2], off[3], B, crop, None)
+        pos = ops.ObsRef.from_ring(both, idx2[:B], off[4], off[5], B, crop, None)
+        obses.pair = (ops.ObsRef.from_ring(both, idx2, h2, w2, 2 * B, crop, None), next_obses)
+        act, rew, nd = buf[:B * A].view((B,) + tuple(self.actions.shape[1:])), buf[B * A:B * A + B].view(B, 1), \
+            buf[B * A + B:].view(B, 1)
+        return obses, act, rew, next_obses, nd, dict(obs_anchor=obses, obs_pos=pos, time_anchor=None, time_pos=None)
 
     def sample_cpc_refs(self, indices=None):
         """The fused form of sample_cpc: same 6-tuple, but obs / next_obs / pos are

@@ -299,15 +299,18 @@ int curla_mlp_out_head_fwd(const float* h, const float* W, const float* bias, fl
 /* The two forms above with the standard-normal noise of `torch.randn_like(mu)` (curl_sac.py:97) drawn INSIDE the launch
  * instead of read: element i = b * A + a is Box-Muller on outputs (i % 4) & 2, + 1 of Philox4x32-10 with key `seed` and
  * counter `offset + i / 4` (cos branch for even i, sin for odd), and is also stored to noise_out [B][A] (the backward
- * pass reads it).  The caller advances `offset` by ceil(B A / 4) per call. */
+ * pass reads it).  The caller advances `offset` by ceil(B A / 4) per call.  rng_dev != NULL (8-byte aligned device
+ * memory): seed = rng_dev[0] and offset = rng_dev[1] are read when the kernel RUNS and the by-value pair is ignored -- a
+ * captured hipGraph is replayed with new stream positions (CurlSacAgent.enable_update_graphs). */
 int curla_actor_head_fwd_rng(const float* trunk_out, float* noise_out, unsigned long long seed,
-                             unsigned long long offset, int B, int A, float log_std_min, float log_std_max, float* mu,
-                             float* pi, float* log_pi, float* log_std, float* tanh_ls, float* pi_xa, int xa_ld,
-                             void* stream);
+                             unsigned long long offset, const unsigned long long* rng_dev, int B, int A,
+                             float log_std_min, float log_std_max, float* mu, float* pi, float* log_pi, float* log_std,
+                             float* tanh_ls, float* pi_xa, int xa_ld, void* stream);
 int curla_mlp_out_head_fwd_rng(const float* h, const float* W, const float* bias, float* trunk_out, int B, int A, int K,
-                               float* noise_out, unsigned long long seed, unsigned long long offset, float log_std_min,
-                               float log_std_max, float* mu, float* pi, float* log_pi, float* log_std, float* tanh_ls,
-                               float* pi_xa, int xa_ld, void* stream);
+                               float* noise_out, unsigned long long seed, unsigned long long offset,
+                               const unsigned long long* rng_dev, float log_std_min, float log_std_max, float* mu,
+                               float* pi, float* log_pi, float* log_std, float* tanh_ls, float* pi_xa, int xa_ld,
+                               void* stream);
 /* gradient w.r.t. trunk_out of sum(gpi*pi) + glp*log_pi; glp = glp_rows[b] or glp_scale*exp(*log_alpha);
  * gpi[b][a] is read at gpi[b*gpi_ld + a] (+ gpi2[b*gpi_ld + a] when gpi2 is not NULL: the action columns of the twin-Q
  * input gradient summed over the twin in place) */
@@ -365,29 +368,36 @@ int curla_soft_update2(const float* param, float* target, size_t n, size_t split
  * flat run of n fp32 parameters with their gradient and moment runs: replaces torch's multi-tensor Adam launches
  * (~70 workgroups on a 256-CU chip).  `step` is the 1-based count of this step; the hyper-parameters are doubles as in the
  * optimizer's param_group (the bias corrections and lr/(1-beta1^step) are evaluated in double on the host, like
- * torch's single-tensor Adam, and rounded to float once). */
+ * torch's single-tensor Adam, and rounded to float once).
+ * dyn != NULL (device memory, 2 floats): the two step-dependent factors -- dyn[0] = (float)(lr / (1 - beta1^step)),
+ * dyn[1] = (float)sqrt(1 - beta2^step) -- are read when the kernel RUNS instead of being evaluated from `step`: a captured
+ * hipGraph is replayed with new step counts (the host writes the same two floats it would have passed by value). */
 int curla_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
-                    double beta1, double beta2, double eps, long long step, void* stream);
+                    double beta1, double beta2, double eps, long long step, const float* dyn, void* stream);
 /* curla_adam_step plus, in the same launch, the soft update of the target copy of the same flat run with the freshly
  * stepped parameters (critic_optimizer.step() ... soft_update_params x3, curl_sac.py:367,442-445): target[i] <- tau p[i]
  * + (1 - tau) target[i], elements [0, split) with (tau_a, one_minus_tau_a), the rest with (tau_b, one_minus_tau_b);
  * the same arithmetic as curla_adam_step followed by curla_soft_update2. */
 int curla_adam_step_lerp(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
-                         double beta1, double beta2, double eps, long long step, float* target, size_t split, float tau_a,
-                         float one_minus_tau_a, float tau_b, float one_minus_tau_b, void* stream);
+                         double beta1, double beta2, double eps, long long step, const float* dyn, float* target,
+                         size_t split, float tau_a, float one_minus_tau_a, float tau_b, float one_minus_tau_b,
+                         void* stream);
 /* curla_adam_step plus, in the same launch, the Adam step of ONE float64 scalar parameter with its own optimizer state
- * and hyper-parameters (log_alpha, stepped right after the actor: curl_sac.py:393-404), in double. */
+ * and hyper-parameters (log_alpha, stepped right after the actor: curl_sac.py:393-404), in double.  dyn64 (device memory,
+ * 2 doubles, or NULL): the scalar's two step-dependent factors, as `dyn` for the flat run. */
 int curla_adam_step_scalar64(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
-                             double beta1, double beta2, double eps, long long step, double* param64,
+                             double beta1, double beta2, double eps, long long step, const float* dyn, double* param64,
                              const double* grad64, double* exp_avg64, double* exp_avg_sq64, double lr64, double beta1_64,
-                             double beta2_64, double eps64, long long step64, void* stream);
+                             double beta2_64, double eps64, long long step64, const double* dyn64, void* stream);
 /* Two such steps of two optimizers on the same parameters with the same gradient, one after the other, in one pass
  * (encoder_optimizer.step(); cpc_optimizer.step(), curl_sac.py:418-423).  exp_avg2 / exp_avg_sq2 cover n elements, the
- * first n_pre of which (CURL.W) take the second step only; exp_avg1 / exp_avg_sq1 cover the remaining n - n_pre. */
+ * first n_pre of which (CURL.W) take the second step only; exp_avg1 / exp_avg_sq1 cover the remaining n - n_pre.
+ * dyn (device memory, 4 floats, or NULL): (lr1 / (1 - beta1_1^step1), sqrt(1 - beta2_1^step1)) then the same for the
+ * second optimizer, as in curla_adam_step. */
 int curla_adam_step2(float* param, const float* grad, float* exp_avg1, float* exp_avg_sq1, float* exp_avg2,
                      float* exp_avg_sq2, size_t n, size_t n_pre, double lr1, double beta1_1, double beta2_1, double eps1,
                      long long step1, double lr2, double beta1_2, double beta2_2, double eps2, long long step2,
-                     void* stream);
+                     const float* dyn, void* stream);
 
 /* ---- augmentations that produce float observations (augmentations.py:78-205; kornia arithmetic is not
  * vendored by the reference: PARITY UNPINNED, the algorithm is this build's statement of kornia's documented
