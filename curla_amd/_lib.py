@@ -8,7 +8,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcurla_hip.so")
+# CURLA_LIB_PATH: another build of the library (an A/B partner of a measurement, a C-ABI consumer's own build); the
+# in-tree library's source-stamp check does not apply to it
+LIB_PATH = os.environ.get("CURLA_LIB_PATH") or os.path.join(_HERE, "libcurla_hip.so")
 
 c_int, c_ll, c_float, c_size_t, vp = ctypes.c_int, ctypes.c_longlong, ctypes.c_float, ctypes.c_size_t, ctypes.c_void_p
 c_u64 = ctypes.c_ulonglong

@@ -29,6 +29,24 @@ __device__ __forceinline__ void winograd_bt_pk(f32x2& d0, const f32x2& d1, f32x2
       : "v"(d1));
 }
 
+// Cache policy (the `aux` operand) of the conv epilogues' activation stores.  A pixel's 32 channels leave a wave as TWO
+// 64-byte half lines (one per 16-channel MFMA tile half) from two store instructions.  With the streaming policy (2) such
+// half-line stores cost 1.48 x their bytes at the memory side and run at 2.9 TB/s when nothing else is going on; with the
+// default write-back policy (0) the L2 merges the halves: 1.00 x, 5.4 TB/s (tools/micro/store_policy.hip,
+// profiles/r04_checks/r04_store_policy.txt) -- and a layer's output is what the next layer of the same launch, or the
+// next launch, reads first.
+#ifndef CURLA_ACT_STORE_POLICY
+#define CURLA_ACT_STORE_POLICY 0
+#endif
+
+// (the flat-address form of the same choice, for the banded first-layer kernels)
+__device__ __forceinline__ void act_store(f32x4* p, f32x4 v) {
+  if (CURLA_ACT_STORE_POLICY)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
+}
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }

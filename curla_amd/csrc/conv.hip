@@ -298,7 +298,7 @@ __global__ __launch_bounds__(512) void conv1_fwd_kernel(Conv1Args a) {
           f32x4 v = acc[mt];
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(o + mt * 16));
+          act_store(reinterpret_cast<f32x4*>(o + mt * 16), v);
         }
       }
       x += rstep, ty += qstep;  // at most one more wrap
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(512) void conv1_fwd_u8_kernel(Conv1Args a) {
         f32x4 v = acc[mt];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(a.out + g + mt * 16));
+        act_store(reinterpret_cast<f32x4*>(a.out + g + mt * 16), v);
       }
     }
     x += rstep, ty += qstep;  // 8 waves x 16 pixels further: qstep rows + rstep columns, at most one more wrap
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(512, 2) void conv1_u8_walk_kernel(Conv1Args a, rw::
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = rw::relu_bits(v[r]);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rout,
-                                               vo + mt * 64u, 0, 2);
+                                               vo + mt * 64u, 0, CURLA_ACT_STORE_POLICY);
       }
       vo += out_row;
     };

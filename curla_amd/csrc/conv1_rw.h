@@ -127,7 +127,7 @@ __device__ __forceinline__ void conv1_body(const Conv1Args& a, const int bid, co
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = relu_bits(v[r]);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), rout,
-                                                 vo + mt * 64u, 0, 2);
+                                                 vo + mt * 64u, 0, CURLA_ACT_STORE_POLICY);
         }
         vo += out_row;
       };

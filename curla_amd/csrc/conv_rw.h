@@ -301,11 +301,11 @@ __device__ __forceinline__ void run_layer(const Geom& G, const Problem& P0, cons
 #pragma unroll
             for (int r = 0; r < 4; ++r) ya[r] = mk[0][mt][r] > 0.f ? ya[r] : 0.f, yb[r] = mk[1][mt][r] > 0.f ? yb[r] : 0.f;
           }
-          // streaming stores: this kernel does not read them again (the next layer's loads come a whole layer later)
+          // (store policy: common.h, CURLA_ACT_STORE_POLICY)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, ya), rout,
-                                                 oa + mt * 64u, 0, 2);
+                                                 oa + mt * 64u, 0, CURLA_ACT_STORE_POLICY);
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, yb), rout,
-                                                 ob + mt * 64u, 0, 2);
+                                                 ob + mt * 64u, 0, CURLA_ACT_STORE_POLICY);
         }
         oa += out_row, ob += out_row;
       };

@@ -283,9 +283,9 @@ __device__ __forceinline__ void run_layer(const Geom& G, const Problem& P0, cons
 #pragma unroll
               for (int r = 0; r < 4; ++r) y[p][r] = mk[p][mt][r] > 0.f ? y[p][r] : 0.f;
             }
-            // streaming stores: this kernel does not read them again (the next layer's loads come a whole layer later)
+            // (store policy: common.h, CURLA_ACT_STORE_POLICY)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, y[p]),
-                                                   rout, oo[p] + mt * 64u, 0, 2);
+                                                   rout, oo[p] + mt * 64u, 0, CURLA_ACT_STORE_POLICY);
           }
         }
 #pragma unroll
