@@ -82,6 +82,15 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   }
 }
 
+// ... and the data gradient in the same form (one wave per SIMD: it cannot share a launch with the 256-register weight
+// gradient, so wide layers run the two as two launches -- at their size a launch boundary is noise)
+__global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_rw43_dgrad_kernel(rw::Args A) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  rw43::build_filter<MODE_DGRAD, 256>(lds, A.p[0][0].w, nullptr, threadIdx.x);
+  __syncthreads();
+  rw43::run_layer<MODE_DGRAD, 4>(A.g[0], A.p[0][0], A.p[0][1], lds, blockIdx.x, gridDim.x);
+}
+
 // data gradient alone (256-thread workgroups: the form that shares a launch with the weight gradient below)
 __global__ __launch_bounds__(256, 2) void conv_rw_dgrad_kernel(rw::Args A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1298,11 +1307,30 @@ rw::Args rw_dgrad_args(const float* g, const float* w, const float* act_below, f
   return A;
 }
 
+// Does the data gradient of a layer whose INPUT is Wi wide take the F(4,3) kernel?  (option s1_fwd, as the forward)
+bool dgrad_f43(int Wi) {
+  const int opt = curla_opt(kOptS1Fwd);
+  return opt == 2 || (opt == 0 && (Wi + 3) / 4 >= 16);
+}
+
+int launch_dgrad43(const float* g, const float* w, const float* act_below, float* gin, int B, int Ho, int Wo,
+                   hipStream_t st) {
+  rw::Args A = rw_dgrad_args(g, w, act_below, gin, B, Ho, Wo);
+  A.g[0] = rw43::plan(Ho, Wo, Ho + 2, Wo + 2);
+  const int cap = curla_cu_count();
+  const size_t lds = rw43::kWFloats * sizeof(float);
+  int rc = set_lds(conv_rw43_dgrad_kernel, lds);
+  if (rc != CURLA_OK) return rc;
+  hipLaunchKernelGGL(conv_rw43_dgrad_kernel, dim3(B < cap ? B : cap), dim3(256), lds, st, A);
+  return curla_launch_status();
+}
+
 int launch_conv_s1(int mode, const float* in, const float* w, const float* aux, float* out, int B, int Hs, int Ws,
                    hipStream_t st, const float* in2 = nullptr, const float* w2 = nullptr, const float* aux2 = nullptr,
                    float* out2 = nullptr, int B2 = 0) {
   if (!rw_supported(Hs, Ws)) return CURLA_ERR_UNSUPPORTED;
   if (mode == MODE_FWD) return launch_rw_fwd(1, in, &w, &aux, &out, B, in2, &w2, &aux2, &out2, B2, Hs, Ws, false, st);
+  if (dgrad_f43(Ws + 2)) return launch_dgrad43(in, w, aux, out, B, Hs, Ws, st);
   const rw::Args A = rw_dgrad_args(in, w, aux, out, B, Hs, Ws);
   const int cap = 2 * curla_cu_count();
   const size_t lds = rw::kWFloats * sizeof(float);
@@ -1607,6 +1635,12 @@ int curla_conv3x3_s1_bwd_slabs(const float* in, const float* g, const float* w, 
   CURLA_REQUIRE(aligned16(in) && aligned16(g) && aligned16(w) && aligned16(gin));
   const int Ho = Hi - 2, Wo = Wi - 2;
   if (!rw_supported(Hi, Wi)) return CURLA_ERR_UNSUPPORTED;
+  if (dgrad_f43(Wi)) {
+    // wide rows: the data gradient with Winograd F(4,3) (one wave per SIMD), the weight gradient as its own launch
+    const int rcw = launch_wgrad_s1(in, g, workspace, B, Hi, Wi, channels, static_cast<hipStream_t>(stream), nslabs);
+    if (rcw != CURLA_OK) return rcw;
+    return launch_dgrad43(g, w, in, gin, B, Ho, Wo, static_cast<hipStream_t>(stream));
+  }
   // Weight gradient and data gradient of the layer in ONE launch (both only read the layer's output gradient): the
   // first n workgroups run the weight-gradient body, the next n the data-gradient body, each owning samples k, k + n,
   // ... (the two do about the same number of MFMAs per sample).  Grid: 2 x CUs workgroups of each kind, run one kind

@@ -73,7 +73,7 @@ def test_conv_s1_fwd(ops, s1_impl, B, H, W):
 
 
 @pytest.mark.parametrize("B,H,W", [(3, 11, 14), (2, 35, 35), (1, 81, 81), (4, 3, 39), (7, 13, 13)])
-def test_conv_s1_dgrad(ops, B, H, W):
+def test_conv_s1_dgrad(ops, s1_impl, B, H, W):
     # g: gradient w.r.t. the conv output [B,32,H,W]; input was [B,32,H+2,W+2]
     below = rnd(B, 32, H + 2, W + 2, seed=4)
     act_below = torch.relu(below)
@@ -980,7 +980,7 @@ def test_mlp_forward_two_level_batch(ops, B, din, H):
 
 
 @pytest.mark.parametrize("B,H,W", [(3, 13, 16), (2, 37, 37), (300, 9, 9), (5, 17, 15)])
-def test_conv_s1_backward_one_launch(ops, B, H, W):
+def test_conv_s1_backward_one_launch(ops, s1_impl, B, H, W):
     """curla_conv3x3_s1_bwd_slabs: weight-gradient slabs and data gradient of a layer in one launch.  The data gradient
     is bit-identical to the separate kernel's; the weight gradient is dealt to as many or half as many workgroups
     (slabs) as the separate kernel's, i.e. the same sums in another fixed order."""

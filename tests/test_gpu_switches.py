@@ -119,6 +119,8 @@ def _one_update(aug_name, options=None, env=None, lr=0.0, steps=1):
                 m.call = real_call
         params = {"critic": agent._critic_flat.detach().cpu().clone(), "actor": agent._actor_flat.detach().cpu().clone(),
                   "target": agent._target_flat.detach().cpu().clone()}
+        # the online conv activations of obs (their signs are the ReLU branches the conv gradients went along)
+        params["acts"] = [a.detach().clone() for a in agent._ws(B).acts_main[:layers]]
         return dict(L.scalars), grads, calls, params
 
 
@@ -132,8 +134,21 @@ def _default(aug_name):
 
 
 def _compare(tag, got, want):
+    """Per tensor at 1e-4.  One exception, with its own check: two correct fp32 evaluations of a conv layer may put an
+    activation within rounding of zero on different sides of the ReLU, and ONE such element moves the conv weight
+    gradients at and below that layer by ~1e-4 .. 1e-3 of their size (tests/test_gpu_fullsize.py).  When the two runs'
+    ReLU branches differ -- in at most 8 elements, all within 1e-5 of zero on both sides -- the conv gradients are held
+    to 2e-3 instead."""
     bad = []
-    (losses, grads, _, _), (losses0, grads0, _, _) = got, want
+    (losses, grads, _, par), (losses0, grads0, _, par0) = got, want
+    flips = 0
+    for a, b in zip(par["acts"], par0["acts"]):
+        differ = (a > 0) != (b > 0)
+        k = int(differ.sum())
+        if k:
+            assert float(torch.maximum(a[differ].abs(), b[differ].abs()).max()) <= 1e-5, tag
+        flips += k
+    assert flips <= 8, (tag, flips)
     assert set(losses) == set(losses0) and set(grads) == set(grads0) == {"critic", "actor", "cpc"}
     for k in losses0:
         if "loss" in k or "entropy" in k:
@@ -146,7 +161,8 @@ def _compare(tag, got, want):
         for k, v in grads0[phase].items():
             e = rel_err(grads[phase][k], v)
             n += 1
-            if not (np.isfinite(e) and e <= RTOL):
+            tol = 2e-3 if (flips and ".convs." in k) else RTOL
+            if not (np.isfinite(e) and e <= tol):
                 bad.append((tag, phase, k, e))
     assert n == 24 + 11 + 13
     assert not bad, bad
@@ -203,7 +219,7 @@ def test_torch_adam_and_flat_adam_take_the_same_steps():
     gradient is zero to rounding may differ by 2 lr per step; everything else agrees."""
     flat = _one_update("random_crop", lr=1e-3, steps=2)[3]
     fused = _one_update("random_crop", env={"CURLA_TORCH_ADAM": "1"}, lr=1e-3, steps=2)[3]
-    for k in flat:
+    for k in ("critic", "actor", "target"):
         d = (flat[k] - fused[k]).abs()
         assert float(d.max()) <= 4 * 2 * 1e-3 + 1e-6, (k, float(d.max()))  # (a conv weight takes 4 steps in two updates)
         assert float((d > 1e-5).float().mean()) <= 5e-3, (k, float((d > 1e-5).float().mean()))
