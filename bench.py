@@ -162,7 +162,7 @@ def committed_counters(cfg_name, kernel):
     cur = build.source_hash()
     traffic = busy = None
     note = "no committed PMC summary for this configuration"
-    for rnd in ("r03", "r02"):
+    for rnd in ("r04", "r03", "r02"):
         for fn, key in ((f"{rnd}_pmc_traffic_{cfg_name}.json", "traffic"), (f"{rnd}_pmc_sq_{cfg_name}.json", "sq")):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
@@ -482,7 +482,13 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
         # the dominant kernel: all stride-1 forward layers of two minibatches in one launch when the batch sizes allow,
         # else one launch per layer
         stacked = B % job.cu_count() == 0  # (ops.stack_granule(): one workgroup per CU owns its samples)
-        kname = "conv_rw_fwd_kernel"
+        # which Winograd form the stride-1 forward takes (option s1_fwd = auto, curla_amd/csrc/conv.hip launch_rw_fwd):
+        # F(4,3) when the narrowest layer of the stack has at least 16 pixel quads per row, else F(2,3)
+        hw = cfg["crop"] or cfg["obs"][1:]
+        w_last = (hw[1] - 3) // 2 + 1 - 2 * (cfg["layers"] - 1)
+        f43 = (w_last + 3) // 4 >= 16
+        kname = "conv_rw43_fwd_kernel" if f43 else "conv_rw_fwd_kernel"
+        wino, wino_factor = ("F(4,3)", 2.0) if f43 else ("F(2,3)", 1.5)
         traffic, mfma_busy, pmc_note = (None, None, "dry run") if job.dry else committed_counters(name, kname)
         n_launch = max(1, len(ev_pairs))
         avg_ms = kms / n_launch
@@ -502,19 +508,19 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
             "conv_algorithmic_gflop_per_update": per_update / 1e9,
             "conv_roofline_frac_whole_update": per_update * (steps / dt) / (PEAK_F32_TFLOPS * 1e12),
             "roofline": {"bound": "mfma",
-                         "kernel": ("conv_rw_fwd_kernel (row-walk Winograd F(2,3): all 3x3 s1 32->32 + bias + ReLU layers of "
-                                    "two minibatches per launch, f32 MFMA 16x16x4; FLOPs counted as direct-conv FLOPs)")
+                         "kernel": (f"{kname} (row-walk Winograd {wino} along x: all 3x3 s1 32->32 + bias + ReLU layers of "
+                                    "two minibatches per launch, f32 MFMA 16x16x4)")
                                    if stacked else
-                                   "conv_rw_fwd_kernel (row-walk Winograd F(2,3): one 3x3 s1 32->32 + bias + ReLU layer per "
-                                   "launch, f32 MFMA 16x16x4; FLOPs counted as direct-conv FLOPs)",
-                         # The kernel is Winograd F(2,3) along x: it issues 2/3 of the direct-convolution FLOPs of
-                         # SURVEY.md 8(d).  `achieved` / `frac` are what the matrix pipe really executes (compare with
-                         # 1.0 and with `mfma_busy_frac_pmc`); the SURVEY 8(d) accounting in direct-conv FLOPs, which can
-                         # exceed 1 because the algorithm skips work, is under `direct_equiv_*`.
-                         "achieved": achieved / 1.5, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / 1.5 / PEAK_F32_TFLOPS, "traffic": traffic,
-                         "achieved_note": "MFMA FLOPs issued = algorithmic direct-conv FLOPs / 1.5 (Winograd F(2,3) in one "
-                                          "dimension; strip padding not counted)",
+                                   f"{kname} (row-walk Winograd {wino} along x: one 3x3 s1 32->32 + bias + ReLU layer per "
+                                   "launch, f32 MFMA 16x16x4)",
+                         # The kernel is Winograd F(2,3) / F(4,3) along x: it issues 1/1.5 resp. 1/2 of the direct-
+                         # convolution FLOPs of SURVEY.md 8(d).  `achieved` / `frac` are what the matrix pipe really
+                         # executes (compare with 1.0 and with `mfma_busy_frac_pmc`); the SURVEY 8(d) accounting in
+                         # direct-conv FLOPs, which can exceed 1 because the algorithm skips work, is under `direct_equiv_*`.
+                         "achieved": achieved / wino_factor, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / wino_factor / PEAK_F32_TFLOPS, "traffic": traffic,
+                         "achieved_note": f"MFMA FLOPs issued = algorithmic direct-conv FLOPs / {wino_factor} (Winograd "
+                                          f"{wino} in one dimension; strip padding not counted)",
                          "direct_equiv_achieved": achieved, "direct_equiv_frac": achieved / PEAK_F32_TFLOPS,
                          "traffic_unit": "HBM bytes per launch; " + pmc_note,
                          "algorithmic_bytes_per_launch": kbytes / n_launch,
