@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Random-shape parity sweep of the stride-1 conv kernels (forward, data gradient, weight gradient) and the
-first-layer kernels against PyTorch fp32 on the CPU.  Usage: tools/fuzz_conv.py [n_cases] [seed]"""
+first-layer kernels against PyTorch fp32 on the CPU.  Usage: tools/fuzz_conv.py [n_cases] [seed] [s1_fwd]
+(s1_fwd = auto | f23 | f43: the Winograd form of the forward and the data gradient, option s1_fwd; widths up to 200 so
+that `auto` takes both)"""
 import os
 import sys
 
@@ -10,7 +12,7 @@ import torch.nn.functional as F
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from curla_amd import ops  # noqa: E402
+from curla_amd import _lib, ops  # noqa: E402
 
 
 def rel(a, b):
@@ -20,10 +22,13 @@ def rel(a, b):
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rs = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    if len(sys.argv) > 3:
+        _lib.set_option("s1_fwd", sys.argv[3])
+    print("s1_fwd =", _lib.get_option("s1_fwd"))
     worst = 0.0
     for case in range(n):
         B = int(rs.choice([1, 2, 3, 5, 8, 17, 64, 130]))
-        H, W = int(rs.randint(3, 60)), int(rs.randint(3, 100))
+        H, W = int(rs.randint(3, 60)), int(rs.randint(3, 200))
         if B * H * W > 300000:
             B = max(1, 300000 // (H * W))
         g = torch.Generator().manual_seed(case)
