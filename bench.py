@@ -546,6 +546,29 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
     return out
 
 
+_JSON_FD = None
+
+
+def own_stdout():
+    """stdout carries the JSON line(s) and nothing else: from here on everything any library writes to file descriptor
+    1 -- gloo's and RCCL's C++ side report their connections there, several ranks at once, fragments and all -- goes to
+    stderr, and emit() writes to the original stdout."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    data = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(data.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, data)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -589,6 +612,7 @@ def main():
 
     if "RANK" not in os.environ and args.gpus > 1:
         respawn_under_torchrun(args)
+    own_stdout()
     job = Job(args)
     cpu_bl = not args.no_cpu_baseline and job.world == 1 and not job.dry and not args.sweep
     try:
@@ -604,7 +628,7 @@ def main():
         if job.rank == 0:
             if extra:
                 out["other_configs"] = extra
-            print(json.dumps(out), flush=True)
+            emit(out)
     finally:
         job.close()
 
@@ -687,7 +711,7 @@ def sweep(job, main_cfg, others, budget):
                     one = lines[(name, 1)]
                     r["sweep"]["scaling_efficiency_vs_this_jobs_n1"] = r["value"] / (n * one["value"])
                 lines[(name, n)] = r
-                print(json.dumps(r), flush=True)
+                emit(r)
     if job.rank == 0:
         summary = {"sweep_summary": True, "job_ranks": world, "dry_run": bool(job.dry), "configs": {}}
         for name in [main_cfg] + list(others):
@@ -704,7 +728,7 @@ def sweep(job, main_cfg, others, budget):
                 "how_to_apply": (None if chosen is None else
                                  ("CURLA_DP_OVERLAP=1 / enable_data_parallel(overlap=True)" if chosen == "overlapped"
                                   else "the default (CURLA_DP_OVERLAP unset / overlap=False)"))}
-        print(json.dumps(summary), flush=True)
+        emit(summary)
 
 
 if __name__ == "__main__":

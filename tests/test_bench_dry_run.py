@@ -28,12 +28,10 @@ def _run(cmd, n_lines=1):
         env.pop(k, None)
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
-    # gloo's C++ side reports its connections on stdout ("[Gloo] Rank r is connected to ..."); anything else on
-    # stdout must be the ONE JSON line, from rank 0 only
-    # (the ranks' reports interleave, so they are recognised by their text, not by their first characters)
-    lines = [ln for ln in p.stdout.splitlines() if ln.strip() and "peer ranks" not in ln and "[Gloo]" not in ln]
-    # (a library's report can also land on the same line as another rank's: what must hold is ONE JSON object, and
-    # nothing on stdout that is not a Gloo connection report)
+    # stdout carries the JSON line(s) and NOTHING else: bench.py moves file descriptor 1 to stderr for everything but its
+    # own lines (gloo's / RCCL's C++ sides report their connections on stdout, several ranks at once -- fragments of those
+    # reports used to land between the lines)
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
     objs = [ln for ln in lines if ln.lstrip().startswith("{")]
     assert len(objs) == n_lines and len(lines) == n_lines, lines
     return json.loads(objs[0]) if n_lines == 1 else [json.loads(o) for o in objs]
