@@ -218,22 +218,26 @@ def _conv2d(x, w, b, stride):
     """F.conv2d (encoder.py:80,85).  float64 inputs (the arbiter passes of tests/test_gpu_fullsize.py) go through
     PyTorch's im2col path, whose column buffer covers the whole batch (15 GB for one layer of configs[4]): those are
     evaluated 64 samples at a time -- a sample's result does not depend on its batch."""
-    if x.dtype != torch.float64 or x.shape[0] <= 64:
+    if x.dtype != torch.float64 or x.shape[0] <= 64 or x.is_cuda:
         return F.conv2d(x, w, b, stride=stride)
     return torch.cat([F.conv2d(xc, w, b, stride=stride) for xc in x.split(64)])
 
 
-def as_dtype(x, dtype):
+def as_dtype(x, dtype, device=None):
     """Tensors / dicts / lists of tensors cast to ``dtype`` (detached copies; None and non-float tensors pass
-    through): the float64 evaluation of a phase is the same function on ``as_dtype(..., torch.float64)`` arguments."""
+    through): the float64 evaluation of a phase is the same function on ``as_dtype(..., torch.float64)`` arguments.
+    ``device`` (tests only): also move them there -- the full-size float64 arbiter lets PyTorch's own float64 kernels on
+    the GPU evaluate these same functions (240 s -> 15 s for configs[4]; pinned to the host evaluation by the test)."""
     if x is None:
         return None
     if isinstance(x, dict):
-        return {k: as_dtype(v, dtype) for k, v in x.items()}
+        return {k: as_dtype(v, dtype, device) for k, v in x.items()}
     if isinstance(x, (list, tuple)):
-        return type(x)(as_dtype(v, dtype) for v in x)
+        return type(x)(as_dtype(v, dtype, device) for v in x)
     if torch.is_tensor(x) and x.is_floating_point():
-        return x.detach().to(dtype)
+        return x.detach().to(device=device, dtype=dtype) if device is not None else x.detach().to(dtype)
+    if torch.is_tensor(x) and device is not None:
+        return x.to(device)
     return x
 
 
@@ -423,7 +427,7 @@ def cpc_phase(critic: Params, critic_target: Params, W: torch.Tensor, obs_anchor
     with torch.no_grad():
         z_pos = encoder_forward(critic_target, "encoder.", obs_pos, num_layers)
     logits = curl_logits(Wl, z_a, z_pos)
-    labels = torch.arange(logits.shape[0]).long()
+    labels = torch.arange(logits.shape[0], device=logits.device).long()
     loss = F.cross_entropy(logits, labels)
     loss.backward(retain_graph=regrad)
     out = dict(loss=loss.detach(), z_a=z_a.detach(), z_pos=z_pos, logits=logits.detach(),
