@@ -118,8 +118,9 @@ __global__ __launch_bounds__(256) void color_jiggle_pixel_kernel(const uint8_t* 
                                                                    float* out) {
   constexpr int C = 3 * K;
   const int b = blockIdx.y;
-  const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= HW) return;
+  const int p_raw = blockIdx.x * 256 + threadIdx.x;
+  if ((p_raw & ~63) >= HW) return;             // (whole waves past the image leave; a partly covered wave stays whole:
+  const int p = p_raw < HW ? p_raw : HW - 1;   //  its lanes past the image redo the last pixel and help with the stores)
   const int o0 = order[0], o1 = order[1], o2 = order[2], o3 = order[3];
   const int64_t fi = idx ? idx[b] : b;
   const uint8_t* src = frames + ((size_t)fi * HW + p) * C;
@@ -143,11 +144,28 @@ __global__ __launch_bounds__(256) void color_jiggle_pixel_kernel(const uint8_t* 
     v[3 * fr] = r * 255.f, v[3 * fr + 1] = g * 255.f, v[3 * fr + 2] = bl * 255.f;
   }
   float* dst = out + ((size_t)b * HW + p) * C;
-  if (C % 4 == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+  if (C % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) {
+    // A lane holds its pixel's C floats: stored directly, a wave's store instruction would write 16 bytes per lane
+    // C * 4 bytes apart (a third of every 128-byte line per instruction at C = 12).  Through LDS instead: the wave's
+    // 64 pixels are 64 C / 4 consecutive 16-byte chunks of the output; lane l stores chunks l, l + 64, ... -- whole lines.
+    __shared__ __attribute__((aligned(16))) float stage[4][64 * C];
+    float* mine = stage[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int u = 0; u < C / 4; ++u)
-      reinterpret_cast<f32x4*>(dst)[u] = f32x4{v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]};
-  } else {
+      *reinterpret_cast<f32x4*>(mine + lane * C + 4 * u) = f32x4{v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]};
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int p0 = blockIdx.x * 256 + (threadIdx.x & ~63);  // the wave's first pixel
+    const int nvalid = min(64, HW - p0);                    // pixels of this wave inside the image (> 0: p < HW here)
+    float* wave_out = out + ((size_t)b * HW + p0) * C;
+#pragma unroll
+    for (int u = 0; u < C / 4; ++u) {
+      const int chunk = lane + 64 * u;  // 16-byte chunk of the wave's output: floats [4 chunk, 4 chunk + 4)
+      if (4 * chunk < nvalid * C) *reinterpret_cast<f32x4*>(wave_out + 4 * chunk) = *reinterpret_cast<const f32x4*>(mine + 4 * chunk);
+    }
+  } else if (p_raw < HW) {
 #pragma unroll
     for (int u = 0; u < C; ++u) dst[u] = v[u];
   }

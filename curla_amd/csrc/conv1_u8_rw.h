@@ -16,7 +16,7 @@
 // channels and walks down: output row y needs input rows 2y, 2y+1, 2y+2, the last of which is the next row's first, so
 // a step loads and converts two new rows (2 loads, 2 E conversions) for 6 E MFMAs.  No LDS, no barrier.
 //
-// Status: OPT-IN (CURLA_C1_U8=rw).  Alone -- the same ring slots re-read out of the Infinity Cache from launch to
+// Status: OPT-IN (option conv1_u8 = rw).  Alone -- the same ring slots re-read out of the Infinity Cache from launch to
 // launch -- it is the faster kernel (1024 samples of 76x76x9: 66-71 us against 85; 1536: 100-105 against 128).  On slots
 // drawn afresh from a ring of gigabytes for every launch, which is what update() does, it is the slower one: 114 us on
 // average against 104 under rocprofv3 on the same box (88 against 88 per 1024 samples in the microbenchmark).  More
