@@ -1216,13 +1216,14 @@ def test_flat_adam_step_with_float64_scalar():
     assert float(res[1][3]) != float(np.log(0.1))
 
 
+@pytest.mark.parametrize("hw", [(13, 13), (9, 75)])  # (75 wide: rows of >= 16 pixel quads through all three layers)
 @pytest.mark.parametrize("two", [False, True])
-def test_conv_s1_forward_stack_one_launch(ops, s1_impl, two):
+def test_conv_s1_forward_stack_one_launch(ops, s1_impl, two, hw):
     """curla_conv3x3_s1_fwd_stack: three stride-1 layers of one or two minibatches in ONE launch (a workgroup owns its
     samples through the layers) -- every layer's activations bit-identical to the per-layer launches.  Batch sizes
     must be multiples of the persistent grid (ops.stack_granule()); anything else is refused."""
     G = ops.stack_granule()
-    H = W = 13
+    H, W = hw
     B1, B2 = 2 * G, G
     L = 3
     x1, x2 = torch.relu(rnd(B1, H, W, 32, seed=101)).cuda(), torch.relu(rnd(B2, H, W, 32, seed=102)).cuda()
