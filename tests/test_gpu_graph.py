@@ -99,3 +99,24 @@ def test_unsupported_setups_are_refused():
     rb = curla_amd.ReplayBuffer((12, 20, 24), (2,), 64, 8, dev, aug)
     with pytest.raises(ValueError):
         agent.enable_update_graphs(rb)  # float augmentation: parameters staged per call
+
+
+def test_bench_graphs_flag_runs_and_reports():
+    """``bench.py --graphs``: the timed updates are graph replays, the dominant kernel's HIP-event timing comes from
+    eager updates after the timed region; one JSON line, nothing else on stdout."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "bench.py", "--config", "c3", "--steps", "6", "--warmup", "2", "--graphs",
+                        "--no-cpu-baseline", "--capacity", "4096", "--clock-warmup-s", "0"], cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["config"]["update_graphs"] is True and d["steps"] == 6 and d["value"] > 0
+    r = d["roofline"]
+    assert r["launches"] > 0 and r["avg_launch_ms"] > 0 and "after the timed region" in r["launch_timing"]
+    assert 0.3 < r["frac"] < 1.0
