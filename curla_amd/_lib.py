@@ -16,6 +16,8 @@ c_int, c_ll, c_float, c_size_t, vp = ctypes.c_int, ctypes.c_longlong, ctypes.c_f
 c_u64 = ctypes.c_ulonglong
 c_double = ctypes.c_double
 
+ABI_VERSION = 5  # include/curla_hip.h CURLA_ABI_VERSION this table was written for
+
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/curla_hip.h
 SIGNATURES = {
     "curla_conv1_fwd": [vp, c_int, vp, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, vp],
@@ -104,6 +106,7 @@ SIGNATURES = {
     "curla_color_jiggle_nchw": [vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp],
     "curla_noisy_cover_nchw": [vp, vp, c_float, c_float, c_float, c_int, c_int, c_int, c_int, c_int, c_int, vp, vp],
     "curla_version": [],
+    "curla_abi_version": [],
     "curla_set_option": [ctypes.c_char_p, ctypes.c_char_p],
     "curla_get_option": [ctypes.c_char_p],
 }
@@ -143,6 +146,17 @@ def load():
                                 f"(stamp {build.built_hash()} != {want}): rebuild it with "
                                 "`python -m curla_amd.build` (or CURLA_SKIP_SRCHASH=1 for an externally built library)")
     lib = ctypes.CDLL(LIB_PATH)
+    # the argument lists below are positional: a library with another ABI number would be called with shifted
+    # arguments (silent memory corruption, not an error) -- this matters most for CURLA_LIB_PATH builds, which skip
+    # the source-stamp check above
+    try:
+        lib.curla_abi_version.restype = c_int
+        got = int(lib.curla_abi_version())
+    except AttributeError:
+        got = None
+    if got != ABI_VERSION:
+        raise CurlaHipError(f"{LIB_PATH} has C-ABI version {got}, this binding was written for {ABI_VERSION} "
+                            "(include/curla_hip.h CURLA_ABI_VERSION): rebuild the library or use the matching package")
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library drift apart
         fn.argtypes = args

@@ -1869,6 +1869,8 @@ int curla_nhwc_to_nchw(const float* in, float* out, int B, int H, int W, int C, 
   return curla_launch_status();
 }
 
-const char* curla_version(void) { return "curla_hip 0.1 (gfx950)"; }
+const char* curla_version(void) { return "curla_hip 0.5 (gfx950, abi 5)"; }
+
+int curla_abi_version(void) { return CURLA_ABI_VERSION; }
 
 }  // extern "C"

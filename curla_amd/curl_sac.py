@@ -435,6 +435,7 @@ class CurlSacAgent(object):
         self._dp_world = 1
         self._dp_active = False
         self._dp_avg = False
+        self._dp_staged = False
         self._dp_overlap = False
         self._dp_check_every = 0
         self._dp_pending = []
@@ -557,6 +558,9 @@ class CurlSacAgent(object):
         self._dp_world = dist.get_world_size(self._dp_group)
         self._dp_active = self._dp_world > 1 or single_rank_collectives
         self._dp_avg = dist.get_backend(self._dp_group) == "nccl"
+        # A backend without a device path of its own (gloo: the CPU tests, and the two-ranks-on-one-GPU test that RCCL
+        # refuses) gets the buckets through the host: device -> host copy, collective, copy back, all synchronous.
+        self._dp_staged = not self._dp_avg and self.device.type == "cuda"
         if overlap is None:
             overlap = os.environ.get("CURLA_DP_OVERLAP", "0") == "1"
         self._dp_overlap = bool(overlap)
@@ -568,7 +572,12 @@ class CurlSacAgent(object):
             src = dist.get_global_rank(self._dp_group, 0)
             with torch.no_grad():
                 for t in (self._critic_flat, self._target_flat, self._actor_flat, self.log_alpha):
-                    dist.broadcast(t, src=src, group=self._dp_group)
+                    if self._dp_staged:
+                        h = t.detach().cpu()
+                        dist.broadcast(h, src=src, group=self._dp_group)
+                        t.copy_(h)
+                    else:
+                        dist.broadcast(t, src=src, group=self._dp_group)
 
     def _replica_checksum(self):
         """float64 sums of the replicated state (deterministic: same kernel, same data => same bits)."""
@@ -583,6 +592,8 @@ class CurlSacAgent(object):
         import torch.distributed as dist
         s = self._replica_checksum()
         both = torch.stack([s, -s])  # max over ranks of (s, -s) = (max, -min)
+        if self._dp_staged:
+            both = both.cpu()
         dist.all_reduce(both, op=dist.ReduceOp.MAX, group=self._dp_group)
         hi, lo = both[0], -both[1]
         if not bool(torch.equal(hi, lo)):
@@ -602,7 +613,11 @@ class CurlSacAgent(object):
                 continue
             avg = self._dp_avg and t.dtype == torch.float32  # (the float64 log_alpha scalar takes the sum path)
             op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
-            if async_op:
+            if self._dp_staged:  # (synchronous whatever async_op says: same elements, same sum)
+                h = t.detach().cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self._dp_group)
+                t.copy_(h.div_(self._dp_world))
+            elif async_op:
                 self._dp_pending.append((dist.all_reduce(t, op=op, group=self._dp_group, async_op=True), t, not avg))
             else:
                 dist.all_reduce(t, op=op, group=self._dp_group)
@@ -1029,6 +1044,9 @@ class CurlSacAgent(object):
         buffer is used through the reference's ``sample_cpc()`` tensors."""
         if self._graphs is not None and self._graph_usable(replay_buffer, step, only_cpc):
             return self._update_graphed(replay_buffer, L, step)
+        self._update_eager(replay_buffer, L, step, only_cpc)
+
+    def _update_eager(self, replay_buffer, L, step, only_cpc=False):
         if hasattr(replay_buffer, "sample_cpc_refs"):
             sample = replay_buffer.sample_cpc_refs()
         else:
@@ -1087,8 +1105,13 @@ class CurlSacAgent(object):
         wait for the replay two updates back before every update).
         Results are bit-identical to the eager path (tests/test_gpu_graph.py).  Steps the graphs do not cover run
         eagerly, in any mix: logging steps (``step % log_interval == 0``: they compute extra scalars), histogram /
-        image recording steps, ``only_cpc``, data-parallel runs, float augmentations (ColorJiggle / NoisyCover stage
-        their parameters per call), other replay buffers."""
+        image recording steps, ``only_cpc``, float augmentations (ColorJiggle / NoisyCover stage their parameters per
+        call), other replay buffers, data-parallel runs on a backend other than RCCL.  Data-parallel updates over RCCL
+        ARE captured, collectives included (round 5; the replica check stays on the host, in front of the replay).
+        Values the graphs hold as kernel arguments (discount, taus, betas / eps, detach_encoder, the update
+        frequencies, the data-parallel group and schedule) are fingerprinted at capture: editing one of them drops the
+        graphs and they are captured again; so does ``load_checkpoint``.  A capture that raises leaves the agent's
+        state untouched and that update runs eagerly."""
         if self.device.type != "cuda":
             raise RuntimeError("update graphs need the HIP device")
         if not getattr(replay_buffer, "graph_supported", lambda: False)():
@@ -1103,6 +1126,7 @@ class CurlSacAgent(object):
         self._graph_warm = int(warm)
         self._graph_depth = max(1, int(depth))
         self._graph_seen = {}
+        self._graph_key_at_capture = None
 
     def disable_update_graphs(self):
         self._graphs = None
@@ -1112,17 +1136,42 @@ class CurlSacAgent(object):
                 (not self.pixel_sac) and step % self.cpc_update_freq == 0)
 
     def _graph_usable(self, replay_buffer, step, only_cpc):
-        return (replay_buffer is self._graph_rb and not only_cpc and not self._dp_active and not self._records(step)
+        # data parallel: RCCL collectives are capturable (they are enqueued on streams like kernels); a backend that is
+        # staged through the host (gloo) is not
+        return (replay_buffer is self._graph_rb and not only_cpc and not (self._dp_active and self._dp_staged)
+                and not (self._dp_active and not self._dp_avg) and not self._records(step)
                 and step % self.log_interval != 0 and self.training)
+
+    def _graph_live(self, opt):
+        """The parameters ``opt``'s step touches in a captured update (None: all).  Under detach_encoder the critic's
+        convs have no gradient at step time (curl_sac.py:358): Adam skips them and their step counts stay behind."""
+        if opt is self.critic_optimizer and self.detach_encoder:
+            convs = {id(p) for m in self.critic.encoder.convs for p in (m.weight, m.bias)}
+            return [p for p in opt._plist if id(p) not in convs]
+        return None
+
+    def _graph_key(self):
+        """Everything a captured graph holds BY VALUE (kernel arguments baked in at capture): a change of any of it
+        makes the captured graphs stale -- they are dropped and re-captured (``lr`` travels as data and is not here)."""
+        opts = (self.critic_optimizer, self.actor_optimizer, self.encoder_optimizer, self.cpc_optimizer,
+                self.log_alpha_optimizer)
+        hyper = tuple((float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g.get("weight_decay", 0)))
+                      for o in opts for g in o.param_groups)
+        return (float(self.discount), float(self.critic_tau), float(self.encoder_tau), bool(self.detach_encoder),
+                bool(self.pixel_sac), float(self.target_entropy), float(self.actor.log_std_min),
+                float(self.actor.log_std_max), self.actor_update_freq, self.critic_target_update_freq,
+                self.cpc_update_freq, self._dp_active, self._dp_overlap, id(self._dp_group) if self._dp_active else 0,
+                hyper)
 
     def _graph_tail(self, kind, B):
         """The 80 control bytes of one graphed update (ReplayBuffer.GRAPH_TAIL) -- and the host-side bookkeeping of
         everything they stand for: the torch generator's offset moves on as _noise() would move it, every optimizer that
-        steps in this kind of update counts its step."""
+        steps in this kind of update counts its step.  Returns (bytes, undo): ``undo()`` takes the bookkeeping back."""
         do_actor, _, do_cpc = kind
         u64 = np.zeros(4, dtype=np.uint64)
         gen = torch.cuda.default_generators[self.device.index if self.device.index is not None
                                             else torch.cuda.current_device()]
+        gen_off0 = gen.get_offset()
         n = B * self.action_dim
         for j in range(2 if do_actor else 1):  # critic-phase draw, then the actor phase's (curl_sac.py:352, 378)
             off = gen.get_offset()
@@ -1131,6 +1180,7 @@ class CurlSacAgent(object):
         f64 = np.zeros(2, dtype=np.float64)
         f32 = np.zeros(8, dtype=np.float32)
         steps = [(0, self.critic_optimizer)]
+        la_prev = None
         if do_actor:
             steps.append((1, self.actor_optimizer))
             lo = self.log_alpha_optimizer
@@ -1139,32 +1189,58 @@ class CurlSacAgent(object):
             if len(st) == 0:
                 st["step"] = torch.tensor(0.0, dtype=torch.float32)
                 st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
+            la_prev = st["step"]
             t64 = int(round(float(st["step"]))) + 1
             b1, b2 = float(g["betas"][0]), float(g["betas"][1])
             f64[0], f64[1] = float(g["lr"]) / (1.0 - b1 ** float(t64)), (1.0 - b2 ** float(t64)) ** 0.5
             st["step"] = torch.tensor(float(t64), dtype=torch.float32)
         if do_cpc:
             steps += [(2, self.encoder_optimizer), (3, self.cpc_optimizer)]
+        done = []
         for slot, opt in steps:
-            f32[2 * slot], f32[2 * slot + 1] = opt.hyper_floats(opt.next_step())
-            opt.advance()
-        return u64.tobytes() + f64.tobytes() + f32.tobytes()
+            live = self._graph_live(opt)
+            f32[2 * slot], f32[2 * slot + 1] = opt.hyper_floats(opt.next_step(live))
+            opt.advance(live)
+            done.append((opt, live))
+
+        def undo():
+            gen.set_offset(gen_off0)
+            for opt, live in done:
+                opt.advance(live, by=-1)
+            if la_prev is not None:
+                lo = self.log_alpha_optimizer
+                lo.state[lo.param_groups[0]["params"][0]]["step"] = la_prev
+        return u64.tobytes() + f64.tobytes() + f32.tobytes(), undo
+
+    def _drop_graphs(self):
+        """Forget the captured graphs (they are re-captured after ``warm`` further eager updates of each kind)."""
+        if self._graphs is not None:
+            torch.cuda.synchronize()
+            self._graphs = {}
+            self._graph_seen = {}
+            self._graph_key_at_capture = None
 
     def _update_graphed(self, rb, L, step):
+        key = self._graph_key()
+        if self._graphs and key != self._graph_key_at_capture:
+            self._drop_graphs()  # a value the graphs hold as a kernel argument has been edited since the capture
         kind = self._graph_kind(step)
         seen = self._graph_seen.get(kind, 0)
         self._graph_seen[kind] = seen + 1
         if seen < self._graph_warm:  # (first uses allocate workspaces and set kernel attributes: not capturable)
-            return self._update_phases(rb.sample_cpc_refs(), L, step)
+            return self._update_eager(rb, L, step)
         ring = self._graphs.setdefault(kind, [])
         turn = (seen - self._graph_warm) % self._graph_depth
         if turn >= len(ring):
             ring.append(dict(slot=sum(len(r) for r in self._graphs.values()), graph=None))
         st = ring[turn]
         B = rb.batch_size
-        idxs, offs = rb.draw_indices()
-        blk = rb.graph_write(st["slot"], idxs, offs, self._graph_tail(kind, B))
         if st["graph"] is None:
+            # capture FIRST, commit the host's bookkeeping (NumPy draw, generator offset, step counts) only once the
+            # capture has succeeded: a capture that raises (a first-use attribute call after an option change, a HIP
+            # call from another thread) leaves the agent exactly where it was, and this update runs eagerly
+            np_state = np.random.get_state()
+            blk = rb.graph_block(st["slot"])
             base = blk["dev"].data_ptr() + blk["tail"]
             dyn = {self.critic_optimizer: base + 48, self.actor_optimizer: base + 56, self.encoder_optimizer: base + 64,
                    self.cpc_optimizer: base + 72}
@@ -1176,14 +1252,26 @@ class CurlSacAgent(object):
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             try:
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     self._update_phases(rb.graph_refs(st["slot"]), null, step)
+            except Exception as e:  # noqa: BLE001
+                np.random.set_state(np_state)
+                warnings.warn(f"curla_amd: capturing the update graph of {kind} failed ({e!r}); this update runs "
+                              "eagerly and the capture is tried again next time", RuntimeWarning, stacklevel=3)
+                self._graph_seen[kind] = seen  # (the slot keeps its empty entry: the same turn captures again)
+                return self._update_eager(rb, L, step)
             finally:
                 self._graph_cap = None
                 for opt in dyn:
                     opt._dyn = None
                 self.log_alpha_optimizer._curla_dyn64 = None
             st["graph"] = graph
+            self._graph_key_at_capture = key
+        idxs, offs = rb.draw_indices()
+        tail, _ = self._graph_tail(kind, B)
+        blk = rb.graph_write(st["slot"], idxs, offs, tail)
+        if self._dp_active and self._dp_check_every > 0 and step % self._dp_check_every == 0:
+            self.check_replicas()
         st["graph"].replay()
         if blk["event"] is None:
             blk["event"] = torch.cuda.Event()
@@ -1257,5 +1345,7 @@ class CurlSacAgent(object):
             if self.device.type == "cuda" and "cuda" in ck["rng"]:
                 torch.cuda.set_rng_state(ck["rng"]["cuda"], self.device)
         self._anchor_cache = None
+        # captured graphs hold the addresses of log_alpha's Adam moments, which load_state_dict has just replaced
+        self._drop_graphs()
         return ck["step"]
 

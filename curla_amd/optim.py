@@ -78,9 +78,21 @@ class FlatAdam(torch.optim.Adam):
                 st["step"] = torch.tensor(float(self._steps[i]), dtype=torch.float32)
 
     # -- captured graphs: the step-dependent factors as data ------------------------------------------------------
-    def next_step(self):
-        """The 1-based count of the step the next ``step()`` takes (all parameters share it in graph mode)."""
-        return self._steps[0] + 1
+    def live_indices(self, live=None):
+        """Indices of the parameters a step touches: ``live`` (an iterable of Parameters) or all of them."""
+        if live is None:
+            return range(len(self._plist))
+        ids = {id(p) for p in live}
+        return [i for i, p in enumerate(self._plist) if id(p) in ids]
+
+    def next_step(self, live=None):
+        """The 1-based count of the step the next ``step()`` takes for the parameters it touches (they share it in
+        graph mode; parameters whose gradient is None at step time -- the convs under detach_encoder -- are not
+        ``live`` and keep their own count, as in torch's Adam)."""
+        counts = {self._steps[i] for i in self.live_indices(live)}
+        if len(counts) != 1:
+            raise RuntimeError("FlatAdam: the parameters of a captured step must share one step count")
+        return counts.pop() + 1
 
     def hyper_floats(self, t):
         """(lr / (1 - beta1^t), sqrt(1 - beta2^t)) as the two float32 values curla_adam_step evaluates from ``step`` on
@@ -90,11 +102,12 @@ class FlatAdam(torch.optim.Adam):
         b1, b2 = float(g["betas"][0]), float(g["betas"][1])
         return np.float32(float(g["lr"]) / (1.0 - b1 ** float(t))), np.float32((1.0 - b2 ** float(t)) ** 0.5)
 
-    def advance(self):
-        """One step's worth of host bookkeeping (what step() does besides launching)."""
-        for i in range(len(self._plist)):
+    def advance(self, live=None, by=1):
+        """One step's worth of host bookkeeping (what step() does besides launching) for the parameters the step
+        touches; ``by=-1`` takes it back (a capture that failed after the bookkeeping)."""
+        for i in self.live_indices(live):
             self._ensure_state(i)
-            self._steps[i] += 1
+            self._steps[i] += by
 
     # -- the step --------------------------------------------------------------------------------------------
     def _plan(self, gi, group, live):

@@ -591,7 +591,7 @@ class ReplayBuffer(object):
     # A captured graph replays the SAME pointers: its minibatch block lives in its own pinned host slot and its own
     # device block, never in the rotating ones above.  Behind the indices the block carries GRAPH_TAIL bytes of per-update
     # control values (RNG stream positions, Adam step factors) that the graph's kernels read from the device copy.
-    GRAPH_TAIL = 80  # u64[4] (seed, critic-noise offset, actor-noise offset, -) | f64[2] log_alpha | f32[8] four Adams
+    GRAPH_TAIL = 80  # u64[4] (seed, critic-noise offset, seed, actor-noise offset) | f64[2] log_alpha | f32[8] four Adams
 
     def graph_supported(self):
         """Graph replay covers the uint8-ring minibatches (RandomCrop / identity, plain storage, one allocation for both

@@ -34,6 +34,12 @@ extern "C" {
 
 const char* curla_version(void);
 
+/* The C ABI's number: bumped whenever an entry point's argument list changes (round 4 put dyn / dyn64 / rng_dev
+ * pointers into the middle of the Adam and policy-head calls: 4 -> 5 names that).  A binding written for another
+ * number must refuse the library -- curla_amd/_lib.py does -- instead of calling with shifted arguments. */
+#define CURLA_ABI_VERSION 5
+int curla_abi_version(void);
+
 /* Run-time kernel-selection options (curla_amd/csrc/options.h).  Every option's default is the measured-best path;
  * the other values are fallbacks for shapes the default does not take or A/B partners for measurements, and every
  * value runs under the whole-update parity test (tests/test_gpu_switches.py).  The environment variable

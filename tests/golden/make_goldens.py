@@ -29,6 +29,18 @@ Fixtures:
   c1shape.npz   9x84x84 -> 76x76, hidden 128, B=4, weights from a NumPy
                 recipe (regenerable from seed): losses + per-tensor gradient
                 summaries of one update.
+  mode_*.npz    (round 5) the branches of update() that tiny.npz does not walk,
+                one whole reference update() each from seeded weights and fresh
+                optimizers (tests/golden_recipes.py: MODES):
+                  mode_odd       step 1: no actor phase, no target update (curl_sac.py:436,441)
+                  mode_pixel_sac pixel_sac=True: no CURL phase (curl_sac.py:448)
+                  mode_only_cpc  update(..., only_cpc=True) (train.py:425-429)
+                  mode_detach    detach_encoder=True (curl_sac.py:358)
+                  mode_l6c12     num_layers=6, 12 input channels, identity augmentation
+                                 (encoder.py:54-63; utils.py:168-182): configs[4]'s geometry, small
+                every gradient an optimizer consumed (full tensors), the logged
+                scalars, the RNG draws / noise, and the parameters after the
+                update (small tensors whole, the first 10000 elements of big ones).
 """
 import copy
 import hashlib
@@ -126,7 +138,7 @@ class Recorder:
         self.randint_calls = []
         self.noises = []
 
-    def run(self, rb, step):
+    def run(self, rb, step, only_cpc=False):
         agent, rec = self.agent, self.rec
         L = NullLogger()
         orig_randint, orig_randn_like = np.random.randint, torch.randn_like
@@ -204,6 +216,8 @@ class Recorder:
         def update_cpc(obs_anchor, obs_pos, cpc_kwargs, L_, step_):
             rec.update(sd_np("target_after/", agent.critic_target.state_dict()))
             rec["batch/pos"] = obs_pos.numpy().astype(np.uint8)
+            if "batch/obs" not in rec:  # (only_cpc: update_critic, which records the batch, does not run)
+                rec["batch/obs"] = obs_anchor.numpy().astype(np.uint8)
             return orig_cpc(obs_anchor, obs_pos, cpc_kwargs, L_, step_)
         agent.update_cpc = update_cpc
         orig_uc = agent.update_critic
@@ -219,7 +233,10 @@ class Recorder:
 
         np.random.randint, torch.randn_like = randint, randn_like
         try:
-            agent.update(rb, L, step)
+            if only_cpc:
+                agent.update(rb, L, step, only_cpc=True)
+            else:
+                agent.update(rb, L, step)
         finally:
             np.random.randint, torch.randn_like = orig_randint, orig_randn_like
             for opt, o in origs:
@@ -232,24 +249,31 @@ class Recorder:
         # RNG draws: idxs, then (h1, w1) x3
         rc = self.randint_calls
         rec["rng/idxs"] = rc[0]
-        for j, nm in enumerate(("obs", "next_obs", "pos")):
-            rec[f"rng/h1_{nm}"], rec[f"rng/w1_{nm}"] = rc[1 + 2 * j], rc[2 + 2 * j]
+        if len(rc) >= 7:  # (an identity augmentation draws the indices only)
+            for j, nm in enumerate(("obs", "next_obs", "pos")):
+                rec[f"rng/h1_{nm}"], rec[f"rng/w1_{nm}"] = rc[1 + 2 * j], rc[2 + 2 * j]
         rec["batch/obs_full"] = rb.obses[rc[0]].copy()
         rec["batch/next_obs_full"] = rb.next_obses[rc[0]].copy()
-        rec["noise/critic"], rec["noise/actor"] = self.noises[0], self.noises[1]
+        if len(self.noises) >= 1:
+            rec["noise/critic"] = self.noises[0]
+        if len(self.noises) >= 2:
+            rec["noise/actor"] = self.noises[1]
         # forwards: actor#0 = actor(next_obs) [critic phase], actor#1 = actor(obs) [actor phase]
-        a0, a1 = calls["actor"]
-        rec["critic/policy_action"], rec["critic/next_log_pi"] = a0[1], a0[2]
-        rec["critic/tq1"], rec["critic/tq2"] = calls["critic_target"][0]
-        rec["critic/q1"], rec["critic/q2"] = calls["critic"][0]
-        rec["actor/mu"], rec["actor/pi"], rec["actor/log_pi"], rec["actor/log_std"] = a1
-        rec["actor/q1"], rec["actor/q2"] = calls["critic"][1]
+        if len(calls["actor"]) >= 1:
+            a0 = calls["actor"][0]
+            rec["critic/policy_action"], rec["critic/next_log_pi"] = a0[1], a0[2]
+            rec["critic/tq1"], rec["critic/tq2"] = calls["critic_target"][0]
+            rec["critic/q1"], rec["critic/q2"] = calls["critic"][0]
+        if len(calls["actor"]) >= 2:
+            a1 = calls["actor"][1]
+            rec["actor/mu"], rec["actor/pi"], rec["actor/log_pi"], rec["actor/log_std"] = a1
+            rec["actor/q1"], rec["actor/q2"] = calls["critic"][1]
         for k, v in L.scalars.items():
             rec["scalar/" + k] = np.float64(v)
         return rec
 
 
-def build_agent(obs_shape_key, real_hw, hidden, num_layers, seed, aug):
+def build_agent(obs_shape_key, real_hw, hidden, num_layers, seed, aug, detach_encoder=False, pixel_sac=False):
     encoder.OUT_DIM = {num_layers: list(conv_out_hw(real_hw[0], real_hw[1], num_layers))}
     utils.set_seed_everywhere(seed)
     agent = curl_sac.CurlSacAgent(
@@ -258,7 +282,7 @@ def build_agent(obs_shape_key, real_hw, hidden, num_layers, seed, aug):
         actor_lr=1e-3, actor_beta=0.9, actor_log_std_min=-10, actor_log_std_max=2, actor_update_freq=2,
         critic_lr=1e-3, critic_beta=0.9, critic_tau=0.01, critic_target_update_freq=2,
         encoder_feature_dim=50, encoder_lr=1e-3, encoder_tau=0.05, num_layers=num_layers, num_filters=32,
-        log_interval=1, log_param_hist_imgs=False, detach_encoder=False, pixel_sac=False)
+        log_interval=1, log_param_hist_imgs=False, detach_encoder=detach_encoder, pixel_sac=pixel_sac)
     agent.image_shape = tuple(real_hw)
     return agent
 
@@ -429,11 +453,77 @@ def gen_noisy_cover():
                         out=out.numpy().astype(np.float16), out_sum=np.float64(out.double().sum().item()))
 
 
+def apply_recipe_weights(agent, seeds):
+    """Weights from tests/golden_recipes.numpy_weights, as gen_c1shape applies them (= golden_recipes.synthetic_state)."""
+    with torch.no_grad():
+        for mod, seed in ((agent.critic, seeds[0]), (agent.actor, seeds[1])):
+            shapes = [(k, tuple(v.shape)) for k, v in mod.named_parameters()]
+            w = numpy_weights(shapes, seed)
+            for k, v in mod.named_parameters():
+                v.copy_(torch.from_numpy(w[k]))
+        agent.critic_target.load_state_dict(agent.critic.state_dict())
+        shapes = [(k, tuple(v.shape)) for k, v in agent.critic_target.named_parameters()]
+        w = numpy_weights(shapes, seeds[2])
+        for k, v in agent.critic_target.named_parameters():
+            v.mul_(0.9).add_(0.1 * torch.from_numpy(w[k]))
+        agent.CURL.W.copy_(torch.from_numpy(np.random.RandomState(seeds[3]).rand(50, 50).astype(np.float32)))
+
+
+POST_CLIP = 10000  # elements kept of a parameter after the update (tests/golden_recipes.py uses the same number)
+
+
+def gen_modes():
+    """One whole reference update() per mode from seeded weights and FRESH optimizers (so the oracle's and the HIP
+    agent's own Adam steps can follow it to the post-update parameters)."""
+    from tests.golden_recipes import MODES
+    for name, m in MODES.items():
+        c, in_hw, out_hw, layers = m["channels"], tuple(m["in_hw"]), tuple(m["out_hw"]), m["num_layers"]
+        if m["crop"]:
+            aug = make_crop_augmentor(in_hw, out_hw)
+        else:
+            aug = augmentations.IdentityAugmentation(in_hw)
+        agent = build_agent((c, 84, 84), out_hw, hidden=m["hidden"], num_layers=layers, seed=1, aug=aug,
+                            detach_encoder=m["detach_encoder"], pixel_sac=m["pixel_sac"])
+        apply_recipe_weights(agent, m["weight_seeds"])
+        rb = utils.ReplayBuffer((c,) + in_hw, (2,), m["n_fill"], m["batch"], torch.device("cpu"), aug)
+        fill_buffer(rb, m["n_fill"], (c,) + in_hw, seed=m["buffer_seed"])
+        np.random.seed(m["numpy_seed"])
+        torch.manual_seed(m["numpy_seed"])
+        recorder = Recorder(agent)
+        rec = recorder.run(rb, m["step"], only_cpc=m["only_cpc"])
+        out = {"rng/n_draws": np.int64(len(recorder.randint_calls))}
+        for k, v in rec.items():
+            top = k.split("/")[0]
+            if top in ("rng", "noise", "scalar") or "/grad/" in k or k in (
+                    "batch/action", "batch/reward", "batch/not_done", "critic/q1", "critic/q2", "critic/tq1",
+                    "critic/tq2", "actor/pi", "actor/log_pi", "cpc/logits"):
+                out[k] = v
+        for key in ("batch/obs", "batch/next_obs", "batch/pos"):
+            if key in rec:
+                out[key + "_sha256"] = np.array(hashlib.sha256(rec[key].tobytes()).hexdigest())
+        for tag, sd in (("actor", agent.actor.state_dict()), ("critic", agent.critic.state_dict()),
+                        ("critic_target", agent.critic_target.state_dict())):
+            for k, v in sd.items():
+                out[f"post/{tag}/{k}"] = v.detach().numpy().ravel()[:POST_CLIP].copy()
+        out["post/W"] = agent.CURL.W.detach().numpy().copy()
+        out["post/log_alpha"] = agent.log_alpha.detach().numpy().copy()
+        for tag, opt in (("critic", agent.critic_optimizer), ("actor", agent.actor_optimizer),
+                         ("alpha", agent.log_alpha_optimizer), ("encoder", agent.encoder_optimizer),
+                         ("cpc", agent.cpc_optimizer)):
+            steps = [int(st["step"]) for st in opt.state.values() if "step" in st]
+            out[f"post/adam_steps/{tag}"] = np.array([len(steps), max(steps) if steps else 0], dtype=np.int64)
+        np.savez_compressed(os.path.join(HERE, "mode_%s.npz" % name), **out)
+
+
 if __name__ == "__main__":
+    if "--modes-only" in sys.argv:
+        gen_modes()
+        sys.exit(0)
     gen_noisy_cover()
     gen_tiny()
     gen_crop84()
     gen_c1shape()
+    gen_modes()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

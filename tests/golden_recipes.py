@@ -98,3 +98,43 @@ def c1shape_inputs(g):
     return dict(obs=crop(obses, "obs"), next_obs=crop(nexts, "next_obs"), pos=crop(obses, "pos"),
                 obs_full=obses[idxs], next_obs_full=nexts[idxs],
                 actor=actor, critic=critic, target=target, W=W, log_alpha=torch.tensor(np.log(0.1)), agent=agent)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# round 5: the branches of update() beside the even CURL step (tests/golden/mode_*.npz; make_goldens.gen_modes applies
+# these recipes to the reference, the parity tests to the oracle and to the HIP agent)
+_MODE = dict(channels=9, in_hw=(26, 30), out_hw=(22, 26), crop=True, num_layers=4, hidden=32, batch=8, n_fill=16,
+             step=0, only_cpc=False, detach_encoder=False, pixel_sac=False, buffer_seed=5, numpy_seed=99,
+             weight_seeds=(11, 12, 13, 14))
+MODES = {
+    "odd": dict(_MODE, step=1, numpy_seed=101),
+    "pixel_sac": dict(_MODE, pixel_sac=True, numpy_seed=102),
+    "only_cpc": dict(_MODE, only_cpc=True, numpy_seed=103),
+    "detach": dict(_MODE, detach_encoder=True, numpy_seed=104),
+    "l6c12": dict(_MODE, channels=12, in_hw=(30, 32), out_hw=(30, 32), crop=False, num_layers=6, numpy_seed=105),
+}
+POST_CLIP = 10000
+
+
+def mode_inputs(name, g):
+    """Rebuild a mode fixture's inputs from its seeds and recorded draws: frames of the whole buffer, the minibatch's
+    crops, the seeded parameters."""
+    m = MODES[name]
+    c, in_hw, out_hw = m["channels"], tuple(m["in_hw"]), tuple(m["out_hw"])
+    trans = fill_transitions(m["n_fill"], (c,) + in_hw, m["buffer_seed"])
+    obses, nexts = np.stack([t[0] for t in trans]), np.stack([t[3] for t in trans])
+    acts = np.stack([t[1] for t in trans])
+    rews = np.array([t[2] for t in trans], dtype=np.float32)
+    dones = np.array([t[4] for t in trans])
+    idxs = g["rng/idxs"]
+    if m["crop"]:
+        crop = lambda src, nm: O.random_crop(src[idxs], g[f"rng/h1_{nm}"], g[f"rng/w1_{nm}"], out_hw)  # noqa: E731
+        offs = np.stack([g[f"rng/{hw}1_{nm}"] for nm in ("obs", "next_obs", "pos") for hw in ("h", "w")]).astype(np.int32)
+    else:
+        crop = lambda src, nm: src[idxs].copy()  # noqa: E731
+        offs = np.zeros((6, len(idxs)), dtype=np.int32)
+    actor, critic, target, W = synthetic_state(c, out_hw, num_layers=m["num_layers"], hidden=m["hidden"],
+                                               seeds=m["weight_seeds"])
+    return dict(m=m, obses=obses, nexts=nexts, acts=acts, rews=rews, dones=dones, idxs=idxs, offs=offs,
+                obs=crop(obses, "obs"), next_obs=crop(nexts, "next_obs"), pos=crop(obses, "pos"),
+                actor=actor, critic=critic, target=target, W=W, log_alpha=torch.tensor(np.log(0.1)))

@@ -37,14 +37,14 @@ def nccl_world1():
     dist.destroy_process_group()
 
 
-def _run(mode, steps=4):
+def _run(mode, steps=4, graphs=False, B=16, hp=None):
     """mode None: plain single-GPU agent; else dict of enable_data_parallel kwargs."""
     import curla_amd
     dev = torch.device("cuda", 0)
     curla_amd.set_seed_everywhere(7)
-    in_hw, out_hw, B = (40, 44), (32, 36), 16
+    in_hw, out_hw = (40, 44), (32, 36)
     aug = curla_amd.RandomCrop(in_hw, out_hw)
-    agent = curla_amd.CurlSacAgent((9,) + out_hw, (2,), dev, aug, hidden_dim=96, **HP)
+    agent = curla_amd.CurlSacAgent((9,) + out_hw, (2,), dev, aug, hidden_dim=96, **(hp or HP))
     if mode is not None:
         agent.enable_data_parallel(single_rank_collectives=True, **mode)
     rb = curla_amd.ReplayBuffer((9,) + in_hw, (2,), 64, B, dev, aug)
@@ -54,11 +54,14 @@ def _run(mode, steps=4):
                  rs.randn(n).astype(np.float32), rs.randint(0, 256, (n, 9) + in_hw, dtype=np.uint8),
                  (np.arange(n) % 9) == 8)
     curla_amd.set_seed_everywhere(11)  # sampling and policy-noise streams
+    if graphs:
+        agent.enable_update_graphs(rb)
     L = Log()
     for step in range(steps):
         agent.update(rb, L, step)
     torch.cuda.synchronize()
     assert not agent._dp_pending
+    _run.last_agent = agent
     return (agent._critic_flat.clone(), agent._target_flat.clone(), agent._actor_flat.clone(),
             agent.log_alpha.detach().clone(), dict(L.s))
 
@@ -101,3 +104,38 @@ def test_broadcast_and_drift_check_on_rccl(nccl_world1):
     agent.enable_data_parallel(single_rank_collectives=True)
     assert torch.equal(before, agent._replica_checksum())  # rank 0 broadcasts to itself: nothing moves
     agent.check_replicas()  # a world of one cannot diverge; the collective itself must run on RCCL
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_update_graphs_capture_the_collectives(nccl_world1, overlap):
+    """Round 5: data-parallel updates over RCCL are captured into the update graphs WITH their all-reduces (the
+    replica check stays on the host, in front of the replay).  A world-1 RCCL run with graphs enabled must be the eager
+    data-parallel run -- and the plain single-GPU run -- bit for bit, and the replayed updates must make no
+    ``all_reduce`` call from the host."""
+    dist = nccl_world1
+    hp = dict(HP, log_interval=7)
+    base = _run(None, steps=16, hp=hp)
+    eager = _run(dict(overlap=overlap, check_every=0), steps=16, hp=hp)
+    calls = []
+    real = dist.all_reduce
+
+    def spy(t, **k):
+        calls.append(t.numel())
+        return real(t, **k)
+    dist.all_reduce = spy
+    try:
+        graph = _run(dict(overlap=overlap, check_every=0), steps=16, graphs=True, hp=hp)
+    finally:
+        dist.all_reduce = real
+    agent = _run.last_agent
+    assert agent._graphs and all(g["graph"] is not None for r in agent._graphs.values() for g in r)
+    for what, a, b, c in zip(("critic", "target", "actor", "log_alpha"), base, eager, graph):
+        assert torch.equal(a, b), f"eager DP differs from single-GPU in {what}"
+        assert torch.equal(a, c), f"graphed DP differs from single-GPU in {what}"
+    assert base[4] == graph[4]
+    # 16 updates: 0, 7, 14 log (eager), 1, 2 warm up, 3, 4, 5, 6 capture (their collectives are recorded: the host
+    # still calls all_reduce while capturing), 8 .. 13 and 15 replay with no host-side collective call
+    per_even, per_odd = ((2 + 3 + 2), (2 + 2)) if overlap else ((1 + 2 + 1), (1 + 1))
+    host_side = [0, 1, 2, 3, 4, 5, 6, 7, 14]
+    want = sum(per_even if s % 2 == 0 else per_odd for s in host_side)
+    assert len(calls) == want, (len(calls), want)

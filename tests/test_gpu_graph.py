@@ -16,7 +16,8 @@ from tests.test_gpu_agent import HP, NullLogger
 pytestmark = pytest.mark.gpu
 
 
-def _run(graphs, steps=14, pixel_sac=False):
+def _run(graphs, steps=14, pixel_sac=False, detach_encoder=False, edit=None):
+    """``edit`` = (step, fn): ``fn(agent)`` is applied before that step's update (a hyper-parameter edited mid-run)."""
     import curla_amd
     import curla_amd.ops as ops_mod
     import curla_amd.optim as optim_mod
@@ -28,7 +29,7 @@ def _run(graphs, steps=14, pixel_sac=False):
     C, in_hw, out_hw = 9, (40, 44), (32, 36)
     aug = curla_amd.RandomCrop(in_hw, out_hw)
     agent = curla_amd.CurlSacAgent((C,) + out_hw, (2,), dev, aug, hidden_dim=hidden, pixel_sac=pixel_sac,
-                                   **{**HP, "log_interval": 5})
+                                   detach_encoder=detach_encoder, **{**HP, "log_interval": 5})
     rb = curla_amd.ReplayBuffer((C,) + in_hw, (2,), 512, B, dev, aug)
     rs = np.random.RandomState(6)
     n = 400
@@ -37,6 +38,7 @@ def _run(graphs, steps=14, pixel_sac=False):
                  (np.arange(n) % 7) == 6)
     if graphs:
         agent.enable_update_graphs(rb)
+    agent._test_rb = rb
     calls_per_step = []
     real_call = _lib.call
     counter = collections.Counter()
@@ -51,6 +53,8 @@ def _run(graphs, steps=14, pixel_sac=False):
     try:
         for step in range(steps):
             counter.clear()
+            if edit is not None and edit[0] == step:
+                edit[1](agent)
             agent.update(rb, L, step)
             calls_per_step.append(sum(counter.values()))
         torch.cuda.synchronize()
@@ -89,6 +93,69 @@ def test_graph_replay_is_the_eager_update_bit_for_bit(pixel_sac):
     for k in eager:
         assert torch.equal(eager[k], graph[k]), k
     assert float(eager["critic_steps"][0]) == 14 and float(eager["actor_steps"][0]) == 7
+
+
+def test_detach_encoder_graphs_keep_the_convs_step_counts_behind():
+    """Under detach_encoder the critic's convs have no gradient at the critic's step (curl_sac.py:358): torch's Adam
+    skips them, so in ``critic_optimizer`` their step counts stay at zero while fc / ln / Q count on.  The captured
+    step must take its bias-correction factors from the LIVE parameters' count and the replay bookkeeping must not
+    advance (or create state for) the skipped ones."""
+    eager, _, np_e, logs_e, _ = _run(False, detach_encoder=True)
+    graph, calls_g, np_g, logs_g, agent = _run(True, detach_encoder=True)
+    assert [calls_g[s] for s in (8, 9, 11, 12, 13)] == [0] * 5, calls_g
+    assert np_e == np_g and logs_e == logs_g
+    for k in eager:
+        assert torch.equal(eager[k], graph[k]), k
+    steps = eager["critic_steps"].tolist()
+    assert set(steps) == {0, 14} and steps.count(0) == 8  # 4 conv layers x (weight, bias) never stepped by the critic
+    assert len(eager["critic_sd_steps"]) == len(steps) - 8  # ... and have no Adam state, as with torch.optim.Adam
+
+
+def test_editing_a_captured_value_recaptures_instead_of_replaying_stale_arguments():
+    """discount, the taus, betas / eps are kernel ARGUMENTS inside a captured graph.  An edit after capture must not be
+    ignored: the graphs are dropped and captured again (eager updates in between), and the run equals the eager run
+    with the same edit at the same step."""
+    def edit(agent):
+        agent.discount = 0.9
+        agent.critic_tau = 0.02
+        agent.critic_optimizer.param_groups[0]["betas"] = (0.8, 0.99)
+        agent.actor_optimizer.param_groups[0]["lr"] = 3e-4   # (lr travels as data: needs no re-capture, must still act)
+    eager, _, np_e, logs_e, _ = _run(False, steps=20, edit=(11, edit))
+    graph, calls_g, np_g, logs_g, agent = _run(True, steps=20, edit=(11, edit))
+    assert calls_g[9] == 0 and calls_g[11] > 15  # replaying before the edit, eager (warm-up of the new graphs) after
+    assert calls_g[19] == 0                       # ... and replaying again at the end
+    assert np_e == np_g and logs_e == logs_g
+    for k in eager:
+        assert torch.equal(eager[k], graph[k]), k
+    plain, _, _, _, _ = _run(False, steps=20)
+    assert not torch.equal(plain["critic"], eager["critic"])  # (the edit matters)
+
+
+def test_load_checkpoint_drops_the_captured_graphs(tmp_path):
+    """The captured log_alpha step holds the addresses of its Adam moments; ``load_state_dict`` replaces those
+    tensors.  A resume must therefore re-capture -- and continue bit for bit like an eager agent resumed the same way."""
+    out = []
+    for graphs in (False, True):
+        _, _, _, _, agent = _run(graphs, steps=10)
+        path = str(tmp_path / ("g.pt" if graphs else "e.pt"))
+        agent.save_checkpoint(path, 10)
+        if graphs:  # steps 3, 4, 6, 7 captured
+            assert sum(len(r) for r in agent._graphs.values()) == 4
+        assert agent.load_checkpoint(path) == 10
+        if graphs:
+            assert agent._graphs == {}  # still enabled, nothing captured
+        L = NullLogger()
+        for step in range(10, 20):
+            agent.update(agent._test_rb, L, step)
+        torch.cuda.synchronize()
+        if graphs:
+            assert sum(len(r) for r in agent._graphs.values()) == 4
+        la = agent.log_alpha_optimizer.state[agent.log_alpha]
+        out.append({k: v.detach().cpu().clone() for k, v in dict(
+            critic=agent._critic_flat, target=agent._target_flat, actor=agent._actor_flat,
+            log_alpha=agent.log_alpha.detach(), la_m=la["exp_avg"], la_v=la["exp_avg_sq"]).items()})
+    for k in out[0]:
+        assert torch.equal(out[0][k], out[1][k]), k
 
 
 def test_unsupported_setups_are_refused():
