@@ -91,6 +91,35 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
   rw43::run_layer<MODE_DGRAD, 4>(A.g[0], A.p[0][0], A.p[0][1], lds, blockIdx.x, gridDim.x);
 }
 
+#include "conv_rwb.h"
+
+// The same layers on the bf16 matrix cores with fp32 operands split into three bf16 parts (conv_rwb.h): 512-thread
+// workgroups, one per CU, 108 KB of LDS for the split filters of the two problems of a layer.
+template <int NW>
+__device__ __forceinline__ void rwb_fwd_body(const rw::Args& A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds_h[];
+  for (int l = 0; l < A.nlayers; ++l) {
+    rwb::build_filter<MODE_FWD, 64 * NW>(lds_h, A.p[l][0].w, A.p[l][1].B > 0 ? A.p[l][1].w : nullptr, threadIdx.x);
+    __syncthreads();
+    rwb::run_layer<MODE_FWD, NW>(A.g[l], A.p[l][0], A.p[l][1], lds_h, blockIdx.x, gridDim.x);
+    if (l + 1 < A.nlayers) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __syncthreads();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 1) void conv_rwb_fwd_kernel(rw::Args A) { rwb_fwd_body<8>(A); }
+__global__ __launch_bounds__(1024, 1) void conv_rwb_fwd16_kernel(rw::Args A) { rwb_fwd_body<16>(A); }
+
+__global__ __launch_bounds__(512, 1) void conv_rwb_dgrad_kernel(rw::Args A) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds_h[];
+  rwb::build_filter<MODE_DGRAD, 512>(lds_h, A.p[0][0].w, nullptr, threadIdx.x);
+  __syncthreads();
+  rwb::run_layer<MODE_DGRAD, 8>(A.g[0], A.p[0][0], A.p[0][1], lds_h, blockIdx.x, gridDim.x);
+}
+
 // data gradient alone (256-thread workgroups: the form that shares a launch with the weight gradient below)
 __global__ __launch_bounds__(256, 2) void conv_rw_dgrad_kernel(rw::Args A) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -1268,13 +1297,16 @@ int launch_rw_fwd(int nlayers, const float* in, const float* const* w, const flo
   // (9 quads: every strip is a 5-row segment with 2 halo rows), where it is not worth its 2.5 x rounding noise
   // (tools/micro/wino_error.py).  auto = F(4,3) when the narrowest layer of the launch has >= 16 quads per row.
   const int opt43 = curla_opt(kOptS1Fwd);
+  const bool b3 = opt43 == 3;
   const bool f43 = opt43 == 2 || (opt43 == 0 && (Wi - 2 * nlayers + 3) / 4 >= 16);
   rw::Args A;
   A.nlayers = nlayers;
   for (int l = 0; l < rw::kMaxLayers; ++l) {
     const bool on = l < nlayers;
     const int hi = Hi - 2 * l, wi = Wi - 2 * l;
-    A.g[l] = on ? (f43 ? rw43::plan(hi, wi, hi - 2, wi - 2) : rw::plan(hi, wi, hi - 2, wi - 2)) : rw::Geom{};
+    A.g[l] = !on ? rw::Geom{}
+             : b3 ? rwb::plan(hi, wi, hi - 2, wi - 2)
+                  : (f43 ? rw43::plan(hi, wi, hi - 2, wi - 2) : rw::plan(hi, wi, hi - 2, wi - 2));
     A.p[l][0] = on ? rw::Problem{l == 0 ? in : out[l - 1], w[l], bias[l], out[l], B} : rw::Problem{};
     A.p[l][1] = (on && B2 > 0) ? rw::Problem{l == 0 ? in2 : out2[l - 1], w2[l], bias2[l], out2[l], B2} : rw::Problem{};
     if (on && (hi < 3 || wi < 3)) return CURLA_ERR_UNSUPPORTED;
@@ -1283,6 +1315,20 @@ int launch_rw_fwd(int nlayers, const float* in, const float* const* w, const flo
   const int cus = curla_cu_count();
   const int bmax = B > B2 ? B : B2;
   const int grid = owned ? cus : (bmax < cus ? bmax : cus);
+  if (b3) {
+    const size_t ldsb = (size_t)(B2 > 0 ? 2 : 1) * rwb::kWBytes;
+    static const bool w16 = getenv("CURLA_RWB_WAVES") && atoi(getenv("CURLA_RWB_WAVES")) == 16;  // (experiment)
+    if (w16) {
+      int rcb = set_lds(conv_rwb_fwd16_kernel, ldsb);
+      if (rcb != CURLA_OK) return rcb;
+      hipLaunchKernelGGL(conv_rwb_fwd16_kernel, dim3(grid), dim3(1024), ldsb, st, A);
+      return curla_launch_status();
+    }
+    int rcb = set_lds(conv_rwb_fwd_kernel, ldsb);
+    if (rcb != CURLA_OK) return rcb;
+    hipLaunchKernelGGL(conv_rwb_fwd_kernel, dim3(grid), dim3(512), ldsb, st, A);
+    return curla_launch_status();
+  }
   if (f43) {
     const size_t lds43 = (size_t)(B2 > 0 ? 2 : 1) * rw43::kWFloats * sizeof(float);
     int rc43 = set_lds(conv_rw43_fwd_kernel, lds43);
@@ -1313,6 +1359,20 @@ bool dgrad_f43(int Wi) {
   return opt == 2 || (opt == 0 && (Wi + 3) / 4 >= 16);
 }
 
+// ... or the bf16x3 kernel (conv_rwb.h)?
+bool dgrad_b3() { return curla_opt(kOptS1Fwd) == 3; }
+
+int launch_dgrad_b3(const float* g, const float* w, const float* act_below, float* gin, int B, int Ho, int Wo,
+                    hipStream_t st) {
+  rw::Args A = rw_dgrad_args(g, w, act_below, gin, B, Ho, Wo);
+  A.g[0] = rwb::plan(Ho, Wo, Ho + 2, Wo + 2);
+  const int cap = curla_cu_count();
+  int rc = set_lds(conv_rwb_dgrad_kernel, rwb::kWBytes);
+  if (rc != CURLA_OK) return rc;
+  hipLaunchKernelGGL(conv_rwb_dgrad_kernel, dim3(B < cap ? B : cap), dim3(512), rwb::kWBytes, st, A);
+  return curla_launch_status();
+}
+
 int launch_dgrad43(const float* g, const float* w, const float* act_below, float* gin, int B, int Ho, int Wo,
                    hipStream_t st) {
   rw::Args A = rw_dgrad_args(g, w, act_below, gin, B, Ho, Wo);
@@ -1330,6 +1390,7 @@ int launch_conv_s1(int mode, const float* in, const float* w, const float* aux, 
                    float* out2 = nullptr, int B2 = 0) {
   if (!rw_supported(Hs, Ws)) return CURLA_ERR_UNSUPPORTED;
   if (mode == MODE_FWD) return launch_rw_fwd(1, in, &w, &aux, &out, B, in2, &w2, &aux2, &out2, B2, Hs, Ws, false, st);
+  if (dgrad_b3()) return launch_dgrad_b3(in, w, aux, out, B, Hs, Ws, st);
   if (dgrad_f43(Ws + 2)) return launch_dgrad43(in, w, aux, out, B, Hs, Ws, st);
   const rw::Args A = rw_dgrad_args(in, w, aux, out, B, Hs, Ws);
   const int cap = 2 * curla_cu_count();
@@ -1635,6 +1696,12 @@ int curla_conv3x3_s1_bwd_slabs(const float* in, const float* g, const float* w, 
   CURLA_REQUIRE(aligned16(in) && aligned16(g) && aligned16(w) && aligned16(gin));
   const int Ho = Hi - 2, Wo = Wi - 2;
   if (!rw_supported(Hi, Wi)) return CURLA_ERR_UNSUPPORTED;
+  if (dgrad_b3()) {
+    // the data gradient on the bf16 matrix cores (512-thread workgroups), the weight gradient as its own launch
+    const int rcw = launch_wgrad_s1(in, g, workspace, B, Hi, Wi, channels, static_cast<hipStream_t>(stream), nslabs);
+    if (rcw != CURLA_OK) return rcw;
+    return launch_dgrad_b3(g, w, in, gin, B, Ho, Wo, static_cast<hipStream_t>(stream));
+  }
   if (dgrad_f43(Wi)) {
     // wide rows: the data gradient with Winograd F(4,3) (one wave per SIMD), the weight gradient as its own launch
     const int rcw = launch_wgrad_s1(in, g, workspace, B, Hi, Wi, channels, static_cast<hipStream_t>(stream), nslabs);

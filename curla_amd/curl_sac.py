@@ -1038,15 +1038,17 @@ class CurlSacAgent(object):
         assert e1 == q0  # [encoder | Q1 | Q2] are adjacent: one launch, two rates
         ops.soft_update2(self._critic_flat[e0:q1], self._target_flat[e0:q1], e1 - e0, self.encoder_tau, self.critic_tau)
 
-    def update(self, replay_buffer, L, step, only_cpc=False):
+    def update(self, replay_buffer, L, step, only_cpc=False, noise=None):
         """curl_sac.py:426-451.  A curla_amd ReplayBuffer hands over references
         into its HBM ring (gather + crop fused into the first conv); any other
-        buffer is used through the reference's ``sample_cpc()`` tensors."""
-        if self._graphs is not None and self._graph_usable(replay_buffer, step, only_cpc):
+        buffer is used through the reference's ``sample_cpc()`` tensors.
+        ``noise`` (parity tests): (critic-phase, actor-phase) tensors in place of the two ``torch.randn_like`` draws
+        (curl_sac.py:97 via :352 and :375)."""
+        if noise is None and self._graphs is not None and self._graph_usable(replay_buffer, step, only_cpc):
             return self._update_graphed(replay_buffer, L, step)
-        self._update_eager(replay_buffer, L, step, only_cpc)
+        self._update_eager(replay_buffer, L, step, only_cpc, noise)
 
-    def _update_eager(self, replay_buffer, L, step, only_cpc=False):
+    def _update_eager(self, replay_buffer, L, step, only_cpc=False, noise=None):
         if hasattr(replay_buffer, "sample_cpc_refs"):
             sample = replay_buffer.sample_cpc_refs()
         else:
@@ -1054,11 +1056,12 @@ class CurlSacAgent(object):
 
         if self._dp_active and self._dp_check_every > 0 and step % self._dp_check_every == 0:
             self.check_replicas()
-        self._update_phases(sample, L, step, only_cpc)
+        self._update_phases(sample, L, step, only_cpc, noise)
 
-    def _update_phases(self, sample, L, step, only_cpc=False):
+    def _update_phases(self, sample, L, step, only_cpc=False, noise=None):
         """The phases of one update on a drawn minibatch (curl_sac.py:431-451)."""
         obs, action, reward, next_obs, not_done, cpc_kwargs = sample
+        noise_c, noise_a = noise if noise is not None else (None, None)
         if step % self.log_interval == 0:
             ws = self._ws(action.shape[0])
             ops.mean(reward.contiguous(), reward.numel(), ws.scalars[6:7])
@@ -1069,7 +1072,7 @@ class CurlSacAgent(object):
             soft = step % self.critic_target_update_freq == 0
             self._soft_update_hint, self._soft_update_done = soft, False
             try:
-                self.update_critic(obs, action, reward, next_obs, not_done, L, step)
+                self.update_critic(obs, action, reward, next_obs, not_done, L, step, noise=noise_c)
             finally:
                 self._soft_update_hint = False
             # The target soft update reads the critic's parameters, which the actor phase does not touch (it steps the
@@ -1082,7 +1085,7 @@ class CurlSacAgent(object):
             if step % self.actor_update_freq == 0:
                 if do_cpc and isinstance(cpc_kwargs.get("obs_pos"), ObsRef):
                     self._pos_hint = cpc_kwargs["obs_pos"]
-                self.update_actor_and_alpha(obs, L, step)
+                self.update_actor_and_alpha(obs, L, step, noise=noise_a)
                 self._pos_hint = None
 
         if do_cpc:

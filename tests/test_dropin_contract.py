@@ -151,7 +151,7 @@ def test_documented_bindings_resolve_every_name_the_drivers_touch(how):
                     "encoder_feature_dim", "encoder_lr", "encoder_tau", "num_layers", "num_filters", "cpc_update_freq",
                     "log_interval", "log_param_hist_imgs", "detach_encoder", "pixel_sac"]
     # train.py:425-429, 149-151, 418, 368; eval.py:78,165
-    assert _params(CurlSacAgent.update)[1:] == ["replay_buffer", "L", "step", "only_cpc"]
+    assert _params(CurlSacAgent.update)[1:5] == ["replay_buffer", "L", "step", "only_cpc"]  # (+ keyword-only-in-practice test hooks behind)
     assert inspect.signature(CurlSacAgent.update).parameters["only_cpc"].default is False
     assert _params(CurlSacAgent.update_critic)[1:8] == ["obs", "action", "reward", "next_obs", "not_done", "L", "step"]
     assert _params(CurlSacAgent.update_actor_and_alpha)[1:4] == ["obs", "L", "step"]

@@ -700,6 +700,168 @@ def test_other_config_geometries_vs_oracle(name, obs_shape, layers, pixel_sac, B
 
 
 
+@pytest.mark.parametrize("name", ["odd", "pixel_sac", "only_cpc", "detach", "l6c12"])
+def test_update_modes_vs_reference_fixtures(name):
+    """The branches of ``update()`` beside the even CURL step -- an odd step (curl_sac.py:436,441), ``pixel_sac``
+    (:448), ``only_cpc`` (train.py:425-429), ``detach_encoder`` (:358) and the 6-layer / 12-channel / identity geometry
+    of configs[4] (encoder.py:54-63, utils.py:168-182) -- against ONE WHOLE reference ``update()`` each
+    (tests/golden/mode_*.npz: seeded weights, fresh optimizers), through the public entry point: the ring is filled with
+    the reference buffer's frames, NumPy is seeded as the reference was, and ``agent.update(rb, L, step, only_cpc=...)``
+    draws the minibatch itself.  Per phase: the loss and every gradient the optimizer consumes against the fixture (1e-4
+    for the first phase, 5e-3 for phases behind an Adam step -- SURVEY.md D11) and against the oracle evaluated on the
+    agent's own parameters at the start of that phase (1e-4); then the parameters after the update element by element,
+    what must not have moved bit for bit, and which tensors each Adam stepped."""
+    import curla_amd
+    from oracle import curla_oracle as O
+    from tests.golden_recipes import mode_inputs
+    g = load(f"mode_{name}.npz")
+    inp = mode_inputs(name, g)
+    m = inp["m"]
+    c, in_hw, out_hw, layers, B = m["channels"], tuple(m["in_hw"]), tuple(m["out_hw"]), m["num_layers"], m["batch"]
+    dev = torch.device("cuda")
+    aug = curla_amd.RandomCrop(in_hw, out_hw) if m["crop"] else curla_amd.IdentityAugmentation(in_hw)
+    torch.manual_seed(0)
+    agent = curla_amd.CurlSacAgent((c,) + out_hw, (2,), dev, aug, hidden_dim=m["hidden"], detach_encoder=m["detach_encoder"],
+                                   pixel_sac=m["pixel_sac"], **{**HP, "num_layers": layers})
+    load_state(agent, inp["actor"], inp["critic"], inp["target"], inp["W"], inp["log_alpha"])
+    rb = curla_amd.ReplayBuffer((c,) + in_hw, (2,), m["n_fill"], B, dev, aug)
+    rb.add_batch(inp["obses"], inp["acts"], inp["rews"], inp["nexts"], inp["dones"])
+    pre = {k: v.detach().clone() for k, v in (("critic", agent._critic_flat), ("target", agent._target_flat),
+                                              ("actor", agent._actor_flat))}
+    cpu = lambda sd: {k: v.detach().cpu().clone() for k, v in sd.items()}  # noqa: E731
+    phases = []
+    real = agent._allreduce  # (called once per phase right in front of its optimizer step; a no-op without DP)
+
+    def tap(*buckets, async_op=False):
+        ws = agent._ws(B)
+        phases.append(dict(
+            size=int(buckets[0].numel()), critic=grads_of(agent.critic), actor=grads_of(agent.actor),
+            W=agent.CURL.W.grad.detach().cpu().clone(), log_alpha=agent.log_alpha.grad.detach().cpu().clone(),
+            state=(cpu(agent.actor.state_dict()), cpu(agent.critic.state_dict()), cpu(agent.critic_target.state_dict()),
+                   agent.CURL.W.detach().cpu().clone(), agent.log_alpha.detach().cpu().clone()),
+            branches=[(a.permute(0, 3, 1, 2) > 0).cpu() for a in ws.acts_main], scalars=dict(L.scalars)))
+        return real(*buckets, async_op=async_op)
+    agent._allreduce = tap
+    L = NullLogger()
+    nc = _t(g["noise/critic"]) if "noise/critic" in g else None
+    na = _t(g["noise/actor"]) if "noise/actor" in g else None
+    np.random.seed(m["numpy_seed"])  # the reference's stream: update() must draw the reference's minibatch
+    agent.update(rb, L, m["step"], only_cpc=m["only_cpc"], noise=(nc, na))
+    torch.cuda.synchronize()
+    del agent._allreduce
+    sac, curl, even = not m["only_cpc"], not m["pixel_sac"], m["step"] % 2 == 0
+    want_phases = (["critic"] if sac else []) + (["actor"] if sac and even else []) + (["cpc"] if curl else [])
+    assert len(phases) == len(want_phases), (len(phases), want_phases)
+    ph = dict(zip(want_phases, phases))
+    tag = f"mode {name}"
+    # the minibatch update() drew is the reference's (same NumPy stream, same order of draws)
+    assert np.array_equal(rb._d_index[rb._sample_slot][:B * 8].view(torch.int64).cpu().numpy(), g["rng/idxs"])
+    f = lambda a: torch.from_numpy(np.asarray(a)).float()  # noqa: E731
+    o_obs, o_nxt, o_pos = f(inp["obs"]), f(inp["next_obs"]), f(inp["pos"])
+    idxs = inp["idxs"]
+    o_act, o_rew = torch.from_numpy(inp["acts"][idxs]), torch.from_numpy(inp["rews"][idxs])[:, None]
+    o_nd = torch.from_numpy(1.0 - inp["dones"][idxs].astype(np.float32))[:, None]
+    kw = dict(num_layers=layers, log_std_min=-10, log_std_max=2)
+    first = want_phases[0]
+    if sac:
+        p = ph["critic"]
+        check(f"{tag} critic loss", L.scalars["train_critic/loss"], g["scalar/train_critic/loss"])
+        ref = sub(g, "critic/grad/")
+        assert len(ref) == (4 + 12 if m["detach_encoder"] else 2 * layers + 4 + 12)
+        for k, v in ref.items():
+            check(f"{tag} critic grad {k} (fixture)", p["critic"][k], v)
+        a, c_, t_, _, la = p["state"]
+        own = O.critic_phase(a, c_, t_, la, o_obs, o_act, o_rew, o_nxt, o_nd, nc.cpu(), discount=0.99,
+                             detach_encoder=m["detach_encoder"], relu_branches=p["branches"], **kw)
+        for k, v in own["grads"].items():
+            if v is not None:
+                check(f"{tag} critic grad {k} (oracle, own parameters)", p["critic"][k], v)
+            else:
+                assert m["detach_encoder"] and ".convs." in k
+    if sac and even:
+        p = ph["actor"]
+        a, c_, _, _, la = p["state"]
+        own = O.actor_phase(a, c_, la, o_obs, na.cpu(), target_entropy=-2.0, **kw)
+        check(f"{tag} actor loss (own parameters)", L.scalars["train_actor/loss"], own["actor_loss"])
+        check(f"{tag} actor loss (fixture)", L.scalars["train_actor/loss"], g["scalar/train_actor/loss"], 5e-3)
+        check(f"{tag} alpha loss (fixture)", L.scalars["train_alpha/loss"], g["scalar/train_alpha/loss"], 5e-3)
+        check(f"{tag} log_alpha grad (fixture)", p["log_alpha"], g["alpha/grad/log_alpha"], 5e-3)
+        check(f"{tag} log_alpha grad (own parameters)", p["log_alpha"], own["log_alpha_grad"])
+        ref = sub(g, "actor/grad/")
+        assert len(ref) == 10
+        for k, v in ref.items():
+            check(f"{tag} actor grad {k} (fixture)", p["actor"][k], v, 5e-3)
+            check(f"{tag} actor grad {k} (oracle, own parameters)", p["actor"][k], own["grads"][k])
+    if curl:
+        p = ph["cpc"]
+        _, c_, t_, W_, _ = p["state"]
+        own = O.cpc_phase(c_, t_, W_, o_obs, o_pos, num_layers=layers, relu_branches=p["branches"])
+        tol = RTOL if first == "cpc" else 5e-3
+        check(f"{tag} curl loss (fixture)", L.scalars["train/curl_loss"], g["scalar/train/curl_loss"], tol)
+        check(f"{tag} curl loss (own parameters)", L.scalars["train/curl_loss"], own["loss"])
+        ref = sub(g, "cpc/grad/")
+        assert len(ref) == 2 * layers + 4 + 1
+        for k, v in ref.items():
+            got = p["W"] if k == "W" else p["critic"][k]
+            check(f"{tag} cpc grad {k} (fixture)", got, v, tol)
+            check(f"{tag} cpc grad {k} (oracle, own parameters)", got, own["W_grad"] if k == "W" else own["grads"][k])
+    # ---- after the update: every parameter against the reference's, element by element.  Adam's first step is
+    # lr * g / (|g| + eps) (SURVEY.md D11): lr * sign(g) for all but the elements whose gradient is within rounding of
+    # zero -- those may land up to 2 lr away per Adam that steps them (the encoder is stepped by three) -- and the
+    # elements with |g| ~ eps = 1e-8, whose step follows g itself (the CURL gradients of these fixtures' first conv
+    # layer are that small: softmax over logits of magnitude ~40 is close to one-hot).  A few in a hundred; a wrong
+    # rate, order or state would move ALL of them.
+    lr = 1e-3
+    post = dict(actor=agent.actor.state_dict(), critic=agent.critic.state_dict(), critic_target=agent.critic_target.state_dict())
+    worst_off = 0.0
+    for net, sd in post.items():
+        for k, want in sub(g, f"post/{net}/", as_torch=False).items():
+            got = sd[k].detach().cpu().numpy().ravel()[:len(want)].astype(np.float64)
+            err = np.abs(got - want.astype(np.float64))
+            scale = max(np.abs(want).max(), 1e-3)
+            off = float((err > RTOL * scale).mean())
+            worst_off = max(worst_off, off)
+            n_adams = 3 if k.startswith("encoder.") and net != "critic_target" else 1
+            assert off <= 0.03 and err.max() <= n_adams * 2.1 * lr + RTOL * scale, (net, k, off, err.max())
+    REPORT.append((f"{tag} parameters after update(): largest fraction of a tensor's elements off by > 1e-4", worst_off))
+    check(f"{tag} W after update()", agent.CURL.W.detach().cpu(), g["post/W"], 3e-3)
+    assert abs(float(agent.log_alpha.detach()) - float(g["post/log_alpha"])) <= 2.1e-4
+    # ---- what must not have moved, bit for bit
+    lay = agent._lay
+    (e0, e1), (q0, q1) = lay["enc"], lay["q"]
+    now = dict(critic=agent._critic_flat, target=agent._target_flat, actor=agent._actor_flat)
+    if not (sac and even):
+        assert torch.equal(pre["actor"], now["actor"]) and torch.equal(pre["target"], now["target"])
+        assert float(agent.log_alpha) == float(inp["log_alpha"])
+    else:
+        assert not torch.equal(pre["actor"], now["actor"]) and not torch.equal(pre["target"][e0:q1], now["target"][e0:q1])
+    if not sac:
+        assert torch.equal(pre["critic"][q0:q1], now["critic"][q0:q1])
+    else:
+        assert not torch.equal(pre["critic"][q0:q1], now["critic"][q0:q1])
+    assert torch.equal(pre["critic"][:e0], now["critic"][:e0]) == (not curl)   # CURL.W
+    assert not torch.equal(pre["critic"][e0:e1], now["critic"][e0:e1])
+    # ---- which tensors each Adam stepped (curl_sac.py:299-313; detach_encoder: the critic's Adam skips the convs)
+    n_enc = 2 * layers + 4
+    critic_steps = dict(collections.Counter(agent.critic_optimizer._steps))
+    if not sac:
+        assert critic_steps == {0: n_enc + 12}
+    elif m["detach_encoder"]:
+        assert critic_steps == {0: 2 * layers, 1: n_enc - 2 * layers + 12}
+    else:
+        assert critic_steps == {1: n_enc + 12}
+    assert set(agent.actor_optimizer._steps) == ({1} if sac and even else {0})
+    assert set(agent.encoder_optimizer._steps) == ({1} if curl else {0})
+    assert set(agent.cpc_optimizer._steps) == ({1} if curl else {0})
+    la_state = agent.log_alpha_optimizer.state.get(agent.log_alpha, {})
+    assert int(float(la_state.get("step", 0))) == (1 if sac and even else 0)
+    for key, opt in (("critic", agent.critic_optimizer), ("actor", agent.actor_optimizer),
+                     ("encoder", agent.encoder_optimizer), ("cpc", agent.cpc_optimizer)):
+        n_ref, t_ref = g[f"post/adam_steps/{key}"].tolist()
+        live = [t for t in opt._steps if t > 0]  # (the reference counts the tensors its Adam holds state for)
+        assert len(live) == n_ref and (max(live) if live else 0) == t_ref, (key, len(live), n_ref)
+
+
 def test_detach_encoder_and_only_cpc_modes(tiny):
     """--detach_encoder (curl_sac.py:358: h.detach() between conv and fc): conv tensors get no gradient, so
     Adam must leave them untouched while fc/ln/Q still move; only_cpc (train.py:425) touches only the encoder/W."""

@@ -54,9 +54,10 @@ def rnd(*shape, seed=0, scale=1.0):
     return torch.randn(*shape, generator=g) * scale
 
 
-@pytest.fixture(params=["f23", "f43"])
+@pytest.fixture(params=["f23", "f43", "b3"])
 def s1_impl(request):
-    """The two stride-1 forwards: Winograd F(2,3) (conv_rw.h) and F(4,3) (conv_rw43.h), option s1_fwd."""
+    """The stride-1 forwards / data gradients: Winograd F(2,3) (conv_rw.h), F(4,3) (conv_rw43.h) and the bf16x3 form on
+    the bf16 matrix cores (conv_rwb.h), option s1_fwd."""
     from curla_amd import _lib
     with _lib.option("s1_fwd", request.param):
         yield request.param
