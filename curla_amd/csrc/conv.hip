@@ -99,14 +99,29 @@ template <int NW>
 __device__ __forceinline__ void rwb_fwd_body(const rw::Args& A) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds_h[];
   for (int l = 0; l < A.nlayers; ++l) {
+#ifdef RWB_STAMP
+    const unsigned long long k0 = __builtin_readcyclecounter();
+#endif
     rwb::build_filter<MODE_FWD, 64 * NW>(lds_h, A.p[l][0].w, A.p[l][1].B > 0 ? A.p[l][1].w : nullptr, threadIdx.x);
     __syncthreads();
+#ifdef RWB_STAMP
+    const unsigned long long k1 = __builtin_readcyclecounter();
+#endif
     rwb::run_layer<MODE_FWD, NW>(A.g[l], A.p[l][0], A.p[l][1], lds_h, blockIdx.x, gridDim.x);
+#ifdef RWB_STAMP
+    const unsigned long long k2 = __builtin_readcyclecounter();
+#endif
     if (l + 1 < A.nlayers) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __syncthreads();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
+#ifdef RWB_STAMP
+    const unsigned long long k3 = __builtin_readcyclecounter();
+    if (threadIdx.x == 0 && blockIdx.x == 7) {
+      rwb::g_rwb_stamp[4] += k1 - k0, rwb::g_rwb_stamp[5] += k2 - k1, rwb::g_rwb_stamp[6] += k3 - k2, rwb::g_rwb_stamp[7] += 1;
+    }
+#endif
   }
 }
 
@@ -1429,6 +1444,16 @@ extern "C" {
 
 #ifdef CURLA_ABLATE
 void curla_debug_ablate(int flags) { g_ablate = flags; }
+#endif
+#ifdef RWB_STAMP
+// timing-only debug build (tools/build_variant.sh stamp -DRWB_STAMP): cycle sums of wave 0 of workgroup 7 over its full steps
+int curla_debug_rwb_stamps(unsigned long long* out8, int reset) {
+  if (reset) {
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(rwb::g_rwb_stamp), z, sizeof(z)) == hipSuccess ? 0 : -2;
+  }
+  return hipMemcpyFromSymbol(out8, HIP_SYMBOL(rwb::g_rwb_stamp), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
 #endif
 
 int curla_conv3x3_s1_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Hi, int Wi,

@@ -36,6 +36,10 @@
 // problem), read one group ahead.
 #pragma once
 
+#ifndef RWB_STAGGER
+#define RWB_STAGGER 0  // s_sleep units (64 cycles) by which the second wave of every SIMD starts a layer late
+#endif
+
 namespace rwb {
 
 using rw::Args;
@@ -152,6 +156,10 @@ __device__ __forceinline__ void build_filter(unsigned short* lds_w, const float*
   }
 }
 
+#ifdef RWB_STAMP
+__device__ unsigned long long g_rwb_stamp[16];  // [0] split phase, [1] product phase, [2] finish, [3] steps, [4] whole pieces
+#endif
+
 struct Acc {
   f32x4 m[2][4];  // [channel half][Winograd position]: 16 output channels x 16 pairs per entry
 };
@@ -172,6 +180,9 @@ __device__ __forceinline__ void run_layer(const Geom& G, const Problem& P0, cons
   // this wave's share of the workgroup's steps: [lo, hi) of the concatenation over (sample, strip)
   const int lo = (int)((long)wave * T / NW), hi = (int)((long)(wave + 1) * T / NW);
   const int in_row = G.Wi * 128, out_row = G.Wo * 128;  // bytes per row
+#if RWB_STAGGER
+  if (wave >= NW / 2) __builtin_amdgcn_s_sleep(RWB_STAGGER);
+#endif
 
   int before = 0;  // steps of the instances before the current one
   for (int si = 0; si < cnt0 + cnt1; ++si) {
@@ -252,7 +263,8 @@ __device__ __forceinline__ void run_layer(const Geom& G, const Problem& P0, cons
       Acc S0, S1, S2;
       f32x4 mk[2][2];  // data gradient: activation below at (pixel a / b, channel half)
 
-      // six products of one (position, row tap, channel half) into one accumulator, smallest terms first
+      // six products of one (position, row tap, channel half) into one accumulator, smallest terms first (`acc` of a
+      // row's first tap: zeros, or the bias for position 1 -- the C operand of the first instruction, no register moves)
       auto mul6 = [&](f32x4 acc, const W3& w, const B3& x) {
         acc = mfma_bf16(w.l, x.h, acc);
         acc = mfma_bf16(w.h, x.l, acc);
@@ -281,10 +293,14 @@ __device__ __forceinline__ void run_layer(const Geom& G, const Problem& P0, cons
         }
         oa += out_row, ob += out_row;
       };
+
       // step t: input row t of the piece -> output rows t-2 (completed), t-1, t (started).  On entry Wa holds the
       // weights of group 0; on exit again (of the next step).
       W3 Wa, Wb;
       auto step = [&](Acc& Sdy2, Acc& Sdy1, Acc& Sdy0, const int t) {
+#ifdef RWB_STAMP
+        const unsigned long long c0 = __builtin_readcyclecounter();
+#endif
         // B^T d per channel (v0 = d0 - d2, v1 = d1 + d2, v2 = d2 - d1, v3 = d1 - d3), then the split
         B3 X[4];
         {
@@ -311,11 +327,9 @@ __device__ __forceinline__ void run_layer(const Geom& G, const Problem& P0, cons
             mk[1][mt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(raux, ob + mt * 64u, 0, 0));
           }
         }
-        if (do0) {  // the row starts here: zeros, the bias in position 1 (both outputs of a pair contain +m1)
-          const f32x4 z = {0, 0, 0, 0};
-#pragma unroll
-          for (int mt = 0; mt < 2; ++mt) Sdy0.m[mt][0] = z, Sdy0.m[mt][1] = bias[mt], Sdy0.m[mt][2] = z, Sdy0.m[mt][3] = z;
-        }
+#ifdef RWB_STAMP
+        const unsigned long long c1 = __builtin_readcyclecounter();
+#endif
 #pragma unroll
         for (int g = 0; g < 24; ++g) {
           const int pos = g / 6, which = (g / 2) % 3, mt = g & 1;  // which: 0 = row tap 2, 1 = tap 1, 2 = tap 0
@@ -328,13 +342,31 @@ __device__ __forceinline__ void run_layer(const Geom& G, const Problem& P0, cons
           } else if (which == 1) {
             if (do1) Sdy1.m[mt][pos] = mul6(Sdy1.m[mt][pos], cur, X[pos]);
           } else {
-            if (do0) Sdy0.m[mt][pos] = mul6(Sdy0.m[mt][pos], cur, X[pos]);
+            // (the row starts here: zeros, the bias in position 1 -- both outputs of a pair contain +m1)
+            const f32x4 z = {0, 0, 0, 0};
+            if (do0) Sdy0.m[mt][pos] = mul6(pos == 1 ? bias[mt] : z, cur, X[pos]);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
+#ifdef RWB_STAMP
+        const unsigned long long c2 = __builtin_readcyclecounter();
+#endif
         if (do2) finish(Sdy2);
+#ifdef RWB_STAMP
+        const unsigned long long c3 = __builtin_readcyclecounter();
+        if (threadIdx.x == 0 && blockIdx.x == 7 && t >= 2 && t < n) {
+          g_rwb_stamp[0] += c1 - c0, g_rwb_stamp[1] += c2 - c1, g_rwb_stamp[2] += c3 - c2, g_rwb_stamp[3] += 1;
+        }
+        if (threadIdx.x == 0 && blockIdx.x == 7 && !(t >= 2 && t < n)) {
+          const int e = t < 2 ? t : (t == n ? 2 : 3);
+          g_rwb_stamp[11 + e] += c3 - c0;
+        }
+#endif
       };
 
+#ifdef RWB_STAMP
+      const unsigned long long p1 = __builtin_readcyclecounter();
+#endif
       load_row();
       Wa = wread(0);
       for (int t = 0;;) {
@@ -345,6 +377,12 @@ __device__ __forceinline__ void run_layer(const Geom& G, const Problem& P0, cons
         step(S0, S1, S2, t);
         if (++t > n + 1) break;
       }
+#ifdef RWB_STAMP
+      if (threadIdx.x == 0 && blockIdx.x == 7) {
+        g_rwb_stamp[8] += __builtin_readcyclecounter() - p1, g_rwb_stamp[9] += 1, g_rwb_stamp[10] += n;
+      }
+#endif
+
     }
   }
 }

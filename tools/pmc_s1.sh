@@ -10,7 +10,9 @@ O=gpurun_out/pmc_s1_$IMPL; rm -rf $O; mkdir -p $O
 i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" \
            "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_ACTIVE_INST_VALU" \
-           "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS"; do
+           "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \
+           "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" \
+           "SQ_INST_CYCLES_VMEM SQ_INSTS_SALU SQ_INSTS_VMEM SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
   rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $O/g$i -- $PY tools/s1_bench.py --impls $IMPL "$@" > $O/g$i.log 2>&1 || { tail -5 $O/g$i.log; exit 1; }
 done
@@ -40,5 +42,9 @@ for k, c in agg.items():
         m.get("SQ_INSTS_MFMA", 0) / 1e6, m.get("SQ_INSTS_VALU", 0) / 1e6,
         m.get("SQ_INSTS_VALU", 0) / max(1, m.get("SQ_INSTS_MFMA", 1)), m.get("SQ_INSTS_LDS", 0) / 1e6,
         m.get("SQ_WAIT_INST_ANY", 0) / max(1, m.get("SQ_WAVE_CYCLES", 1))))
+    wc = max(1.0, m.get("SQ_WAVE_CYCLES", 1))
+    print("  shares of wave cycles: " + "  ".join("%s %.3f" % (n.replace("SQ_", ""), m[n] / wc) for n in sorted(m)
+                                                    if n.startswith(("SQ_WAIT", "SQ_ACTIVE", "SQ_INST_CYCLES"))))
+    print("  raw means per launch: " + "  ".join("%s %.3g" % (n.replace("SQ_", ""), m[n]) for n in sorted(m)))
 PY
 rm -rf $O
