@@ -51,6 +51,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_TFLOPS = 157.3  # MI355X dense fp32 (vector == f32 MFMA), MI355X_MICROARCH.md chip table
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (no sparsity), MI355X_MICROARCH.md chip table
 HIDDEN, CAPACITY = 1024, 100_000
 
 CONFIGS = {
@@ -162,7 +163,7 @@ def committed_counters(cfg_name, kernel):
     cur = build.source_hash()
     traffic = busy = None
     note = "no committed PMC summary for this configuration"
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         for fn, key in ((f"{rnd}_pmc_traffic_{cfg_name}.json", "traffic"), (f"{rnd}_pmc_sq_{cfg_name}.json", "sq")):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
@@ -482,13 +483,17 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
         # the dominant kernel: all stride-1 forward layers of two minibatches in one launch when the batch sizes allow,
         # else one launch per layer
         stacked = B % job.cu_count() == 0  # (ops.stack_granule(): one workgroup per CU owns its samples)
-        # which Winograd form the stride-1 forward takes (option s1_fwd = auto, curla_amd/csrc/conv.hip launch_rw_fwd):
-        # F(4,3) when the narrowest layer of the stack has at least 16 pixel quads per row, else F(2,3)
-        hw = cfg["crop"] or cfg["obs"][1:]
-        w_last = (hw[1] - 3) // 2 + 1 - 2 * (cfg["layers"] - 1)
-        f43 = (w_last + 3) // 4 >= 16
-        kname = "conv_rw43_fwd_kernel" if f43 else "conv_rw_fwd_kernel"
-        wino, wino_factor = ("F(4,3)", 2.0) if f43 else ("F(2,3)", 1.5)
+        # which form the stride-1 forward takes (option s1_fwd, curla_amd/csrc/conv.hip launch_rw_fwd): auto = b3, the
+        # bf16-matrix-core form with fp32 operands split into three bf16 parts (conv_rwb.h); f23 / f43 = Winograd on the
+        # f32-input MFMA
+        from curla_amd import _lib as _clib
+        s1 = "auto" if job.dry else _clib.get_option("s1_fwd")
+        kname, wino, wino_factor, mfma, peak_tf, terms = {
+            "auto": ("conv_rwb_fwd_kernel", "F(2,3)", 1.5, "bf16 MFMA 16x16x32, fp32 operands as three bf16 parts", PEAK_BF16_TFLOPS, 6),
+            "b3": ("conv_rwb_fwd_kernel", "F(2,3)", 1.5, "bf16 MFMA 16x16x32, fp32 operands as three bf16 parts", PEAK_BF16_TFLOPS, 6),
+            "f23": ("conv_rw_fwd_kernel", "F(2,3)", 1.5, "f32 MFMA 16x16x4", PEAK_F32_TFLOPS, 1),
+            "f43": ("conv_rw43_fwd_kernel", "F(4,3)", 2.0, "f32 MFMA 16x16x4", PEAK_F32_TFLOPS, 1)}[s1]
+        issued = achieved / wino_factor * terms  # what the matrix pipe executes, in its own FLOPs
         traffic, mfma_busy, pmc_note = (None, None, "dry run") if job.dry else committed_counters(name, kname)
         n_launch = max(1, len(ev_pairs))
         avg_ms = kms / n_launch
@@ -500,6 +505,11 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
             "ms_per_step": 1e3 * dt / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "dtype_note": "float32 tensors and float32-accurate arithmetic throughout (parity 1e-4 against the float32 reference, "
+                          "float64 arbiter in tests/test_gpu_fullsize.py); the stride-1 conv forward runs on the bf16 matrix "
+                          "cores with every fp32 operand as the exact sum of three bf16 parts (six products per fp32 product, "
+                          "fp32 accumulation: measured error below a float32 fmaf chain's, tools/micro/bf16x3_error.py); "
+                          "everything else on the f32-input MFMA / VALU",
             "config": {"workload": cfg["workload"], "baseline_config": f"configs[{cfg['baseline_index']}]",
                        "replay_capacity": cap * world, "shards": shards, "prefill": prefill,
                        "parallelism": f"dp{world}", "priming_updates": 1, "clock_warmup_s": args.clock_warmup_s,
@@ -509,18 +519,20 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
             "conv_roofline_frac_whole_update": per_update * (steps / dt) / (PEAK_F32_TFLOPS * 1e12),
             "roofline": {"bound": "mfma",
                          "kernel": (f"{kname} (row-walk Winograd {wino} along x: all 3x3 s1 32->32 + bias + ReLU layers of "
-                                    "two minibatches per launch, f32 MFMA 16x16x4)")
+                                    f"two minibatches per launch, {mfma})")
                                    if stacked else
                                    f"{kname} (row-walk Winograd {wino} along x: one 3x3 s1 32->32 + bias + ReLU layer per "
-                                   "launch, f32 MFMA 16x16x4)",
+                                   f"launch, {mfma})",
                          # The kernel is Winograd F(2,3) / F(4,3) along x: it issues 1/1.5 resp. 1/2 of the direct-
                          # convolution FLOPs of SURVEY.md 8(d).  `achieved` / `frac` are what the matrix pipe really
                          # executes (compare with 1.0 and with `mfma_busy_frac_pmc`); the SURVEY 8(d) accounting in
                          # direct-conv FLOPs, which can exceed 1 because the algorithm skips work, is under `direct_equiv_*`.
-                         "achieved": achieved / wino_factor, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / wino_factor / PEAK_F32_TFLOPS, "traffic": traffic,
-                         "achieved_note": f"MFMA FLOPs issued = algorithmic direct-conv FLOPs / {wino_factor} (Winograd "
-                                          f"{wino} in one dimension; strip padding not counted)",
+                         "achieved": issued, "peak": peak_tf, "unit": "TFLOP/s",
+                         "frac": issued / peak_tf, "traffic": traffic,
+                         "achieved_note": (f"MFMA FLOPs issued = algorithmic direct-conv FLOPs / {wino_factor} (Winograd "
+                                           f"{wino} in one dimension; strip padding not counted)"
+                                           + (f" x {terms} (six bf16 x bf16 products per fp32 product: x = xh + xm + xl exactly, the "
+                                              "three products below 2^-24 dropped), against the dense bf16 MFMA peak" if terms > 1 else "")),
                          "direct_equiv_achieved": achieved, "direct_equiv_frac": achieved / PEAK_F32_TFLOPS,
                          "traffic_unit": "HBM bytes per launch; " + pmc_note,
                          "algorithmic_bytes_per_launch": kbytes / n_launch,

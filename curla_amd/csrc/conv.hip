@@ -1305,15 +1305,15 @@ bool rw_supported(int Hi, int Wi) { return (long long)(Hi + 2) * (Wi + 2) * 128 
 int launch_rw_fwd(int nlayers, const float* in, const float* const* w, const float* const* bias, float* const* out, int B,
                   const float* in2, const float* const* w2, const float* const* bias2, float* const* out2, int B2, int Hi,
                   int Wi, bool owned, hipStream_t st) {
-  // Winograd F(4,3) (conv_rw43.h) or F(2,3) (conv_rw.h) along x.  F(4,3) issues 0.78 x the MFMAs but ~0.9 VALU
-  // instructions per MFMA instead of 0.4 (input / output transforms, accumulator reads) at one wave per SIMD: measured
-  // on the stacks update() launches (tools/s1_bench.py), it wins 15 % where rows hold at least one full strip of 16 pixel
-  // quads (configs[4]: 83 -> 73 wide, 8.68 -> 7.42 ms and 5.86 -> 4.95 ms) and 5-7 % on configs[1]'s 35-wide rows
-  // (9 quads: every strip is a 5-row segment with 2 halo rows), where it is not worth its 2.5 x rounding noise
-  // (tools/micro/wino_error.py).  auto = F(4,3) when the narrowest layer of the launch has >= 16 quads per row.
+  // Three forms (option s1_fwd).  auto = b3, the bf16-matrix-core form (conv_rwb.h: fp32 operands as three bf16 parts,
+  // Winograd F(2,3) in front): measured on the stacks update() launches (tools/s1_bench.py) it takes 365 / 253 us on
+  // configs[1]'s two stacks against 491 / 337 for F(2,3) and 451 / 309 for F(4,3) on the f32-input MFMA, and 5.99 / 4.01 ms
+  // against F(4,3)'s 7.15 / 4.71 on configs[4]'s.  f23 / f43 (conv_rw.h / conv_rw43.h) remain selectable: F(4,3) issues
+  // 0.78 x the f32 MFMAs of F(2,3) but ~0.9 VALU instructions per MFMA instead of 0.4 at one wave per SIMD, and wins among
+  // the two where rows hold at least one full strip of 16 pixel quads.
   const int opt43 = curla_opt(kOptS1Fwd);
-  const bool b3 = opt43 == 3;
-  const bool f43 = opt43 == 2 || (opt43 == 0 && (Wi - 2 * nlayers + 3) / 4 >= 16);
+  const bool b3 = opt43 == 3 || opt43 == 0;
+  const bool f43 = opt43 == 2;
   rw::Args A;
   A.nlayers = nlayers;
   for (int l = 0; l < rw::kMaxLayers; ++l) {

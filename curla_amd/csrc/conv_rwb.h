@@ -56,21 +56,6 @@ constexpr int kWBytes = 3 * 4 * 2 * 3 * 64 * 16;  // split filter of one problem
 // strip plan: 16 pixel-pair columns per wave (conv_rw.h's)
 inline Geom plan(int Hi, int Wi, int Ho, int Wo) { return rw::plan(Hi, Wi, Ho, Wo); }
 
-// round-to-nearest-even bf16 of an fp32 value, as the high half of a word
-__device__ __forceinline__ unsigned bf16_hi(float x) {
-  const unsigned u = __builtin_bit_cast(unsigned, x);
-  return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-}
-
-// x = h + m + l with h, m, l bf16 values (returned as fp32 bit patterns whose low halves are zero)
-__device__ __forceinline__ void split3(float x, unsigned& h, unsigned& m, unsigned& l) {
-  h = bf16_hi(x);
-  const float r = x - __builtin_bit_cast(float, h);
-  m = bf16_hi(r);
-  const float r2 = r - __builtin_bit_cast(float, m);
-  l = bf16_hi(r2);
-}
-
 struct B3 {
   u32x4 h, m, l;  // 8 bf16 each: element j in the low / high half of word j >> 1
 };
@@ -108,51 +93,42 @@ __device__ __forceinline__ f32x4 mfma_bf16(const u32x4 a, const u32x4 b, const f
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// OIHW weights -> the Winograd-transformed (conv_rw.h: rw::filter_transform), split filter image.  Thread <- (o, i)
-// pairs, 9 contiguous floats each.
-template <int MODE>
-__device__ __forceinline__ void put_filter(unsigned short* lds_w, const float (&t)[9], int pr) {
-  const int o = pr >> 5, i = pr & 31;
-  // forward: cout = o, cin = i, taps as stored.  data gradient: cout = i, cin = o, taps flipped in both directions.
-  const int co = MODE == MODE_FWD ? o : i, ci = MODE == MODE_FWD ? i : o;
-  const int mt = co >> 4, li = co & 15, kq = ci >> 3, j = ci & 7;
-#pragma unroll
-  for (int dy = 0; dy < 3; ++dy) {
-    float u[4];
-    if (MODE == MODE_FWD)
-      rw::filter_transform(t[dy * 3 + 0], t[dy * 3 + 1], t[dy * 3 + 2], u);
-    else
-      rw::filter_transform(t[(2 - dy) * 3 + 2], t[(2 - dy) * 3 + 1], t[(2 - dy) * 3 + 0], u);
-#pragma unroll
-    for (int pos = 0; pos < 4; ++pos) {
-      unsigned h, m, l;
-      split3(u[pos], h, m, l);
-      unsigned short* p = lds_w + ((((dy * 4 + pos) * 2 + mt) * 3) * 64 + kq * 16 + li) * 8 + j;
-      p[0] = (unsigned short)(h >> 16), p[64 * 8] = (unsigned short)(m >> 16), p[2 * 64 * 8] = (unsigned short)(l >> 16);
-    }
-  }
-}
-
-// (w1 may be null: one problem.  All loads of a pass are issued before the first LDS write.)
+// OIHW weights -> the Winograd-transformed (conv_rw.h: rw::filter_transform), split filter image.  A work item is one
+// LANE SLOT of one (row tap, channel half): output channel co = 16 mt + li, input channels 8 kq .. 8 kq + 7 -- the 24
+// taps it reads, the 4 x 8 transformed values, their split and twelve 16-byte LDS writes (lane slot kq * 16 + li of the
+// (dy, pos, mt, part) blocks: a wave writes 1 KB contiguous, no bank conflicts).  (The first version gave a thread one
+// (o, i) pair and 108 two-byte writes: 16 k cycles per layer, 8 % of a configs[1] launch; this one ~4 k.)
+// (w1 may be null: one problem.)
 template <int MODE, int NT>
 __device__ __forceinline__ void build_filter(unsigned short* lds_w, const float* __restrict__ w0,
                                              const float* __restrict__ w1, int tid) {
-  constexpr int NP = 1024 / NT;
-  float t0[NP][9], t1[NP][9];
+  const int nitems = (w1 ? 2 : 1) * 6 * 64;
+  for (int item = tid; item < nitems; item += NT) {
+    const int slot = item & 63, dm = (item >> 6) % 6, prob = item / 384;
+    const int li = slot & 15, kq = slot >> 4, dy = dm >> 1, mt = dm & 1;
+    const float* __restrict__ w = prob ? w1 : w0;
+    const int co = 16 * mt + li;
+    float u[8][4];
 #pragma unroll
-  for (int u = 0; u < NP; ++u) {
-    const int pr = tid + u * NT;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) t0[u][k] = w0[pr * 9 + k];
-    if (w1) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) t1[u][k] = w1[pr * 9 + k];
+    for (int j = 0; j < 8; ++j) {
+      const int ci = 8 * kq + j;
+      // forward: cout = o, cin = i, taps as stored.  data gradient: cout = i, cin = o, taps flipped in both directions.
+      const float* t = MODE == MODE_FWD ? w + (co * 32 + ci) * 9 + dy * 3 : w + (ci * 32 + co) * 9 + (2 - dy) * 3;
+      if (MODE == MODE_FWD)
+        rw::filter_transform(t[0], t[1], t[2], u[j]);
+      else
+        rw::filter_transform(t[2], t[1], t[0], u[j]);
     }
-  }
+    u32x4* img = reinterpret_cast<u32x4*>(lds_w + prob * (kWBytes / 2));
 #pragma unroll
-  for (int u = 0; u < NP; ++u) {
-    put_filter<MODE>(lds_w, t0[u], tid + u * NT);
-    if (w1) put_filter<MODE>(lds_w + kWBytes / 2, t1[u], tid + u * NT);
+    for (int pos = 0; pos < 4; ++pos) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = u[j][pos];
+      const B3 x = split8(v);
+      u32x4* p = img + ((((dy * 4 + pos) * 2 + mt) * 3)) * 64 + slot;
+      p[0] = x.h, p[64] = x.m, p[128] = x.l;
+    }
   }
 }
 
