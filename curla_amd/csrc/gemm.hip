@@ -28,7 +28,12 @@ constexpr int RSTR = BK + 8;   // LDS stride, row-major tile [64][BK]: 40 floats
 // disjoint halves of the banks.  (80, the stride of rounds 1-2, put both on the same 16 banks: SQ_LDS_BANK_CONFLICT 0.3-0.4
 // of the LDS cycles of the kernels with a k-major operand.)
 constexpr int KSTR = CURLA_GEMM_KSTR;
-constexpr int kGemmTileFloats = (BK * KSTR > BM * RSTR) ? BK * KSTR : BM * RSTR;
+// bf16x3 form (round 5, gemm_tile<..., B3 = true>): an operand tile is THREE bf16 images [part][row][32 k], rows 80 bytes
+// apart (64 of data: a lane's fragment is one 16-byte read, a staging thread's four k one 8-byte write) = 15 KB
+constexpr int kB3RowBytes = 80;
+constexpr int kB3TileFloats = 3 * BM * kB3RowBytes / 4;
+constexpr int kGemmTileFloatsF32 = (BK * KSTR > BM * RSTR) ? BK * KSTR : BM * RSTR;
+constexpr int kGemmTileFloats = kB3TileFloats > kGemmTileFloatsF32 ? kB3TileFloats : kGemmTileFloatsF32;
 
 struct GemmArgs {
   const float* A;
@@ -149,6 +154,83 @@ __device__ __forceinline__ void frags(const float* __restrict__ S, int row, int 
   }
 }
 
+// ---- bf16x3 operands (the heads' 512 x 1024 x 1024 products ran at 0.6-0.7 of the f32-input MFMA: a barrier per 32-deep
+// k tile with 32 matrix instructions of 32 cycles between two of them).  Every fp32 operand element is split ONCE, when
+// its tile is staged into LDS, into three bf16 parts (x = xh + xm + xl exactly, conv_rwb.h); a k tile is then one k-step
+// of v_mfma_f32_16x16x32_bf16 per term, six terms per fp32 product: 24 matrix instructions of 16 cycles per wave and
+// tile instead of 32 of 32, and the split costs 5.5 VALU instructions per element against the 2 x 16 .. 4 x 16
+// products the element takes part in.  Both operand kinds end in the same image: a row-major operand is loaded as
+// float4 along k, a k-major one as four dword loads along k per thread (a wave reads 64 consecutive rows of one k: 256
+// contiguous bytes), so a thread always holds four consecutive k of one row.
+typedef short gbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned gu32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 gbf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned g_cvt_pk_bf16(float x0, float x1) {
+  const f32x2 v = {x0, x1};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, gbf16x2));
+}
+
+template <bool KMAJOR, int ROWS>
+__device__ __forceinline__ void tile_load_b3(const float* __restrict__ P, int ld, int rows_total, int r0, int k0, int tid,
+                                             f32x4 (&reg)[ROWS / 32]) {
+#pragma unroll
+  for (int u = 0; u < ROWS / 32; ++u) {
+    if (!KMAJOR) {
+      const int row = min(r0 + (tid >> 3) + 32 * u, rows_total - 1), k4 = (tid & 7) * 4;
+      reg[u] = *reinterpret_cast<const f32x4*>(P + (size_t)row * ld + k0 + k4);
+    } else {
+      const int row = tid % ROWS, k4 = 4 * (tid / ROWS + (256 / ROWS) * u);
+      const float* p = P + (size_t)(k0 + k4) * ld + r0 + row;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) reg[u][e] = p[(size_t)e * ld];
+    }
+  }
+}
+
+template <bool KMAJOR, int ROWS>
+__device__ __forceinline__ void tile_store_b3(float* __restrict__ S, int tid, const f32x4 (&reg)[ROWS / 32]) {
+  char* base = reinterpret_cast<char*>(S);
+#pragma unroll
+  for (int u = 0; u < ROWS / 32; ++u) {
+    const int row = KMAJOR ? tid % ROWS : (tid >> 3) + 32 * u;
+    const int k4 = KMAJOR ? 4 * (tid / ROWS + (256 / ROWS) * u) : (tid & 7) * 4;
+    gu32x2 h, m, l;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const float x0 = reg[u][2 * q], x1 = reg[u][2 * q + 1];
+      const unsigned hh = g_cvt_pk_bf16(x0, x1);
+      const float r0 = x0 - __builtin_bit_cast(float, hh << 16), r1 = x1 - __builtin_bit_cast(float, hh & 0xFFFF0000u);
+      const unsigned mm = g_cvt_pk_bf16(r0, r1);
+      const float s0 = r0 - __builtin_bit_cast(float, mm << 16), s1 = r1 - __builtin_bit_cast(float, mm & 0xFFFF0000u);
+      h[q] = hh, m[q] = mm, l[q] = g_cvt_pk_bf16(s0, s1);
+    }
+    char* p = base + row * kB3RowBytes + k4 * 2;
+    *reinterpret_cast<gu32x2*>(p) = h;
+    *reinterpret_cast<gu32x2*>(p + ROWS * kB3RowBytes) = m;
+    *reinterpret_cast<gu32x2*>(p + 2 * ROWS * kB3RowBytes) = l;
+  }
+}
+
+struct Frag3 {
+  gu32x4 h, m, l;
+};
+
+template <int ROWS>
+__device__ __forceinline__ Frag3 frags_b3(const float* __restrict__ S, int row, int kq) {
+  const char* p = reinterpret_cast<const char*>(S) + row * kB3RowBytes + kq * 16;
+  Frag3 f;
+  f.h = *reinterpret_cast<const gu32x4*>(p);
+  f.m = *reinterpret_cast<const gu32x4*>(p + ROWS * kB3RowBytes);
+  f.l = *reinterpret_cast<const gu32x4*>(p + 2 * ROWS * kB3RowBytes);
+  return f;
+}
+
+__device__ __forceinline__ f32x4 g_mfma_bf16(const gu32x4 a, const gu32x4 b, const f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gbf16x8, a), __builtin_bit_cast(gbf16x8, b), c, 0, 0, 0);
+}
+
 // 256 threads = 2 x 2 waves; a wave computes 32 x (TBN/2) of the 64 x TBN tile.
 // TBN = 32 doubles the workgroup count for the mid-sized GEMMs of the heads
 // (512 x 1024 x 1024 is only 128 tiles of 64 x 64 on a 256-CU chip).
@@ -158,9 +240,10 @@ __device__ __forceinline__ void frags(const float* __restrict__ S, int row, int 
 using GemmLds = float[2][kGemmTileFloats];
 
 // one TBM x TBN output tile (tile column bx, tile row by, batch x split item z) by the 256 threads of a workgroup
-template <bool AK, bool BKM, int TBM, int TBN, bool FAST>
+template <bool AK, bool BKM, int TBM, int TBN, bool FAST, bool B3 = false>
 __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int z, GemmLds& As,
                                           GemmLds& Bs) {
+  static_assert(!B3 || FAST, "the bf16x3 form takes interior, aligned tiles only");
   constexpr int MI = TBM / 32;  // 16-row fragments per wave
   constexpr int WM = TBM / 2;   // rows per wave
   constexpr int NJ = TBN / 32;
@@ -205,7 +288,10 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 
   f32x4 ra0[TBM / 32], rb0[TBN / 32], ra1[TBM / 32], rb1[TBN / 32];
   auto load = [&](int k0, f32x4 (&ra)[TBM / 32], f32x4 (&rb)[TBN / 32]) {
-    if (FAST) {
+    if (B3) {
+      tile_load_b3<AK, TBM>(A, g.lda, g.M, m0, k0, tid, ra);
+      tile_load_b3<BKM, TBN>(B, g.ldb, g.N, n0, k0, tid, rb);
+    } else if (FAST) {
       tile_load_fast<AK, TBM>(A, g.lda, g.M, m0, k0, tid, ra);
       tile_load_fast<BKM, TBN>(B, g.ldb, g.N, n0, k0, tid, rb);
     } else {
@@ -214,10 +300,34 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     }
   };
   auto stage = [&](int buf, const f32x4 (&ra)[TBM / 32], const f32x4 (&rb)[TBN / 32]) {
+    if (B3) {
+      tile_store_b3<AK, TBM>(As[buf], tid, ra);
+      tile_store_b3<BKM, TBN>(Bs[buf], tid, rb);
+      return;
+    }
     tile_store<AK, TBM>(As[buf], tid, ra);
     tile_store<BKM, TBN>(Bs[buf], tid, rb);
   };
   auto multiply = [&](int buf) {
+    if (B3) {
+      Frag3 xa[MI], xb[NJ];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) xa[i] = frags_b3<TBM>(As[buf], wm * WM + i * 16 + li, kq);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) xb[j] = frags_b3<TBN>(Bs[buf], wn * WN + j * 16 + li, kq);
+      // six terms per product, smallest first; the (i, j) accumulators interleaved term by term
+#pragma unroll
+      for (int term = 0; term < 6; ++term)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) {
+            const gu32x4& pb = term == 0 ? xb[j].l : (term == 2 || term == 3) ? xb[j].m : xb[j].h;
+            const gu32x4& pa = (term == 0 || term == 3 || term == 5) ? xa[i].h : (term == 1) ? xa[i].l : xa[i].m;
+            acc[i][j] = g_mfma_bf16(pb, pa, acc[i][j]);
+          }
+      return;
+    }
     float fa[MI][8], fb[NJ][8];
 #pragma unroll
     for (int i = 0; i < MI; ++i) frags<AK>(As[buf], wm * WM + i * 16 + li, kq, fa[i]);
@@ -302,28 +412,28 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     }
 }
 
-template <bool AK, bool BKM, int TBM, int TBN, bool FAST>
+template <bool AK, bool BKM, int TBM, int TBN, bool FAST, bool B3 = false>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   __shared__ __attribute__((aligned(16))) GemmLds As, Bs;
-  gemm_tile<AK, BKM, TBM, TBN, FAST>(g, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+  gemm_tile<AK, BKM, TBM, TBN, FAST, B3>(g, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
 }
 
 // Backward of a linear layer as ONE launch: the weight gradient dW = dy^T x (both operands k-major, k = the batch rows)
 // and the data gradient dx = (dy W) masked (W k-major) are independent products over the same dy -- the first `n1`
 // workgroups take the tiles of the first, the rest the tiles of the second (grids gx x gy x batch each).  Saves a
 // launch's ramp and tail per layer and lets the second product's first workgroups fill the first one's last round.
-template <int TM1, int TN1, int TM2, int TN2>
+template <int TM1, int TN1, int TM2, int TN2, bool B3 = false>
 __global__ __launch_bounds__(256) void gemm_pair_kernel(GemmArgs g1, GemmArgs g2, int n1, int gx1, int gy1, int gx2,
                                                         int gy2) {
   __shared__ __attribute__((aligned(16))) GemmLds As, Bs;
   int bid = blockIdx.x;
   if (bid < n1) {
     const int r = bid / gx1;
-    gemm_tile<true, true, TM1, TN1, true>(g1, bid - r * gx1, r % gy1, r / gy1, As, Bs);
+    gemm_tile<true, true, TM1, TN1, true, B3>(g1, bid - r * gx1, r % gy1, r / gy1, As, Bs);
   } else {
     bid -= n1;
     const int r = bid / gx2;
-    gemm_tile<false, true, TM2, TN2, true>(g2, bid - r * gx2, r % gy2, r / gy2, As, Bs);
+    gemm_tile<false, true, TM2, TN2, true, B3>(g2, bid - r * gx2, r % gy2, r / gy2, As, Bs);
   }
 }
 
@@ -1133,6 +1243,13 @@ static int gemm_plan(GemmArgs& g, int a_kmajor, int b_kmajor, GemmPlan& p) {
   return CURLA_OK;
 }
 
+// the tiled kernel's arithmetic (option gemm_mfma): the f32-input MFMA (auto), or bf16x3 on the bf16 matrix cores for
+// interior, aligned tiles (b3).  Measured on configs[1]'s heads (profiles/r05_checks/r05_gemm_b3_vs_f32.txt): 64 x 64 tiles
+// 37.9 against 43.2 us, the dW / dx pair 45.1 against 45.2, 32 x 32 tiles 19.4 against 17.7 -- these products are bound by
+// the barrier per 32-deep k tile and the staging latency, not by the matrix pipe, so a 2.7 x faster pipe buys nothing:
+// opt-in, not the default.
+static bool gemm_b3() { return curla_opt(kOptGemmMfma) == 2; }
+
 static int gemm_launch(GemmArgs& g, int a_kmajor, int b_kmajor, hipStream_t st) {
   const int M = g.M, N = g.N, nbatch = g.nbatch, ksplit = g.ksplit;
   GemmPlan p;
@@ -1161,15 +1278,18 @@ static int gemm_launch(GemmArgs& g, int a_kmajor, int b_kmajor, hipStream_t st) 
   }
   const int tbm = p.tbm, tbn = p.tbn;
   const bool fast = p.fast;
-#define CURLA_GEMM_LAUNCH3(AKM, BKMAJ, TM, TN, FS)                                                          \
-  hipLaunchKernelGGL((gemm_kernel<AKM, BKMAJ, TM, TN, FS>), dim3((N + TN - 1) / TN, (M + TM - 1) / TM, nbatch * ksplit), \
+  const bool b3 = fast && gemm_b3();
+#define CURLA_GEMM_LAUNCH3(AKM, BKMAJ, TM, TN, FS, B3F)                                                     \
+  hipLaunchKernelGGL((gemm_kernel<AKM, BKMAJ, TM, TN, FS, B3F>), dim3((N + TN - 1) / TN, (M + TM - 1) / TM, nbatch * ksplit), \
                      dim3(256), 0, st, g)
 #define CURLA_GEMM_LAUNCH2(AKM, BKMAJ, TM, TN)               \
   do {                                                       \
-    if (fast)                                                \
-      CURLA_GEMM_LAUNCH3(AKM, BKMAJ, TM, TN, true);          \
+    if (b3)                                                  \
+      CURLA_GEMM_LAUNCH3(AKM, BKMAJ, TM, TN, true, true);    \
+    else if (fast)                                           \
+      CURLA_GEMM_LAUNCH3(AKM, BKMAJ, TM, TN, true, false);   \
     else                                                     \
-      CURLA_GEMM_LAUNCH3(AKM, BKMAJ, TM, TN, false);         \
+      CURLA_GEMM_LAUNCH3(AKM, BKMAJ, TM, TN, false, false);  \
   } while (0)
 #define CURLA_GEMM_LAUNCH(AKM, BKMAJ)                        \
   do {                                                       \
@@ -1280,8 +1400,12 @@ int curla_linear_bwd(const float* dy, long long stride_dy, const float* x, long 
     if (!p1.small && !p2.small && p1.fast && p2.fast) {
 #define CURLA_PAIR(TM1, TN1, TM2, TN2)                                                                                   \
   if (p1.tbm == TM1 && p1.tbn == TN1 && p2.tbm == TM2 && p2.tbn == TN2) {                                               \
-    hipLaunchKernelGGL((gemm_pair_kernel<TM1, TN1, TM2, TN2>), dim3((unsigned)(n1 + n2)), dim3(256), 0, st, g1, g2,      \
-                       (int)n1, gx1, gy1, gx2, gy2);                                                                     \
+    if (gemm_b3())                                                                                                       \
+      hipLaunchKernelGGL((gemm_pair_kernel<TM1, TN1, TM2, TN2, true>), dim3((unsigned)(n1 + n2)), dim3(256), 0, st, g1,  \
+                         g2, (int)n1, gx1, gy1, gx2, gy2);                                                               \
+    else                                                                                                                 \
+      hipLaunchKernelGGL((gemm_pair_kernel<TM1, TN1, TM2, TN2>), dim3((unsigned)(n1 + n2)), dim3(256), 0, st, g1, g2,    \
+                         (int)n1, gx1, gy1, gx2, gy2);                                                                   \
     return curla_launch_status();                                                                                        \
   }
       // (the shapes the twin-Q and the actor MLPs produce at batch 512 and 1024, hidden 1024)

@@ -14,6 +14,8 @@ enum CurlaOpt {
   kOptBwdSplit,     // stride-1 backward launch: 0 auto, 1 two + two workgroups per CU, 2 one + one side by side
   kOptGemmTile,     // tile shape of the tiled GEMM: 0 auto, 1 64x64, 2 64x32, 3 32x32
   kOptLinearBwd,    // backward of a linear layer: 0 one launch for dW and dx, 1 two launches
+  kOptGemmMfma,     // arithmetic of the tiled GEMM: 0 auto (= f32), 1 f32 (the f32-input MFMA), 2 b3 (bf16x3 on the bf16 matrix
+                    // cores for interior, aligned tiles: measured no faster on the heads' shapes, gemm.hip gemm_b3)
   kOptCount
 };
 

@@ -26,6 +26,7 @@ const OptDef kDefs[kOptCount] = {
     {"bwd_split", {"auto", "0", "1", nullptr}, {nullptr, "off", "on", nullptr}},
     {"gemm_tile", {"auto", "6464", "6432", "3232", nullptr}, {nullptr, "64x64", "64x32", "32x32", nullptr}},
     {"linear_bwd", {"pair", "split", nullptr}, {nullptr, nullptr, nullptr}},
+    {"gemm_mfma", {"auto", "f32", "b3", nullptr}, {nullptr, nullptr, "bf16x3", nullptr}},
 };
 
 std::atomic<int> g_value[kOptCount];

@@ -52,6 +52,8 @@ int curla_abi_version(void);
  *   bwd_split   auto | 0 | 1           stride-1 backward: 2 + 2 workgroups per CU, or 1 + 1 side by side
  *   gemm_tile   auto | 6464 | 6432 | 3232
  *   linear_bwd  pair | split           dW and dx of a linear layer in one launch or two
+ *   gemm_mfma   auto | f32 | b3        arithmetic of the tiled GEMM: f32-input MFMA (auto), or b3: interior aligned tiles with fp32
+ *                                      operands as three bf16 parts on the bf16 matrix cores, split once when a tile is staged
  * curla_set_option returns CURLA_ERR_ARG for an unknown name or value; curla_get_option NULL for an unknown name. */
 int curla_set_option(const char* name, const char* value);
 const char* curla_get_option(const char* name);

@@ -184,6 +184,7 @@ SWITCHES = [
     ("gemm_tile=6432", {"gemm_tile": "6432"}, {}, "random_crop", (), ()),
     ("gemm_tile=3232", {"gemm_tile": "3232"}, {}, "random_crop", (), ()),
     ("linear_bwd=split", {"linear_bwd": "split"}, {}, "random_crop", (), ()),
+    ("gemm_mfma=b3", {"gemm_mfma": "b3"}, {}, "random_crop", (), ()),
     ("CURLA_CURL_HEAD=unfused", {}, {"CURLA_CURL_HEAD": "unfused"}, "random_crop", ("curla_curl_ce",), ("curla_curl_head",)),
     ("CURLA_FC_FWD=gemm", {}, {"CURLA_FC_FWD": "gemm"}, "random_crop", ("curla_gemm_multi",), ("curla_fc_fwd_multi",)),
     ("CURLA_FOUR_Q=0", {}, {"CURLA_FOUR_Q": "0"}, "random_crop", (), ("curla_gemm_nested",)),
