@@ -98,6 +98,9 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 template <int NW>
 __device__ __forceinline__ void rwb_fwd_body(const rw::Args& A) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds_h[];
+#ifdef RWB_STAMP
+  const unsigned long long kt0 = __builtin_readcyclecounter(), kr0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int l = 0; l < A.nlayers; ++l) {
 #ifdef RWB_STAMP
     const unsigned long long k0 = __builtin_readcyclecounter();
@@ -123,6 +126,12 @@ __device__ __forceinline__ void rwb_fwd_body(const rw::Args& A) {
     }
 #endif
   }
+#ifdef RWB_STAMP
+  if (threadIdx.x == 0 && blockIdx.x == 7) {
+    rwb::g_rwb_stamp[15] += __builtin_readcyclecounter() - kt0;
+    rwb::g_rwb_stamp[14] += __builtin_amdgcn_s_memrealtime() - kr0;
+  }
+#endif
 }
 
 __global__ __launch_bounds__(512, 1) void conv_rwb_fwd_kernel(rw::Args A) { rwb_fwd_body<8>(A); }
@@ -816,6 +825,19 @@ __global__ __launch_bounds__(256, 2) void bwd_rw2_kernel(rw::WgradArgs wa, rw::A
   }
 }
 
+// ... and with the data gradient in its bf16x3 form (conv_rwb.h) beside it: 256-thread workgroups of both kinds, the data
+// gradient's with 72 KB of LDS for its split filter
+__global__ __launch_bounds__(256, 2) void bwd_rwb2_kernel(rw::WgradArgs wa, rw::Args da, int nw) {
+  if ((int)blockIdx.x < nw) {
+    rw::wgrad_body<4>(wa, blockIdx.x, nw);
+  } else {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds_hb[];
+    rwb::build_filter<MODE_DGRAD, 256>(lds_hb, da.p[0][0].w, nullptr, threadIdx.x);
+    __syncthreads();
+    rwb::run_layer<MODE_DGRAD, 4>(da.g[0], da.p[0][0], da.p[0][1], lds_hb, (int)blockIdx.x - nw, (int)gridDim.x - nw);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // weight gradient of the first layer (stride 2, Cin = C, input re-read from
 // the uint8 frames / float tensor exactly as the forward does).
@@ -1374,8 +1396,9 @@ bool dgrad_f43(int Wi) {
   return opt == 2 || (opt == 0 && (Wi + 3) / 4 >= 16);
 }
 
-// ... or the bf16x3 kernel (conv_rwb.h)?
-bool dgrad_b3() { return curla_opt(kOptS1Fwd) == 3; }
+// ... or the bf16x3 kernel (conv_rwb.h)?  (auto: yes -- beside the weight gradient's workgroups in one launch it takes
+// configs[1] from 474.6 to 487.3 update()/s and configs[4] from 34.6 to 35.2 against the F(2,3) / F(4,3) forms)
+bool dgrad_b3() { return curla_opt(kOptS1Fwd) == 3 || curla_opt(kOptS1Fwd) == 0; }
 
 int launch_dgrad_b3(const float* g, const float* w, const float* act_below, float* gin, int B, int Ho, int Wo,
                     hipStream_t st) {
@@ -1722,10 +1745,22 @@ int curla_conv3x3_s1_bwd_slabs(const float* in, const float* g, const float* w, 
   const int Ho = Hi - 2, Wo = Wi - 2;
   if (!rw_supported(Hi, Wi)) return CURLA_ERR_UNSUPPORTED;
   if (dgrad_b3()) {
-    // the data gradient on the bf16 matrix cores (512-thread workgroups), the weight gradient as its own launch
-    const int rcw = launch_wgrad_s1(in, g, workspace, B, Hi, Wi, channels, static_cast<hipStream_t>(stream), nslabs);
-    if (rcw != CURLA_OK) return rcw;
-    return launch_dgrad_b3(g, w, in, gin, B, Ho, Wo, static_cast<hipStream_t>(stream));
+    // the data gradient on the bf16 matrix cores, beside the weight gradient's workgroups in one launch (one of each
+    // kind per CU side by side, or two and two)
+    const int split_opt = curla_opt(kOptBwdSplit);
+    const bool split2 = split_opt ? split_opt == 2 : (long long)B * Ho * Wo <= (1LL << 20);
+    const int cap2 = split2 ? curla_cu_count() : 2 * curla_cu_count();
+    const int n2 = B < cap2 ? B : cap2;
+    rw::WgradArgs wr{in, g, workspace, B, Hi, Wi, Ho, Wo, rw::plan4(Hi, Wi, Ho, Wo)};
+    rw::Args dr = rw_dgrad_args(g, w, in, gin, B, Ho, Wo);
+    dr.g[0] = rwb::plan(Ho, Wo, Ho + 2, Wo + 2);
+    size_t lds2 = rwb::kWBytes;
+    if (lds2 < kPartialS1 * sizeof(float)) lds2 = kPartialS1 * sizeof(float);
+    int rc2 = set_lds(bwd_rwb2_kernel, lds2);
+    if (rc2 != CURLA_OK) return rc2;
+    hipLaunchKernelGGL(bwd_rwb2_kernel, dim3(2 * n2), dim3(256), lds2, static_cast<hipStream_t>(stream), wr, dr, n2);
+    *nslabs = n2;
+    return curla_launch_status();
   }
   if (dgrad_f43(Wi)) {
     // wide rows: the data gradient with Winograd F(4,3) (one wave per SIMD), the weight gradient as its own launch

@@ -8,9 +8,8 @@
 enum CurlaOpt {
   kOptConv1U8 = 0,  // first layer from the uint8 ring: 0 hybrid (crop in LDS, row walk out of LDS), 1 band, 2 rw (no LDS)
   kOptConv1F32,     // first layer (and its weight gradient) from a float NHWC minibatch: 0 rw (conv1_rw.h), 1 band
-  kOptS1Fwd,        // stride-1 forward / data gradient: 0 auto (forward: b3; data gradient: F(4,3) for rows of at least 16
-                    // pixel quads, else F(2,3) in one launch with the weight gradient), 1 Winograd F(2,3) on the f32-input
-                    // MFMA (conv_rw.h), 2 F(4,3) (conv_rw43.h), 3 bf16x3 on the bf16 matrix cores (conv_rwb.h)
+  kOptS1Fwd,        // stride-1 forward / data gradient: 0 auto (= b3), 1 Winograd F(2,3) on the f32-input MFMA (conv_rw.h),
+                    // 2 F(4,3) (conv_rw43.h), 3 bf16x3 on the bf16 matrix cores behind F(2,3) (conv_rwb.h)
   kOptBwdSplit,     // stride-1 backward launch: 0 auto, 1 two + two workgroups per CU, 2 one + one side by side
   kOptGemmTile,     // tile shape of the tiled GEMM: 0 auto, 1 64x64, 2 64x32, 3 32x32
   kOptLinearBwd,    // backward of a linear layer: 0 one launch for dW and dx, 1 two launches

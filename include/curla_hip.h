@@ -47,8 +47,7 @@ int curla_abi_version(void);
  *   conv1_u8    hybrid | band | rw     first layer from the uint8 ring (utils.py:151-166 + encoder.py:78-81)
  *   conv1_f32   rw | band              first layer and its weight gradient from a float NHWC minibatch
  *   s1_fwd      auto | f23 | f43 | b3  stride-1 forward / data gradient: Winograd F(2,3) or F(4,3) along x on the f32-input MFMA, or
- *                                      b3: fp32 operands as three bf16 parts on the bf16 matrix cores behind F(2,3) (auto: b3 for the
- *                                      forward; data gradient F(4,3) / F(2,3) by row width)
+ *                                      b3 (= auto): fp32 operands as three bf16 parts on the bf16 matrix cores behind F(2,3)
  *   bwd_split   auto | 0 | 1           stride-1 backward: 2 + 2 workgroups per CU, or 1 + 1 side by side
  *   gemm_tile   auto | 6464 | 6432 | 3232
  *   linear_bwd  pair | split           dW and dx of a linear layer in one launch or two

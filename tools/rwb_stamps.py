@@ -35,6 +35,8 @@ print(f"pieces {out[9]} with {out[10]} rows: {out[8] / max(1, out[9]):.0f} cycle
 np_ = max(1, out[9])
 print("edge steps, cycles each: t=0 %.0f  t=1 %.0f  t=n %.0f  t=n+1 %.0f" % tuple(out[11 + e] / np_ for e in range(4)))
 n = max(1, out[3])
+print(f"whole kernel, wave 0 of workgroup 7: {out[15]} shader cycles in {out[14]} ticks of the 100 MHz clock: "
+      f"{out[15] / max(1, out[14]) * 0.1:.2f} GHz, {out[14] / 20 / 100:.1f} us per launch")
 nl = max(1, out[7])
 print(f"layers {nl}: filter build + barrier {out[4] / nl:.0f}  run_layer {out[5] / nl:.0f}  end-of-layer barrier {out[6] / nl:.0f} cycles per layer; "
       f"sum over a launch's 3 layers {(out[4] + out[5] + out[6]) / nl * 3:.0f}")
