@@ -389,7 +389,18 @@ def _run(tag, obs_shape, in_hw, aug_name, layers, B, pixel_sac, capacity):
     REPORT.append((f"{tag} largest un-aligned gradient error against float64: fp32 oracle", worst[1]))
     REPORT.append((f"{tag} (fp32 oracle seconds on {torch.get_num_threads()} host threads)", t_oracle))
     REPORT.append((f"{tag} (float64 arbiter seconds, PyTorch float64 on the device)", t_oracle64))
-    assert n_hip64 <= 2 * n_ref64 + 8, (n_hip64, n_ref64)
+    # (round 5: with the stride-1 convs on the bf16x3 form the device disagrees with float64 as often as the fp32 oracle
+    # does -- 108 against 109 branches at configs[4], 7 / 5 and 16 / 13 at configs[1] / [2]; F(4,3) had 154 -- so the
+    # bound is 1.5 x the reference's own count, not 2 x)
+    assert n_hip64 <= 1.5 * n_ref64 + 8, (n_hip64, n_ref64)
+    # Why the un-aligned GRADIENT errors are bounded per configuration and not per tensor (per tensor they are
+    # reported, second column of gpurun_out/fullsize_arbiter.txt): the events are discrete and few.  One hidden unit of
+    # a 1024-wide MLP layer, or one conv activation, whose pre-activation is within fp32 rounding of zero moves the
+    # gradients below it by 1e-4 .. 1e-3 of their size, on whichever side it happens: in the round-5 run
+    # `critic grad Q1.trunk.0.bias` at configs[4] is 1.6e-4 from float64 on the device and 8.6e-8 for the fp32 oracle
+    # (ratio 1900: the device has one such unit in Q1's first hidden layer, the oracle none), while
+    # `critic grad encoder.convs.0.weight` at configs[1] is 2.6e-4 / 2.4e-4.  A per-tensor ratio test would fail or pass
+    # by the draw; aligned along either side's own branches every tensor is within 5e-6 (asserted above, per tensor).
     if not worst[0] <= max(RTOL, 4.0 * worst[1]):
         bad.append((f"{tag} largest un-aligned gradient error [device vs 4 x fp32 oracle]", worst[0], 4.0 * worst[1]))
     bad = [b for b in bad if b is not None]

@@ -42,6 +42,23 @@ def test_random_crop_bit_exact_84_to_76():
     assert np.array_equal(O.center_crop(imgs[0], (76, 76)), g["center_crop0"])
 
 
+def test_crop_fixture_under_the_genuine_skimage():
+    """make_goldens.py records crop84.npz with ``sliding_window_view`` standing in for skimage's ``view_as_windows``
+    (this interpreter has no scikit-image).  Where the image's conda interpreter with the GENUINE scikit-image and the
+    reference are both present (the build container), the reference's RandomCrop is re-run under it and must give the
+    fixture's bytes; elsewhere (the GPU box has no /root/reference) the check is skipped."""
+    import os
+    import subprocess
+
+    import pytest
+    conda, ref = "/opt/conda/bin/python3.9", os.environ.get("CURLA_REFERENCE", "/root/reference")
+    if not (os.path.exists(conda) and os.path.exists(os.path.join(ref, "augmentations.py"))):
+        pytest.skip("needs the build container: /opt/conda (scikit-image) and /root/reference")
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "check_crop_with_skimage.py")
+    r = subprocess.run([conda, script], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "crop84.npz confirmed" in r.stdout, r.stdout + r.stderr
+
+
 def test_sample_cpc_draw_order_bit_exact():
     g = load("tiny.npz")
     rs = np.random.RandomState()
