@@ -242,9 +242,11 @@ __device__ __forceinline__ void run_layer(const Geom& G, const Problem& P0, cons
       // six products of one (position, row tap, channel half) into one accumulator, smallest terms first (`acc` of a
       // row's first tap: zeros, or the bias for position 1 -- the C operand of the first instruction, no register moves)
       auto mul6 = [&](f32x4 acc, const W3& w, const B3& x) {
+#if !(defined(RWB_ABL) && (RWB_ABL & 4))  // timing-only ablation: three of the six products (results wrong)
         acc = mfma_bf16(w.l, x.h, acc);
         acc = mfma_bf16(w.h, x.l, acc);
         acc = mfma_bf16(w.m, x.m, acc);
+#endif
         acc = mfma_bf16(w.m, x.h, acc);
         acc = mfma_bf16(w.h, x.m, acc);
         acc = mfma_bf16(w.h, x.h, acc);

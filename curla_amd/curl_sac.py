@@ -1287,11 +1287,14 @@ class CurlSacAgent(object):
         torch.save(self.critic.state_dict(), '%s/%s_critic_%s.pt' % (model_dir, augmentation, step))
 
     def load(self, model_dir, augmentation, step):
-        """curl_sac.py:458-465."""
+        """curl_sac.py:458-465 (same files, same three progress lines on stdout)."""
         self.CURL.load_state_dict(torch.load('%s/%s_curl_%s.pt' % (model_dir, augmentation, step)))
+        print('Loaded model %s/%s_curl_%s.pt' % (model_dir, augmentation, step))
         self.actor.load_state_dict(torch.load('%s/%s_actor_%s.pt' % (model_dir, augmentation, step)))
+        print('Loaded model %s/%s_actor_%s.pt' % (model_dir, augmentation, step))
         self.critic.load_state_dict(torch.load('%s/%s_critic_%s.pt' % (model_dir, augmentation, step)))
         self.critic_target.load_state_dict(self.critic.state_dict())
+        print('Loaded model %s/%s_critic_%s.pt' % (model_dir, augmentation, step))
 
     # -- full training state (SURVEY.md 8f rank 2: the reference only writes the three state_dicts above and
     #    cannot resume; this adds log_alpha, the target critic, the five Adam states, the RNG streams and the step)
