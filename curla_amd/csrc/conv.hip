@@ -1312,13 +1312,15 @@ int set_lds(K kernel, size_t bytes) {
   return curla_set_dyn_lds(reinterpret_cast<const void*>(kernel), kMaxLds);
 }
 
-// Which uint8 first-layer forward runs (option conv1_u8, options.h): the default is the hybrid conv1_u8_walk_kernel
-// (crop staged in LDS as bytes, row walk out of LDS) whenever the crop fits one band of LDS, else the banded loop;
-// "band" forces the banded loop, "rw" the LDS-free row walk (conv1_u8_rw.h).  Measured on 1024 + 512 / 512 + 512 samples
-// of configs[1]: alone, re-reading the same ring slots out of the Infinity Cache, the LDS-free walk takes 100 / 66 us
-// against the banded loop's 128 / 86; on slots drawn afresh for every launch from a ring of gigabytes -- what update()
-// does -- 114 us on average against 104 (hybrid: 102).
-bool use_rw_u8() { return curla_opt(kOptConv1U8) == 2; }
+// Which uint8 first-layer forward runs (option conv1_u8, options.h): "rw" = the LDS-free row walk (conv1_u8_rw.h),
+// "hybrid" = conv1_u8_walk_kernel (crop staged in LDS as bytes, row walk out of LDS) whenever the crop fits one band of
+// LDS, else the banded loop, "band" = the banded loop.  Measured on 1024 + 512 / 512 + 512 samples of configs[1]: alone,
+// re-reading the same ring slots out of the Infinity Cache, the LDS-free walk takes 100 / 66 us against the banded
+// loop's 128 / 86; on slots drawn afresh for every launch from a ring of gigabytes -- what update() does -- it was the
+// slower one in rounds 3-4 (114 us on average against the hybrid's 102) and is the faster one since the stride-1
+// convs around it run on the bf16 matrix cores (round 5, whole update, alternating runs on one box: configs[1] 493.4 /
+// 493.4 against 489.0 / 490.2 update()/s, configs[2] 634.3 against 632.0).  auto = rw where it applies.
+bool use_rw_u8() { return curla_opt(kOptConv1U8) == 3 || curla_opt(kOptConv1U8) == 0; }
 
 // The row-walk forward keeps (pixel pair, 32 channels) of a whole row in flight per wave; any width works, the strips
 // only get more numerous.  Limits: byte offsets inside one sample must fit 31 bits.
@@ -1637,7 +1639,7 @@ static int conv1_fwd_impl(const void* src, int src_kind, const int64_t* idx, con
   }
     // one band = the whole crop in LDS: the hybrid form (row walk out of LDS) unless option conv1_u8 = band asks for the
     // banded loop (its staging gives a lane one 16-byte run of a crop row: rows of at most 64 runs)
-    if (a.nbands == 1 && Wc * C <= 64 * 16 && curla_opt(kOptConv1U8) != 1) {
+    if (a.nbands == 1 && Wc * C <= 64 * 16 && curla_opt(kOptConv1U8) != 2) {
       rw::Geom G;
       G.Hi = Hc, G.Wi = Wc, G.Ho = a.Ho, G.Wo = a.Wo;
       rw::plan_units(G, a.Ho, a.Wo, 16);

@@ -20,7 +20,7 @@ struct OptDef {
 };
 
 const OptDef kDefs[kOptCount] = {
-    {"conv1_u8", {"hybrid", "band", "rw", nullptr}, {nullptr, nullptr, nullptr, nullptr}},
+    {"conv1_u8", {"auto", "hybrid", "band", "rw", nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}},
     {"conv1_f32", {"rw", "band", nullptr}, {nullptr, nullptr, nullptr}},
     {"s1_fwd", {"auto", "f23", "f43", "b3", nullptr}, {nullptr, nullptr, nullptr, "bf16x3", nullptr}},
     {"bwd_split", {"auto", "0", "1", nullptr}, {nullptr, "off", "on", nullptr}},

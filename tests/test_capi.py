@@ -71,7 +71,7 @@ def test_options_api_refuses_unknown_names_and_values():
     refused, ``_lib.option`` scopes a value to a block."""
     from curla_amd import _lib
     assert set(_lib.OPTIONS) == {"conv1_u8", "conv1_f32", "s1_fwd", "bwd_split", "gemm_tile", "linear_bwd", "gemm_mfma"}
-    defaults = {"conv1_u8": "hybrid", "conv1_f32": "rw", "s1_fwd": "auto", "bwd_split": "auto", "gemm_tile": "auto",
+    defaults = {"conv1_u8": "auto", "conv1_f32": "rw", "s1_fwd": "auto", "bwd_split": "auto", "gemm_tile": "auto",
                 "linear_bwd": "pair", "gemm_mfma": "auto"}
     for k in _lib.OPTIONS:
         if "CURLA_" + k.upper() not in os.environ:

@@ -170,6 +170,7 @@ def _compare(tag, got, want):
 
 # (options, environment, augmentation, C-ABI entry points that must / must not have been called)
 SWITCHES = [
+    ("conv1_u8=hybrid", {"conv1_u8": "hybrid"}, {}, "random_crop", (), ()),
     ("conv1_u8=band", {"conv1_u8": "band"}, {}, "random_crop", (), ()),
     ("conv1_u8=rw", {"conv1_u8": "rw"}, {}, "random_crop", (), ()),
     ("conv1_f32=band", {"conv1_f32": "band"}, {}, "color_jiggle", (), ()),
