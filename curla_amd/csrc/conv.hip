@@ -6,14 +6,16 @@
 //
 // Layout: activations are NHWC fp32 in HBM ([B][H][W][32]); conv weights stay
 // in the reference OIHW layout (they are nn.Parameters shared with Adam) and
-// are re-gathered into MFMA operand images at kernel start.  Every inner
-// product runs on the exact-f32 matrix pipe (v_mfma_f32_16x16x4_f32), which has
-// the same 157 TFLOP/s roof as the fp32 vector pipe but needs one operand VGPR
-// per lane instead of 2 per FMA.  The stride-1 layers (forward, data gradient, weight gradient) are the row-walk
-// kernels of conv_rw.h / conv_rw_wgrad.h: 1-D Winograd F(2,3) along x, a wave walks down a strip of pixel-pair
-// columns with the transformed filter streamed from LDS; the first layer has a banded form (crop staged in LDS) and
-// row-walk forms (conv1_rw.h, conv1_u8_rw.h).  What bounds the loops is VALU issue time (a VALU instruction and an
-// f32 MFMA cannot issue in the same cycle), so everything in them is counted in instructions.  (Rounds 1-3 also
+// are re-gathered into MFMA operand images at kernel start.  The stride-1 forward and data gradient run on the bf16
+// matrix cores with fp32 operands as exact sums of three bf16 parts (conv_rwb.h, round 5: six exact bf16 products per
+// fp32 product, fp32 accumulation); every other inner product runs on the exact-f32 matrix pipe
+// (v_mfma_f32_16x16x4_f32), which has the same 157 TFLOP/s roof as the fp32 vector pipe but needs one operand VGPR
+// per lane instead of 2 per FMA.  The stride-1 layers (forward, data gradient, weight gradient) are row-walk
+// kernels (conv_rwb.h; conv_rw.h / conv_rw43.h: the f32-input forms, selectable; conv_rw_wgrad.h): 1-D Winograd F(2,3)
+// along x, a wave walks down a strip of pixel-pair columns with the transformed filter streamed from LDS; the first
+// layer has a banded form (crop staged in LDS) and row-walk forms (conv1_rw.h, conv1_u8_rw.h).  What bounds the
+// f32-input loops is VALU issue time (a VALU instruction and an f32 MFMA cannot issue in the same cycle), so
+// everything in them is counted in instructions.  (Rounds 1-3 also
 // carried a banded LDS-tiled form of the stride-1 kernels; it was removed in round 4 once the row walk covered
 // every shape -- DESIGN.md section 3.)
 #include <cstdlib>
@@ -135,7 +137,6 @@ __device__ __forceinline__ void rwb_fwd_body(const rw::Args& A) {
 }
 
 __global__ __launch_bounds__(512, 1) void conv_rwb_fwd_kernel(rw::Args A) { rwb_fwd_body<8>(A); }
-__global__ __launch_bounds__(1024, 1) void conv_rwb_fwd16_kernel(rw::Args A) { rwb_fwd_body<16>(A); }
 
 __global__ __launch_bounds__(512, 1) void conv_rwb_dgrad_kernel(rw::Args A) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds_h[];
@@ -1356,13 +1357,6 @@ int launch_rw_fwd(int nlayers, const float* in, const float* const* w, const flo
   const int grid = owned ? cus : (bmax < cus ? bmax : cus);
   if (b3) {
     const size_t ldsb = (size_t)(B2 > 0 ? 2 : 1) * rwb::kWBytes;
-    static const bool w16 = getenv("CURLA_RWB_WAVES") && atoi(getenv("CURLA_RWB_WAVES")) == 16;  // (experiment)
-    if (w16) {
-      int rcb = set_lds(conv_rwb_fwd16_kernel, ldsb);
-      if (rcb != CURLA_OK) return rcb;
-      hipLaunchKernelGGL(conv_rwb_fwd16_kernel, dim3(grid), dim3(1024), ldsb, st, A);
-      return curla_launch_status();
-    }
     int rcb = set_lds(conv_rwb_fwd_kernel, ldsb);
     if (rcb != CURLA_OK) return rcb;
     hipLaunchKernelGGL(conv_rwb_fwd_kernel, dim3(grid), dim3(512), ldsb, st, A);

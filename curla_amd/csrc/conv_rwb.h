@@ -36,10 +36,6 @@
 // problem), read one group ahead.
 #pragma once
 
-#ifndef RWB_STAGGER
-#define RWB_STAGGER 0  // s_sleep units (64 cycles) by which the second wave of every SIMD starts a layer late
-#endif
-
 namespace rwb {
 
 using rw::Args;
@@ -156,9 +152,6 @@ __device__ __forceinline__ void run_layer(const Geom& G, const Problem& P0, cons
   // this wave's share of the workgroup's steps: [lo, hi) of the concatenation over (sample, strip)
   const int lo = (int)((long)wave * T / NW), hi = (int)((long)(wave + 1) * T / NW);
   const int in_row = G.Wi * 128, out_row = G.Wo * 128;  // bytes per row
-#if RWB_STAGGER
-  if (wave >= NW / 2) __builtin_amdgcn_s_sleep(RWB_STAGGER);
-#endif
 
   int before = 0;  // steps of the instances before the current one
   for (int si = 0; si < cnt0 + cnt1; ++si) {
