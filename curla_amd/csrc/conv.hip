@@ -189,6 +189,23 @@ __global__ __launch_bounds__(kC1U8Threads, kC1U8PerCU) void conv1_u8_rw_fwd_kern
     rw::conv1_u8_body<C, kC1U8Threads / 64, false>(a, lds_img, blockIdx.x, gridDim.x);
 }
 
+// ... and on the bf16 matrix cores (uint8 pixels are exact in bf16: one part for the pixels, three for the weights; C <= 10).
+// The weight fragments take 72 registers (148 in all): three 256-thread workgroups per CU (3 waves per SIMD)
+constexpr int kC1U8bThreads = 256, kC1U8bPerCU = 3;
+template <int C>
+__global__ __launch_bounds__(kC1U8bThreads, kC1U8bPerCU) void conv1_u8_rwb_fwd_kernel(rw::Conv1U8Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_imgb[2 * rw::kConv1U8B3ImageBytes];
+  rw::conv1_u8b_stage_weights<C, kC1U8bThreads>(lds_imgb, a.p[0].w, a.p[0].bias, a.scale, threadIdx.x);
+  if (a.p[1].B > 0)
+    rw::conv1_u8b_stage_weights<C, kC1U8bThreads>(lds_imgb + rw::kConv1U8B3ImageBytes, a.p[1].w, a.p[1].bias, a.scale,
+                                                  threadIdx.x);
+  __syncthreads();
+  if ((a.Ws * C) % 4 == 0)
+    rw::conv1_u8b_body<C, kC1U8bThreads / 64, true>(a, lds_imgb, blockIdx.x, gridDim.x);
+  else
+    rw::conv1_u8b_body<C, kC1U8bThreads / 64, false>(a, lds_imgb, blockIdx.x, gridDim.x);
+}
+
 // ---------------------------------------------------------------------------
 // first layer: Cin = C (9 or 12 ...), stride 2, input either the uint8 replay
 // frames (gather by index + random-crop offsets + /255 fused into the load) or
@@ -1321,7 +1338,7 @@ int set_lds(K kernel, size_t bytes) {
 // slower one in rounds 3-4 (114 us on average against the hybrid's 102) and is the faster one since the stride-1
 // convs around it run on the bf16 matrix cores (round 5, whole update, alternating runs on one box: configs[1] 493.4 /
 // 493.4 against 489.0 / 490.2 update()/s, configs[2] 634.3 against 632.0).  auto = rw where it applies.
-bool use_rw_u8() { return curla_opt(kOptConv1U8) == 3 || curla_opt(kOptConv1U8) == 0; }
+bool use_rw_u8() { return curla_opt(kOptConv1U8) == 3 || curla_opt(kOptConv1U8) == 0 || curla_opt(kOptConv1U8) == 4; }
 
 // The row-walk forward keeps (pixel pair, 32 channels) of a whole row in flight per wave; any width works, the strips
 // only get more numerous.  Limits: byte offsets inside one sample must fit 31 bits.
@@ -1610,6 +1627,17 @@ static int conv1_fwd_impl(const void* src, int src_kind, const int64_t* idx, con
     const long long pool = (long long)(B + a.B2) * ra.g.steps;
     const int want = (int)((pool + 63) / 64);
     const int grid_rw = want < cap ? (want < 1 ? 1 : want) : cap;
+    // the bf16 form where an input row's 3 C operand bytes are one k-step of 32 (option conv1_u8 = auto / rwb)
+    const int o8 = curla_opt(kOptConv1U8);
+    if ((o8 == 0 || o8 == 4) && 3 * C <= 32) {
+      const int capb = kC1U8bPerCU * curla_cu_count();
+      const int wantb = (int)((pool + 31) / 32);
+      const int grid_rwb = wantb < capb ? (wantb < 1 ? 1 : wantb) : capb;
+#define CONV1_U8_RWB_LAUNCH(CC) hipLaunchKernelGGL((conv1_u8_rwb_fwd_kernel<CC>), dim3(grid_rwb), dim3(kC1U8bThreads), 0, st, ra)
+      if (C == 9) CONV1_U8_RWB_LAUNCH(9); else if (C == 6) CONV1_U8_RWB_LAUNCH(6); else CONV1_U8_RWB_LAUNCH(3);
+#undef CONV1_U8_RWB_LAUNCH
+      return curla_launch_status();
+    }
 #define CONV1_U8_RW_LAUNCH(CC) hipLaunchKernelGGL((conv1_u8_rw_fwd_kernel<CC>), dim3(grid_rw), dim3(kC1U8Threads), 0, st, ra)
     if (C == 9) CONV1_U8_RW_LAUNCH(9); else if (C == 12) CONV1_U8_RW_LAUNCH(12); else if (C == 6) CONV1_U8_RW_LAUNCH(6); else CONV1_U8_RW_LAUNCH(3);
 #undef CONV1_U8_RW_LAUNCH
@@ -1741,10 +1769,11 @@ int curla_conv3x3_s1_bwd_slabs(const float* in, const float* g, const float* w, 
   const int Ho = Hi - 2, Wo = Wi - 2;
   if (!rw_supported(Hi, Wi)) return CURLA_ERR_UNSUPPORTED;
   if (dgrad_b3()) {
-    // the data gradient on the bf16 matrix cores, beside the weight gradient's workgroups in one launch (one of each
-    // kind per CU side by side, or two and two)
+    // the data gradient on the bf16 matrix cores, beside the weight gradient's workgroups in one launch: one workgroup
+    // of each kind per CU side by side (auto; with this data gradient it is the faster split for long launches too --
+    // configs[4] 35.9 against 35.2 update()/s), or two and two (option bwd_split = 0)
     const int split_opt = curla_opt(kOptBwdSplit);
-    const bool split2 = split_opt ? split_opt == 2 : (long long)B * Ho * Wo <= (1LL << 20);
+    const bool split2 = split_opt ? split_opt == 2 : true;
     const int cap2 = split2 ? curla_cu_count() : 2 * curla_cu_count();
     const int n2 = B < cap2 ? B : cap2;
     rw::WgradArgs wr{in, g, workspace, B, Hi, Wi, Ho, Wo, rw::plan4(Hi, Wi, Ho, Wo)};

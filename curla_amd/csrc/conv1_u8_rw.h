@@ -16,7 +16,8 @@
 // channels and walks down: output row y needs input rows 2y, 2y+1, 2y+2, the last of which is the next row's first, so
 // a step loads and converts two new rows (2 loads, 2 E conversions) for 6 E MFMAs.  No LDS, no barrier.
 //
-// Status: OPT-IN (option conv1_u8 = rw).  Alone -- the same ring slots re-read out of the Infinity Cache from launch to
+// Status (rounds 3-4; since round 5 this walk is what option conv1_u8 = auto takes, see conv.hip use_rw_u8 and the bf16 form at the end
+// of this file): opt-in.  Alone -- the same ring slots re-read out of the Infinity Cache from launch to
 // launch -- it is the faster kernel (1024 samples of 76x76x9: 66-71 us against 85; 1536: 100-105 against 128).  On slots
 // drawn afresh from a ring of gigabytes for every launch, which is what update() does, it is the slower one: 114 us on
 // average against 104 under rocprofv3 on the same box (88 against 88 per 1024 samples in the microbenchmark).  More
@@ -253,6 +254,228 @@ __device__ __forceinline__ void conv1_u8_body(const Conv1U8Args& a, const float*
       };
 
       Row S0, S1, S2, S3, S4;
+      Pair P0, P1, P2;
+      {
+        Raw R0;
+        load_row(R0, 0), load_row(P0.a, 1), load_row(P0.b, 2), load_row(P1.a, 3), load_row(P1.b, 4);
+        convert(S0, R0);
+      }
+      for (int t = 0;;) {  // rows of step t sit in sets (2t, 2t+1, 2t+2) mod 5, its bytes in pair t mod 3
+        step(S0, S1, S2, P0, P2, t);
+        if (++t >= n) break;
+        step(S2, S3, S4, P1, P0, t);
+        if (++t >= n) break;
+        step(S4, S0, S1, P2, P1, t);
+        if (++t >= n) break;
+        step(S1, S2, S3, P0, P2, t);
+        if (++t >= n) break;
+        step(S3, S4, S0, P1, P0, t);
+        if (++t >= n) break;
+        step(S0, S1, S2, P2, P1, t);
+        if (++t >= n) break;
+        step(S2, S3, S4, P0, P2, t);
+        if (++t >= n) break;
+        step(S4, S0, S1, P1, P0, t);
+        if (++t >= n) break;
+        step(S1, S2, S3, P2, P1, t);
+        if (++t >= n) break;
+        step(S3, S4, S0, P0, P2, t);
+        if (++t >= n) break;
+        step(S0, S1, S2, P1, P0, t);
+        if (++t >= n) break;
+        step(S2, S3, S4, P2, P1, t);
+        if (++t >= n) break;
+        step(S4, S0, S1, P0, P2, t);
+        if (++t >= n) break;
+        step(S1, S2, S3, P1, P0, t);
+        if (++t >= n) break;
+        step(S3, S4, S0, P2, P1, t);
+        if (++t >= n) break;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same layer on the BF16 matrix cores (round 5; 3 C <= 32, i.e. C <= 10).  A uint8 pixel value is EXACT in bf16 (8
+// significand bits), so the pixel operand needs ONE part; the weight (with obs / 255's 1 / 255 folded in, as above)
+// is split into three bf16 parts (conv_rwb.h), and a product is three exact bf16 x bf16 products accumulated in fp32 --
+// the same value an fp32 multiply-add chain gives, up to the order of the sum.  The 3 C <= 32 operand bytes of an output
+// pixel and one input row are ONE k-step of v_mfma_f32_16x16x32_bf16: lane group kq takes bytes 8 kq .. 8 kq + 7 of
+// the run (one aligned three-dword load + v_alignbyte, then 8 v_cvt_f32_ubyte + 4 packs: a float that holds an integer
+// below 256 has nothing in its low half, so the bf16 is its high half) -- 18 matrix instructions of 16 cycles per
+// output row of 16 pixels instead of 6 E = 42 of 32 cycles.  The three split parts of every (row tap, channel half)
+// weight fragment stay in 72 registers (re-read from an LDS image when a piece changes minibatch).  Everything else --
+// the pool of steps, the pieces, the two-steps-ahead row requests -- is conv1_u8_body's.
+struct U8Frag {
+  unsigned d[4];  // 8 bf16
+};
+
+// image of one problem: [dy][mt][part][lane slot (kq * 16 + li)][8 bf16] + 32 float biases
+constexpr int kConv1U8B3ImageBytes = 3 * 2 * 3 * 64 * 16 + 32 * 4;
+
+template <int C, int NT>
+__device__ __forceinline__ void conv1_u8b_stage_weights(unsigned char* img, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float scale, int tid) {
+  static_assert(3 * C <= 32, "one k-step per input row");
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  auto pk = [](float x0, float x1) {
+    const f32x2 v = {x0, x1};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+  };
+  for (int item = tid; item < 3 * 2 * 64; item += NT) {
+    const int slot = item & 63, dm = item >> 6, dy = dm >> 1, mt = dm & 1;
+    const int li = slot & 15, kq = slot >> 4, co = 16 * mt + li;
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float x[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int rr = 8 * kq + 2 * q + e, dx = rr / C, c = rr - dx * C;
+        x[e] = rr < 3 * C ? w[(co * C + c) * 9 + dy * 3 + dx] * scale : 0.f;
+      }
+      h[q] = pk(x[0], x[1]);
+      const float r0 = x[0] - __builtin_bit_cast(float, h[q] << 16), r1 = x[1] - __builtin_bit_cast(float, h[q] & 0xFFFF0000u);
+      m[q] = pk(r0, r1);
+      const float s0 = r0 - __builtin_bit_cast(float, m[q] << 16), s1 = r1 - __builtin_bit_cast(float, m[q] & 0xFFFF0000u);
+      l[q] = pk(s0, s1);
+    }
+    typedef unsigned u4 __attribute__((ext_vector_type(4)));
+    u4* p = reinterpret_cast<u4*>(img) + (dm * 3) * 64 + slot;
+    p[0] = u4{h[0], h[1], h[2], h[3]}, p[64] = u4{m[0], m[1], m[2], m[3]}, p[128] = u4{l[0], l[1], l[2], l[3]};
+  }
+  if (tid < 32) reinterpret_cast<float*>(img + 3 * 2 * 3 * 64 * 16)[tid] = bias[tid];
+}
+
+template <int C, int NW, bool AL>
+__device__ __forceinline__ void conv1_u8b_body(const Conv1U8Args& a, const unsigned char* lds_img, const int bid,
+                                               const int nblk) {
+  constexpr int E = 8;                             // operand bytes per lane group and input row (one k-step of 32)
+  constexpr int NW_ = 2;                           // dwords that hold them once they start at byte 0
+  constexpr int NL = AL ? 3 : NW_;                 // dwords per load (aligned: the run starts at byte 0..3 of the first)
+  typedef short bf16x8 __attribute__((ext_vector_type(8)));
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const Geom& G = a.g;
+
+  const int B0 = a.p[0].B;
+  const int pool = (B0 + a.p[1].B) * G.steps;
+  const int per = pool / nblk, rem = pool - per * nblk;
+  const int g0 = bid * per + (bid < rem ? bid : rem), len = per + (bid < rem ? 1 : 0);
+  const int lo = g0 + len * wave / NW, hi = g0 + len * (wave + 1) / NW;
+  const int in_row = a.Ws * C, out_row = a.Wo * 128;  // bytes per row
+  const int frame = a.Hs * in_row;
+
+  u4 wf[3][2][3];  // [row tap][channel half][part h / m / l]: the lane's fragment of the split, scaled weights
+  f32x4 bias4[2];
+  int have = -1;
+
+  for (int g = lo; g < hi;) {
+    const int u = g / G.steps;      // sample (both minibatches counted through)
+    const int r = g - u * G.steps;  // step inside the sample -> strip k, row sb of the strip
+    int k, sb, n_strip;
+    if (r < G.nfull * G.Ho) {
+      k = r / G.Ho, sb = r - k * G.Ho, n_strip = G.Ho;
+    } else {
+      const int q = (r - G.nfull * G.Ho) / G.nr;
+      k = G.nfull + q, sb = r - G.nfull * G.Ho - q * G.nr, n_strip = G.nr;
+    }
+    const int n = hi - g < n_strip - sb ? hi - g : n_strip - sb;  // this wave runs output rows [sb, sb + n) of the strip
+    g += n;
+    const int prob = u >= B0 ? 1 : 0;
+    const int b = u - (prob ? B0 : 0);
+    const Conv1U8Problem& P = a.p[prob];
+    if (prob != have) {
+      have = prob;
+      const unsigned char* im = lds_img + prob * kConv1U8B3ImageBytes;
+      const u4* wl = reinterpret_cast<const u4*>(im) + lane;
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int p = 0; p < 3; ++p) wf[dy][mt][p] = wl[((dy * 2 + mt) * 3 + p) * 64];
+      const float* bl = reinterpret_cast<const float*>(im + 3 * 2 * 3 * 64 * 16);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) bias4[mt] = *reinterpret_cast<const f32x4*>(bl + mt * 16 + 4 * kq);
+    }
+    // (descriptors, scalar index loads, lane geometry: as conv1_u8_body; the lane group's run is 8 bytes at 8 kq, of
+    // which bytes >= 3 C -- the next pixels' -- meet zero weights; the last lane group's window ends up to 5 + 3 bytes
+    // past the 3 C bytes of a pixel run: + 16 bytes of range, the ring's 32 readable bytes of slack cover them)
+    const long long slot = P.idx ? const_load(P.idx, b) : b;
+    const int origin = ((P.h1 ? const_load(P.h1, b) : 0) * a.Ws + (P.w1 ? const_load(P.w1, b) : 0)) * C;
+    const uint8_t* crop = a.src + (size_t)slot * frame + origin;
+    const int mis = AL ? (int)(reinterpret_cast<uintptr_t>(crop) & 3) : 0;
+    const __amdgpu_buffer_rsrc_t rin = uniform_rsrc(crop - mis, frame - origin + 16 + mis);
+    const __amdgpu_buffer_rsrc_t rout = uniform_rsrc(P.out + (size_t)b * a.Ho * a.Wo * 32, a.Ho * out_row);
+    {
+      int x, y0;
+      bool lane_on;
+      if (k < G.nfull) {
+        x = 16 * k + li, y0 = 0, lane_on = true;
+      } else {
+        const int uu = (k - G.nfull) * 16 + li;
+        const int col = uu / G.nseg, sg = uu - col * G.nseg;
+        lane_on = col < G.brem;
+        x = 16 * G.nfull + col, y0 = sg * G.nr;
+      }
+      const int Y = y0 + sb;
+      const unsigned run = (unsigned)((2 * Y * a.Ws + 2 * x) * C + E * kq + mis);
+      const unsigned vin = lane_on ? (AL ? run & ~3u : run) : 0x80000000u;
+      const unsigned sh = run & 3u;
+      unsigned vo = lane_on ? (unsigned)((Y * a.Wo + x) * 128 + kq * 16) : 0x80000000u;
+
+      using Raw = RawBytes<NL>;
+      auto load_row = [&](Raw& R, int rr) {  // crop row 2 Y + rr
+        load_raw<NL>(R, rin, vin, __builtin_amdgcn_readfirstlane((unsigned)(rr * in_row)));
+      };
+      // 8 bytes -> 8 bf16: the float of an integer below 256 is exact and its low half is zero
+      auto convert = [&](u4& F, const Raw& R) {
+        RawBytes<NW_> Wd;
+#pragma unroll
+        for (int j = 0; j < NW_; ++j)
+          Wd.d[j] = AL ? __builtin_amdgcn_alignbyte(R.d[j + 1], R.d[j], sh) : R.d[j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float f0 = byte_f32<NW_>(Wd, 2 * q), f1 = byte_f32<NW_>(Wd, 2 * q + 1);
+          F[q] = (__builtin_bit_cast(unsigned, f0) >> 16) | (__builtin_bit_cast(unsigned, f1) & 0xFFFF0000u);
+        }
+      };
+      auto mma_row = [&](f32x4 (&acc)[2], const u4& F, const int dy) {
+        const bf16x8 xb = __builtin_bit_cast(bf16x8, F);
+#pragma unroll
+        for (int p = 2; p >= 0; --p)  // smallest part first
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[dy][mt][p]), xb, acc[mt], 0, 0, 0);
+      };
+      struct Pair {
+        Raw a, b;
+      };
+      auto step = [&](const u4& r0, u4& r1, u4& r2, const Pair& cur, Pair& nxt, const int t) {
+        load_row(nxt.a, 2 * t + 2 * kDepth + 1);
+        load_row(nxt.b, 2 * t + 2 * kDepth + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[2] = {bias4[0], bias4[1]};
+        mma_row(acc, r0, 0);
+        convert(r1, cur.a);
+        convert(r2, cur.b);
+        mma_row(acc, r1, 1);
+        mma_row(acc, r2, 2);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+          f32x4 v = acc[mt];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) v[rr] = relu_bits(v[rr]);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), rout, vo + mt * 64u, 0, CURLA_ACT_STORE_POLICY);
+        }
+        vo += out_row;
+      };
+
+      u4 S0, S1, S2, S3, S4;
       Pair P0, P1, P2;
       {
         Raw R0;

@@ -6,8 +6,8 @@
 #pragma once
 
 enum CurlaOpt {
-  kOptConv1U8 = 0,  // first layer from the uint8 ring: 0 auto (= rw where it applies), 1 hybrid (crop in LDS, row walk out of
-                    // LDS), 2 band, 3 rw (no LDS)
+  kOptConv1U8 = 0,  // first layer from the uint8 ring: 0 auto (= rwb where 3 C <= 32, else rw), 1 hybrid (crop in LDS, row walk
+                    // out of LDS), 2 band, 3 rw (no LDS, f32-input MFMA), 4 rwb (no LDS, bf16 matrix cores: uint8 is exact in bf16)
   kOptConv1F32,     // first layer (and its weight gradient) from a float NHWC minibatch: 0 rw (conv1_rw.h), 1 band
   kOptS1Fwd,        // stride-1 forward / data gradient: 0 auto (= b3), 1 Winograd F(2,3) on the f32-input MFMA (conv_rw.h),
                     // 2 F(4,3) (conv_rw43.h), 3 bf16x3 on the bf16 matrix cores behind F(2,3) (conv_rwb.h)

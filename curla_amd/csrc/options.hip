@@ -15,12 +15,12 @@ namespace {
 
 struct OptDef {
   const char* name;           // curla_set_option's name; the environment variable is CURLA_ + upper case
-  const char* values[5];      // value i of the option has the text values[i]; alias[i] is accepted as well
-  const char* alias[5];
+  const char* values[6];      // value i of the option has the text values[i]; alias[i] is accepted as well
+  const char* alias[6];
 };
 
 const OptDef kDefs[kOptCount] = {
-    {"conv1_u8", {"auto", "hybrid", "band", "rw", nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr}},
+    {"conv1_u8", {"auto", "hybrid", "band", "rw", "rwb", nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}},
     {"conv1_f32", {"rw", "band", nullptr}, {nullptr, nullptr, nullptr}},
     {"s1_fwd", {"auto", "f23", "f43", "b3", nullptr}, {nullptr, nullptr, nullptr, "bf16x3", nullptr}},
     {"bwd_split", {"auto", "0", "1", nullptr}, {nullptr, "off", "on", nullptr}},
@@ -33,7 +33,7 @@ std::atomic<int> g_value[kOptCount];
 std::once_flag g_once;
 
 int parse(const OptDef& d, const char* text) {
-  for (int i = 0; i < 5 && d.values[i]; ++i)
+  for (int i = 0; i < 6 && d.values[i]; ++i)
     if (!strcmp(text, d.values[i]) || (d.alias[i] && !strcmp(text, d.alias[i]))) return i;
   return -1;
 }

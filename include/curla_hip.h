@@ -44,7 +44,8 @@ int curla_abi_version(void);
  * the other values are fallbacks for shapes the default does not take or A/B partners for measurements, and every
  * value runs under the whole-update parity test (tests/test_gpu_switches.py).  The environment variable
  * CURLA_<NAME> sets the initial value (read once, at first use); afterwards only these calls change it.
- *   conv1_u8    auto | hybrid | band | rw   first layer from the uint8 ring (utils.py:151-166 + encoder.py:78-81); auto = rw
+ *   conv1_u8    auto | hybrid | band | rw | rwb   first layer from the uint8 ring (utils.py:151-166 + encoder.py:78-81); auto = rwb
+ *                                      (LDS-free row walk on the bf16 matrix cores: a uint8 pixel is exact in bf16) where 3 C <= 32, else rw
  *   conv1_f32   rw | band              first layer and its weight gradient from a float NHWC minibatch
  *   s1_fwd      auto | f23 | f43 | b3  stride-1 forward / data gradient: Winograd F(2,3) or F(4,3) along x on the f32-input MFMA, or
  *                                      b3 (= auto): fp32 operands as three bf16 parts on the bf16 matrix cores behind F(2,3)

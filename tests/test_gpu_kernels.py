@@ -136,11 +136,12 @@ CONV1_CASES = [  # C, Hs, Ws, Hc, Wc, B
 ]
 
 
-@pytest.fixture(params=["hybrid", "band", "rw"])
+@pytest.fixture(params=["hybrid", "band", "rw", "rwb"])
 def u8_impl(request):
     """The three uint8 first-layer forwards: the hybrid (crop staged in LDS + row walk out of LDS when the crop fits
     one band, else the banded loop), the banded loop alone (option conv1_u8 = band) and the row walk straight from
-    memory (conv1_u8 = rw, conv1_u8_rw.h: what `auto` takes)."""
+    memory, on the f32-input MFMA (conv1_u8 = rw) and on the bf16 matrix cores (conv1_u8 = rwb: what `auto` takes where
+    3 C <= 32; conv1_u8_rw.h)."""
     from curla_amd import _lib
     with _lib.option("conv1_u8", request.param):
         yield request.param

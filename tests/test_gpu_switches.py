@@ -173,6 +173,7 @@ SWITCHES = [
     ("conv1_u8=hybrid", {"conv1_u8": "hybrid"}, {}, "random_crop", (), ()),
     ("conv1_u8=band", {"conv1_u8": "band"}, {}, "random_crop", (), ()),
     ("conv1_u8=rw", {"conv1_u8": "rw"}, {}, "random_crop", (), ()),
+    ("conv1_u8=rwb", {"conv1_u8": "rwb"}, {}, "random_crop", (), ()),
     ("conv1_f32=band", {"conv1_f32": "band"}, {}, "color_jiggle", (), ()),
     ("s1_fwd=f43", {"s1_fwd": "f43"}, {}, "random_crop", (), ()),
     ("s1_fwd=f23", {"s1_fwd": "f23"}, {}, "random_crop", (), ()),
