@@ -28,12 +28,19 @@ constexpr int RSTR = BK + 8;   // LDS stride, row-major tile [64][BK]: 40 floats
 // disjoint halves of the banks.  (80, the stride of rounds 1-2, put both on the same 16 banks: SQ_LDS_BANK_CONFLICT 0.3-0.4
 // of the LDS cycles of the kernels with a k-major operand.)
 constexpr int KSTR = CURLA_GEMM_KSTR;
-// bf16x3 form (round 5, gemm_tile<..., B3 = true>): an operand tile is THREE bf16 images [part][row][32 k], rows 80 bytes
-// apart (64 of data: a lane's fragment is one 16-byte read, a staging thread's four k one 8-byte write) = 15 KB
-constexpr int kB3RowBytes = 80;
-constexpr int kB3TileFloats = 3 * BM * kB3RowBytes / 4;
+// bf16x3 form (round 5, gemm_tile<..., B3 = true>): an operand tile is THREE bf16 images [part][row][32 k], rows 96 bytes
+// apart (64 of data: a lane's fragment is one 16-byte read, a staging thread's four k one 8-byte write).  96: the four
+// 16-lane groups of a ds_read_b128 (MI355X_MICROARCH.md, LDS) each see 16 different 16-byte slots of the 256-byte bank
+// row at row * 96 + kq * 16 (80, the first version's stride, was 2-way); the parts sit 64 bytes off a multiple of 128
+// apart so that the h / m / l stores of one thread do not share banks either.
+constexpr int kB3RowBytes = 96;
+constexpr int b3_part_bytes(int rows) { return rows * kB3RowBytes + 64; }
+constexpr int b3_tile_floats(int rows) { return 3 * b3_part_bytes(rows) / 4; }
 constexpr int kGemmTileFloatsF32 = (BK * KSTR > BM * RSTR) ? BK * KSTR : BM * RSTR;
-constexpr int kGemmTileFloats = kB3TileFloats > kGemmTileFloatsF32 ? kB3TileFloats : kGemmTileFloatsF32;
+// floats of one operand tile buffer with `rows` rows (the f32 forms exist for up to 64 rows only)
+constexpr int gemm_tile_floats(int rows) {
+  return rows > 64 ? b3_tile_floats(rows) : (b3_tile_floats(64) > kGemmTileFloatsF32 ? b3_tile_floats(64) : kGemmTileFloatsF32);
+}
 
 struct GemmArgs {
   const float* A;
@@ -172,16 +179,16 @@ __device__ __forceinline__ unsigned g_cvt_pk_bf16(float x0, float x1) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, gbf16x2));
 }
 
-template <bool KMAJOR, int ROWS>
+template <bool KMAJOR, int ROWS, int NT = 256>
 __device__ __forceinline__ void tile_load_b3(const float* __restrict__ P, int ld, int rows_total, int r0, int k0, int tid,
-                                             f32x4 (&reg)[ROWS / 32]) {
+                                             f32x4 (&reg)[ROWS * 8 / NT]) {
 #pragma unroll
-  for (int u = 0; u < ROWS / 32; ++u) {
+  for (int u = 0; u < ROWS * 8 / NT; ++u) {
     if (!KMAJOR) {
-      const int row = min(r0 + (tid >> 3) + 32 * u, rows_total - 1), k4 = (tid & 7) * 4;
+      const int row = min(r0 + (tid >> 3) + (NT / 8) * u, rows_total - 1), k4 = (tid & 7) * 4;
       reg[u] = *reinterpret_cast<const f32x4*>(P + (size_t)row * ld + k0 + k4);
     } else {
-      const int row = tid % ROWS, k4 = 4 * (tid / ROWS + (256 / ROWS) * u);
+      const int row = tid % ROWS, k4 = 4 * (tid / ROWS + (NT / ROWS) * u);
       const float* p = P + (size_t)(k0 + k4) * ld + r0 + row;
 #pragma unroll
       for (int e = 0; e < 4; ++e) reg[u][e] = p[(size_t)e * ld];
@@ -189,13 +196,13 @@ __device__ __forceinline__ void tile_load_b3(const float* __restrict__ P, int ld
   }
 }
 
-template <bool KMAJOR, int ROWS>
-__device__ __forceinline__ void tile_store_b3(float* __restrict__ S, int tid, const f32x4 (&reg)[ROWS / 32]) {
+template <bool KMAJOR, int ROWS, int NT = 256>
+__device__ __forceinline__ void tile_store_b3(float* __restrict__ S, int tid, const f32x4 (&reg)[ROWS * 8 / NT]) {
   char* base = reinterpret_cast<char*>(S);
 #pragma unroll
-  for (int u = 0; u < ROWS / 32; ++u) {
-    const int row = KMAJOR ? tid % ROWS : (tid >> 3) + 32 * u;
-    const int k4 = KMAJOR ? 4 * (tid / ROWS + (256 / ROWS) * u) : (tid & 7) * 4;
+  for (int u = 0; u < ROWS * 8 / NT; ++u) {
+    const int row = KMAJOR ? tid % ROWS : (tid >> 3) + (NT / 8) * u;
+    const int k4 = KMAJOR ? 4 * (tid / ROWS + (NT / ROWS) * u) : (tid & 7) * 4;
     gu32x2 h, m, l;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -208,8 +215,8 @@ __device__ __forceinline__ void tile_store_b3(float* __restrict__ S, int tid, co
     }
     char* p = base + row * kB3RowBytes + k4 * 2;
     *reinterpret_cast<gu32x2*>(p) = h;
-    *reinterpret_cast<gu32x2*>(p + ROWS * kB3RowBytes) = m;
-    *reinterpret_cast<gu32x2*>(p + 2 * ROWS * kB3RowBytes) = l;
+    *reinterpret_cast<gu32x2*>(p + b3_part_bytes(ROWS)) = m;
+    *reinterpret_cast<gu32x2*>(p + 2 * b3_part_bytes(ROWS)) = l;
   }
 }
 
@@ -222,8 +229,8 @@ __device__ __forceinline__ Frag3 frags_b3(const float* __restrict__ S, int row, 
   const char* p = reinterpret_cast<const char*>(S) + row * kB3RowBytes + kq * 16;
   Frag3 f;
   f.h = *reinterpret_cast<const gu32x4*>(p);
-  f.m = *reinterpret_cast<const gu32x4*>(p + ROWS * kB3RowBytes);
-  f.l = *reinterpret_cast<const gu32x4*>(p + 2 * ROWS * kB3RowBytes);
+  f.m = *reinterpret_cast<const gu32x4*>(p + b3_part_bytes(ROWS));
+  f.l = *reinterpret_cast<const gu32x4*>(p + 2 * b3_part_bytes(ROWS));
   return f;
 }
 
@@ -231,21 +238,28 @@ __device__ __forceinline__ f32x4 g_mfma_bf16(const gu32x4 a, const gu32x4 b, con
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gbf16x8, a), __builtin_bit_cast(gbf16x8, b), c, 0, 0, 0);
 }
 
-// 256 threads = 2 x 2 waves; a wave computes 32 x (TBN/2) of the 64 x TBN tile.
+// NT = 256 threads = 2 x 2 waves, a wave computes (TBM/2) x (TBN/2) of the TBM x TBN tile; NT = 512 (the 128 x 64 bf16x3
+// tile): 4 x 2 waves of 32 x 32 -- two waves per SIMD (with one wave per SIMD, 64 x 32 each, the k tile's phases ran
+// back to back: 37 against 32 us for the twin critics' hidden layer).
 // TBN = 32 doubles the workgroup count for the mid-sized GEMMs of the heads
 // (512 x 1024 x 1024 is only 128 tiles of 64 x 64 on a 256-CU chip).
 // The k loop is double-buffered in LDS (two operand tile pairs, 40 KB): while the waves multiply tile t out of one
 // buffer, tile t+1 goes from registers into the other and tile t+2 is in flight from HBM/L2 -- ONE barrier per k tile,
 // and the LDS write -> barrier -> fragment read latency of the next tile sits under the current tile's MFMAs.
-using GemmLds = float[2][kGemmTileFloats];
+template <int ROWS>
+using GemmLds = float[2][gemm_tile_floats(ROWS)];
 
 // one TBM x TBN output tile (tile column bx, tile row by, batch x split item z) by the 256 threads of a workgroup
-template <bool AK, bool BKM, int TBM, int TBN, bool FAST, bool B3 = false>
-__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int z, GemmLds& As,
-                                          GemmLds& Bs) {
+template <bool AK, bool BKM, int TBM, int TBN, bool FAST, bool B3 = false, int NT = 256>
+__device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const int by, const int z, float (*As)[gemm_tile_floats(TBM)],
+                                          float (*Bs)[gemm_tile_floats(TBN)]) {
   static_assert(!B3 || FAST, "the bf16x3 form takes interior, aligned tiles only");
-  constexpr int MI = TBM / 32;  // 16-row fragments per wave
-  constexpr int WM = TBM / 2;   // rows per wave
+  static_assert(TBM <= 64 || B3, "tiles of more than 64 rows exist in the bf16x3 form only");
+  static_assert(NT == 256 || B3, "the f32 forms are written for 256 threads");
+  constexpr int WR = NT / 128;        // rows of waves (two columns of waves always)
+  constexpr int WM = TBM / WR;        // rows per wave
+  constexpr int MI = WM / 16;         // 16-row fragments per wave
+  constexpr int RA = TBM * 8 / NT, RB = TBN * 8 / NT;  // staging registers (float4) per thread and operand
   constexpr int NJ = TBN / 32;
   constexpr int WN = TBN / 2;  // columns per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -286,12 +300,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0, 0, 0, 0};
 
-  f32x4 ra0[TBM / 32], rb0[TBN / 32], ra1[TBM / 32], rb1[TBN / 32];
-  auto load = [&](int k0, f32x4 (&ra)[TBM / 32], f32x4 (&rb)[TBN / 32]) {
-    if (B3) {
-      tile_load_b3<AK, TBM>(A, g.lda, g.M, m0, k0, tid, ra);
-      tile_load_b3<BKM, TBN>(B, g.ldb, g.N, n0, k0, tid, rb);
-    } else if (FAST) {
+  auto load = [&](int k0, f32x4 (&ra)[RA], f32x4 (&rb)[RB]) {
+    if constexpr (B3) {
+      tile_load_b3<AK, TBM, NT>(A, g.lda, g.M, m0, k0, tid, ra);
+      tile_load_b3<BKM, TBN, NT>(B, g.ldb, g.N, n0, k0, tid, rb);
+    } else if constexpr (FAST) {
       tile_load_fast<AK, TBM>(A, g.lda, g.M, m0, k0, tid, ra);
       tile_load_fast<BKM, TBN>(B, g.ldb, g.N, n0, k0, tid, rb);
     } else {
@@ -299,17 +312,17 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
       tile_load<BKM, TBN>(B, g.ldb, g.N, n0, k0, kend, g.vecB, tid, rb);
     }
   };
-  auto stage = [&](int buf, const f32x4 (&ra)[TBM / 32], const f32x4 (&rb)[TBN / 32]) {
-    if (B3) {
-      tile_store_b3<AK, TBM>(As[buf], tid, ra);
-      tile_store_b3<BKM, TBN>(Bs[buf], tid, rb);
-      return;
+  auto stage = [&](int buf, const f32x4 (&ra)[RA], const f32x4 (&rb)[RB]) {
+    if constexpr (B3) {
+      tile_store_b3<AK, TBM, NT>(As[buf], tid, ra);
+      tile_store_b3<BKM, TBN, NT>(Bs[buf], tid, rb);
+    } else {
+      tile_store<AK, TBM>(As[buf], tid, ra);
+      tile_store<BKM, TBN>(Bs[buf], tid, rb);
     }
-    tile_store<AK, TBM>(As[buf], tid, ra);
-    tile_store<BKM, TBN>(Bs[buf], tid, rb);
   };
   auto multiply = [&](int buf) {
-    if (B3) {
+    if constexpr (B3) {
       Frag3 xa[MI], xb[NJ];
 #pragma unroll
       for (int i = 0; i < MI; ++i) xa[i] = frags_b3<TBM>(As[buf], wm * WM + i * 16 + li, kq);
@@ -326,8 +339,7 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
             const gu32x4& pa = (term == 0 || term == 3 || term == 5) ? xa[i].h : (term == 1) ? xa[i].l : xa[i].m;
             acc[i][j] = g_mfma_bf16(pb, pa, acc[i][j]);
           }
-      return;
-    }
+    } else {
     float fa[MI][8], fb[NJ][8];
 #pragma unroll
     for (int i = 0; i < MI; ++i) frags<AK>(As[buf], wm * WM + i * 16 + li, kq, fa[i]);
@@ -339,9 +351,11 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(fb[j][s], fa[i][s], acc[i][j]);
+    }
   };
   const int ntiles = (kend - kbeg + BK - 1) / BK;
   if (ntiles > 0) {
+    f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
     load(kbeg, ra0, rb0);
     load(ntiles > 1 ? kbeg + BK : kbeg, ra1, rb1);  // (a single-tile product re-reads its tile: keeps this branch-free)
     stage(0, ra0, rb0);
@@ -412,28 +426,61 @@ __device__ __forceinline__ void gemm_tile(const GemmArgs& g, const int bx, const
     }
 }
 
-template <bool AK, bool BKM, int TBM, int TBN, bool FAST, bool B3 = false>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) GemmLds As, Bs;
-  gemm_tile<AK, BKM, TBM, TBN, FAST, B3>(g, blockIdx.x, blockIdx.y, blockIdx.z, As, Bs);
+#ifndef CURLA_GEMM_XCD
+#define CURLA_GEMM_XCD 1
+#endif
+// Workgroup b runs on XCD b mod 8 (each XCD has its own L2).  xcd_order gives XCD x the x-th eighth of the tile list, so
+// that with the tiles listed row tile fastest, then column tile, then problem, an XCD's workgroups share a few column
+// tiles of B and the rows of A of ONE problem instead of touching every problem's A.
+__device__ __forceinline__ int xcd_order(int b, int total) {
+  return (CURLA_GEMM_XCD && (total & 7) == 0) ? (b & 7) * (total >> 3) + (b >> 3) : b;
+}
+
+template <bool AK, bool BKM, int TBM, int TBN, bool FAST, bool B3 = false, int NT = 256>
+__global__ __launch_bounds__(NT) void gemm_kernel(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) GemmLds<TBM> As;
+  __shared__ __attribute__((aligned(16))) GemmLds<TBN> Bs;
+  // one-dimensional grid: gx * gy * (nbatch * ksplit) workgroups in XCD order
+  const int gx = (g.N + TBN - 1) / TBN, gy = (g.M + TBM - 1) / TBM;
+  const int v = xcd_order(blockIdx.x, gx * gy * g.nbatch * g.ksplit);
+  const int r = v / gy;
+  gemm_tile<AK, BKM, TBM, TBN, FAST, B3, NT>(g, r % gx, v - r * gy, r / gx, As, Bs);
 }
 
 // Backward of a linear layer as ONE launch: the weight gradient dW = dy^T x (both operands k-major, k = the batch rows)
 // and the data gradient dx = (dy W) masked (W k-major) are independent products over the same dy -- the first `n1`
 // workgroups take the tiles of the first, the rest the tiles of the second (grids gx x gy x batch each).  Saves a
 // launch's ramp and tail per layer and lets the second product's first workgroups fill the first one's last round.
-template <int TM1, int TN1, int TM2, int TN2, bool B3 = false>
-__global__ __launch_bounds__(256) void gemm_pair_kernel(GemmArgs g1, GemmArgs g2, int n1, int gx1, int gy1, int gx2,
-                                                        int gy2) {
-  __shared__ __attribute__((aligned(16))) GemmLds As, Bs;
+template <int TM1, int TN1, int TM2, int TN2, bool B3 = false, bool SECOND_FIRST = false, int NT = 256>
+__global__ __launch_bounds__(NT) void gemm_pair_kernel(GemmArgs g1, GemmArgs g2, int n1, int gx1, int gy1, int gx2,
+                                                        int gy2, int n2) {
+  constexpr int RA = TM1 > TM2 ? TM1 : TM2, RB = TN1 > TN2 ? TN1 : TN2;
+  __shared__ __attribute__((aligned(16))) GemmLds<RA> As;
+  __shared__ __attribute__((aligned(16))) GemmLds<RB> Bs;
   int bid = blockIdx.x;
+  // XCD order inside each product (xcd_order), the second product's share of an XCD first when SECOND_FIRST (its tiles
+  // are the longer ones: k = N against k = the batch rows -- the short ones then fill the last round)
+  if (CURLA_GEMM_XCD && ((n1 | n2) & 7) == 0) {
+    const int x = bid & 7, i = bid >> 3, s1 = n1 >> 3, s2 = n2 >> 3;
+    const int fst = SECOND_FIRST ? s2 : s1;
+    const bool in_first = i < fst;
+    const bool second = SECOND_FIRST ? in_first : !in_first;
+    const int j = in_first ? i : i - fst;
+    bid = second ? n1 + x * s2 + j : x * s1 + j;
+  } else if (SECOND_FIRST) {
+    bid = bid < n2 ? bid + n1 : bid - n2;
+  }
   if (bid < n1) {
-    const int r = bid / gx1;
-    gemm_tile<true, true, TM1, TN1, true, B3>(g1, bid - r * gx1, r % gy1, r / gy1, As, Bs);
+    const int r = bid / gy1;
+    gemm_tile<true, true, TM1, TN1, true, B3, NT>(g1, r % gx1, bid - r * gy1, r / gx1,
+                                                  reinterpret_cast<float(*)[gemm_tile_floats(TM1)]>(&As[0][0]),
+                                                  reinterpret_cast<float(*)[gemm_tile_floats(TN1)]>(&Bs[0][0]));
   } else {
     bid -= n1;
-    const int r = bid / gx2;
-    gemm_tile<false, true, TM2, TN2, true, B3>(g2, bid - r * gx2, r % gy2, r / gy2, As, Bs);
+    const int r = bid / gy2;
+    gemm_tile<false, true, TM2, TN2, true, B3, NT>(g2, r % gx2, bid - r * gy2, r / gx2,
+                                                   reinterpret_cast<float(*)[gemm_tile_floats(TM2)]>(&As[0][0]),
+                                                   reinterpret_cast<float(*)[gemm_tile_floats(TN2)]>(&Bs[0][0]));
   }
 }
 
@@ -1195,14 +1242,31 @@ static bool small_shape(int M, int N, int K, int nbatch) {
 
 // which kernel a product takes: the small-output kernel (16 or 4 waves per tile) or the tiled one with its tile shape
 struct GemmPlan {
-  bool small, wide, fast;
+  bool small, wide, fast, b3;
   int tbm, tbn;
 };
 
-static int gemm_plan(GemmArgs& g, int a_kmajor, int b_kmajor, GemmPlan& p) {
+// the tiled kernel's arithmetic (option gemm_mfma): f32 = the f32-input MFMA everywhere; b3 = bf16x3 on the bf16 matrix
+// cores for every interior, aligned tile; auto = bf16x3 where the 128 x 64 tile applies, f32 elsewhere.  History
+// (profiles/r05_checks/r05_gemm_b3_vs_f32.txt): with the f32 form's own 64 x 64 / 64 x 32 / 32 x 32 tiles bf16x3 bought
+// nothing (37.9 against 43.2 us, 45.1 / 45.2, 19.4 / 17.7) -- three bf16 images are 1.5 x the LDS bytes of the f32 tile
+// and the matrix instructions take a sixth of the time, so those tiles are bound by LDS stores and fragment reads, not by
+// the matrix pipe.  A 128 x 64 tile (a wave: 64 x 32, six fragment reads per 48 matrix instructions) halves the LDS
+// traffic per product.
+static int gemm_mfma_opt() { return curla_opt(kOptGemmMfma); }
+static bool gemm_b3() { return gemm_mfma_opt() == 2; }
+
+// whether the 128 x 64 bf16x3 tile can take this product at all (whole tiles, aligned operands, no k split)
+static bool big_tile_ok(const GemmArgs& g) {
+  return gemm_mfma_opt() != 1 && g.ksplit == 1 && g.vecA && g.vecB && g.K % BK == 0 && g.K >= 4 * BK && g.M % 128 == 0 &&
+         g.N % 64 == 0 && !g.colsum;
+}
+static long long big_tile_count(const GemmArgs& g) { return (long long)(g.M / 128) * (g.N / 64) * g.nbatch; }
+
+static int gemm_plan(GemmArgs& g, int a_kmajor, int b_kmajor, GemmPlan& p, bool force_big = false) {
   const int M = g.M, N = g.N, K = g.K, nbatch = g.nbatch, ksplit = g.ksplit;
   p.small = ksplit == 1 && !g.bias && !g.mask && !g.relu && g.nptr == 0 && small_shape(M, N, K, nbatch);
-  p.wide = false, p.fast = false, p.tbm = p.tbn = 16;
+  p.wide = false, p.fast = false, p.b3 = false, p.tbm = p.tbn = 16;
   if (g.colsum && !p.small) return CURLA_ERR_UNSUPPORTED;
   if (p.small) {
     const long long t16 = (long long)((M + 15) / 16) * ((N + 15) / 16) * nbatch;
@@ -1229,26 +1293,29 @@ static int gemm_plan(GemmArgs& g, int a_kmajor, int b_kmajor, GemmPlan& p) {
   // instead of 128-B pieces of each HBM row and is faster even at one workgroup per CU
   if (tbn == 32 && M <= 64 && a_kmajor && b_kmajor && 2 * wgs64 >= cu2) tbn = 64;
   if (tbn == 32 && wgs6432 < cu2 && M > 32) tbm = 32;
-  switch (curla_opt(kOptGemmTile)) {  // option gemm_tile (options.h; tools/gemm_shapes.py): a forced tile shape
-    case 1: tbm = 64, tbn = 64; break;
-    case 2: tbm = 64, tbn = 32; break;
-    case 3: tbm = 32, tbn = 32; break;
+  // the 128 x 64 bf16x3 tile where it gives every CU a workgroup (or the caller has counted a pair's tiles together)
+  const int tile_opt = curla_opt(kOptGemmTile);
+  bool big = big_tile_ok(g) && (force_big || big_tile_count(g) >= curla_cu_count());
+  switch (tile_opt) {  // option gemm_tile (options.h; tools/gemm_shapes.py): a forced tile shape
+    case 1: tbm = 64, tbn = 64, big = false; break;
+    case 2: tbm = 64, tbn = 32, big = false; break;
+    case 3: tbm = 32, tbn = 32, big = false; break;
+    case 4: big = big_tile_ok(g); break;
     default: break;
+  }
+  if (big) {
+    p.tbm = 128, p.tbn = 64, p.fast = true, p.b3 = true;
+    g.kchunk = g.K;
+    return CURLA_OK;
   }
   p.tbm = tbm, p.tbn = tbn;
   // interior + aligned everywhere: the k loop runs without bounds / alignment tests
   // (a k-major operand still needs whole tiles: its float4 runs along the rows)
   p.fast = g.vecA && g.vecB && (K % BK == 0) && (g.kchunk % BK == 0) && (!a_kmajor || M % tbm == 0) &&
            (!b_kmajor || N % tbn == 0);
+  p.b3 = p.fast && gemm_b3();
   return CURLA_OK;
 }
-
-// the tiled kernel's arithmetic (option gemm_mfma): the f32-input MFMA (auto), or bf16x3 on the bf16 matrix cores for
-// interior, aligned tiles (b3).  Measured on configs[1]'s heads (profiles/r05_checks/r05_gemm_b3_vs_f32.txt): 64 x 64 tiles
-// 37.9 against 43.2 us, the dW / dx pair 45.1 against 45.2, 32 x 32 tiles 19.4 against 17.7 -- these products are bound by
-// the barrier per 32-deep k tile and the staging latency, not by the matrix pipe, so a 2.7 x faster pipe buys nothing:
-// opt-in, not the default.
-static bool gemm_b3() { return curla_opt(kOptGemmMfma) == 2; }
 
 static int gemm_launch(GemmArgs& g, int a_kmajor, int b_kmajor, hipStream_t st) {
   const int M = g.M, N = g.N, nbatch = g.nbatch, ksplit = g.ksplit;
@@ -1278,9 +1345,9 @@ static int gemm_launch(GemmArgs& g, int a_kmajor, int b_kmajor, hipStream_t st) 
   }
   const int tbm = p.tbm, tbn = p.tbn;
   const bool fast = p.fast;
-  const bool b3 = fast && gemm_b3();
+  const bool b3 = p.b3;
 #define CURLA_GEMM_LAUNCH3(AKM, BKMAJ, TM, TN, FS, B3F)                                                     \
-  hipLaunchKernelGGL((gemm_kernel<AKM, BKMAJ, TM, TN, FS, B3F>), dim3((N + TN - 1) / TN, (M + TM - 1) / TM, nbatch * ksplit), \
+  hipLaunchKernelGGL((gemm_kernel<AKM, BKMAJ, TM, TN, FS, B3F>), dim3(((N + TN - 1) / TN) * ((M + TM - 1) / TM) * nbatch * ksplit), \
                      dim3(256), 0, st, g)
 #define CURLA_GEMM_LAUNCH2(AKM, BKMAJ, TM, TN)               \
   do {                                                       \
@@ -1293,7 +1360,9 @@ static int gemm_launch(GemmArgs& g, int a_kmajor, int b_kmajor, hipStream_t st) 
   } while (0)
 #define CURLA_GEMM_LAUNCH(AKM, BKMAJ)                        \
   do {                                                       \
-    if (tbm == 32)                                           \
+    if (tbm == 128)                                          \
+      hipLaunchKernelGGL((gemm_kernel<AKM, BKMAJ, 128, 64, true, true, 512>), dim3((N / 64) * (M / 128) * nbatch), dim3(512), 0, st, g); \
+    else if (tbm == 32)                                      \
       CURLA_GEMM_LAUNCH2(AKM, BKMAJ, 32, 32);                \
     else if (tbn == 32)                                      \
       CURLA_GEMM_LAUNCH2(AKM, BKMAJ, 64, 32);                \
@@ -1382,11 +1451,13 @@ int curla_linear_bwd(const float* dy, long long stride_dy, const float* x, long 
   gemm_args_plain(g2, dy, N, stride_dy, W, K, stride_W, dx, K, stride_dx, B, K, N, nbatch);
   g2.mask = mask, g2.ldmask = K, g2.sMask = stride_mask;
   GemmPlan p1, p2;
-  int rc = gemm_plan(g1, 1, 1, p1);
-  if (rc != CURLA_OK) return rc;
-  rc = gemm_plan(g2, 0, 1, p2);
-  if (rc != CURLA_OK) return rc;
   const bool split = curla_opt(kOptLinearBwd) == 1;  // (option linear_bwd, options.h)
+  // the two products' 128 x 64 tiles are counted together: one launch holds both
+  const bool both_big = !split && big_tile_ok(g1) && big_tile_ok(g2) && big_tile_count(g1) + big_tile_count(g2) >= curla_cu_count();
+  int rc = gemm_plan(g1, 1, 1, p1, both_big);
+  if (rc != CURLA_OK) return rc;
+  rc = gemm_plan(g2, 0, 1, p2, both_big);
+  if (rc != CURLA_OK) return rc;
   const int T1 = p1.small ? 16 : 0, T2 = p2.small ? 16 : 0;
   const int gx1 = (g1.N + (T1 ? T1 : p1.tbn) - 1) / (T1 ? T1 : p1.tbn), gy1 = (g1.M + (T1 ? T1 : p1.tbm) - 1) / (T1 ? T1 : p1.tbm);
   const int gx2 = (g2.N + (T2 ? T2 : p2.tbn) - 1) / (T2 ? T2 : p2.tbn), gy2 = (g2.M + (T2 ? T2 : p2.tbm) - 1) / (T2 ? T2 : p2.tbm);
@@ -1397,15 +1468,25 @@ int curla_linear_bwd(const float* dy, long long stride_dy, const float* x, long 
                          gy1, gx2, gy2);
       return curla_launch_status();
     }
-    if (!p1.small && !p2.small && p1.fast && p2.fast) {
+    if (!p1.small && !p2.small && p1.fast && p2.fast && p1.tbm == 128 && p2.tbm == 128) {
+      // (the data gradient's tiles run over k = N, the weight gradient's over k = the batch rows: the longer ones first)
+      if (g2.K >= g1.K)
+        hipLaunchKernelGGL((gemm_pair_kernel<128, 64, 128, 64, true, true, 512>), dim3((unsigned)(n1 + n2)), dim3(512), 0, st, g1,
+                           g2, (int)n1, gx1, gy1, gx2, gy2, (int)n2);
+      else
+        hipLaunchKernelGGL((gemm_pair_kernel<128, 64, 128, 64, true, false, 512>), dim3((unsigned)(n1 + n2)), dim3(512), 0, st, g1,
+                           g2, (int)n1, gx1, gy1, gx2, gy2, (int)n2);
+      return curla_launch_status();
+    }
+    if (!p1.small && !p2.small && p1.fast && p2.fast && p1.b3 == p2.b3) {
 #define CURLA_PAIR(TM1, TN1, TM2, TN2)                                                                                   \
   if (p1.tbm == TM1 && p1.tbn == TN1 && p2.tbm == TM2 && p2.tbn == TN2) {                                               \
-    if (gemm_b3())                                                                                                       \
+    if (p1.b3)                                                                                                           \
       hipLaunchKernelGGL((gemm_pair_kernel<TM1, TN1, TM2, TN2, true>), dim3((unsigned)(n1 + n2)), dim3(256), 0, st, g1,  \
-                         g2, (int)n1, gx1, gy1, gx2, gy2);                                                               \
+                         g2, (int)n1, gx1, gy1, gx2, gy2, (int)n2);                                                      \
     else                                                                                                                 \
       hipLaunchKernelGGL((gemm_pair_kernel<TM1, TN1, TM2, TN2>), dim3((unsigned)(n1 + n2)), dim3(256), 0, st, g1, g2,    \
-                         (int)n1, gx1, gy1, gx2, gy2);                                                                   \
+                         (int)n1, gx1, gy1, gx2, gy2, (int)n2);                                                          \
     return curla_launch_status();                                                                                        \
   }
       // (the shapes the twin-Q and the actor MLPs produce at batch 512 and 1024, hidden 1024)

@@ -12,10 +12,10 @@ enum CurlaOpt {
   kOptS1Fwd,        // stride-1 forward / data gradient: 0 auto (= b3), 1 Winograd F(2,3) on the f32-input MFMA (conv_rw.h),
                     // 2 F(4,3) (conv_rw43.h), 3 bf16x3 on the bf16 matrix cores behind F(2,3) (conv_rwb.h)
   kOptBwdSplit,     // stride-1 backward launch: 0 auto, 1 two + two workgroups per CU, 2 one + one side by side
-  kOptGemmTile,     // tile shape of the tiled GEMM: 0 auto, 1 64x64, 2 64x32, 3 32x32
+  kOptGemmTile,     // tile shape of the tiled GEMM: 0 auto, 1 64x64, 2 64x32, 3 32x32, 4 128x64 (bf16x3) wherever it applies
   kOptLinearBwd,    // backward of a linear layer: 0 one launch for dW and dx, 1 two launches
-  kOptGemmMfma,     // arithmetic of the tiled GEMM: 0 auto (= f32), 1 f32 (the f32-input MFMA), 2 b3 (bf16x3 on the bf16 matrix
-                    // cores for interior, aligned tiles: measured no faster on the heads' shapes, gemm.hip gemm_b3)
+  kOptGemmMfma,     // arithmetic of the tiled GEMM: 0 auto (bf16x3 on 128x64 tiles where those fill the chip, else f32), 1 f32
+                    // (the f32-input MFMA), 2 b3 (bf16x3 on the bf16 matrix cores for every interior, aligned tile)
   kOptCount
 };
 

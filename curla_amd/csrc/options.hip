@@ -24,7 +24,7 @@ const OptDef kDefs[kOptCount] = {
     {"conv1_f32", {"rw", "band", nullptr}, {nullptr, nullptr, nullptr}},
     {"s1_fwd", {"auto", "f23", "f43", "b3", nullptr}, {nullptr, nullptr, nullptr, "bf16x3", nullptr}},
     {"bwd_split", {"auto", "0", "1", nullptr}, {nullptr, "off", "on", nullptr}},
-    {"gemm_tile", {"auto", "6464", "6432", "3232", nullptr}, {nullptr, "64x64", "64x32", "32x32", nullptr}},
+    {"gemm_tile", {"auto", "6464", "6432", "3232", "12864", nullptr}, {nullptr, "64x64", "64x32", "32x32", "128x64", nullptr}},
     {"linear_bwd", {"pair", "split", nullptr}, {nullptr, nullptr, nullptr}},
     {"gemm_mfma", {"auto", "f32", "b3", nullptr}, {nullptr, nullptr, "bf16x3", nullptr}},
 };

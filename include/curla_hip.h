@@ -50,10 +50,11 @@ int curla_abi_version(void);
  *   s1_fwd      auto | f23 | f43 | b3  stride-1 forward / data gradient: Winograd F(2,3) or F(4,3) along x on the f32-input MFMA, or
  *                                      b3 (= auto): fp32 operands as three bf16 parts on the bf16 matrix cores behind F(2,3)
  *   bwd_split   auto | 0 | 1           stride-1 backward: 2 + 2 workgroups per CU, or 1 + 1 side by side
- *   gemm_tile   auto | 6464 | 6432 | 3232
+ *   gemm_tile   auto | 6464 | 6432 | 3232 | 12864   tile of the tiled GEMM (12864: the 128 x 64 bf16x3 tile wherever it applies)
  *   linear_bwd  pair | split           dW and dx of a linear layer in one launch or two
- *   gemm_mfma   auto | f32 | b3        arithmetic of the tiled GEMM: f32-input MFMA (auto), or b3: interior aligned tiles with fp32
- *                                      operands as three bf16 parts on the bf16 matrix cores, split once when a tile is staged
+ *   gemm_mfma   auto | f32 | b3        arithmetic of the tiled GEMM: f32 = the f32-input MFMA; b3 = interior aligned tiles with fp32
+ *                                      operands as three bf16 parts on the bf16 matrix cores, split once when a tile is staged;
+ *                                      auto = b3 on 128 x 64 tiles where those give every CU a workgroup, f32 elsewhere
  * curla_set_option returns CURLA_ERR_ARG for an unknown name or value; curla_get_option NULL for an unknown name. */
 int curla_set_option(const char* name, const char* value);
 const char* curla_get_option(const char* name);

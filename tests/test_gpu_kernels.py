@@ -240,6 +240,35 @@ def test_gemm(ops, M, N, K, ak, bk, nb):
 
 
 @pytest.mark.parametrize("ak,bk", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K,nb,tile", [(128, 64, 128, 1, "12864"), (256, 192, 160, 3, "12864"), (512, 1024, 1024, 4, "auto"),
+                                           (384, 128, 512, 2, "12864")])
+def test_gemm_bf16x3_128x64_tile(ops, M, N, K, nb, tile, ak, bk):
+    """The 128 x 64 tile of the tiled GEMM (512 threads, fp32 operands as three bf16 parts on the bf16 matrix cores; what
+    `auto` takes where it gives every CU a workgroup -- the last but one case -- and gemm_tile = 12864 forces wherever whole
+    tiles fit): every operand layout, batches, the bias + ReLU and the mask epilogues, against float64."""
+    from curla_amd import _lib
+    A, Bm = rnd(nb, M, K, seed=51), rnd(nb, N, K, seed=52)
+    bias, mask = rnd(nb, N, seed=53), rnd(nb, M, N, seed=54)
+    ref = torch.einsum("zmk,znk->zmn", A.double(), Bm.double())
+    Ad = dev(A.transpose(1, 2)) if ak else dev(A)
+    Bd = dev(Bm.transpose(1, 2)) if bk else dev(Bm)
+    lda, ldb = (M if ak else K), (N if bk else K)
+    with _lib.option("gemm_tile", tile):
+        C = torch.full((nb, M, N), float("nan"), device="cuda")
+        ops.gemm(Ad, ak, lda, M * K, Bd, bk, ldb, N * K, C, N, M * N, M, N, K, nb, alpha=0.5, bias=dev(bias), sBias=N, relu=1)
+        C2 = torch.full((nb, M, N), float("nan"), device="cuda")
+        ops.gemm(Ad, ak, lda, M * K, Bd, bk, ldb, N * K, C2, N, M * N, M, N, K, nb, mask=dev(mask), ldmask=N, sMask=M * N)
+        with _lib.option("gemm_mfma", "f32"):  # (the option that keeps everything on the f32-input MFMA)
+            C3 = torch.full((nb, M, N), float("nan"), device="cuda")
+            ops.gemm(Ad, ak, lda, M * K, Bd, bk, ldb, N * K, C3, N, M * N, M, N, K, nb, mask=dev(mask), ldmask=N, sMask=M * N)
+    check(f"gemm 128x64 bias+relu {M}x{N}x{K} ak{ak} bk{bk} nb{nb}", C.cpu(),
+          torch.relu(0.5 * ref + bias.double()[:, None, :]).float(), 2e-5)
+    check(f"gemm 128x64 mask {M}x{N}x{K} ak{ak} bk{bk} nb{nb}", C2.cpu(), (ref * (mask > 0)).float(), 2e-5)
+    check(f"gemm f32 mask {M}x{N}x{K} ak{ak} bk{bk} nb{nb}", C3.cpu(), (ref * (mask > 0)).float(), 2e-5)
+    assert not torch.equal(C2, C3)  # (two arithmetics: the tile was really taken)
+
+
+@pytest.mark.parametrize("ak,bk", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K,nb", [(512, 54, 1024, 2), (50, 50, 512, 1), (37, 70, 256, 3), (1024, 54, 512, 2),
                                       (16, 16, 64 * 5, 1), (512, 50, 512, 1)])
 def test_gemm_small_output_long_k(ops, M, N, K, ak, bk, nb):
@@ -267,20 +296,29 @@ def test_gemm_small_output_long_k(ops, M, N, K, ak, bk, nb):
 
 
 # B, N (out features), K (in features), nbatch, shared x, bias gradient
-LINEAR_BWD_CASES = [(512, 1024, 1024, 2, False, False),  # twin-Q hidden layer: tiled pair 64x64 + 64x32
+LINEAR_BWD_CASES = [(512, 1024, 1024, 2, False, False),  # twin-Q hidden layer: tiled pair 64x64 + 64x32 / bf16x3 128x64 (auto)
                     (512, 1024, 1024, 1, False, False),  # actor hidden layer: tiled pair 64x32 + 32x32
-                    (1024, 1024, 1024, 2, False, False),  # batch 1024: 64x64 + 64x64
-                    (1024, 1024, 1024, 1, False, False),  # 64x32 + 64x32
+                    (1024, 1024, 1024, 2, False, False),  # batch 1024: 64x64 + 64x64 / bf16x3 128x64 (auto)
+                    (1024, 1024, 1024, 1, False, False),  # 64x32 + 64x32 / bf16x3 128x64 (auto)
                     (512, 1024, 54, 2, True, True),      # twin-Q first layer: the small-output pair, x shared, db folded
                     (512, 1024, 50, 1, False, True),     # actor first layer
                     (96, 40, 24, 1, False, False),       # neither family fits both: two launches
                     (256, 1024, 1024, 2, False, False)]
 
 
+@pytest.mark.parametrize("mfma", ["auto", "f32"])
 @pytest.mark.parametrize("B,N,K,nb,shared_x,with_db", LINEAR_BWD_CASES)
-def test_linear_bwd_pair_launch(ops, B, N, K, nb, shared_x, with_db):
-    """curla_linear_bwd: dW = dy^T x (+ db) and dx = (dy W) masked from one launch, against float64 and against the
-    two separate products bit for bit (same kernels, same tiles, same order of summation)."""
+def test_linear_bwd_pair_launch(ops, B, N, K, nb, shared_x, with_db, mfma):
+    """curla_linear_bwd: dW = dy^T x (+ db) and dx = (dy W) masked from one launch, against float64 and -- on the f32-input
+    MFMA, where the pair and the single launches take the same tiles -- against the two separate products bit for bit
+    (same kernels, same tiles, same order of summation).  Under `auto` the pair counts its two products' 128 x 64 tiles
+    together, so a product can be on bf16x3 in the pair and on the f32 form alone: float64 is the only arbiter there."""
+    from curla_amd import _lib
+    with _lib.option("gemm_mfma", mfma):
+        _linear_bwd_pair(ops, B, N, K, nb, shared_x, with_db, bitwise=(mfma == "f32"))
+
+
+def _linear_bwd_pair(ops, B, N, K, nb, shared_x, with_db, bitwise):
     dy, W = rnd(nb, B, N, seed=71), rnd(nb, N, K, seed=72) * 0.1
     x = rnd(1 if shared_x else nb, B, K, seed=73)
     mask = rnd(nb, B, K, seed=74)
@@ -303,7 +341,11 @@ def test_linear_bwd_pair_launch(ops, B, N, K, nb, shared_x, with_db):
     db2 = torch.full_like(db, float("nan")) if with_db else None
     ops.linear_dw(dyd, B * N, xd, sx, dW2, N * K, B, N, K, nb, colsum=db2, s_colsum=N)
     ops.linear_dx(dyd, B * N, Wd, N * K, dx2, B * K, B, N, K, nb, mask=md, smask=B * K)
-    assert torch.equal(dW, dW2) and torch.equal(dx, dx2)
+    if bitwise:
+        assert torch.equal(dW, dW2) and torch.equal(dx, dx2)
+    else:
+        check(f"linear_bwd dW pair against single {B}x{N}x{K} nb{nb}", dW.cpu(), dW2.cpu(), tol)
+        check(f"linear_bwd dx pair against single {B}x{N}x{K} nb{nb}", dx.cpu(), dx2.cpu(), tol)
     if with_db:
         assert torch.equal(db, db2)
 

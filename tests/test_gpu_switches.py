@@ -187,6 +187,8 @@ SWITCHES = [
     ("gemm_tile=6464", {"gemm_tile": "6464"}, {}, "random_crop", (), ()),
     ("gemm_tile=6432", {"gemm_tile": "6432"}, {}, "random_crop", (), ()),
     ("gemm_tile=3232", {"gemm_tile": "3232"}, {}, "random_crop", (), ()),
+    ("gemm_tile=12864 (bf16x3 wherever whole tiles fit)", {"gemm_tile": "12864"}, {}, "random_crop", (), ()),
+    ("gemm_mfma=f32", {"gemm_mfma": "f32"}, {}, "random_crop", (), ()),
     ("linear_bwd=split", {"linear_bwd": "split"}, {}, "random_crop", (), ()),
     ("gemm_mfma=b3", {"gemm_mfma": "b3"}, {}, "random_crop", (), ()),
     ("CURLA_CURL_HEAD=unfused", {}, {"CURLA_CURL_HEAD": "unfused"}, "random_crop", ("curla_curl_ce",), ("curla_curl_head",)),

@@ -14,8 +14,9 @@ run "defaults (again)" X=1
 for v in band rw; do run "conv1_u8=$v" CURLA_CONV1_U8=$v; done
 for v in 0 1; do run "bwd_split=$v" CURLA_BWD_SPLIT=$v; done
 for v in f23 f43; do run "s1_fwd=$v" CURLA_S1_FWD=$v; done
-for v in 6464 6432 3232; do run "gemm_tile=$v" CURLA_GEMM_TILE=$v; done
+for v in 6464 6432 3232 12864; do run "gemm_tile=$v" CURLA_GEMM_TILE=$v; done
 run "gemm_mfma=b3" CURLA_GEMM_MFMA=b3
+run "gemm_mfma=f32" CURLA_GEMM_MFMA=f32
 run "linear_bwd=split" CURLA_LINEAR_BWD=split
 run "CURLA_FC_FWD=gemm" CURLA_FC_FWD=gemm
 run "CURLA_CURL_HEAD=unfused" CURLA_CURL_HEAD=unfused
