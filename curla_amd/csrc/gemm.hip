@@ -28,13 +28,16 @@ constexpr int RSTR = BK + 8;   // LDS stride, row-major tile [64][BK]: 40 floats
 // disjoint halves of the banks.  (80, the stride of rounds 1-2, put both on the same 16 banks: SQ_LDS_BANK_CONFLICT 0.3-0.4
 // of the LDS cycles of the kernels with a k-major operand.)
 constexpr int KSTR = CURLA_GEMM_KSTR;
-// bf16x3 form (round 5, gemm_tile<..., B3 = true>): an operand tile is THREE bf16 images [part][row][32 k], rows 96 bytes
-// apart (64 of data: a lane's fragment is one 16-byte read, a staging thread's four k one 8-byte write).  96: the four
-// 16-lane groups of a ds_read_b128 (MI355X_MICROARCH.md, LDS) each see 16 different 16-byte slots of the 256-byte bank
-// row at row * 96 + kq * 16 (80, the first version's stride, was 2-way); the parts sit 64 bytes off a multiple of 128
-// apart so that the h / m / l stores of one thread do not share banks either.
-constexpr int kB3RowBytes = 96;
-constexpr int b3_part_bytes(int rows) { return rows * kB3RowBytes + 64; }
+// bf16x3 form (round 5, gemm_tile<..., B3 = true>): an operand tile is THREE bf16 images [part][row][32 k], rows of 64
+// bytes = four 16-byte chunks (a lane's fragment is one chunk, a staging thread's four k half a chunk), chunk c of row r at
+// slot c ^ b3_swz(r).  With that XOR the four 16-lane groups of a ds_read_b128 (MI355X_MICROARCH.md, LDS: {0-3, 12-15,
+// 20-27}, ...) each read 16 different slots of the 256-byte bank row, and the 8-byte stores of a row-major operand (16
+// lanes = 2 rows x 8 pieces) cover all 32 banks once; a k-major operand's stores (16 rows, one piece) are 2-way.  (The
+// first two versions padded rows to 80 and 96 bytes: fragment reads 2-way at 80, stores 2- and 4-way at 96 -- PMC
+// SQ_LDS_BANK_CONFLICT 0.30 / 0.50 of the LDS cycles of the 128 x 64 kernels.)
+constexpr int kB3RowBytes = 64;
+__device__ __forceinline__ int b3_swz(int row) { return (-((row >> 2) & 3)) & 3; }
+constexpr int b3_part_bytes(int rows) { return rows * kB3RowBytes; }
 constexpr int b3_tile_floats(int rows) { return 3 * b3_part_bytes(rows) / 4; }
 constexpr int kGemmTileFloatsF32 = (BK * KSTR > BM * RSTR) ? BK * KSTR : BM * RSTR;
 // floats of one operand tile buffer with `rows` rows (the f32 forms exist for up to 64 rows only)
@@ -213,7 +216,7 @@ __device__ __forceinline__ void tile_store_b3(float* __restrict__ S, int tid, co
       const float s0 = r0 - __builtin_bit_cast(float, mm << 16), s1 = r1 - __builtin_bit_cast(float, mm & 0xFFFF0000u);
       h[q] = hh, m[q] = mm, l[q] = g_cvt_pk_bf16(s0, s1);
     }
-    char* p = base + row * kB3RowBytes + k4 * 2;
+    char* p = base + row * kB3RowBytes + (((k4 >> 3) ^ b3_swz(row)) << 4) + ((k4 & 4) << 1);
     *reinterpret_cast<gu32x2*>(p) = h;
     *reinterpret_cast<gu32x2*>(p + b3_part_bytes(ROWS)) = m;
     *reinterpret_cast<gu32x2*>(p + 2 * b3_part_bytes(ROWS)) = l;
@@ -226,7 +229,7 @@ struct Frag3 {
 
 template <int ROWS>
 __device__ __forceinline__ Frag3 frags_b3(const float* __restrict__ S, int row, int kq) {
-  const char* p = reinterpret_cast<const char*>(S) + row * kB3RowBytes + kq * 16;
+  const char* p = reinterpret_cast<const char*>(S) + row * kB3RowBytes + ((kq ^ b3_swz(row)) << 4);
   Frag3 f;
   f.h = *reinterpret_cast<const gu32x4*>(p);
   f.m = *reinterpret_cast<const gu32x4*>(p + b3_part_bytes(ROWS));
