@@ -826,15 +826,24 @@ __global__ __launch_bounds__(512, 2) void conv1_u8_walk_kernel(Conv1Args a, rw::
 constexpr int kPartialS1 = 32 * 288 + 32;
 
 #include "conv_rw_wgrad.h"
+#include "conv_rw_wgrad2.h"
+
+// the weight-gradient body of a workgroup: Winograd along x (conv_rw_wgrad.h) or in both directions (conv_rw_wgrad2.h)
+__device__ __forceinline__ void wgrad_any(const rw::WgradArgs& wa, const int bid, const int nblk) {
+  if (wa.two_d)
+    rw::wgrad2_body<4>(wa, bid, nblk);
+  else
+    rw::wgrad_body<4>(wa, bid, nblk);
+}
 
 // weight gradient in its row-walk form (conv_rw_wgrad.h), alone and in one launch with the row-walk data gradient
 __global__ __launch_bounds__(256, 2) void wgrad_rw_kernel(rw::WgradArgs wa) {
-  rw::wgrad_body<4>(wa, blockIdx.x, gridDim.x);
+  wgrad_any(wa, blockIdx.x, gridDim.x);
 }
 
 __global__ __launch_bounds__(256, 2) void bwd_rw2_kernel(rw::WgradArgs wa, rw::Args da, int nw) {
   if ((int)blockIdx.x < nw) {
-    rw::wgrad_body<4>(wa, blockIdx.x, nw);
+    wgrad_any(wa, blockIdx.x, nw);
   } else {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     rw::build_filter<MODE_DGRAD, 256>(lds, da.p[0][0].w, nullptr, threadIdx.x);
@@ -847,7 +856,7 @@ __global__ __launch_bounds__(256, 2) void bwd_rw2_kernel(rw::WgradArgs wa, rw::A
 // gradient's with 72 KB of LDS for its split filter
 __global__ __launch_bounds__(256, 2) void bwd_rwb2_kernel(rw::WgradArgs wa, rw::Args da, int nw) {
   if ((int)blockIdx.x < nw) {
-    rw::wgrad_body<4>(wa, blockIdx.x, nw);
+    wgrad_any(wa, blockIdx.x, nw);
   } else {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds_hb[];
     rwb::build_filter<MODE_DGRAD, 256>(lds_hb, da.p[0][0].w, nullptr, threadIdx.x);
@@ -1727,12 +1736,23 @@ size_t curla_conv_wgrad_workspace_floats(int cin) {
   return (size_t)4 * curla_cu_count() * ((size_t)32 * cin * 9 + 32);  // at most four workgroups (slabs) per CU
 }
 
+// option s1_wgrad (options.h): Winograd F(3,2) along x, or in both directions (auto: a third fewer matrix instructions for
+// ~40 instead of ~10 VALU instructions per step; alone 77 -> 69 us, beside the bf16x3 data gradient 125 -> 118 us for
+// 512 samples of 35 x 35 gradients, 1179 -> 1080 us for 1024 of 79 x 79: tools/s1_bwd_bench.py)
+static bool wgrad_two_d() { return curla_opt(kOptS1Wgrad) != 1; }
+
+static rw::WgradArgs wgrad_args(const float* in, const float* g, float* workspace, int B, int Hi, int Wi, int Ho, int Wo) {
+  const bool two_d = wgrad_two_d();
+  return rw::WgradArgs{in, g, workspace, B, Hi, Wi, Ho, Wo, two_d ? rw::plan4p(Hi, Wi, Ho, Wo) : rw::plan4(Hi, Wi, Ho, Wo),
+                       two_d ? 1 : 0};
+}
+
 static int launch_wgrad_s1(const float* in, const float* g, float* workspace, int B, int Hi, int Wi, int channels,
                            hipStream_t st, int* nslabs) {
   CURLA_REQUIRE(in && g && workspace && B > 0 && Hi >= 3 && Wi >= 3);
   if (channels != 32 || !rw_supported(Hi, Wi)) return CURLA_ERR_UNSUPPORTED;
   CURLA_REQUIRE(aligned16(in) && aligned16(g));
-  rw::WgradArgs ra{in, g, workspace, B, Hi, Wi, Hi - 2, Wi - 2, rw::plan4(Hi, Wi, Hi - 2, Wi - 2)};
+  const rw::WgradArgs ra = wgrad_args(in, g, workspace, B, Hi, Wi, Hi - 2, Wi - 2);
   const int cap = 2 * curla_cu_count();
   const int grid = B < cap ? B : cap;
   const size_t lds = kPartialS1 * sizeof(float);
@@ -1776,7 +1796,7 @@ int curla_conv3x3_s1_bwd_slabs(const float* in, const float* g, const float* w, 
     const bool split2 = split_opt ? split_opt == 2 : true;
     const int cap2 = split2 ? curla_cu_count() : 2 * curla_cu_count();
     const int n2 = B < cap2 ? B : cap2;
-    rw::WgradArgs wr{in, g, workspace, B, Hi, Wi, Ho, Wo, rw::plan4(Hi, Wi, Ho, Wo)};
+    const rw::WgradArgs wr = wgrad_args(in, g, workspace, B, Hi, Wi, Ho, Wo);
     rw::Args dr = rw_dgrad_args(g, w, in, gin, B, Ho, Wo);
     dr.g[0] = rwb::plan(Ho, Wo, Ho + 2, Wo + 2);
     size_t lds2 = rwb::kWBytes;
@@ -1805,7 +1825,7 @@ int curla_conv3x3_s1_bwd_slabs(const float* in, const float* g, const float* w, 
   const bool split2 = split_opt ? split_opt == 2 : (long long)B * Ho * Wo <= (1LL << 20);
   const int cap2 = split2 ? curla_cu_count() : 2 * curla_cu_count();
   const int n2 = B < cap2 ? B : cap2;
-  rw::WgradArgs wr{in, g, workspace, B, Hi, Wi, Ho, Wo, rw::plan4(Hi, Wi, Ho, Wo)};
+  const rw::WgradArgs wr = wgrad_args(in, g, workspace, B, Hi, Wi, Ho, Wo);
   const rw::Args dr = rw_dgrad_args(g, w, in, gin, B, Ho, Wo);
   size_t lds2 = rw::kWFloats * sizeof(float);
   if (lds2 < kPartialS1 * sizeof(float)) lds2 = kPartialS1 * sizeof(float);

@@ -28,7 +28,8 @@ struct WgradArgs {
   const float* g;   // [B][Ho][Wo][32]
   float* partial;   // [grid][kPartialS1]
   int B, Hi, Wi, Ho, Wo;
-  Geom gg;          // strips of 4 pair columns over the GRADIENT image (plan4)
+  Geom gg;          // strips of 4 pair columns over the GRADIENT image (plan4; plan4p when two_d)
+  int two_d;        // Winograd in both directions (conv_rw_wgrad2.h)
 };
 
 // strips of 4 pair columns (one per lane group)

@@ -237,6 +237,21 @@ __device__ __forceinline__ Frag3 frags_b3(const float* __restrict__ S, int row, 
   return f;
 }
 
+// eight fp32 values (a lane's 8 consecutive k of one row) -> the three bf16 operands (x = h + m + l exactly)
+__device__ __forceinline__ Frag3 g_split8(const f32x4 lo, const f32x4 hi) {
+  Frag3 o;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const float x0 = p < 2 ? lo[2 * p] : hi[2 * p - 4], x1 = p < 2 ? lo[2 * p + 1] : hi[2 * p - 3];
+    const unsigned hh = g_cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, hh << 16), r1 = x1 - __builtin_bit_cast(float, hh & 0xFFFF0000u);
+    const unsigned mm = g_cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __builtin_bit_cast(float, mm << 16), s1 = r1 - __builtin_bit_cast(float, mm & 0xFFFF0000u);
+    o.h[p] = hh, o.m[p] = mm, o.l[p] = g_cvt_pk_bf16(s0, s1);
+  }
+  return o;
+}
+
 __device__ __forceinline__ f32x4 g_mfma_bf16(const gu32x4 a, const gu32x4 b, const f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gbf16x8, a), __builtin_bit_cast(gbf16x8, b), c, 0, 0, 0);
 }
@@ -931,7 +946,7 @@ struct FcFwdArgs {
 constexpr int kFcChunk = 4;            // k-slices per W chunk in LDS
 constexpr int kFcPitch = 32 * kFcChunk + 4;  // floats per feature row of a chunk (16-byte aligned, off the bank stride)
 
-template <int NT, int NTAIL>
+template <int NT, int NTAIL, bool B3 = false>
 __global__ __launch_bounds__(256, 2) void fc_fwd_kernel(FcFwdArgs g) {
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [2][F][kFcPitch]
   constexpr int NTL = NTAIL > 0 ? NTAIL : 1;
@@ -1019,6 +1034,26 @@ __global__ __launch_bounds__(256, 2) void fc_fwd_kernel(FcFwdArgs g) {
         for (int h = 0; h < 2; ++h)
           wt[j][h] = *reinterpret_cast<const f32x4*>(wc + (16 * NT + j) * kFcPitch + 32 * sj + 8 * kq + 4 * h);
     }
+    if constexpr (B3) {
+      // bf16x3 (conv_rwb.h): a slice is ONE k-step of v_mfma_f32_16x16x32_bf16 -- a lane's 8 contiguous k of x and of W
+      // are exactly its operand -- six terms per fp32 product, smallest first: 36 matrix instructions of 16 cycles per
+      // slice instead of 48 of 32; the split is 5.5 VALU per value (x: 16 values per lane, W: 8 per feature tile)
+      Frag3 xb[2];
+#pragma unroll
+      for (int bt = 0; bt < 2; ++bt) xb[bt] = g_split8(X.v[bt][0], X.v[bt][1]);
+#pragma unroll
+      for (int ft = 0; ft < NT; ++ft) {
+        const Frag3 wf = g_split8(wv[ft][0], wv[ft][1]);
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+          for (int bt = 0; bt < 2; ++bt) {
+            const gu32x4& pw = term == 0 ? wf.l : (term == 2 || term == 3) ? wf.m : wf.h;
+            const gu32x4& px = (term == 0 || term == 3 || term == 5) ? xb[bt].h : (term == 1) ? xb[bt].l : xb[bt].m;
+            acc[bt][ft] = g_mfma_bf16(pw, px, acc[bt][ft]);
+          }
+      }
+    } else {
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -1027,6 +1062,7 @@ __global__ __launch_bounds__(256, 2) void fc_fwd_kernel(FcFwdArgs g) {
         for (int ft = 0; ft < NT; ++ft)
 #pragma unroll
           for (int bt = 0; bt < 2; ++bt) acc[bt][ft] = mfma16(wv[ft][h][e], X.v[bt][h][e], acc[bt][ft]);
+    }
     if (NTAIL > 0) {
 #pragma unroll
       for (int j = 0; j < NTAIL; ++j)
@@ -1570,13 +1606,18 @@ int curla_fc_fwd_multi(int nprob, const float* const* x, const float* const* W, 
   const int grid = nprob * g.nrg * nsplit;
   const size_t lds = (size_t)2 * 64 * kFcPitch * sizeof(float);
   hipStream_t st = static_cast<hipStream_t>(stream);
+#define CURLA_FC_FWD(NTF, NTL, B3F)                                                                                       \
+  do {                                                                                                                    \
+    if (curla_set_dyn_lds(reinterpret_cast<const void*>(fc_fwd_kernel<NTF, NTL, B3F>), lds) != CURLA_OK) return CURLA_ERR_LAUNCH; \
+    hipLaunchKernelGGL((fc_fwd_kernel<NTF, NTL, B3F>), dim3(grid), dim3(256), lds, st, g);                                \
+  } while (0)
+  const bool b3 = gemm_mfma_opt() != 1;  // option gemm_mfma: f32 keeps the f32-input MFMA
   if (F == 50) {
-    if (curla_set_dyn_lds(reinterpret_cast<const void*>(fc_fwd_kernel<3, 2>), lds) != CURLA_OK) return CURLA_ERR_LAUNCH;
-    hipLaunchKernelGGL((fc_fwd_kernel<3, 2>), dim3(grid), dim3(256), lds, st, g);
+    if (b3) CURLA_FC_FWD(3, 2, true); else CURLA_FC_FWD(3, 2, false);
   } else {
-    if (curla_set_dyn_lds(reinterpret_cast<const void*>(fc_fwd_kernel<4, 0>), lds) != CURLA_OK) return CURLA_ERR_LAUNCH;
-    hipLaunchKernelGGL((fc_fwd_kernel<4, 0>), dim3(grid), dim3(256), lds, st, g);
+    if (b3) CURLA_FC_FWD(4, 0, true); else CURLA_FC_FWD(4, 0, false);
   }
+#undef CURLA_FC_FWD
   return curla_launch_status();
 }
 

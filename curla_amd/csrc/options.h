@@ -16,6 +16,8 @@ enum CurlaOpt {
   kOptLinearBwd,    // backward of a linear layer: 0 one launch for dW and dx, 1 two launches
   kOptGemmMfma,     // arithmetic of the tiled GEMM: 0 auto (bf16x3 on 128x64 tiles where those fill the chip, else f32), 1 f32
                     // (the f32-input MFMA), 2 b3 (bf16x3 on the bf16 matrix cores for every interior, aligned tile)
+  kOptS1Wgrad,      // stride-1 weight gradient: 0 auto (= xy), 1 x (Winograd F(3,2) along x, conv_rw_wgrad.h), 2 xy (both directions,
+                    // conv_rw_wgrad2.h)
   kOptCount
 };
 

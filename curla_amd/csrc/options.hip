@@ -27,6 +27,7 @@ const OptDef kDefs[kOptCount] = {
     {"gemm_tile", {"auto", "6464", "6432", "3232", "12864", nullptr}, {nullptr, "64x64", "64x32", "32x32", "128x64", nullptr}},
     {"linear_bwd", {"pair", "split", nullptr}, {nullptr, nullptr, nullptr}},
     {"gemm_mfma", {"auto", "f32", "b3", nullptr}, {nullptr, nullptr, "bf16x3", nullptr}},
+    {"s1_wgrad", {"auto", "x", "xy", nullptr}, {nullptr, "1d", "2d", nullptr}},
 };
 
 std::atomic<int> g_value[kOptCount];

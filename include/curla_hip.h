@@ -55,6 +55,8 @@ int curla_abi_version(void);
  *   gemm_mfma   auto | f32 | b3        arithmetic of the tiled GEMM: f32 = the f32-input MFMA; b3 = interior aligned tiles with fp32
  *                                      operands as three bf16 parts on the bf16 matrix cores, split once when a tile is staged;
  *                                      auto = b3 on 128 x 64 tiles where those give every CU a workgroup, f32 elsewhere
+ *   s1_wgrad    auto | x | xy          stride-1 weight gradient: Winograd F(3,2) along x, or (auto) in both directions (2 x 2 gradient
+ *                                      blocks: a third fewer f32 matrix instructions)
  * curla_set_option returns CURLA_ERR_ARG for an unknown name or value; curla_get_option NULL for an unknown name. */
 int curla_set_option(const char* name, const char* value);
 const char* curla_get_option(const char* name);

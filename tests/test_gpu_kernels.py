@@ -63,6 +63,15 @@ def s1_impl(request):
         yield request.param
 
 
+@pytest.fixture(params=["x", "xy"])
+def s1_wgrad(request):
+    """The stride-1 weight gradients: Winograd F(3,2) along x (conv_rw_wgrad.h) and in both directions (conv_rw_wgrad2.h),
+    option s1_wgrad."""
+    from curla_amd import _lib
+    with _lib.option("s1_wgrad", request.param):
+        yield request.param
+
+
 @pytest.mark.parametrize("B,H,W", [(3, 13, 16), (2, 37, 37), (5, 35, 35), (1, 83, 83), (2, 5, 41), (9, 17, 15), (3, 6, 7),
                                    (2, 3, 3), (1, 21, 130)])
 def test_conv_s1_fwd(ops, s1_impl, B, H, W):
@@ -88,8 +97,9 @@ def test_conv_s1_dgrad(ops, s1_impl, B, H, W):
 
 # (rows of >= 8 pixel pairs take the scalar pair walk, even and odd widths differently: 18, 26, 102 / 17, 19, 37 ...)
 @pytest.mark.parametrize("B,H,W", [(3, 13, 16), (2, 37, 37), (6, 35, 35), (1, 83, 83), (300, 9, 9), (3, 12, 18),
-                                   (2, 20, 26), (2, 19, 19), (1, 40, 102), (2, 5, 17), (4, 3, 40), (5, 4, 33)])
-def test_conv_s1_wgrad(ops, B, H, W):
+                                   (2, 20, 26), (2, 19, 19), (1, 40, 102), (2, 5, 17), (4, 3, 40), (5, 4, 33), (600, 37, 37),
+                                   (2, 4, 4), (1, 3, 3)])
+def test_conv_s1_wgrad(ops, s1_wgrad, B, H, W):
     x = torch.relu(rnd(B, 32, H, W, seed=7))
     g = rnd(B, 32, H - 2, W - 2, seed=8) * (rnd(B, 32, H - 2, W - 2, seed=9) > 0)
     w = torch.zeros(32, 32, 3, 3, requires_grad=True)
@@ -99,8 +109,8 @@ def test_conv_s1_wgrad(ops, B, H, W):
     db = torch.full((32,), float("nan"), device="cuda")
     ws = torch.empty(ops.wgrad_workspace_floats(32), device="cuda")
     ops.conv_s1_wgrad(nhwc(x), nhwc(g), dw, db, ws)
-    check(f"conv_s1_wgrad dW B{B} {H}x{W}", dw.cpu(), w.grad)
-    check(f"conv_s1_wgrad db B{B} {H}x{W}", db.cpu(), b.grad)
+    check(f"conv_s1_wgrad [{s1_wgrad}] dW B{B} {H}x{W}", dw.cpu(), w.grad)
+    check(f"conv_s1_wgrad [{s1_wgrad}] db B{B} {H}x{W}", db.cpu(), b.grad)
 
 
 def _ring(N, C, Hs, Ws, seed):
@@ -1024,7 +1034,7 @@ def test_mlp_forward_two_level_batch(ops, B, din, H):
 
 
 @pytest.mark.parametrize("B,H,W", [(3, 13, 16), (2, 37, 37), (300, 9, 9), (5, 17, 15)])
-def test_conv_s1_backward_one_launch(ops, s1_impl, B, H, W):
+def test_conv_s1_backward_one_launch(ops, s1_impl, s1_wgrad, B, H, W):
     """curla_conv3x3_s1_bwd_slabs: weight-gradient slabs and data gradient of a layer in one launch.  The data gradient
     is bit-identical to the separate kernel's; the weight gradient is dealt to as many or half as many workgroups
     (slabs) as the separate kernel's, i.e. the same sums in another fixed order."""

@@ -182,6 +182,8 @@ SWITCHES = [
     ("s1_fwd=f23 (wide rows)", {"s1_fwd": "f23"}, {}, "wide", (), ()),
     ("s1_fwd=b3 (forward and data gradient)", {"s1_fwd": "b3"}, {}, "random_crop", (), ()),
     ("s1_fwd=b3 (wide rows)", {"s1_fwd": "b3"}, {}, "wide", (), ()),
+    ("s1_wgrad=x", {"s1_wgrad": "x"}, {}, "random_crop", (), ()),
+    ("s1_wgrad=x (wide rows)", {"s1_wgrad": "x"}, {}, "wide", (), ()),
     ("bwd_split=0", {"bwd_split": "0"}, {}, "random_crop", (), ()),
     ("bwd_split=1", {"bwd_split": "1"}, {}, "random_crop", (), ()),
     ("gemm_tile=6464", {"gemm_tile": "6464"}, {}, "random_crop", (), ()),
