@@ -33,8 +33,38 @@ inline Geom plan4p(int Hi, int Wi, int Ho, int Wo) {
 
 struct Wg2Loads {
   f32x2 d[2][4];  // input rows 2s + 2, 2s + 3: window pixel c, (cin tile 0, cin tile 1)
-  float g[2][2];  // gradient rows 2s, 2s + 1: the pair's two pixels
+  f32x2 g[2];     // gradient rows 2s, 2s + 1: the pair's two pixels
 };
+
+// (g0, g1) -> (g0 + g1, g0 - g1) in one packed instruction (both results read the first operand's low and the second's
+// high half; the second is negated for the high result).  Inline asm: the trailing s_nop is the two wait states a VALU
+// result needs before a matrix instruction reads it (conv_rw.h, bt_pk).
+__device__ __forceinline__ f32x2 sum_diff(const f32x2 g) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]\n\t"
+      "s_nop 1"
+      : "=&v"(r)
+      : "v"(g));
+  return r;
+}
+
+// the y-direction combinations of two x positions' rows E0 .. E3 (each a packed pair over the two cin tiles):
+// (E0 - E2, E1 + E2, E2 - E1, E1 - E3).  One opaque block: written as vector arithmetic the compiler splits the packed
+// operations into scalar ones (24 instead of 12 per step)
+__device__ __forceinline__ void vy_pk(f32x2 (&Va)[4], f32x2 (&Vb)[4], const f32x2 a0, const f32x2 a1, const f32x2 a2,
+                                      const f32x2 a3, const f32x2 b0, const f32x2 b1, const f32x2 b2, const f32x2 b3) {
+  asm("v_pk_add_f32 %0, %8, %10 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %1, %9, %10\n\t"
+      "v_pk_add_f32 %2, %10, %9 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %3, %9, %11 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %4, %12, %14 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %5, %13, %14\n\t"
+      "v_pk_add_f32 %6, %14, %13 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "v_pk_add_f32 %7, %13, %15 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+      "s_nop 1"
+      : "=&v"(Va[0]), "=&v"(Va[1]), "=&v"(Va[2]), "=&v"(Va[3]), "=&v"(Vb[0]), "=&v"(Vb[1]), "=&v"(Vb[2]), "=&v"(Vb[3])
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+}
 
 template <int NW>
 __device__ __forceinline__ void wgrad2_body(const WgradArgs& a, const int bid, const int nblk) {
@@ -107,39 +137,44 @@ __device__ __forceinline__ void wgrad2_body(const WgradArgs& a, const int bid, c
         for (int r = 0; r < 2; ++r) {
           const unsigned sg_ = __builtin_amdgcn_readfirstlane((unsigned)((2 * s + r) * g_row));
           L.g[r][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, vg0, sg_, 0));
-          L.g[r][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, vg1, sg_, 0));
+          L.g[r][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rg, vg1, sg_, 0));  // (two halves of a register pair)
         }
       };
 
-      // x-transformed input rows 2s, 2s + 1 of the coming step
-      f32x2 P0[4], P1[4], h0[4], h1[4];
+      // x-transformed input rows 2s, 2s + 1 of the coming step (P) and 2s + 2, 2s + 3 (Q): the two sets swap roles from
+      // step to step
+      f32x2 P0[4], P1[4], Q0[4], Q1[4], h0[4], h1[4];
       load_in_row(h0, 0);
       load_in_row(h1, 1);
       Wg2Loads L0, L1;  // loads of even / odd steps, issued two steps ahead (unconditionally: rows past the piece are
                         // ordinary rows of the image or out of range -- read and dropped; conv_rw_wgrad.h)
-      auto step = [&](Wg2Loads& L, const int s) {
-        f32x2 Q2[4], Q3[4];
-        bt_pk(Q2[0], Q2[1], Q2[2], Q2[3], L.d[0][0], L.d[0][1], L.d[0][2], L.d[0][3]);
-        bt_pk(Q3[0], Q3[1], Q3[2], Q3[3], L.d[1][0], L.d[1][1], L.d[1][2], L.d[1][3]);
-        float R0[4], R1[4];
-        g_transform(R0, bsum, L.g[0][0], L.g[0][1], 1.0f);
-        g_transform(R1, bsum, L.g[1][0], L.g[1][1], 1.0f);
+      auto step = [&](Wg2Loads& L, const f32x2 (&E0)[4], const f32x2 (&E1)[4], f32x2 (&E2)[4], f32x2 (&E3)[4], const int s) {
+        bt_pk(E2[0], E2[1], E2[2], E2[3], L.d[0][0], L.d[0][1], L.d[0][2], L.d[0][3]);
+        bt_pk(E3[0], E3[1], E3[2], E3[3], L.d[1][0], L.d[1][1], L.d[1][2], L.d[1][3]);
+        // the 2 x 2 gradient block -> its 16 operands: rows R = (g0, g0 + g1, g0 - g1, g1), then (R0, R0 + R1, R0 - R1, R1):
+        // six packed instructions (and the bias gradient's sum of the four pixels falls out of them)
+        const f32x2 G0 = L.g[0], G1 = L.g[1];
+        const f32x2 S0 = sum_diff(G0), S1 = sum_diff(G1);
+        const f32x2 H1 = G0 + G1, H2 = G0 - G1, F1 = S0 + S1, F2 = S0 - S1;
+        bsum += F1[0];
+        const float A[4][4] = {{G0[0], S0[0], S0[1], G0[1]},
+                               {H1[0], F1[0], F1[1], H1[1]},
+                               {H2[0], F2[0], F2[1], H2[1]},
+                               {G1[0], S1[0], S1[1], G1[1]}};
         issue(L, s + 2);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int xp = 0; xp < 4; ++xp) {
-          const f32x2 V0 = P0[xp] - Q2[xp], V1 = P1[xp] + Q2[xp], V2 = Q2[xp] - P1[xp], V3 = P1[xp] - Q3[xp];
-          const float A0 = R0[xp], A1 = R0[xp] + R1[xp], A2 = R0[xp] - R1[xp], A3 = R1[xp];
+        for (int xq = 0; xq < 4; xq += 2) {
+          f32x2 Va[4], Vb[4];
+          vy_pk(Va, Vb, E0[xq], E1[xq], E2[xq], E3[xq], E0[xq + 1], E1[xq + 1], E2[xq + 1], E3[xq + 1]);
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) {
-            acc[0][xp][ct] = mfma16(A0, V0[ct], acc[0][xp][ct]);
-            acc[1][xp][ct] = mfma16(A1, V1[ct], acc[1][xp][ct]);
-            acc[2][xp][ct] = mfma16(A2, V2[ct], acc[2][xp][ct]);
-            acc[3][xp][ct] = mfma16(A3, V3[ct], acc[3][xp][ct]);
-          }
+          for (int yp = 0; yp < 4; ++yp)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) {
+              acc[yp][xq][ct] = mfma16(A[yp][xq], Va[yp][ct], acc[yp][xq][ct]);
+              acc[yp][xq + 1][ct] = mfma16(A[yp][xq + 1], Vb[yp][ct], acc[yp][xq + 1][ct]);
+            }
         }
-#pragma unroll
-        for (int xp = 0; xp < 4; ++xp) P0[xp] = Q2[xp], P1[xp] = Q3[xp];
         __builtin_amdgcn_sched_barrier(0);
       };
 
@@ -147,9 +182,9 @@ __device__ __forceinline__ void wgrad2_body(const WgradArgs& a, const int bid, c
       bt_pk(P0[0], P0[1], P0[2], P0[3], h0[0], h0[1], h0[2], h0[3]);
       bt_pk(P1[0], P1[1], P1[2], P1[3], h1[0], h1[1], h1[2], h1[3]);
       for (int s = 0;;) {
-        step(L0, s);
+        step(L0, P0, P1, Q0, Q1, s);
         if (++s >= n) break;
-        step(L1, s);
+        step(L1, Q0, Q1, P0, P1, s);
         if (++s >= n) break;
       }
     }
