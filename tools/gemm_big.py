@@ -47,7 +47,13 @@ def main():
         ref_dx = torch.einsum("zmn,znk->zmk", dy64, W64) * (x64 > 0)
         ref_dW = torch.einsum("zmn,zmk->znk", dy64, x64)
         if nb == 4:  # the critic and the target critic, two Q functions each: a two-level batch
-            fwd = lambda: ops.linear_fwd(x, B * H, W, H * H, b, H, out, B * H, B, H, H, 2, relu=1,  # noqa: E731
+            # (ops.linear_fwd: the outer level's bias stride is the weights' outer stride -- biases live behind their
+            # weights in the agent's flat parameter buffers)
+            bflat = torch.zeros(2 * 2 * H * H, device="cuda")
+            for o in range(2):
+                for z in range(2):
+                    bflat[o * 2 * H * H + z * H:o * 2 * H * H + (z + 1) * H] = b[2 * o + z]
+            fwd = lambda: ops.linear_fwd(x, B * H, W, H * H, bflat, H, out, B * H, B, H, H, 2, relu=1,  # noqa: E731
                                          outer=(2, 2 * B * H, 2 * H * H, 2 * B * H))
         else:
             fwd = lambda: ops.linear_fwd(x, B * H, W, H * H, b, H, out, B * H, B, H, H, nb, relu=1)  # noqa: E731
