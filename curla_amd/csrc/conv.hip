@@ -11,8 +11,9 @@
 // fp32 product, fp32 accumulation); every other inner product runs on the exact-f32 matrix pipe
 // (v_mfma_f32_16x16x4_f32), which has the same 157 TFLOP/s roof as the fp32 vector pipe but needs one operand VGPR
 // per lane instead of 2 per FMA.  The stride-1 layers (forward, data gradient, weight gradient) are row-walk
-// kernels (conv_rwb.h; conv_rw.h / conv_rw43.h: the f32-input forms, selectable; conv_rw_wgrad.h): 1-D Winograd F(2,3)
-// along x, a wave walks down a strip of pixel-pair columns with the transformed filter streamed from LDS; the first
+// kernels (conv_rwb.h; conv_rw.h / conv_rw43.h: the f32-input forms, selectable; conv_rw_wgrad2.h / conv_rw_wgrad.h): 1-D
+// Winograd F(2,3) along x (the weight gradient: F(3,2) in both directions), a wave walks down a strip of pixel-pair
+// columns with the transformed filter streamed from LDS; the first
 // layer has a banded form (crop staged in LDS) and row-walk forms (conv1_rw.h, conv1_u8_rw.h).  What bounds the
 // f32-input loops is VALU issue time (a VALU instruction and an f32 MFMA cannot issue in the same cycle), so
 // everything in them is counted in instructions.  (Rounds 1-3 also

@@ -14,8 +14,9 @@ enum CurlaOpt {
   kOptBwdSplit,     // stride-1 backward launch: 0 auto, 1 two + two workgroups per CU, 2 one + one side by side
   kOptGemmTile,     // tile shape of the tiled GEMM: 0 auto, 1 64x64, 2 64x32, 3 32x32, 4 128x64 (bf16x3) wherever it applies
   kOptLinearBwd,    // backward of a linear layer: 0 one launch for dW and dx, 1 two launches
-  kOptGemmMfma,     // arithmetic of the tiled GEMM: 0 auto (bf16x3 on 128x64 tiles where those fill the chip, else f32), 1 f32
-                    // (the f32-input MFMA), 2 b3 (bf16x3 on the bf16 matrix cores for every interior, aligned tile)
+  kOptGemmMfma,     // arithmetic of the tiled GEMM and of the encoder fc forward: 0 auto (GEMM: bf16x3 on 128x64 tiles where those
+                    // fill the chip, else f32; fc forward: bf16x3), 1 f32 (the f32-input MFMA everywhere), 2 b3 (bf16x3 on the
+                    // bf16 matrix cores for every interior, aligned tile)
   kOptS1Wgrad,      // stride-1 weight gradient: 0 auto (= xy), 1 x (Winograd F(3,2) along x, conv_rw_wgrad.h), 2 xy (both directions,
                     // conv_rw_wgrad2.h)
   kOptCount

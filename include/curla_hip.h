@@ -52,7 +52,8 @@ int curla_abi_version(void);
  *   bwd_split   auto | 0 | 1           stride-1 backward: 2 + 2 workgroups per CU, or 1 + 1 side by side
  *   gemm_tile   auto | 6464 | 6432 | 3232 | 12864   tile of the tiled GEMM (12864: the 128 x 64 bf16x3 tile wherever it applies)
  *   linear_bwd  pair | split           dW and dx of a linear layer in one launch or two
- *   gemm_mfma   auto | f32 | b3        arithmetic of the tiled GEMM: f32 = the f32-input MFMA; b3 = interior aligned tiles with fp32
+ *   gemm_mfma   auto | f32 | b3        arithmetic of the tiled GEMM (and of the encoder fc forward: bf16x3 unless f32): f32 = the
+ *                                      f32-input MFMA; b3 = interior aligned tiles with fp32
  *                                      operands as three bf16 parts on the bf16 matrix cores, split once when a tile is staged;
  *                                      auto = b3 on 128 x 64 tiles where those give every CU a workgroup, f32 elsewhere
  *   s1_wgrad    auto | x | xy          stride-1 weight gradient: Winograd F(3,2) along x, or (auto) in both directions (2 x 2 gradient
