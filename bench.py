@@ -11,11 +11,13 @@ configuration (default c2 = configs[1], the one the metric is quoted on):
   c2  B=512, 84x84x9 uint8 ring -> random_crop 76x76, 4 conv layers, CURL+critic+actor
   c3  --pixel_sac: identity augmentation (84x84 un-cropped, train.py:262-264), no CURL head, B=512
   c5  B=1024, 168x168x12 (frame_stack 4), color_jiggle, 6 conv layers (configs[4] per GPU)
+  c1t the reference AS SHIPPED (train.py:45-46,72; augmentations.py:21-24; encoder.py:26,42-43): B=512, 90x160x9 uint8
+      ring -> the default RandomCrop (factor 0.84: 76x135), 4 conv layers (31x61 out, fc over 60512), CURL+critic+actor
 With N>1 every rank does the same on its own ring shard and the gradient buckets
 are all-reduced over RCCL (weak scaling).  Prints ONE JSON line on rank 0.
 
 Without ``--config`` the line's ``metric`` / ``value`` / ``config`` are c2's and, at N = 1, the same process then
-measures c3 and c5 as well (the c2 ring is freed first) and reports them under ``other_configs`` -- each with its own
+measures c1t, c3 and c5 as well (the c2 ring is freed first) and reports them under ``other_configs`` -- each with its own
 ``value``, ``ms_per_step``, ``steps``, ``roofline`` and ``cpu_baseline``; ``--no-others`` or an explicit ``--config``
 measures one configuration only.  At N > 1 only c2 is measured unless ``--others`` asks for all three (a failure in a
 secondary configuration of a multi-GPU job would take the headline line down with it).
@@ -72,6 +74,14 @@ CONFIGS = {
                         "168x168x12 uint8 replay ring (frame_stack 4), color_jiggle augmentation, encoder 6x32 filters "
                         "feat 50, hidden 1024, CURL+critic+actor (actor/target every 2nd step)",
                cpu_batch=32, cpu_calls=2),
+    # not a BASELINE.json configuration: the one geometry the unmodified reference runs (its encoder's shape table and
+    # its RandomCrop's factor admit nothing else with 90x160 frames), at train.py's batch size -- reported beside them
+    "c1t": dict(baseline_index=None, obs=(9, 90, 160), crop=(76, 135), aug="random_crop_default", layers=4, batch=512,
+                pixel_sac=False, metric="SAC+CURL gradient updates/sec, batch=512 90x160x9 -> 76x135 (reference as shipped)",
+                workload="the reference's shipped configuration (train.py:45-46,72; augmentations.py:21-24; encoder.py:26,"
+                         "42-43): CurlSacAgent.update(), per-GPU batch 512, 90x160x9 uint8 replay ring -> default RandomCrop "
+                         "(ceil(0.84 x side) = 76x135), encoder 4x32 filters (31x61 out) feat 50, hidden 1024, "
+                         "CURL+critic+actor (actor/target every 2nd step)", cpu_batch=128, cpu_calls=3),
 }
 
 
@@ -292,7 +302,9 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
     curla_amd.set_seed_everywhere(1)
     from curla_amd import augmentations as A  # (make_augmentor prints a banner; stdout carries the JSON line only)
     aug = {"random_crop": lambda: A.RandomCrop((H, W), cfg["crop"]), "identity": lambda: A.IdentityAugmentation((H, W)),
+           "random_crop_default": lambda: A.RandomCrop((H, W)),  # (the reference's own factor decides the crop)
            "color_jiggle": lambda: A.ColorJiggle((H, W))}[cfg["aug"]]()
+    assert cfg["crop"] is None or tuple(aug.output_shape) == tuple(cfg["crop"]), (aug.output_shape, cfg["crop"])
     agent = curla_amd.CurlSacAgent(
         (C,) + tuple(aug.output_shape), (2,), dev, aug, hidden_dim=HIDDEN, discount=0.99, init_temperature=0.1,
         alpha_lr=1e-4, alpha_beta=0.5, actor_lr=1e-3, actor_beta=0.9, critic_lr=1e-3, critic_beta=0.9, critic_tau=0.01,
@@ -510,7 +522,9 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
                           "cores with every fp32 operand as the exact sum of three bf16 parts (six products per fp32 product, "
                           "fp32 accumulation: measured error below a float32 fmaf chain's, tools/micro/bf16x3_error.py); "
                           "everything else on the f32-input MFMA / VALU",
-            "config": {"workload": cfg["workload"], "baseline_config": f"configs[{cfg['baseline_index']}]",
+            "config": {"workload": cfg["workload"],
+                       "baseline_config": (f"configs[{cfg['baseline_index']}]" if cfg["baseline_index"] is not None else
+                                           "none (the reference's shipped geometry, beside BASELINE.json's)"),
                        "replay_capacity": cap * world, "shards": shards, "prefill": prefill,
                        "parallelism": f"dp{world}", "priming_updates": 1, "clock_warmup_s": args.clock_warmup_s,
                        "update_graphs": graphed},
@@ -587,7 +601,7 @@ def main():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", choices=sorted(CONFIGS), default=None,
-                    help="measure this configuration only (default: c2, then c3 and c5 under other_configs)")
+                    help="measure this configuration only (default: c2, then c3, c5 and c1t under other_configs)")
     ap.add_argument("--no-others", action="store_true", help="without --config: measure c2 only")
     ap.add_argument("--others", action="store_true",
                     help="measure c3 and c5 after c2 at N > 1 as well (default: only at N = 1 -- a multi-GPU run that "
@@ -611,7 +625,8 @@ def main():
     args = ap.parse_args()
     main_cfg = args.config or "c2"
     world_env = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
-    others = [] if (args.config is not None or args.no_others or (world_env > 1 and not args.others)) else ["c3", "c5"]
+    others = [] if (args.config is not None or args.no_others or (world_env > 1 and not args.others)) else \
+        ["c3", "c5", "c1t"]
 
     def budget(name):
         """(steps, warmup) of a configuration: the command line's for the main one and c3; c5's updates are 15x

@@ -1141,9 +1141,9 @@ class CurlSacAgent(object):
     def _graph_usable(self, replay_buffer, step, only_cpc):
         # data parallel: RCCL collectives are capturable (they are enqueued on streams like kernels); a backend that is
         # staged through the host (gloo) is not
-        return (replay_buffer is self._graph_rb and not only_cpc and not (self._dp_active and self._dp_staged)
-                and not (self._dp_active and not self._dp_avg) and not self._records(step)
-                and step % self.log_interval != 0 and self.training)
+        # (_dp_avg: the group's backend is RCCL; every other backend takes the sum-and-divide / staged path)
+        return (replay_buffer is self._graph_rb and not only_cpc and not (self._dp_active and not self._dp_avg)
+                and not self._records(step) and step % self.log_interval != 0 and self.training)
 
     def _graph_live(self, opt):
         """The parameters ``opt``'s step touches in a captured update (None: all).  Under detach_encoder the critic's
@@ -1169,12 +1169,12 @@ class CurlSacAgent(object):
     def _graph_tail(self, kind, B):
         """The 80 control bytes of one graphed update (ReplayBuffer.GRAPH_TAIL) -- and the host-side bookkeeping of
         everything they stand for: the torch generator's offset moves on as _noise() would move it, every optimizer that
-        steps in this kind of update counts its step.  Returns (bytes, undo): ``undo()`` takes the bookkeeping back."""
+        steps in this kind of update counts its step.  Only called once the update's graph exists (a capture that failed
+        has run eagerly instead), so there is nothing to take back."""
         do_actor, _, do_cpc = kind
         u64 = np.zeros(4, dtype=np.uint64)
         gen = torch.cuda.default_generators[self.device.index if self.device.index is not None
                                             else torch.cuda.current_device()]
-        gen_off0 = gen.get_offset()
         n = B * self.action_dim
         for j in range(2 if do_actor else 1):  # critic-phase draw, then the actor phase's (curl_sac.py:352, 378)
             off = gen.get_offset()
@@ -1183,7 +1183,6 @@ class CurlSacAgent(object):
         f64 = np.zeros(2, dtype=np.float64)
         f32 = np.zeros(8, dtype=np.float32)
         steps = [(0, self.critic_optimizer)]
-        la_prev = None
         if do_actor:
             steps.append((1, self.actor_optimizer))
             lo = self.log_alpha_optimizer
@@ -1192,28 +1191,28 @@ class CurlSacAgent(object):
             if len(st) == 0:
                 st["step"] = torch.tensor(0.0, dtype=torch.float32)
                 st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
-            la_prev = st["step"]
             t64 = int(round(float(st["step"]))) + 1
             b1, b2 = float(g["betas"][0]), float(g["betas"][1])
             f64[0], f64[1] = float(g["lr"]) / (1.0 - b1 ** float(t64)), (1.0 - b2 ** float(t64)) ** 0.5
             st["step"] = torch.tensor(float(t64), dtype=torch.float32)
         if do_cpc:
             steps += [(2, self.encoder_optimizer), (3, self.cpc_optimizer)]
-        done = []
         for slot, opt in steps:
             live = self._graph_live(opt)
             f32[2 * slot], f32[2 * slot + 1] = opt.hyper_floats(opt.next_step(live))
             opt.advance(live)
-            done.append((opt, live))
+        return u64.tobytes() + f64.tobytes() + f32.tobytes()
 
-        def undo():
-            gen.set_offset(gen_off0)
-            for opt, live in done:
-                opt.advance(live, by=-1)
-            if la_prev is not None:
-                lo = self.log_alpha_optimizer
-                lo.state[lo.param_groups[0]["params"][0]]["step"] = la_prev
-        return u64.tobytes() + f64.tobytes() + f32.tobytes(), undo
+    GRAPH_CAPTURE_RETRIES = 3  # failed captures (on any rank) after which update graphs are switched off
+
+    def _graph_capture_agreed(self, ok):
+        """True when the capture succeeded on EVERY rank of the data-parallel group (one rank: ``ok`` itself)."""
+        if not (self._dp_active and self._dp_world > 1):
+            return bool(ok)
+        import torch.distributed as dist
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self._dp_group)
+        return bool(int(flag.item()))
 
     def _drop_graphs(self):
         """Forget the captured graphs (they are re-captured after ``warm`` further eager updates of each kind)."""
@@ -1240,9 +1239,10 @@ class CurlSacAgent(object):
         B = rb.batch_size
         if st["graph"] is None:
             # capture FIRST, commit the host's bookkeeping (NumPy draw, generator offset, step counts) only once the
-            # capture has succeeded: a capture that raises (a first-use attribute call after an option change, a HIP
-            # call from another thread) leaves the agent exactly where it was, and this update runs eagerly
-            np_state = np.random.get_state()
+            # capture has succeeded: nothing inside the captured region draws from NumPy or moves the generator
+            # (draw_indices / _graph_tail run after it), so a capture that raises (a first-use attribute call after an
+            # option change, a HIP call from another thread) has touched only the phase-to-phase hints below, which are
+            # reset, and this update runs eagerly
             blk = rb.graph_block(st["slot"])
             base = blk["dev"].data_ptr() + blk["tail"]
             dyn = {self.critic_optimizer: base + 48, self.actor_optimizer: base + 56, self.encoder_optimizer: base + 64,
@@ -1254,24 +1254,43 @@ class CurlSacAgent(object):
             null = _NullLog()
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
+            err = None
             try:
                 with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                     self._update_phases(rb.graph_refs(st["slot"]), null, step)
             except Exception as e:  # noqa: BLE001
-                np.random.set_state(np_state)
-                warnings.warn(f"curla_amd: capturing the update graph of {kind} failed ({e!r}); this update runs "
-                              "eagerly and the capture is tried again next time", RuntimeWarning, stacklevel=3)
-                self._graph_seen[kind] = seen  # (the slot keeps its empty entry: the same turn captures again)
-                return self._update_eager(rb, L, step)
+                err = e
             finally:
                 self._graph_cap = None
                 for opt in dyn:
                     opt._dyn = None
                 self.log_alpha_optimizer._curla_dyn64 = None
+            if err is not None:
+                # what _update_phases sets from one phase to the next and had no chance to clear
+                self._pos_hint = self._anchor_cache = self._pos_cache = None
+                self._pos_fc_done = self._soft_update_hint = self._soft_update_done = False
+                self._dp_pending = []
+            # data parallel: every rank captures at the same step; ONE rank replaying while another runs eagerly would
+            # still pair up collective for collective, but the ranks would sit on different schedules indefinitely with
+            # nothing checking it -- so the outcome is agreed on (one host-side flag, at capture time only)
+            ok_everywhere = self._graph_capture_agreed(err is None)
+            if not ok_everywhere:
+                self._graph_failures = getattr(self, "_graph_failures", 0) + 1
+                where = "on this rank" if err is not None else "on another rank"
+                give_up = self._graph_failures >= self.GRAPH_CAPTURE_RETRIES
+                warnings.warn(f"curla_amd: capturing the update graph of {kind} failed {where} ({err!r}); this update "
+                              "runs eagerly" + (" and update graphs are now disabled (every rank of the group does the same)"
+                                                if give_up else " and the capture is tried again next time"),
+                              RuntimeWarning, stacklevel=3)
+                if give_up:
+                    self._graphs = None
+                else:
+                    self._graph_seen[kind] = seen  # (the slot keeps its empty entry: the same turn captures again)
+                return self._update_eager(rb, L, step)
             st["graph"] = graph
             self._graph_key_at_capture = key
         idxs, offs = rb.draw_indices()
-        tail, _ = self._graph_tail(kind, B)
+        tail = self._graph_tail(kind, B)
         blk = rb.graph_write(st["slot"], idxs, offs, tail)
         if self._dp_active and self._dp_check_every > 0 and step % self._dp_check_every == 0:
             self.check_replicas()

@@ -367,7 +367,10 @@ def critic_phase(actor: Params, critic: Params, critic_target: Params, log_alpha
         alpha = log_alpha.detach().exp()
         target_V = torch.min(tq1, tq2) - alpha * log_pi
         target_Q = reward + (not_done * discount * target_V)
-        target_Q = target_Q.to(reward.dtype)  # (curl_sac.py:355 `.to(torch.float32)`: the float64 log_alpha promotes it)
+        # curl_sac.py:353-355 has no cast: `self.alpha` is a 0-dim float64 tensor, and a 0-dim operand does not promote
+        # a float32 tensor, so the reference's target_Q is float32.  The cast below is therefore a no-op in the fp32
+        # evaluation; it only keeps target_Q in the ARGUMENTS' dtype when the tests evaluate this function in float64.
+        target_Q = target_Q.to(reward.dtype)
     c = _leafify(critic)
     enc, qh = {}, []
     plan = _branch_plan(relu_branches, q_branches, force=regrad)

@@ -38,6 +38,11 @@ Fixtures:
                   mode_detach    detach_encoder=True (curl_sac.py:358)
                   mode_l6c12     num_layers=6, 12 input channels, identity augmentation
                                  (encoder.py:54-63; utils.py:168-182): configs[4]'s geometry, small
+                  mode_thesis, mode_thesis_odd  (round 6) the reference AS SHIPPED: 90x160 frames (train.py:45-46),
+                                 the default RandomCrop factor 0.84 -> 76x135 (augmentations.py:21-24) and the
+                                 encoder's own shape table (encoder.py:26,42-43) -- encoder.OUT_DIM is NOT assigned
+                                 and RandomCrop.output_shape is NOT overridden for these two; B=4, an even and an
+                                 odd update()
                 every gradient an optimizer consumed (full tensors), the logged
                 scalars, the RNG draws / noise, and the parameters after the
                 update (small tensors whole, the first 10000 elements of big ones).
@@ -273,8 +278,16 @@ class Recorder:
         return rec
 
 
-def build_agent(obs_shape_key, real_hw, hidden, num_layers, seed, aug, detach_encoder=False, pixel_sac=False):
-    encoder.OUT_DIM = {num_layers: list(conv_out_hw(real_hw[0], real_hw[1], num_layers))}
+SHIPPED_OUT_DIM = dict(encoder.OUT_DIM)  # encoder.py:21, before any fixture touches it
+
+
+def build_agent(obs_shape_key, real_hw, hidden, num_layers, seed, aug, detach_encoder=False, pixel_sac=False,
+                unpatched=False):
+    if unpatched:  # the shipped shape tables decide (encoder.py:38-47); nothing of the reference is assigned to
+        encoder.OUT_DIM = dict(SHIPPED_OUT_DIM)
+        assert tuple(obs_shape_key[1:]) == tuple(real_hw)
+    else:
+        encoder.OUT_DIM = {num_layers: list(conv_out_hw(real_hw[0], real_hw[1], num_layers))}
     utils.set_seed_everywhere(seed)
     agent = curl_sac.CurlSacAgent(
         obs_shape=obs_shape_key, action_shape=(2,), device=torch.device("cpu"), augmentor=aug,
@@ -283,7 +296,8 @@ def build_agent(obs_shape_key, real_hw, hidden, num_layers, seed, aug, detach_en
         critic_lr=1e-3, critic_beta=0.9, critic_tau=0.01, critic_target_update_freq=2,
         encoder_feature_dim=50, encoder_lr=1e-3, encoder_tau=0.05, num_layers=num_layers, num_filters=32,
         log_interval=1, log_param_hist_imgs=False, detach_encoder=detach_encoder, pixel_sac=pixel_sac)
-    agent.image_shape = tuple(real_hw)
+    if not unpatched:
+        agent.image_shape = tuple(real_hw)
     return agent
 
 
@@ -475,15 +489,21 @@ POST_CLIP = 10000  # elements kept of a parameter after the update (tests/golden
 def gen_modes():
     """One whole reference update() per mode from seeded weights and FRESH optimizers (so the oracle's and the HIP
     agent's own Adam steps can follow it to the post-update parameters)."""
-    from tests.golden_recipes import MODES
+    from tests.golden_recipes import BIG, MODES, big_sample
     for name, m in MODES.items():
         c, in_hw, out_hw, layers = m["channels"], tuple(m["in_hw"]), tuple(m["out_hw"]), m["num_layers"]
-        if m["crop"]:
+        unpatched = bool(m.get("unpatched"))
+        if unpatched:
+            # the reference exactly as shipped: default RandomCrop (augmentations.py:21-24), shipped encoder tables
+            aug = augmentations.RandomCrop(in_hw)
+            assert tuple(aug.output_shape) == out_hw, (aug.output_shape, out_hw)
+        elif m["crop"]:
             aug = make_crop_augmentor(in_hw, out_hw)
         else:
             aug = augmentations.IdentityAugmentation(in_hw)
-        agent = build_agent((c, 84, 84), out_hw, hidden=m["hidden"], num_layers=layers, seed=1, aug=aug,
-                            detach_encoder=m["detach_encoder"], pixel_sac=m["pixel_sac"])
+        agent = build_agent((c,) + out_hw if unpatched else (c, 84, 84), out_hw, hidden=m["hidden"], num_layers=layers,
+                            seed=1, aug=aug, detach_encoder=m["detach_encoder"], pixel_sac=m["pixel_sac"],
+                            unpatched=unpatched)
         apply_recipe_weights(agent, m["weight_seeds"])
         rb = utils.ReplayBuffer((c,) + in_hw, (2,), m["n_fill"], m["batch"], torch.device("cpu"), aug)
         fill_buffer(rb, m["n_fill"], (c,) + in_hw, seed=m["buffer_seed"])
@@ -494,7 +514,11 @@ def gen_modes():
         out = {"rng/n_draws": np.int64(len(recorder.randint_calls))}
         for k, v in rec.items():
             top = k.split("/")[0]
-            if top in ("rng", "noise", "scalar") or "/grad/" in k or k in (
+            if "/grad/" in k and np.size(v) > BIG:
+                # (fc.weight at 76 x 135 is 50 x 60512: a strided sample of its elements + a summary of the whole)
+                out[k] = big_sample(v)
+                out[k.replace("/grad/", "/gradsum/")] = summarize(v)
+            elif top in ("rng", "noise", "scalar") or "/grad/" in k or k in (
                     "batch/action", "batch/reward", "batch/not_done", "critic/q1", "critic/q2", "critic/tq1",
                     "critic/tq2", "actor/pi", "actor/log_pi", "cpc/logits"):
                 out[k] = v

@@ -74,7 +74,9 @@ def test_four_ranks_through_the_self_respawn_all_configs():
         got = d["allreduce"]["buckets"][bucket]
         assert got["bytes"] // 4 in range(floats, floats + 96), (bucket, got)
     others = d["other_configs"]
-    assert sorted(others) == ["c3", "c5"]
+    assert sorted(others) == ["c1t", "c3", "c5"]
+    _check_line(others["c1t"], 4, 512, ("critic", "actor", "cpc"))
+    assert "reference's shipped" in others["c1t"]["config"]["baseline_config"]
     _check_line(others["c3"], 4, 512, ("critic", "actor"))   # pixel_sac: no cpc bucket
     _check_line(others["c5"], 4, 512, ("critic", "actor", "cpc"))
     assert others["c3"]["config"]["baseline_config"] == "configs[2]"

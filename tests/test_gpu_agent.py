@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from tests._util import RTOL, load, rel_err, sub, summarize
+from tests._util import RTOL, like, load, rel_err, sub, summarize
 
 pytestmark = pytest.mark.gpu
 
@@ -81,6 +81,21 @@ def grads_of(module, prefix=""):
             g = enc.fc.to_reference_layout(g)
         out[prefix + n] = g.detach().cpu()
     return out
+
+
+def conv_branch_flips(tag, oracle_acts, device_branches, limit=4):
+    """Conv activations whose ReLU branch differs between the fp32 oracle (``enc`` outputs of a phase function: values
+    are never touched by ``relu_branches``) and the device: at most ``limit`` per layer, each within 1e-5 of zero."""
+    total = 0
+    for i, dev in enumerate(device_branches):
+        a = oracle_acts[f"conv{i + 1}"]
+        differ = (a > 0) != dev
+        k = int(differ.sum())
+        if k:
+            assert float(a[differ].abs().max()) <= 1e-5 and k <= limit, (tag, i, k, float(a[differ].abs().max()))
+        total += k
+    REPORT.append((f"{tag}: conv ReLU branches that differ from the fp32 oracle's", float(total)))
+    return total
 
 
 def fill_ring(rb, obs_full, next_full):
@@ -700,7 +715,7 @@ def test_other_config_geometries_vs_oracle(name, obs_shape, layers, pixel_sac, B
 
 
 
-@pytest.mark.parametrize("name", ["odd", "pixel_sac", "only_cpc", "detach", "l6c12"])
+@pytest.mark.parametrize("name", ["odd", "pixel_sac", "only_cpc", "detach", "l6c12", "thesis", "thesis_odd"])
 def test_update_modes_vs_reference_fixtures(name):
     """The branches of ``update()`` beside the even CURL step -- an odd step (curl_sac.py:436,441), ``pixel_sac``
     (:448), ``only_cpc`` (train.py:425-429), ``detach_encoder`` (:358) and the 6-layer / 12-channel / identity geometry
@@ -710,7 +725,12 @@ def test_update_modes_vs_reference_fixtures(name):
     draws the minibatch itself.  Per phase: the loss and every gradient the optimizer consumes against the fixture (1e-4
     for the first phase, 5e-3 for phases behind an Adam step -- SURVEY.md D11) and against the oracle evaluated on the
     agent's own parameters at the start of that phase (1e-4); then the parameters after the update element by element,
-    what must not have moved bit for bit, and which tensors each Adam stepped."""
+    what must not have moved bit for bit, and which tensors each Adam stepped.
+    Round 6, ``thesis`` / ``thesis_odd``: the reference AS SHIPPED -- 90 x 160 frames, the default ``RandomCrop`` (0.84
+    -> 76 x 135, augmentations.py:21-24), the encoder's own shape table (encoder.py:26,42-43); the fixture was recorded
+    with no assignment to the reference's modules, and this side builds ``RandomCrop(in_hw)`` with no output shape
+    either.  Gradients with more than 2^18 elements (fc.weight: 50 x 60512) are held to the fixture's strided sample and
+    to its summary of the whole tensor."""
     import curla_amd
     from oracle import curla_oracle as O
     from tests.golden_recipes import mode_inputs
@@ -719,7 +739,11 @@ def test_update_modes_vs_reference_fixtures(name):
     m = inp["m"]
     c, in_hw, out_hw, layers, B = m["channels"], tuple(m["in_hw"]), tuple(m["out_hw"]), m["num_layers"], m["batch"]
     dev = torch.device("cuda")
-    aug = curla_amd.RandomCrop(in_hw, out_hw) if m["crop"] else curla_amd.IdentityAugmentation(in_hw)
+    if m.get("unpatched"):
+        aug = curla_amd.RandomCrop(in_hw)  # the default factor decides, as in the reference
+        assert aug.output_shape == out_hw
+    else:
+        aug = curla_amd.RandomCrop(in_hw, out_hw) if m["crop"] else curla_amd.IdentityAugmentation(in_hw)
     torch.manual_seed(0)
     agent = curla_amd.CurlSacAgent((c,) + out_hw, (2,), dev, aug, hidden_dim=m["hidden"], detach_encoder=m["detach_encoder"],
                                    pixel_sac=m["pixel_sac"], **{**HP, "num_layers": layers})
@@ -768,11 +792,16 @@ def test_update_modes_vs_reference_fixtures(name):
         check(f"{tag} critic loss", L.scalars["train_critic/loss"], g["scalar/train_critic/loss"])
         ref = sub(g, "critic/grad/")
         assert len(ref) == (4 + 12 if m["detach_encoder"] else 2 * layers + 4 + 12)
-        for k, v in ref.items():
-            check(f"{tag} critic grad {k} (fixture)", p["critic"][k], v)
         a, c_, t_, _, la = p["state"]
         own = O.critic_phase(a, c_, t_, la, o_obs, o_act, o_rew, o_nxt, o_nd, nc.cpu(), discount=0.99,
                              detach_encoder=m["detach_encoder"], relu_branches=p["branches"], **kw)
+        flips = conv_branch_flips(f"{tag} critic phase", own["enc"], p["branches"])
+        for k, v in ref.items():
+            # (the fixture cannot be re-differentiated along the device's branches: where a conv activation within 1e-5
+            # of zero fell on the other side -- counted and bounded above -- the conv gradients carry that one event)
+            check(f"{tag} critic grad {k} (fixture)", like(p["critic"][k], v), v, 5e-3 if flips and ".convs." in k else RTOL)
+        for k, v in sub(g, "critic/gradsum/", as_torch=False).items():
+            check(f"{tag} critic grad {k} (fixture, summary of the whole tensor)", summarize(p["critic"][k]), v)
         for k, v in own["grads"].items():
             if v is not None:
                 check(f"{tag} critic grad {k} (oracle, own parameters)", p["critic"][k], v)
@@ -790,20 +819,21 @@ def test_update_modes_vs_reference_fixtures(name):
         ref = sub(g, "actor/grad/")
         assert len(ref) == 10
         for k, v in ref.items():
-            check(f"{tag} actor grad {k} (fixture)", p["actor"][k], v, 5e-3)
+            check(f"{tag} actor grad {k} (fixture)", like(p["actor"][k], v), v, 5e-3)
             check(f"{tag} actor grad {k} (oracle, own parameters)", p["actor"][k], own["grads"][k])
     if curl:
         p = ph["cpc"]
         _, c_, t_, W_, _ = p["state"]
         own = O.cpc_phase(c_, t_, W_, o_obs, o_pos, num_layers=layers, relu_branches=p["branches"])
         tol = RTOL if first == "cpc" else 5e-3
+        flips_cpc = conv_branch_flips(f"{tag} cpc phase", own["enc"], p["branches"])
         check(f"{tag} curl loss (fixture)", L.scalars["train/curl_loss"], g["scalar/train/curl_loss"], tol)
         check(f"{tag} curl loss (own parameters)", L.scalars["train/curl_loss"], own["loss"])
         ref = sub(g, "cpc/grad/")
         assert len(ref) == 2 * layers + 4 + 1
         for k, v in ref.items():
             got = p["W"] if k == "W" else p["critic"][k]
-            check(f"{tag} cpc grad {k} (fixture)", got, v, tol)
+            check(f"{tag} cpc grad {k} (fixture)", like(got, v), v, 5e-3 if flips_cpc and ".convs." in k else tol)
             check(f"{tag} cpc grad {k} (oracle, own parameters)", got, own["W_grad"] if k == "W" else own["grads"][k])
     # ---- after the update: every parameter against the reference's, element by element.  Adam's first step is
     # lr * g / (|g| + eps): lr * sign(g) for all but the elements whose gradient is within rounding of
@@ -1112,13 +1142,31 @@ def _perturb_convs(agent, oracle, layers, seed=5):
         agent.critic_target.load_state_dict({k: v.detach().clone() for k, v in oracle.critic_target.items()})
 
 
-@pytest.mark.parametrize("aug_name", ["color_jiggle", "noisy_cover"])
-def test_c5_update_vs_oracle_on_identical_post_augmentation_tensors(aug_name):
+@pytest.mark.parametrize("aug_name,f32_forms", [("color_jiggle", False), ("noisy_cover", False), ("color_jiggle", True)],
+                         ids=["color_jiggle", "noisy_cover", "color_jiggle, f32 forms (tight post-Adam bound)"])
+def test_c5_update_vs_oracle_on_identical_post_augmentation_tensors(aug_name, f32_forms):
     """BASELINE configs[4] (frame_stack 4, 6 conv layers, colour jitter) with everything AFTER the augmentation
     pinned: the augmented float tensors that ``ReplayBuffer.sample_cpc()`` returns are handed,
     byte for byte, to the oracle agent and to update_critic / update_actor_and_alpha / update_cpc; per-phase
     losses and every gradient that reaches Adam must agree to 1e-4.  (The jitter arithmetic itself is kornia's:
-    parity unpinned, test_gpu_augment.py checks it against this build's restatement only.)"""
+    parity unpinned, test_gpu_augment.py checks it against this build's restatement only.)
+    ``f32_forms``: every kernel pinned to its exact-f32 form (tests/test_gpu_switches.py: F32_FORMS); the fraction of
+    post-Adam conv weights that may sit a step away from the oracle's is then held to the round-4 bound (1 %) instead
+    of the 10 % the bf16x3 defaults are given (advisor, round 5)."""
+    import contextlib
+
+    import curla_amd
+    from curla_amd import _lib
+    from oracle import curla_oracle as O
+    with contextlib.ExitStack() as stack:
+        if f32_forms:
+            from tests.test_gpu_switches import F32_FORMS
+            for k_, v_ in F32_FORMS.items():
+                stack.enter_context(_lib.option(k_, v_))
+        _c5_update_vs_oracle(aug_name, 0.01 if f32_forms else 0.10)
+
+
+def _c5_update_vs_oracle(aug_name, post_adam_off):
     import curla_amd
     from oracle import curla_oracle as O
     torch.manual_seed(21)
@@ -1214,7 +1262,7 @@ def test_c5_update_vs_oracle_on_identical_post_augmentation_tensors(aug_name):
         assert float(d.max()) <= 3 * 2 * 1e-3 + 1e-6, (k, float(d.max()))
         # (a conv ReLU branch that differs between the two sides -- see above -- moves the near-zero gradient elements
         # through zero: a few in a hundred; a wrong optimizer would move all of them)
-        assert float((d > 1e-5).float().mean()) <= 0.10, (k, float((d > 1e-5).float().mean()))
+        assert float((d > 1e-5).float().mean()) <= post_adam_off, (k, float((d > 1e-5).float().mean()), post_adam_off)
         assert float(d.median()) <= 1e-6, (k, float(d.median()))
 
 

@@ -153,9 +153,10 @@ def _move_off_init(agent, oracle, layers, seed=5):
                                      **{k: v.detach().clone() for k, v in convs.items()}})
 
 
-def _run(tag, obs_shape, in_hw, aug_name, layers, B, pixel_sac, capacity):
+def _make(obs_shape, in_hw, aug_name, layers, B, pixel_sac, capacity, **hp_extra):
+    """(agent, oracle, ring, hp): an agent and the oracle on the same seeded, moved-off-init weights, all learning rates
+    zero, and a ring of uniform random bytes (BASELINE's synthetic data) filled on the device."""
     import curla_amd
-    from curla_amd import _lib
     from oracle import curla_oracle as O
     torch.manual_seed(31)
     np.random.seed(31)
@@ -165,18 +166,21 @@ def _run(tag, obs_shape, in_hw, aug_name, layers, B, pixel_sac, capacity):
     out_hw = tuple(obs_shape[1:])
     if aug_name == "random_crop":
         aug = curla_amd.RandomCrop(in_hw, out_hw)
+    elif aug_name == "random_crop_default":
+        # the reference's own arithmetic decides the crop: ceil(0.84 * side) (augmentations.py:21-24)
+        aug = curla_amd.RandomCrop(in_hw)
+        assert aug.output_shape == out_hw, (aug.output_shape, out_hw)
     elif aug_name == "identity":
         aug = curla_amd.IdentityAugmentation(in_hw)
     else:
         aug = curla_amd.ColorJiggle(in_hw)
-    hp = {**HP, "num_layers": layers, "alpha_lr": 0.0, "actor_lr": 0.0, "critic_lr": 0.0, "encoder_lr": 0.0}
+    hp = {**HP, "num_layers": layers, "alpha_lr": 0.0, "actor_lr": 0.0, "critic_lr": 0.0, "encoder_lr": 0.0, **hp_extra}
     agent = curla_amd.CurlSacAgent(obs_shape, (2,), dev, aug, hidden_dim=1024, pixel_sac=pixel_sac, **hp)
     oracle = O.OracleAgent(obs_shape, (2,), hidden_dim=1024, pixel_sac=pixel_sac,
                            **{k: v for k, v in hp.items() if k != "log_interval"})
     _copy_agent_into_oracle(agent, oracle)
     _move_off_init(agent, oracle, layers)
 
-    # the ring: uniform random bytes (BASELINE's synthetic data), filled on the device; a host copy feeds the oracle
     rb = curla_amd.ReplayBuffer((C,) + tuple(in_hw), (2,), capacity, B, dev, aug)
     g = torch.Generator(device=dev).manual_seed(7)
     for ring in (rb._obs_store, rb._next_store):
@@ -186,29 +190,47 @@ def _run(tag, obs_shape, in_hw, aug_name, layers, B, pixel_sac, capacity):
     rb.not_dones.fill_(1.0)
     rb.not_dones[9::10] = 0.0
     rb.idx, rb.full = 0, True
+    return agent, oracle, rb, hp
 
-    obs, act, rew, nxt, nd, kw = rb.sample_cpc_refs()
+
+def _host_minibatch(rb, sample, aug_name, out_hw, capacity):
+    """The minibatch the ring handed the kernels, as the float NCHW tensors the reference's sample_cpc() returns
+    (utils.py:144-187): (obs, next_obs, pos)."""
+    from oracle import curla_oracle as O
+    obs, act, rew, nxt, nd, kw = sample
     pos = kw["obs_pos"]
     if aug_name == "color_jiggle":
         # float NHWC tensors, already augmented on the device: the oracle gets the same values in NCHW
         to_cpu = lambda r: r.src.permute(0, 3, 1, 2).contiguous().cpu()  # noqa: E731
         o_obs, o_nxt, o_pos = to_cpu(obs), to_cpu(nxt), to_cpu(pos)
         assert float(o_obs.min()) >= 0.0 and float(o_obs.max()) <= 255.001 and not torch.equal(o_obs, o_pos)
-    else:
-        # uint8 ring + indices + crop offsets: the oracle crops the same frames on the host (augmentations.py:65-73)
-        idx = obs.idx.cpu().numpy()
-        frames = rb._both if rb._both is not None else None
-        assert frames is not None
+        return o_obs, o_nxt, o_pos
+    # uint8 ring + indices + crop offsets: the oracle crops the same frames on the host (augmentations.py:65-73)
+    idx = obs.idx.cpu().numpy()
+    frames = rb._both if rb._both is not None else None
+    assert frames is not None
 
-        def host(ref):
-            f = frames[ref.idx].cpu().numpy().transpose(0, 3, 1, 2)  # [B, C, H, W] uint8 (obs or next_obs half)
-            if aug_name == "random_crop":
-                f = O.random_crop(f, ref.h1.cpu().numpy(), ref.w1.cpu().numpy(), out_hw)
-            return torch.from_numpy(np.ascontiguousarray(f)).float()
-        o_obs, o_nxt, o_pos = host(obs), host(nxt), host(pos)
-        assert np.array_equal(nxt.idx.cpu().numpy(), idx + capacity)
-        if aug_name == "random_crop":
-            assert not torch.equal(o_obs, o_pos)
+    def host(ref):
+        f = frames[ref.idx].cpu().numpy().transpose(0, 3, 1, 2)  # [B, C, H, W] uint8 (obs or next_obs half)
+        if aug_name.startswith("random_crop"):
+            f = O.random_crop(f, ref.h1.cpu().numpy(), ref.w1.cpu().numpy(), out_hw)
+        return torch.from_numpy(np.ascontiguousarray(f)).float()
+    o_obs, o_nxt, o_pos = host(obs), host(nxt), host(pos)
+    assert np.array_equal(nxt.idx.cpu().numpy(), idx + capacity)
+    if aug_name.startswith("random_crop"):
+        assert not torch.equal(o_obs, o_pos)
+    return o_obs, o_nxt, o_pos
+
+
+def _run(tag, obs_shape, in_hw, aug_name, layers, B, pixel_sac, capacity):
+    from curla_amd import _lib
+    from oracle import curla_oracle as O
+    agent, oracle, rb, hp = _make(obs_shape, in_hw, aug_name, layers, B, pixel_sac, capacity)
+    dev = torch.device("cuda")
+    out_hw = tuple(obs_shape[1:])
+
+    obs, act, rew, nxt, nd, kw = rb.sample_cpc_refs()
+    o_obs, o_nxt, o_pos = _host_minibatch(rb, (obs, act, rew, nxt, nd, kw), aug_name, out_hw, capacity)
     o_act, o_rew, o_nd = act.cpu().clone(), rew.cpu().clone(), nd.cpu().clone()
     noise_c, noise_a = torch.randn(B, 2), torch.randn(B, 2)
 
@@ -417,3 +439,164 @@ def test_c3_full_size_pixel_sac_update_vs_oracle():
 
 def test_c5_full_size_update_vs_oracle_on_identical_post_augmentation_tensors():
     _run("c5 B=1024 168x168x12 L=6", (12, 168, 168), (168, 168), "color_jiggle", 6, 1024, False, capacity=1024)
+
+
+def test_c1t_full_size_reference_shipped_geometry_update_vs_oracle():
+    """Round 6: the ONE geometry the reference runs as shipped -- train.py's 90 x 160 camera frames (train.py:45-46)
+    through the default RandomCrop (ceil(0.84 * side) = 76 x 135, augmentations.py:21-24) into the encoder's own shape
+    table (encoder.py:26,42-43: 31 x 61 after four layers, fc over 60512 inputs) at train.py's batch size 512
+    (train.py:72).  Rows of 67 / 65 / 63 / 61 pixels in the stride-1 stack; nothing about the shape is passed in: the
+    augmentor computes it."""
+    _run("c1t B=512 90x160->76x135 L=4", (9, 76, 135), (90, 160), "random_crop_default", 4, 512, False, capacity=1024)
+
+
+def _steps_case(tag, obs_shape, in_hw, aug_name, capacity, B=512, layers=4):
+    """The schedules of update() that the even step of _run() does not walk, at FULL batch, against the fp32 oracle
+    differentiated along the device's ReLU branches (conv layers and twin-Q hidden units: values untouched, SURVEY.md
+    D11), 1e-4 per tensor; all learning rates zero, so every phase of both sides sees the same weights:
+      * an ODD step (curl_sac.py:436,441: no actor phase, no target update; update_cpc encodes anchor AND positives
+        itself -- one two-problem launch per conv layer here, curl_sac.py:984-985 of this package);
+      * ``update(..., only_cpc=True)`` (train.py:425-429): the CURL phase alone;
+      * a GRAPH-REPLAYED odd and even step (enable_update_graphs): replayed from the captured hipGraph, then the same
+        step eagerly from the same NumPy / Philox stream positions -- gradient buffers, features, logits, Q values
+        and the policy noise bit for bit; the eager odd step is then held to the oracle with the noise the kernel
+        drew (read back from the workspace), so the replayed update is pinned to the oracle through it."""
+    from oracle import curla_oracle as O
+    agent, oracle, rb, hp = _make(obs_shape, in_hw, aug_name, layers, B, False, capacity)
+    dev = torch.device("cuda")
+    out_hw = tuple(obs_shape[1:])
+    kwc = dict(num_layers=layers, log_std_min=-10, log_std_max=2)
+    ws = agent._ws(B)
+    bad = []
+    drawn = []
+    real_sample = rb.sample_cpc_refs
+
+    def sample():
+        drawn.append(real_sample())
+        return drawn[-1]
+    rb.sample_cpc_refs = sample
+    phases = []
+    real_allreduce = agent._allreduce  # (called once per phase right in front of its optimizer step; no-op without DP)
+
+    def tap(*buckets, async_op=False):
+        if agent._graph_cap is None:  # (while a graph is being captured nothing may be copied to the host)
+            phases.append(dict(
+                critic=grads_of(agent.critic), W=agent.CURL.W.grad.detach().cpu().clone(),
+                conv=[(a.permute(0, 3, 1, 2) > 0).cpu() for a in ws.acts_main],
+                qh=[t.detach().cpu() > 0 for t in (ws.q_h1[0], ws.q_h2[0], ws.q_h1[1], ws.q_h2[1])]))
+        return real_allreduce(*buckets, async_op=async_op)
+    agent._allreduce = tap
+
+    def oracle_soft_update():  # utils.py:37-41 with train.py's rates, as update() applies it on even steps
+        with torch.no_grad():
+            for prefix, tau in (("Q1.", hp["critic_tau"]), ("Q2.", hp["critic_tau"]), ("encoder.", hp["encoder_tau"])):
+                O.soft_update(oracle.critic, oracle.critic_target, tau, prefix)
+
+    def oracle_critic(p, sample_, noise, what):
+        o_obs, o_nxt, _ = _host_minibatch(rb, sample_, aug_name, out_hw, capacity)
+        _, act, rew, _, nd, _ = sample_
+        r = O.critic_phase(oracle.actor, oracle.critic, oracle.critic_target, oracle.log_alpha, o_obs, act.cpu(),
+                           rew.cpu(), o_nxt, nd.cpu(), noise.cpu(), discount=0.99, relu_branches=p["conv"],
+                           q_branches=[p["qh"][0:2], p["qh"][2:4]], **kwc)
+        assert len(r["grads"]) == 8 + 2 * layers + 8
+        for k, v in r["grads"].items():
+            bad.append(check(f"{tag} {what}: critic grad {k} (fp32 oracle along the device's branches)", p["critic"][k], v))
+        return r
+
+    def oracle_cpc(p, sample_, what, loss=None):
+        o_obs, _, o_pos = _host_minibatch(rb, sample_, aug_name, out_hw, capacity)
+        r = O.cpc_phase(oracle.critic, oracle.critic_target, oracle.W, o_obs, o_pos, num_layers=layers,
+                        relu_branches=p["conv"])
+        lg = ws.logits.cpu()
+        lg = lg - lg.max(1, keepdim=True)[0]
+        vals = [("cpc z_a", ws.z_c.cpu(), "z_a"), ("cpc z_pos", ws.z_pos.cpu(), "z_pos"),
+                ("cpc logits (minus row max)", lg, "logits")]
+        if loss is not None:
+            vals.append(("curl loss", loss, "loss"))
+        for nm, got, key in vals:
+            bad.append(check(f"{tag} {what}: {nm}", got, r[key]))
+        for k, v in r["grads"].items():
+            bad.append(check(f"{tag} {what}: cpc grad {k} (fp32 oracle along the device's branches)", p["critic"][k], v))
+        bad.append(check(f"{tag} {what}: cpc grad W", p["W"], r["W_grad"]))
+
+    # ---- an odd step, eager, explicit noise
+    before = agent._critic_flat.clone()
+    L = NullLogger()
+    noise_c = torch.randn(B, 2)
+    agent.update(rb, L, 1, noise=(noise_c.to(dev), None))
+    torch.cuda.synchronize()
+    assert len(phases) == 2 and len(drawn) == 1  # critic, cpc
+    rc = oracle_critic(phases[0], drawn[0], noise_c, "odd step")
+    bad.append(check(f"{tag} odd step: critic loss", L.scalars["train_critic/loss"], rc["loss"]))
+    oracle_cpc(phases[1], drawn[0], "odd step", L.scalars["train/curl_loss"])
+    assert "train_actor/loss" not in L.scalars
+
+    # ---- only_cpc (train.py:425-429)
+    del phases[:], drawn[:]
+    L = NullLogger()
+    agent.update(rb, L, 2, only_cpc=True)
+    torch.cuda.synchronize()
+    assert len(phases) == 1 and list(L.scalars) == ["train/batch_reward", "train/curl_loss"], list(L.scalars)
+    oracle_cpc(phases[0], drawn[0], "only_cpc", L.scalars["train/curl_loss"])
+    assert torch.equal(before, agent._critic_flat), "learning rate 0: the parameters must not have moved"
+
+    # ---- graph-replayed steps: log_interval off the steps used (logging steps run eagerly by design)
+    agent.log_interval = 1000
+    agent.enable_update_graphs(rb, warm=1, depth=1)
+    gen = torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]
+    agent.update(rb, L, 1001)   # warm: odd kind
+    agent.update(rb, L, 1002)   # warm: even kind (its target soft update is applied to the oracle's target too)
+    oracle_soft_update()
+
+    def snapshot():
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in dict(
+            gcritic=agent._critic_gflat, gactor=agent._actor_gflat, glog_alpha=agent.log_alpha.grad, z_c=ws.z_c,
+            z_pos=ws.z_pos, z_a=ws.z_a, logits=ws.logits, q=ws.q2, noise=ws.noise, scalars=ws.scalars[:6],
+            target=agent._target_flat, conv_last=ws.acts_main[-1]).items()}
+
+    for step in (1003, 1004):
+        what = "graph-replayed %s step" % ("odd" if step % 2 else "even")
+        np_state, gen_off = np.random.get_state(), gen.get_offset()
+        target0 = agent._target_flat.clone()
+        del phases[:], drawn[:]
+        agent.update(rb, L, step)
+        replayed = snapshot()
+        # nothing went through the host-side phases (the tap sits in the eager path): the update WAS a graph replay
+        assert not phases and not drawn, (what, len(phases), len(drawn))
+        kind = agent._graph_kind(step)
+        assert kind in agent._graphs and agent._graphs[kind][0]["graph"] is not None
+        # the same step again, eagerly, from the same stream positions (and the same target: an even step lerps it)
+        np.random.set_state(np_state)
+        gen.set_offset(gen_off)
+        with torch.no_grad():
+            agent._target_flat.copy_(target0)
+        graphs, agent._graphs = agent._graphs, None
+        agent.update(rb, L, step)
+        eager = snapshot()
+        agent._graphs = graphs
+        for k in replayed:
+            assert torch.equal(replayed[k], eager[k]), (what, k)
+        REPORT.append((f"{tag} {what}: buffers bit-identical to the eager step (count)", float(len(replayed))))
+        if step % 2:  # the eager twin against the oracle, with the policy noise the kernel drew
+            assert len(phases) == 2
+            oracle_critic(phases[0], drawn[0], ws.noise.cpu().clone(), what)
+            oracle_cpc(phases[1], drawn[0], what)
+        else:
+            assert len(phases) == 3
+            oracle_soft_update()
+            for k in ("encoder.convs.0.weight", "encoder.fc.weight", "Q1.trunk.2.weight"):
+                bad.append(check(f"{tag} {what}: target after soft update {k}", agent.critic_target.state_dict()[k].cpu(),
+                                 oracle.critic_target[k].detach(), 1e-6))
+            oracle_cpc(phases[2], drawn[0], what)
+    assert torch.equal(before, agent._critic_flat)
+    bad = [b for b in bad if b is not None]
+    assert not bad, bad
+
+
+def test_c2_full_size_odd_only_cpc_and_graph_replayed_steps_vs_oracle():
+    _steps_case("c2 B=512 84->76 L=4", (9, 76, 76), (84, 84), "random_crop", capacity=2048)
+
+
+def test_c1t_full_size_odd_only_cpc_and_graph_replayed_steps_vs_oracle():
+    _steps_case("c1t B=512 90x160->76x135 L=4", (9, 76, 135), (90, 160), "random_crop_default", capacity=1024)

@@ -225,17 +225,29 @@ def test_whole_update_parity_under_switch(tag, options, env, aug_name, must_call
         assert calls[name] == 0, (tag, name, dict(calls))
 
 
-def test_torch_adam_and_flat_adam_take_the_same_steps():
+F32_FORMS = {"s1_fwd": "f23", "gemm_mfma": "f32", "conv1_u8": "rw"}  # every product on the exact f32-input MFMA
+
+
+@pytest.mark.parametrize("forms", ["f32 forms (tight)", "default forms"])
+def test_torch_adam_and_flat_adam_take_the_same_steps(forms):
     """CURLA_TORCH_ADAM=1 (torch's fused multi-tensor Adam) against the default FlatAdam over an even and an odd update
     with train.py's learning rates.  A first Adam step moves every element by lr * g / |g|, so single elements whose
-    gradient is zero to rounding may differ by 2 lr per step; everything else agrees."""
-    flat = _one_update("random_crop", lr=1e-3, steps=2)[3]
-    fused = _one_update("random_crop", env={"CURLA_TORCH_ADAM": "1"}, lr=1e-3, steps=2)[3]
+    gradient is zero to rounding may differ by 2 lr per step; everything else agrees.
+    Two configurations (the advisor's round-5 finding: the bound had been widened from 0.5 % to 10 % of the elements
+    for the bf16x3 defaults, a window that could hide an optimizer regression): with every kernel pinned to its f32 form
+    (``F32_FORMS``) the two optimizers see bit-identical gradients at the first step and the round-4 bound of 0.5 %
+    holds; the default forms keep the wide bound, which there only absorbs one conv ReLU branch that lands on the other
+    side of zero in the second update."""
+    tight = forms.startswith("f32")
+    opts = F32_FORMS if tight else {}
+    flat = _one_update("random_crop", options=opts, lr=1e-3, steps=2)[3]
+    fused = _one_update("random_crop", options=opts, env={"CURLA_TORCH_ADAM": "1"}, lr=1e-3, steps=2)[3]
     for k in ("critic", "actor", "target"):
         d = (flat[k] - fused[k]).abs()
         assert float(d.max()) <= 4 * 2 * 1e-3 + 1e-6, (k, float(d.max()))  # (a conv weight takes 4 steps in two updates)
         # (elements whose gradient is a sum of cancelling terms follow ONE conv ReLU branch that differs between the two
         # runs' second updates -- their first Adam steps differ in the last bit -- by more than 1 % of lr: a twentieth of
-        # the critic in the worst run seen; a different optimizer would move all of them)
-        assert float((d > 1e-5).float().mean()) <= 0.10, (k, float((d > 1e-5).float().mean()))
+        # the critic in the worst run seen on the default forms; a different optimizer would move all of them)
+        off = float((d > 1e-5).float().mean())
+        assert off <= (0.005 if tight else 0.10), (forms, k, off)
         assert float(d.median()) <= 1e-6, (k, float(d.median()))

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from oracle import curla_oracle as O
-from tests._util import assert_close, load, sub, summarize
+from tests._util import assert_close, like, load, sub, summarize
 
 torch.set_num_threads(1)
 HP = dict(num_layers=4, log_std_min=-10, log_std_max=2)
@@ -278,7 +278,7 @@ def _post_check(name, got, want, lr, what):
     assert err.max() <= 2.1 * lr + tight, f"{name} {what}: max error {err.max():.3e}"
 
 
-MODE_NAMES = ("odd", "pixel_sac", "only_cpc", "detach", "l6c12")
+MODE_NAMES = ("odd", "pixel_sac", "only_cpc", "detach", "l6c12", "thesis", "thesis_odd")
 
 
 def _mode_case(name):
@@ -355,7 +355,10 @@ def test_mode_fixtures_match_the_oracle():
             assert set(ref) == live, name  # (detach_encoder: the convs have NO gradient, curl_sac.py:358)
             assert len(ref) == (4 + 6 * 2 + 0 if m["detach_encoder"] else 2 * m["num_layers"] + 4 + 12)
             for k, v in ref.items():
-                assert_close(r["grads"][k], v, 1e-5, f"{name} critic grad {k}")
+                assert_close(like(r["grads"][k], v), v, 1e-5, f"{name} critic grad {k}")
+            for k, v in sub(g, "critic/gradsum/", as_torch=False).items():  # (tensors stored as a sample: the whole)
+                assert_close(summarize(r["grads"][k]), v, 2e-5, f"{name} critic grad {k} (summary)")
+            assert (len(sub(g, "critic/gradsum/")) > 0) == bool(m.get("unpatched")), name
         # the oracle agent's own chained update: later phases see the parameters its Adam steps produced
         ag = _oracle_agent(inp)
         nc = _f(g["noise/critic"]) if "noise/critic" in g else None
