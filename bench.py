@@ -454,7 +454,7 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
         # outside the timed region: cost of the gradient all-reduces of one update, each bucket timed alone
         # (SURVEY.md 8e reporting: all-reduce time per phase and the bus bandwidth it reaches)
         lay = agent._lay
-        buckets = {"critic": agent._critic_gflat[lay["enc"][0]:lay["total"]], "actor": agent._actor_gflat}
+        buckets = {"critic": agent._critic_gflat[lay["enc"][0]:lay["total"]], "actor": agent._actor_gbucket}
         if not cfg["pixel_sac"]:
             buckets["cpc"] = agent._critic_gflat[0:lay["enc"][1]]
         allreduce = {"overlapped_with_backward": bool(agent._dp_overlap), "buckets": {}}

@@ -16,7 +16,7 @@ c_int, c_ll, c_float, c_size_t, vp = ctypes.c_int, ctypes.c_longlong, ctypes.c_f
 c_u64 = ctypes.c_ulonglong
 c_double = ctypes.c_double
 
-ABI_VERSION = 5  # include/curla_hip.h CURLA_ABI_VERSION this table was written for
+ABI_VERSION = 6  # include/curla_hip.h CURLA_ABI_VERSION this table was written for
 
 # name -> argtypes (restype is int unless listed in _RESTYPES); mirrors include/curla_hip.h
 SIGNATURES = {
@@ -73,6 +73,8 @@ SIGNATURES = {
                                  c_double, c_double, c_double, c_double, c_ll, vp, vp],
     "curla_adam_step2": [vp, vp, vp, vp, vp, vp, c_size_t, c_size_t, c_double, c_double, c_double, c_double, c_ll, c_double,
                          c_double, c_double, c_double, c_ll, vp, vp],
+    "curla_f64_pack": [vp, vp, vp],
+    "curla_f64_unpack": [vp, c_double, c_double, vp, vp],
     "curla_gather_transition_scalars": [vp, vp, c_int, c_int, vp, vp, vp, vp],
     "curla_sample_stage": [vp, vp, c_ll, vp, c_int, c_int, vp, vp, vp, vp],
     "curla_host_device_pointer": [vp, vp],

@@ -97,11 +97,19 @@ __global__ __launch_bounds__(256, 1) __attribute__((amdgpu_waves_per_eu(1, 1))) 
 #include "conv_rwb.h"
 
 // The same layers on the bf16 matrix cores with fp32 operands split into three bf16 parts (conv_rwb.h): 512-thread
-// workgroups, one per CU, 108 KB of LDS for the split filters of the two problems of a layer.
+// workgroups, one per CU, 2 x rwb::kWBytes = 144 KB of LDS for the split filters of the two problems of a layer (72 KB
+// each: 16 KB of headroom under the CU's 160 KB, asserted beside kMaxLds below).
+#ifdef RWB_CLOCK
+// diagnostic build (tools/clock_reconcile.sh: -DRWB_CLOCK): per workgroup, summed over launches, wave 0's shader cycles
+// (s_memtime) and 100 MHz ticks (s_memrealtime) from its first instruction to its last, and the launch count.  Two
+// stamps per workgroup and launch: nothing inside the loops (the per-step stamps of RWB_STAMP cost ~11 % of a wave).
+__device__ unsigned long long g_rwb_clock[3 * 1024];
+#endif
+
 template <int NW>
 __device__ __forceinline__ void rwb_fwd_body(const rw::Args& A) {
   extern __shared__ __attribute__((aligned(16))) unsigned short lds_h[];
-#ifdef RWB_STAMP
+#if defined(RWB_STAMP) || defined(RWB_CLOCK)
   const unsigned long long kt0 = __builtin_readcyclecounter(), kr0 = __builtin_amdgcn_s_memrealtime();
 #endif
   for (int l = 0; l < A.nlayers; ++l) {
@@ -133,6 +141,13 @@ __device__ __forceinline__ void rwb_fwd_body(const rw::Args& A) {
   if (threadIdx.x == 0 && blockIdx.x == 7) {
     rwb::g_rwb_stamp[15] += __builtin_readcyclecounter() - kt0;
     rwb::g_rwb_stamp[14] += __builtin_amdgcn_s_memrealtime() - kr0;
+  }
+#endif
+#ifdef RWB_CLOCK
+  if (threadIdx.x == 0 && blockIdx.x < 1024) {
+    g_rwb_clock[3 * blockIdx.x + 0] += __builtin_readcyclecounter() - kt0;
+    g_rwb_clock[3 * blockIdx.x + 1] += __builtin_amdgcn_s_memrealtime() - kr0;
+    g_rwb_clock[3 * blockIdx.x + 2] += 1;
   }
 #endif
 }
@@ -1332,6 +1347,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(ReduceJobs J) 
 
 // ------------------------------ host-side planning ------------------------------
 constexpr int kMaxLds = 160 * 1024;
+static_assert(2 * rwb::kWBytes <= kMaxLds, "the two problems' split filters of conv_rwb_fwd_kernel must fit one CU's LDS");
 // Dynamic LDS limit of a kernel: raised once per (kernel, device) to the largest size this library ever asks for --
 // never lowered, never set per launch (curla_set_dyn_lds, common.h).
 template <typename K>
@@ -1490,6 +1506,16 @@ extern "C" {
 
 #ifdef CURLA_ABLATE
 void curla_debug_ablate(int flags) { g_ablate = flags; }
+#endif
+#ifdef RWB_CLOCK
+int curla_debug_rwb_clock(unsigned long long* out, int n_workgroups, int reset) {
+  if (n_workgroups < 1 || n_workgroups > 1024) return -1;
+  if (reset) {
+    static unsigned long long z[3 * 1024];
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_rwb_clock), z, sizeof(z)) == hipSuccess ? 0 : -2;
+  }
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rwb_clock), 3 * n_workgroups * sizeof(unsigned long long)) == hipSuccess ? 0 : -2;
+}
 #endif
 #ifdef RWB_STAMP
 // timing-only debug build (tools/build_variant.sh stamp -DRWB_STAMP): cycle sums of wave 0 of workgroup 7 over its full steps

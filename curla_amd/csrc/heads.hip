@@ -1708,6 +1708,119 @@ int curla_curl_head(const float* z_a, const float* z_pos, const float* wz, const
   return curla_launch_status();
 }
 
+// ---- a float64 scalar riding in a float32 all-reduce bucket ("pack into the actor bucket") ----------
+// log_alpha's gradient is one float64 (curl_sac.py:397-404); as a collective of its own it is an 8-byte all-reduce per
+// even update.  It travels instead as kF64Words float32 words at the end of the actor's gradient bucket: signed
+// fixed-point digits of 20 bits, digit j with the weight 2^(kF64TopExp - 20 j).  Every float64 below 2^28 in magnitude
+// whose last bit is worth at least 2^-132 is the EXACT sum of its digits, digit sums over up to 16 ranks stay below 2^24
+// (exact in float32), and ncclAvg's division by a power-of-two world size is exact too -- so the receiver recovers the
+// exact sum of the ranks' float64 gradients and rounds ONCE: for two ranks that is bit for bit today's float64
+// all-reduce, (a + b) / 2.  (A world size that is not a power of two rounds each averaged digit to 24 bits: 2^-24 of
+// the value -- the reference's own gradient is a float32 sum widened to float64.)
+constexpr int kF64Words = 8;
+constexpr int kF64TopExp = 8;
+
+__global__ void f64_pack_kernel(const double* __restrict__ v, float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  double r = *v;
+  if (!(fabs(r) < 0x1p28)) {  // out of the fixed-point range, inf or nan: the top word alone carries it, inexactly
+    out[0] = (float)(r * 0x1p-8);
+    for (int j = 1; j < kF64Words; ++j) out[j] = 0.f;
+    return;
+  }
+  for (int j = 0; j < kF64Words; ++j) {  // (every operation here is exact in double)
+    const double p = trunc(ldexp(r, 20 * j - kF64TopExp));
+    r -= ldexp(p, kF64TopExp - 20 * j);
+    out[j] = (float)p;
+  }
+}
+
+struct U192 {
+  unsigned long long w2, w1, w0;
+};
+__device__ __forceinline__ bool u192_bit(const U192& a, int i) {
+  return ((i >= 128 ? a.w2 : i >= 64 ? a.w1 : a.w0) >> (i & 63)) & 1ull;
+}
+__device__ __forceinline__ bool u192_any_below(const U192& a, int i) {  // any set bit at a position < i
+  if (i <= 0) return false;
+  if (i >= 192) return (a.w0 | a.w1 | a.w2) != 0;
+  const unsigned long long mask = (i & 63) ? ((1ull << (i & 63)) - 1ull) : 0ull;
+  if (i >= 128) return (a.w0 | a.w1 | (a.w2 & mask)) != 0;
+  if (i >= 64) return (a.w0 | (a.w1 & mask)) != 0;
+  return (a.w0 & mask) != 0;
+}
+__device__ __forceinline__ unsigned long long u192_shr_low(const U192& a, int s) {  // low 64 bits of a >> s
+  const int q = s >> 6, r = s & 63;
+  const unsigned long long lo = q == 0 ? a.w0 : q == 1 ? a.w1 : q == 2 ? a.w2 : 0ull;
+  const unsigned long long hi = q == 0 ? a.w1 : q == 1 ? a.w2 : 0ull;
+  return r ? (lo >> r) | (hi << (64 - r)) : lo;
+}
+
+// words: the (averaged or summed) digits; n_mul undoes an average (digit sums are integers again), n_div turns the
+// sum into the mean: out = RN(sum over ranks) / n_div.
+__global__ void f64_unpack_kernel(const float* __restrict__ words, double n_mul, double n_div, double* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  long long d[kF64Words];
+  bool ok = true;
+  for (int j = 0; j < kF64Words; ++j) {
+    const double x = (double)words[j] * n_mul;
+    if (!(fabs(x) < 0x1p40)) ok = false;
+    d[j] = ok ? llrint(x) : 0;
+  }
+  if (!ok) {  // an out-of-range / non-finite gradient somewhere: plain double arithmetic, no exactness claimed
+    double s = 0.;
+    for (int j = kF64Words - 1; j >= 0; --j) s += ldexp((double)words[j] * n_mul, kF64TopExp - 20 * j);
+    *out = s / n_div;
+    return;
+  }
+  // carries up the digits: d[1..] in [0, 2^20), d[0] keeps the sign; a negative value is negated and carried again
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int j = kF64Words - 1; j >= 1; --j) {
+      const long long c = d[j] >> 20;  // (arithmetic shift: floor)
+      d[j] -= c << 20;
+      d[j - 1] += c;
+    }
+    if (pass == 1 || d[0] >= 0) break;
+    for (int j = 0; j < kF64Words; ++j) d[j] = -d[j];
+    ok = false;  // (re-used: "the value is negative")
+  }
+  const bool neg = !ok;
+  U192 m = {0ull, 0ull, 0ull};  // the magnitude in units of 2^(kF64TopExp - 20 (kF64Words - 1))
+  for (int j = 0; j < kF64Words; ++j) {
+    m.w2 = (m.w2 << 20) | (m.w1 >> 44);
+    m.w1 = (m.w1 << 20) | (m.w0 >> 44);
+    m.w0 = (m.w0 << 20) | (unsigned long long)d[j];  // (d[0] < 2^41 goes in first: nothing overlaps)
+  }
+  const int msb = m.w2 ? 191 - __clzll(m.w2) : m.w1 ? 127 - __clzll(m.w1) : m.w0 ? 63 - __clzll(m.w0) : -1;
+  double r = 0.;
+  if (msb >= 0) {
+    const int unit = kF64TopExp - 20 * (kF64Words - 1);
+    if (msb <= 52) {
+      r = ldexp((double)m.w0, unit);
+    } else {  // 53 bits, round to nearest even on everything below them
+      const int s = msb - 52;
+      unsigned long long mant = u192_shr_low(m, s) & ((1ull << 53) - 1ull);
+      const bool half = u192_bit(m, s - 1), sticky = u192_any_below(m, s - 1);
+      if (half && (sticky || (mant & 1ull))) mant += 1ull;
+      r = ldexp((double)mant, unit + s);
+    }
+  }
+  *out = (neg ? -r : r) / n_div;
+}
+
+int curla_f64_pack(const double* value, float* words, void* stream) {
+  CURLA_REQUIRE(value && words && (reinterpret_cast<uintptr_t>(value) & 7) == 0 && (reinterpret_cast<uintptr_t>(words) & 3) == 0);
+  hipLaunchKernelGGL(f64_pack_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), value, words);
+  return curla_launch_status();
+}
+
+int curla_f64_unpack(const float* words, double n_mul, double n_div, double* value, void* stream) {
+  CURLA_REQUIRE(value && words && n_mul >= 1. && n_div >= 1. && (reinterpret_cast<uintptr_t>(value) & 7) == 0 &&
+                (reinterpret_cast<uintptr_t>(words) & 3) == 0);
+  hipLaunchKernelGGL(f64_unpack_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), words, n_mul, n_div, value);
+  return curla_launch_status();
+}
+
 int curla_mean(const float* x, int n, float* out, void* stream) {
   CURLA_REQUIRE(x && out && n > 0);
   hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), x, n, out);
@@ -1869,7 +1982,7 @@ int curla_nhwc_to_nchw(const float* in, float* out, int B, int H, int W, int C, 
   return curla_launch_status();
 }
 
-const char* curla_version(void) { return "curla_hip 0.5 (gfx950, abi 5)"; }
+const char* curla_version(void) { return "curla_hip 0.6 (gfx950, abi 6)"; }
 
 int curla_abi_version(void) { return CURLA_ABI_VERSION; }
 

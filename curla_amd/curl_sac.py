@@ -509,7 +509,11 @@ class CurlSacAgent(object):
         actor_own = [(n, p) for n, p in self.actor.named_parameters() if ".convs." not in n]
         a_sz = place(actor_own, True)
         self._actor_flat = torch.zeros(a_sz, device=dev, dtype=torch.float32)
-        self._actor_gflat = torch.zeros(a_sz, device=dev, dtype=torch.float32)
+        # the actor's data-parallel bucket: [fc, ln | trunk | ops.F64_WORDS words]; the words carry log_alpha's float64
+        # gradient through the bucket's all-reduce (ops.f64_pack) -- unused without data parallelism
+        self._actor_gbucket = torch.zeros(a_sz + ops.F64_WORDS, device=dev, dtype=torch.float32)
+        self._actor_gflat = self._actor_gbucket[:a_sz]
+        self._la_words = self._actor_gbucket[a_sz:]
         place(actor_own, False, self._actor_flat, self._actor_gflat, 0)
         self.log_alpha.grad = torch.zeros((), device=dev, dtype=torch.float64)
 
@@ -602,33 +606,52 @@ class CurlSacAgent(object):
             raise RuntimeError("data-parallel replicas have diverged (%s differ across ranks): seed every rank "
                                "identically or keep broadcast=True in enable_data_parallel" % ", ".join(bad))
 
-    def _allreduce(self, *buckets, async_op=False):
+    def _allreduce(self, *buckets, async_op=False, f64_rider=None):
         """Average each tensor over the ranks.  async_op: the collectives are only enqueued (they start once
-        the compute stream reaches this point); _allreduce_wait() makes the compute stream wait for them."""
+        the compute stream reaches this point); _allreduce_wait() makes the compute stream wait for them.
+        ``f64_rider`` = (scalar, words): ``scalar`` (one float64 element: log_alpha's gradient) rides in ``words``, the
+        last ops.F64_WORDS elements of the LAST bucket -- packed before the collective, unpacked (= the mean over the
+        ranks, from the exact sum: curla_hip.h curla_f64_pack) once it has completed."""
         if not self._dp_active:
             return
         import torch.distributed as dist
-        for t in buckets:
+        if f64_rider is not None:
+            scalar, words = f64_rider
+            assert words.data_ptr() + 4 * words.numel() == buckets[-1].data_ptr() + 4 * buckets[-1].numel()
+            ops.f64_pack(scalar, words)
+        last = len(buckets) - 1
+        for i, t in enumerate(buckets):
             if t.numel() == 0:
                 continue
-            avg = self._dp_avg and t.dtype == torch.float32  # (the float64 log_alpha scalar takes the sum path)
+            avg = self._dp_avg and t.dtype == torch.float32  # (a float64 bucket of its own would take the sum path)
             op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+            post = []
+            if not avg and not self._dp_staged:
+                post.append(lambda t=t: t.div_(self._dp_world))
+            if f64_rider is not None and i == last:
+                # every path leaves the AVERAGED digits in the words: n_mul makes them the digit sums again
+                post.append(lambda: ops.f64_unpack(f64_rider[1], self._dp_world, self._dp_world, f64_rider[0]))
             if self._dp_staged:  # (synchronous whatever async_op says: same elements, same sum)
                 h = t.detach().cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self._dp_group)
                 t.copy_(h.div_(self._dp_world))
+                work = None
             elif async_op:
-                self._dp_pending.append((dist.all_reduce(t, op=op, group=self._dp_group, async_op=True), t, not avg))
+                work = dist.all_reduce(t, op=op, group=self._dp_group, async_op=True)
             else:
                 dist.all_reduce(t, op=op, group=self._dp_group)
-                if not avg:
-                    t.div_(self._dp_world)
+                work = None
+            if work is not None:
+                self._dp_pending.append((work, post))
+            else:
+                for fn in post:
+                    fn()
 
     def _allreduce_wait(self):
-        for work, t, divide in self._dp_pending:
+        for work, post in self._dp_pending:
             work.wait()
-            if divide:
-                t.div_(self._dp_world)
+            for fn in post:
+                fn()
         self._dp_pending = []
 
     def _grad_offset(self, p, flat):
@@ -940,10 +963,6 @@ class CurlSacAgent(object):
                            twin_dxa=ws.dxa, F=F)
         _mlp_bwd(ws.z_a, 0, trunk, _Mlp(self.actor.trunk, grads=True), 1, B, F, H, 2 * A, ws.a_h1, ws.a_h2, ws.a_dout,
                  ws.a_dh2, ws.a_dh1, ws.dz)
-        overlap = self._dp_active and self._dp_overlap
-        if overlap:  # bucket = [fc, ln | trunk]: the trunk gradients are final here, fc / ln follow
-            cut = self._grad_offset(self.actor.trunk[0].weight, self._actor_gflat)
-            self._allreduce(self._actor_gflat[cut:], self.log_alpha.grad, async_op=True)
         streams = ops.fc_bwd_streams(F, enc.flat_dim)
         ln = ops.ln_bwd(ws.dz, ws.xhat_a, ws.rstd_a, aenc.ln.weight, B, F, ws.dfc, dgamma=aenc.ln.weight.grad,
                         dbeta=aenc.ln.bias.grad, dbias_in=aenc.fc.bias.grad, defer=ws.ln_partial if streams else None)
@@ -952,11 +971,33 @@ class CurlSacAgent(object):
         else:
             ops.linear_dw(ws.dfc, 0, h, 0, aenc.fc.weight.grad, 0, B, F, enc.flat_dim)
 
-        if overlap:
-            self._allreduce(self._actor_gflat[:cut], async_op=True)
-            self._allreduce_wait()
+        # data parallel: ONE collective for the phase -- the bucket [fc, ln | trunk | words], log_alpha's float64
+        # gradient riding in the words (round 5: an 8-byte all-reduce of its own).  Overlapped schedule: the collective is
+        # asynchronous and, when update() has announced that the CURL phase follows, this phase's two optimizer steps
+        # are taken only after that phase has been enqueued (_finish_actor_step): the CURL phase reads nothing they
+        # write (the actor's own fc / ln / trunk and log_alpha), so the numbers are the reference order's
+        # (curl_sac.py:393-404 before :418-423) and the all-reduce runs underneath the CURL phase's convolutions.
+        rider = (self.log_alpha.grad, self._la_words)
+        if self._dp_active and self._dp_overlap:
+            self._allreduce(self._actor_gbucket, async_op=True, f64_rider=rider)
+            if self._defer_actor_step and not self.log_param_hist_imgs:
+                self._actor_step_pending = True
+            else:
+                self._allreduce_wait()
         else:
-            self._allreduce(self._actor_gflat, self.log_alpha.grad)
+            self._allreduce(self._actor_gbucket, f64_rider=rider)
+        if not self._actor_step_pending:
+            self._actor_steps()
+        if self.log_param_hist_imgs:
+            self.actor.log(L, step)
+        if step % self.log_interval == 0:
+            L.log('train_alpha/loss', ws.scalars[2], step)
+            L.log('train_alpha/value', ws.scalars[4], step)
+
+    _defer_actor_step = False    # set by update(): the CURL phase follows the actor phase (overlapped data parallel)
+    _actor_step_pending = False  # the actor phase has left its optimizer steps to _finish_actor_step()
+
+    def _actor_steps(self):
         # actor_optimizer.step() ... log_alpha_optimizer.step() (curl_sac.py:393-404): nothing in between reads
         # log_alpha (the logged alpha is the loss kernel's), so the two steps share a launch
         if isinstance(self.actor_optimizer, FlatAdam):
@@ -964,11 +1005,12 @@ class CurlSacAgent(object):
         else:
             self.actor_optimizer.step()
             self.log_alpha_optimizer.step()
-        if self.log_param_hist_imgs:
-            self.actor.log(L, step)
-        if step % self.log_interval == 0:
-            L.log('train_alpha/loss', ws.scalars[2], step)
-            L.log('train_alpha/value', ws.scalars[4], step)
+
+    def _finish_actor_step(self):
+        if self._actor_step_pending:
+            self._actor_step_pending = False
+            self._allreduce_wait()
+            self._actor_steps()
 
     def update_cpc(self, obs_anchor, obs_pos, cpc_kwargs, L, step):
         """curl_sac.py:406-423."""
@@ -1085,12 +1127,17 @@ class CurlSacAgent(object):
             if step % self.actor_update_freq == 0:
                 if do_cpc and isinstance(cpc_kwargs.get("obs_pos"), ObsRef):
                     self._pos_hint = cpc_kwargs["obs_pos"]
-                self.update_actor_and_alpha(obs, L, step, noise=noise_a)
-                self._pos_hint = None
+                self._defer_actor_step = do_cpc
+                try:
+                    self.update_actor_and_alpha(obs, L, step, noise=noise_a)
+                finally:
+                    self._pos_hint = None
+                    self._defer_actor_step = False
 
         if do_cpc:
             obs_anchor, obs_pos = cpc_kwargs["obs_anchor"], cpc_kwargs["obs_pos"]
             self.update_cpc(obs_anchor, obs_pos, cpc_kwargs, L, step)
+        self._finish_actor_step()
 
     # ---------------------------------------------------------------- captured update graphs
     def enable_update_graphs(self, replay_buffer, warm=1, depth=2):
@@ -1269,6 +1316,7 @@ class CurlSacAgent(object):
                 # what _update_phases sets from one phase to the next and had no chance to clear
                 self._pos_hint = self._anchor_cache = self._pos_cache = None
                 self._pos_fc_done = self._soft_update_hint = self._soft_update_done = False
+                self._defer_actor_step = self._actor_step_pending = False
                 self._dp_pending = []
             # data parallel: every rank captures at the same step; ONE rank replaying while another runs eagerly would
             # still pair up collective for collective, but the ranks would sit on different schedules indefinitely with

@@ -559,6 +559,57 @@ def mean(x, n, out):
     call("curla_mean", ptr(x), n, ptr(out), stream())
 
 
+# ---- a float64 scalar inside a float32 all-reduce bucket (curla_hip.h: curla_f64_pack / curla_f64_unpack) ------------
+F64_WORDS = 8     # CURLA_F64_WORDS
+_F64_TOP_EXP = 8  # digit j is worth 2^(8 - 20 j)
+
+
+def f64_words_of(value):
+    """The words curla_f64_pack writes for ``value``, on the host (exact: Python floats are IEEE doubles)."""
+    import math
+    r = float(value)
+    if not abs(r) < 2.0 ** 28:
+        return [float(r * 2.0 ** -8)] + [0.0] * (F64_WORDS - 1)
+    out = []
+    for j in range(F64_WORDS):
+        d = float(math.trunc(math.ldexp(r, 20 * j - _F64_TOP_EXP)))
+        r -= math.ldexp(d, _F64_TOP_EXP - 20 * j)
+        out.append(d)
+    return out
+
+
+def f64_of_words(words, n_mul=1.0, n_div=1.0):
+    """What curla_f64_unpack computes, on the host: the exact sum of the digits (Python integers), rounded once."""
+    import math
+    xs = [float(w) * float(n_mul) for w in words]
+    if not all(abs(x) < 2.0 ** 40 for x in xs):  # (nan compares false)
+        return sum(math.ldexp(x, _F64_TOP_EXP - 20 * j) for j, x in reversed(list(enumerate(xs)))) / float(n_div)
+    total = 0
+    for x in xs:
+        total = (total << 20) + int(round(x))  # (round(): half to even, as llrint)
+    # int -> float is correctly rounded (half to even); the power-of-two scale is exact
+    return math.ldexp(float(total), _F64_TOP_EXP - 20 * (F64_WORDS - 1)) / float(n_div)
+
+
+def f64_pack(value, words):
+    """``value``: a one-element float64 tensor; ``words``: F64_WORDS float32 elements (same device).  Host tensors (the
+    gloo path of the CPU tests) take the host arithmetic above -- the same digits, bit for bit."""
+    assert value.dtype == torch.float64 and value.numel() == 1 and words.dtype == F32 and words.numel() == F64_WORDS
+    if not words.is_cuda and _lib._trace_hook is None:
+        words.copy_(torch.tensor(f64_words_of(float(value)), dtype=F32))
+        return
+    call("curla_f64_pack", ptr(value), ptr(words), stream())
+
+
+def f64_unpack(words, n_mul, n_div, value):
+    assert value.dtype == torch.float64 and value.numel() == 1 and words.dtype == F32 and words.numel() == F64_WORDS
+    if not words.is_cuda and _lib._trace_hook is None:
+        with torch.no_grad():
+            value.fill_(f64_of_words(words.tolist(), n_mul, n_div))
+        return
+    call("curla_f64_unpack", ptr(words), float(n_mul), float(n_div), ptr(value), stream())
+
+
 def soft_update(param_flat, target_flat, tau):
     # tau and (1 - tau) are rounded to fp32 separately, as `tau * p + (1 - tau) * t` does in torch (utils.py:39-41)
     call("curla_soft_update", ptr(param_flat), ptr(target_flat), param_flat.numel(), float(tau), float(1 - tau),

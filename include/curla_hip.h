@@ -37,7 +37,7 @@ const char* curla_version(void);
 /* The C ABI's number: bumped whenever an entry point's argument list changes (round 4 put dyn / dyn64 / rng_dev
  * pointers into the middle of the Adam and policy-head calls: 4 -> 5 names that).  A binding written for another
  * number must refuse the library -- curla_amd/_lib.py does -- instead of calling with shifted arguments. */
-#define CURLA_ABI_VERSION 5
+#define CURLA_ABI_VERSION 6
 int curla_abi_version(void);
 
 /* Run-time kernel-selection options (curla_amd/csrc/options.h).  Every option's default is the measured-best path;
@@ -403,6 +403,16 @@ int curla_adam_step_scalar64(float* param, const float* grad, float* exp_avg, fl
                              double beta1, double beta2, double eps, long long step, const float* dyn, double* param64,
                              const double* grad64, double* exp_avg64, double* exp_avg_sq64, double lr64, double beta1_64,
                              double beta2_64, double eps64, long long step64, const double* dyn64, void* stream);
+/* A float64 scalar riding in a float32 all-reduce bucket (data parallel: log_alpha's gradient inside the actor's bucket
+ * instead of an 8-byte collective of its own; the reference has no counterpart -- its one float64
+ * parameter is curl_sac.py:284-286, stepped at :404).  curla_f64_pack writes *value as CURLA_F64_WORDS float32 words:
+ * signed 20-bit fixed-point digits, most significant first, digit j worth 2^(8 - 20 j); exact for |value| < 2^28 (larger
+ * magnitudes, inf and nan travel in word 0 alone, inexactly).  Sums of the words over <= 16 ranks are exact in float32.
+ * curla_f64_unpack: *value = RN(sum of (words[j] * n_mul) * 2^(8 - 20 j)) / n_div with ONE rounding of the exact sum --
+ * n_mul undoes an average taken by the collective (ncclAvg: n_mul = world size), n_div = world size gives the mean. */
+#define CURLA_F64_WORDS 8
+int curla_f64_pack(const double* value, float* words, void* stream);
+int curla_f64_unpack(const float* words, double n_mul, double n_div, double* value, void* stream);
 /* Two such steps of two optimizers on the same parameters with the same gradient, one after the other, in one pass
  * (encoder_optimizer.step(); cpc_optimizer.step(), curl_sac.py:418-423).  exp_avg2 / exp_avg_sq2 cover n elements, the
  * first n_pre of which (CURL.W) take the second step only; exp_avg1 / exp_avg_sq1 cover the remaining n - n_pre.

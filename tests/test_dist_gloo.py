@@ -70,10 +70,11 @@ def _worker(rank, world, port, q):
             if name.endswith("encoder.fc.weight"):
                 g = agent.critic.encoder.fc.to_reference_layout(g)
             out["critic/" + name] = g.clone().numpy()
-        # actor bucket + the float64 log_alpha gradient
+        # actor bucket with the float64 log_alpha gradient riding in its last words (ONE collective)
         _set_grads(agent, mine, "actor")
         _set_grads(agent, mine, "alpha")
-        agent._allreduce(agent._actor_gflat, agent.log_alpha.grad)
+        out["alpha/local"] = agent.log_alpha.grad.clone().numpy()
+        agent._allreduce(agent._actor_gbucket, f64_rider=(agent.log_alpha.grad, agent._la_words))
         for name in sub(mine, "actor/grad/"):
             p = dict(agent.actor.named_parameters())[name]
             g = p.grad
@@ -118,7 +119,7 @@ def _worker(rank, world, port, q):
             sched[overlap] = n_calls
         cuts = dict(enc_fc=agent._grad_offset(agent.critic.encoder.fc.weight, agent._critic_gflat),
                     actor_trunk=agent._grad_offset(agent.actor.trunk[0].weight, agent._actor_gflat),
-                    actor_total=agent._actor_gflat.numel())
+                    actor_total=agent._actor_gbucket.numel())
         # replicas that drift apart are caught: perturb one rank, the check must raise on every rank
         with torch.no_grad():
             if rank == 1:
@@ -155,6 +156,8 @@ def test_n_rank_gradient_mean_matches_reference(world):
     bc = {}
     for rank, out, (sched, cuts, bcast, drift), lay in results:
         for key, got in out.items():
+            if key == "alpha/local":
+                continue
             phase, name = key.split("/", 1)
             want = sum(g[f"{phase}/grad/{name}"].astype(np.float64) for g in fx) / world
             err = np.abs(got - want).max() / max(np.abs(want).max(), 1e-30)
@@ -162,14 +165,16 @@ def test_n_rank_gradient_mean_matches_reference(world):
         e0, e1, total = lay["enc"][0], lay["enc"][1], lay["total"]
         cut, at, an = cuts["enc_fc"], cuts["actor_trunk"], cuts["actor_total"]
         assert e0 < cut < e1 and 0 < at < an
-        # blocking mode -- even step: critic bucket, actor bucket + log_alpha, cpc bucket; odd step: critic + cpc
-        assert sched[False] == [(total - e0, False), (an, False), (1, False), (e1, False),
+        # blocking mode -- even step: THREE collectives: critic bucket, actor bucket (log_alpha's float64 gradient rides
+        # in its last 8 words: round 5 had an 8-byte all-reduce of its own here), cpc bucket; odd step: critic + cpc
+        assert sched[False] == [(total - e0, False), (an, False), (e1, False),
                                 (total - e0, False), (e1, False)], sched[False]
-        # overlapped mode: [fc, ln | Q1 | Q2] before the conv backward then the convs; actor trunk + log_alpha then
-        # fc/ln; cpc [fc, ln] then [W | convs].  The same elements, every one exactly once.
+        # overlapped mode, FIVE per even update: [fc, ln | Q1 | Q2] before the conv backward then the convs; the actor
+        # bucket whole (asynchronous: it runs underneath the CURL phase, whose end takes the actor's steps); cpc
+        # [fc, ln] then [W | convs].  The same elements, every one exactly once.
         crit = [(total - cut, True), (cut - e0, True)]
         cpc = [(e1 - cut, True), (cut, True)]
-        assert sched[True] == crit + [(an - at, True), (1, True), (at, True)] + cpc + crit + cpc, sched[True]
+        assert sched[True] == crit + [(an, True)] + cpc + crit + cpc, sched[True]
         assert "diverged" in drift and "actor" in drift, drift
         bc[rank] = bcast
     # the ranks were seeded differently; after enable_data_parallel all hold rank 0's parameters
@@ -178,7 +183,17 @@ def test_n_rank_gradient_mean_matches_reference(world):
     # all ranks end with identical reduced gradients
     by_rank = {r[0]: r[1] for r in results}
     for k in by_rank[0]:
-        assert all(np.array_equal(by_rank[0][k], by_rank[r][k]) for r in range(1, world)), k
+        if k != "alpha/local":
+            assert all(np.array_equal(by_rank[0][k], by_rank[r][k]) for r in range(1, world)), k
+    # log_alpha's gradient came through the float32 bucket as the correctly rounded EXACT sum of the ranks' float64
+    # values, divided by the (power-of-two) world size -- at world 2 that is the float64 all-reduce's (a + b) / 2 bit
+    # for bit
+    from fractions import Fraction
+    exact = sum(Fraction(float(by_rank[r]["alpha/local"])) for r in range(world))
+    assert float(by_rank[0]["alpha/log_alpha"]) == float(exact) / world
+    if world == 2:
+        a, b = (np.float64(by_rank[r]["alpha/local"]) for r in range(2))
+        assert np.float64(by_rank[0]["alpha/log_alpha"]) == (a + b) / np.float64(2)
     # the minibatches really are different ones (a fixture copied N times would pass everything above)
     idxs = [tuple(g["rng/idxs"].tolist()) for g in fx]
     assert len(set(idxs)) == world

@@ -756,7 +756,7 @@ def test_update_modes_vs_reference_fixtures(name):
     phases = []
     real = agent._allreduce  # (called once per phase right in front of its optimizer step; a no-op without DP)
 
-    def tap(*buckets, async_op=False):
+    def tap(*buckets, **kw):
         ws = agent._ws(B)
         phases.append(dict(
             size=int(buckets[0].numel()), critic=grads_of(agent.critic), actor=grads_of(agent.actor),
@@ -764,7 +764,7 @@ def test_update_modes_vs_reference_fixtures(name):
             state=(cpu(agent.actor.state_dict()), cpu(agent.critic.state_dict()), cpu(agent.critic_target.state_dict()),
                    agent.CURL.W.detach().cpu().clone(), agent.log_alpha.detach().cpu().clone()),
             branches=[(a.permute(0, 3, 1, 2) > 0).cpu() for a in ws.acts_main], scalars=dict(L.scalars)))
-        return real(*buckets, async_op=async_op)
+        return real(*buckets, **kw)
     agent._allreduce = tap
     L = NullLogger()
     nc = _t(g["noise/critic"]) if "noise/critic" in g else None

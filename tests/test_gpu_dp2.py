@@ -133,10 +133,10 @@ def _probe(rank, world):
         rec["draws"].append(out)
         return out
 
-    def allreduce(*buckets, async_op=False):
+    def allreduce(*buckets, **kw):
         ws = agent._ws(B)
         local = _named_grads(agent)
-        real_ar(*buckets, async_op=async_op)
+        real_ar(*buckets, **kw)
         rec["calls"].append(dict(
             sizes=[int(t.numel()) for t in buckets], local=local, reduced=_named_grads(agent),
             noise=ws.noise.detach().cpu().clone(),
@@ -175,7 +175,7 @@ def _train(rank, world, overlap, steps=6):
     assert not agent._dp_pending
     return dict(bits=_replica_bits(agent), sizes=sizes, lay=dict(agent._lay), losses=dict(L.s),
                 enc_cut=agent._grad_offset(agent.critic.encoder.fc.weight, agent._critic_gflat),
-                actor_cut=agent._grad_offset(agent.actor.trunk[0].weight, agent._actor_gflat))
+                actor_bucket=int(agent._actor_gbucket.numel()))
 
 
 def _solo(steps=6):
@@ -273,14 +273,16 @@ def test_encoder_gradients_are_reduced_once_and_consumed_twice(two_ranks, schedu
     lay, sizes = r["lay"], r["sizes"]
     e0, e1, total = lay["enc"][0], lay["enc"][1], lay["total"]
     actor_n = int(r["bits"]["actor"].numel())
-    # 6 updates: critic + cpc every step, actor (+ float64 log_alpha) on the 3 even steps, one 8-element replica check
-    # per update and the final one
+    assert r["actor_bucket"] == actor_n + 8  # [fc, ln | trunk | the 8 words log_alpha's float64 gradient rides in]
+    # 6 updates: critic + cpc every step, the actor bucket on the 3 even steps, one 8-element replica check per update
+    # and the final one.  Round 6: THREE gradient collectives per even update in the blocking schedule (log_alpha's
+    # gradient had an 8-byte all-reduce of its own), FIVE in the overlapped one (was seven)
     if schedule == "blocking":
-        per_even = [8, total - e0, actor_n, 1, e1]
+        per_even = [8, total - e0, actor_n + 8, e1]
         per_odd = [8, total - e0, e1]
-    else:  # each bucket in two pieces: [dense | convs]
-        ec, ac = r["enc_cut"], r["actor_cut"]
-        per_even = [8, total - ec, ec - e0, actor_n - ac, 1, ac, e1 - ec, ec]
+    else:  # critic and cpc buckets in two pieces, [dense | convs]; the actor bucket whole, under the CURL phase
+        ec = r["enc_cut"]
+        per_even = [8, total - ec, ec - e0, actor_n + 8, e1 - ec, ec]
         per_odd = [8, total - ec, ec - e0, e1 - ec, ec]
     assert sizes == (per_even + per_odd) * 3 + [8], (schedule, sizes)
     # one exchange of the encoder's gradients per update -- and both optimizers that own the encoder stepped on it
@@ -309,7 +311,11 @@ def test_reduced_buckets_are_the_mean_of_single_process_and_oracle_gradients(two
             assert not torch.equal(c0["local"][k], c1["local"][k]) or float(c0["local"][k].abs().max()) == 0, (ph, k)
     lay = probes[0]["lay"]
     assert probes[0]["phases"]["critic"]["sizes"] == [lay["total"] - lay["enc"][0]]
-    assert probes[0]["phases"]["actor"]["sizes"][1] == 1
+    assert len(probes[0]["phases"]["actor"]["sizes"]) == 1   # ONE exchange: log_alpha's gradient rides in the bucket
+    # ... and comes out as today's float64 all-reduce would leave it, bit for bit: (a + b) / 2 in double
+    la = [probes[r]["phases"]["actor"]["local"]["log_alpha"].double() for r in range(2)]
+    assert torch.equal(probes[0]["phases"]["actor"]["reduced"]["log_alpha"].double(), (la[0] + la[1]) / 2)
+    assert not torch.equal(la[0], la[1])
     assert probes[0]["phases"]["cpc"]["sizes"] == [lay["enc"][1]]   # [W | encoder] in ONE exchange
 
     # -- single-process gradients: a non-distributed agent in THIS process on rank r's ring, indices and noise

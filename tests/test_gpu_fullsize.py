@@ -478,13 +478,13 @@ def _steps_case(tag, obs_shape, in_hw, aug_name, capacity, B=512, layers=4):
     phases = []
     real_allreduce = agent._allreduce  # (called once per phase right in front of its optimizer step; no-op without DP)
 
-    def tap(*buckets, async_op=False):
+    def tap(*buckets, **kw):
         if agent._graph_cap is None:  # (while a graph is being captured nothing may be copied to the host)
             phases.append(dict(
                 critic=grads_of(agent.critic), W=agent.CURL.W.grad.detach().cpu().clone(),
                 conv=[(a.permute(0, 3, 1, 2) > 0).cpu() for a in ws.acts_main],
                 qh=[t.detach().cpu() > 0 for t in (ws.q_h1[0], ws.q_h2[0], ws.q_h1[1], ws.q_h2[1])]))
-        return real_allreduce(*buckets, async_op=async_op)
+        return real_allreduce(*buckets, **kw)
     agent._allreduce = tap
 
     def oracle_soft_update():  # utils.py:37-41 with train.py's rates, as update() applies it on even steps

@@ -1327,3 +1327,35 @@ def test_conv_s1_forward_stack_full_size(ops, s1_impl):
         assert ops.conv_s1_fwd_stack(x1, w1, b1, o1, x2, w2, b2, o2)
         for i in range(L):
             assert torch.equal(o1[i], r1[i]) and torch.equal(o2[i], r2[i]), (rep, i)
+
+
+def test_f64_rider_kernels_match_the_host_arithmetic_bit_for_bit():
+    """curla_f64_pack / curla_f64_unpack against ops.f64_words_of / f64_of_words (tests/test_host_logic.py pins those to
+    exact rational arithmetic): the words, and the decoded mean of 2 / 4 / 8 ranks' values after a SUM or an AVG."""
+    from curla_amd import ops
+    from tests.test_host_logic import _rider_cases
+    vals = _rider_cases() + [2.0 ** 30, float("inf")]
+    dev = torch.device("cuda")
+    v = torch.zeros((), dtype=torch.float64, device=dev)
+    words = torch.zeros(ops.F64_WORDS, dtype=torch.float32, device=dev)
+    packed = []
+    for x in vals:
+        v.fill_(x)
+        ops.f64_pack(v, words)
+        got = words.cpu().tolist()
+        assert got == [float(np.float32(t)) for t in ops.f64_words_of(x)], x
+        ops.f64_unpack(words, 1, 1, v)
+        assert float(v) == x or (np.isinf(x) and np.isinf(float(v))), (x, float(v))
+        packed.append(words.clone())
+    rs = np.random.RandomState(9)
+    n_finite = len(vals) - 2
+    for world in (2, 4, 8):
+        for _ in range(30):
+            pick = rs.randint(0, n_finite, world)
+            s = torch.stack([packed[i] for i in pick]).sum(0)
+            for w_in, n_mul in ((s, 1), (s / world, world)):
+                ops.f64_unpack(w_in.contiguous(), n_mul, world, v)
+                assert float(v) == ops.f64_of_words(w_in.cpu().tolist(), n_mul, world), (world, pick)
+            if world == 2:
+                a, b = np.float64(vals[pick[0]]), np.float64(vals[pick[1]])
+                assert float(v) == (a + b) / np.float64(2)

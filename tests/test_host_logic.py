@@ -458,3 +458,52 @@ def test_flat_adam_plan_and_state_format():
     opt2.load_state_dict(sd)
     assert opt2._steps == [3, 3, 2, 3, 3]
     assert opt2.state[params[0]]["exp_avg"].data_ptr() == opt2._m.data_ptr()  # moments are views of the flat mirror
+
+
+def _rider_cases():
+    rs = np.random.RandomState(4)
+    vals = [0.0, 1.0, -1.0, 0.1, -0.1, 1e-3, 3.141592653589793, -2.718281828459045e-7, 123456.789, -2.0 ** 27, 2.0 ** 28 - 2.0 ** -20,
+            2.0 ** -60, -2.0 ** -79]
+    vals += list(rs.randn(64) * 10.0 ** rs.uniform(-8, 6, 64))
+    return [float(v) for v in vals]
+
+
+def test_f64_rider_words_are_exact_and_sum_exactly():
+    """log_alpha's float64 gradient inside the actor's float32 all-reduce bucket (ops.f64_words_of /
+    f64_of_words are the host statement of curla_f64_pack / curla_f64_unpack): the 8 words are integers below 2^20 that
+    reproduce the value exactly; sums of the words over 2 .. 16 ranks (exact in float32) decode to the correctly rounded
+    EXACT sum of the ranks' doubles -- for two ranks the float64 all-reduce's (a + b) / 2, bit for bit -- whether the
+    collective summed or averaged (power-of-two worlds)."""
+    from fractions import Fraction
+
+    from curla_amd import ops
+    vals = _rider_cases()
+    for v in vals:
+        w = ops.f64_words_of(v)
+        assert len(w) == ops.F64_WORDS and all(float(np.float32(x)) == x and abs(x) < 2 ** 20 and x == int(x) for x in w)
+        assert ops.f64_of_words(w) == v, v
+    rs = np.random.RandomState(5)
+    for world in (2, 2, 2, 4, 8, 16):
+        for _ in range(40):
+            picks = [vals[i] for i in rs.randint(0, len(vals), world)]
+            words = np.stack([np.array(ops.f64_words_of(v), dtype=np.float32) for v in picks])
+            summed = words.sum(0, dtype=np.float32)       # what a SUM all-reduce leaves ...
+            assert np.array_equal(summed.astype(np.float64), words.astype(np.float64).sum(0))  # ... exactly
+            averaged = (summed / np.float32(world))       # ... and ncclAvg (exact: power of two)
+            exact = sum(Fraction(v) for v in picks)
+            want = float(exact) / world                   # one rounding of the exact sum, then the exact division
+            assert ops.f64_of_words(summed.tolist(), 1, world) == want
+            assert ops.f64_of_words(averaged.tolist(), world, world) == want
+            if world == 2:
+                assert want == (np.float64(picks[0]) + np.float64(picks[1])) / np.float64(2)
+    # below the last digit (2^-132) a value is dropped: an absolute error no gradient step can see
+    assert ops.f64_of_words(ops.f64_words_of(1e-50)) == 0.0 and abs(ops.f64_of_words(ops.f64_words_of(1e-30)) - 1e-30) < 2.0 ** -132
+    # out of range / non-finite values travel in word 0 and come back finite-or-not as they went
+    assert ops.f64_of_words(ops.f64_words_of(2.0 ** 30)) == 2.0 ** 30
+    assert np.isnan(ops.f64_of_words(ops.f64_words_of(float("nan"))))
+    assert np.isinf(ops.f64_of_words(ops.f64_words_of(float("inf"))))
+    # a world size that is not a power of two: averaged digits are rounded to 24 bits -- 2^-24 of the value
+    picks = [vals[3], vals[5], vals[6]]
+    words = np.stack([np.array(ops.f64_words_of(v), dtype=np.float32) for v in picks]).sum(0, dtype=np.float32) / np.float32(3)
+    got = ops.f64_of_words(words.tolist(), 3, 3)
+    assert abs(got - sum(picks) / 3) <= 2.0 ** -22 * abs(sum(picks) / 3)
