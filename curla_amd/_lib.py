@@ -188,7 +188,7 @@ def call(name, *args):
         raise CurlaHipError(f"{name} failed: {_ERRORS.get(rc, rc)}")
 
 
-OPTIONS = ("conv1_u8", "conv1_f32", "s1_fwd", "bwd_split", "gemm_tile", "linear_bwd", "gemm_mfma", "s1_wgrad")  # curla_amd/csrc/options.h
+OPTIONS = ("conv1_u8", "conv1_f32", "s1_fwd", "bwd_split", "gemm_tile", "linear_bwd", "gemm_mfma", "s1_wgrad", "wgrad1_u8")  # curla_amd/csrc/options.h
 
 
 def set_option(name, value):

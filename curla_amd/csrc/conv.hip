@@ -1265,6 +1265,215 @@ __global__ __launch_bounds__(64 * NW) void wgrad1_u8_kernel(Wgrad1Args a) {
 }
 
 
+// The same weight gradient on the BF16 matrix cores (round 6; option wgrad1_u8 = auto / b16).  A uint8 pixel is EXACT in
+// one bf16 (8 significand bits), the gradient is the exact sum of three (conv_rwb.h: split8) -- so a float32 product
+// g x is three exact bf16 x bf16 products accumulated in fp32, nothing dropped.  One v_mfma_f32_16x16x32_bf16 takes a
+// k-step of 32 PIXELS (lane group kq: pixels 8 kq .. 8 kq + 7) where the f32-input instruction takes 4: per 32 pixels
+// 2 x NT x 3 matrix instructions of 16 cycles instead of 8 x 2 x NT of 32 -- 5.3 x fewer matrix cycles, which moves the
+// loop from the matrix pipe (busy 0.53, 1.1 VALU per instruction) to the vector ALU: per unit and wave ~90 instructions
+// split the 16 gradient values, ~70 turn the 8 x NT operand bytes into bf16 (v_cvt_f32_ubyte + one v_perm per pair: the
+// float of an integer below 256 has an empty low half), ~60 walk the pixels.
+// Columns: k' = (dy, rr = dx C + c) with every tap row dy padded to NTD = ceil(3 C / 16) tiles of 16 (96 columns for
+// C = 9, where the unpadded 81 need six tiles as well): tile t = dy NTD + h reads byte (pixel base) + dy RSb + 16 h + li,
+// i.e. ONE per-lane base per (pixel, dy) and compile-time offsets -- the padding columns multiply bytes of the
+// neighbouring pixel (finite) and are dropped by the epilogue.
+// Pixels: the band's pixels in row-major order, 32 per unit, units dealt round-robin to the waves (the gradient of a
+// unit is 32 x 128 contiguous bytes); pixels past the band read zeros through the buffer range check and a clamped
+// (valid) byte address.  What the loop waits for is the gradient (90 MB per 512 crops against 27 MB of bytes: timing-only
+// builds without the byte reads, the split AND the products still take half the loop's time), so: four waves per SIMD
+// (two 512-thread workgroups per CU, 128 registers) rather than three with deeper software pipelining (38 against 32 us),
+// whole 128-byte lines per load instruction, and a tap row's bytes requested one tap row ahead.
+template <int C, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 2) void wgrad1_u8b_kernel(Wgrad1Args a) {
+  constexpr int NTHR = 64 * NW;
+  constexpr int NTD = (3 * C + 15) / 16, NT = 3 * NTD;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  using rwb::u32x4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, kq = lane >> 4;
+  const int RSb = conv1_row_bytes(a.Wc, C);
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[i][t] = f32x4{0, 0, 0, 0};
+  f32x2 bsum = {0.f, 0.f};
+  uint8_t* ldsb = reinterpret_cast<uint8_t*>(lds);
+  const int nitems = a.B * a.nbands;
+  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const int band = item / a.B, b = item - band * a.B;
+    const int y0 = band * a.th;
+    const int tha = min(a.th, a.Ho - y0);
+    const int npix = tha * a.Wo;
+    const int nunits = (npix + 31) >> 5;
+    // the band's gradient, [pixel][32]: lane (li, kq) takes output channels 2 li and 2 li + 1 (rows li of the two channel
+    // tiles: tile mt holds the channels of parity mt) of its 8 pixels -- ONE 8-byte load per pixel, a lane group reads a
+    // pixel's whole 128-byte line (channel li and 16 + li as two 4-byte loads: twice the load instructions, each touching
+    // half a line -- the loop waits for these loads, not for arithmetic); past the band: zeros
+    const __amdgpu_buffer_rsrc_t rg = rw::uniform_rsrc(a.g + ((size_t)(b * a.Ho + y0) * a.Wo) * 32, npix * 128);
+    float graw[2][8];
+    auto gload = [&](int u) {
+      const unsigned v0 = (unsigned)((32 * u + 8 * kq) * 128 + li * 8);
+#pragma unroll
+      for (int jj = 0; jj < 8; ++jj) {
+        const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rg, v0 + 128u * jj, 0, 0));
+        graw[0][jj] = v[0], graw[1][jj] = v[1];
+      }
+    };
+    if (wave < nunits) gload(wave);  // (independent of the crop: in flight while the bytes are staged)
+    if (!ABL(1)) {
+      const int64_t fi = a.idx ? rw::const_load(a.idx, b) : (int64_t)b;  // (scalar loads: b is wave-uniform)
+      const int oh = a.h1 ? rw::const_load(a.h1, b) : 0, ow = a.w1 ? rw::const_load(a.w1, b) : 0;
+      const uint8_t* crop = static_cast<const uint8_t*>(a.src) + ((size_t)fi * a.Hs + oh + 2 * y0) * a.Ws * C + (size_t)ow * C;
+      if (a.Wc * C <= 64 * 16)  // a lane per 16-byte run of a row
+        conv1_stage_rows<10>(ldsb, crop, a.Ws * C, a.Wc * C, 2 * tha + 1, RSb, 0, wave, NW, lane);
+      else
+        conv1_stage_u8(ldsb, static_cast<const uint8_t*>(a.src), a.idx, a.h1, a.w1, b, C, a.Hs, a.Ws, a.Wc, 2 * y0,
+                       2 * tha + 1, RSb, tid, NTHR);
+    }
+    __syncthreads();
+    // first pixel of this lane in unit u = wave: (row, column) -> byte offset of its patch; a unit step is 32 NW pixels
+    int p0 = 32 * wave + 8 * kq;
+    int ty = p0 / a.Wo, x = p0 - ty * a.Wo;
+    const int qstep = (32 * NW) / a.Wo, rstep = 32 * NW - qstep * a.Wo;
+    const int px = 2 * C, wrap_add = 2 * RSb - 2 * (a.Wo - 1) * C;  // next pixel of a row / first pixel of the next row
+    const int pb_last = 2 * (tha - 1) * RSb + 2 * (a.Wo - 1) * C + li;  // (pixels past the band: clamped, zero gradient)
+    for (int u = ABL(2) ? nunits : wave; u < nunits; u += NW) {  // (wave-uniform)
+      // ---- byte address of each of the 8 pixels' patch and the first tap row's bytes, in flight during the split
+      int pb[8];
+      {
+        int xx = x, cur = __mul24(2 * ty, RSb) + 2 * x * C + li;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          pb[jj] = min(cur, pb_last);
+          ++xx;
+          const bool wrap = xx >= a.Wo;
+          cur += wrap ? wrap_add : px;
+          xx = wrap ? 0 : xx;
+        }
+      }
+      uint32_t raw[8 * NTD];
+      auto bread = [&](const int dy) {
+        const uint8_t* rowb = ldsb + dy * RSb;
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+          for (int h = 0; h < NTD; ++h) raw[jj * NTD + h] = rowb[pb[jj] + 16 * h];
+      };
+      if (!ABL(8)) bread(0);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- this unit's gradient values -> three bf16 operands per channel half; the next unit's are requested
+      rwb::B3 G[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        float v[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) v[jj] = graw[mt][jj];
+        bsum[mt] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        if (ABL(16)) {  // timing only: no split arithmetic
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            G[mt].h[q] = __builtin_bit_cast(unsigned, v[q]), G[mt].m[q] = __builtin_bit_cast(unsigned, v[q + 4]), G[mt].l[q] = G[mt].h[q];
+        } else
+          G[mt] = rwb::split8(v);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- tap row by tap row: 8 NTD bytes -> NTD B operands of 8 bf16 (the float of an integer below 256 has an empty
+      // low half: its high half IS the bf16), the next tap row's bytes requested, then the six products of each tile
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        u32x4 X[NTD];
+#pragma unroll
+        for (int h = 0; h < NTD; ++h)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float f0 = (float)raw[(2 * q) * NTD + h], f1 = (float)raw[(2 * q + 1) * NTD + h];
+            X[h][q] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, f1), __builtin_bit_cast(unsigned, f0), 0x07060302u);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+        if (dy < 2 && !ABL(8)) bread(dy + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL(32)) {  // timing only: no matrix instructions
+#pragma unroll
+          for (int h = 0; h < NTD; ++h) acc[0][dy * NTD + h][0] += __builtin_bit_cast(float, X[h][0] ^ X[h][1] ^ X[h][2] ^ X[h][3] ^ G[0].l[0] ^ G[1].m[1] ^ G[0].h[2] ^ G[1].h[3] ^ G[0].m[0] ^ G[1].l[1]);
+        } else
+#pragma unroll
+        for (int h = 0; h < NTD; ++h) {
+          const int t = dy * NTD + h;
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) acc[mt][t] = rwb::mfma_bf16(G[mt].l, X[h], acc[mt][t]);  // smallest part first
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) acc[mt][t] = rwb::mfma_bf16(G[mt].m, X[h], acc[mt][t]);
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt) acc[mt][t] = rwb::mfma_bf16(G[mt].h, X[h], acc[mt][t]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the next unit's gradient values: requested here, behind the unit's arithmetic (their 16 registers are free
+      // again; the SIMD's other three waves cover the latency -- requested before the products they cost 33 spills)
+      if (u + NW < nunits) gload(u + NW);
+      x += rstep, ty += qstep;  // at most one more wrap
+      const bool wrap = x >= a.Wo;
+      x = wrap ? x - a.Wo : x;
+      ty = wrap ? ty + 1 : ty;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[i][t] *= a.scale;
+  bsum[0] += __shfl_xor(bsum[0], 16);
+  bsum[0] += __shfl_xor(bsum[0], 32);
+  bsum[1] += __shfl_xor(bsum[1], 16);
+  bsum[1] += __shfl_xor(bsum[1], 32);
+  // cross-wave sum in wave order and the slab, as wgrad1_u8_kernel (tile t: tap row t / NTD, columns 16 (t % NTD) + li)
+  const int nw = 32 * C * 9;
+  float* slab = a.partial + (size_t)blockIdx.x * (nw + 32);
+  if (ABL(4)) {  // timing only: no cross-wave sum, no slab
+    float t = bsum[0] + bsum[1];
+#pragma unroll
+    for (int q = 0; q < 2 * NT; ++q) t += acc[q / NT][q % NT][0] + acc[q / NT][q % NT][3];
+    if (t == 12345.678f) slab[tid] = t;
+    return;
+  }
+  f32x4* l4 = reinterpret_cast<f32x4*>(lds);
+  const int TC = max(1, min(2 * NT, (int)(a.lds_bytes / (NW * 1024))));  // tiles per pass (1 KB per tile and wave)
+  __syncthreads();
+  for (int t0 = 0; t0 < 2 * NT; t0 += TC) {
+    const int nt = min(TC, 2 * NT - t0);
+#pragma unroll
+    for (int q = 0; q < 2 * NT; ++q)
+      if (q >= t0 && q < t0 + nt) l4[(wave * TC + (q - t0)) * 64 + lane] = acc[q / NT][q % NT];
+    __syncthreads();
+    for (int sl = tid; sl < nt * 64; sl += NTHR) {
+      const int q = t0 + sl / 64, ln = sl & 63;
+      f32x4 v = l4[(0 * TC + (q - t0)) * 64 + ln];
+      for (int w = 1; w < NW; ++w) v += l4[(w * TC + (q - t0)) * 64 + ln];
+      const int mt = q / NT, t = q - mt * NT;
+      const int dy = t / NTD, rr = 16 * (t - dy * NTD) + (ln & 15);
+      if (rr < 3 * C) {
+        const int dx = rr / C, c = rr - dx * C;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = 2 * (4 * (ln >> 4) + r) + mt;  // (tile mt: the output channels of parity mt)
+          slab[(co * C + c) * 9 + dy * 3 + dx] = v[r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (kq == 0) lds[(wave * 2 + 0) * 16 + li] = bsum[0], lds[(wave * 2 + 1) * 16 + li] = bsum[1];
+  __syncthreads();
+  if (tid < 32) {  // tid = mt * 16 + li: output channel 2 li + mt
+    float v = lds[tid];
+    for (int w = 1; w < NW; ++w) v += lds[w * 32 + tid];
+    slab[nw + 2 * (tid & 15) + (tid >> 4)] = v;
+  }
+}
+
+
 // second pass: dW = sum over workgroup slabs.  32 elements x 32 slab-groups per
 // block; each group adds its slabs in slab order, the 32 group sums are added in
 // group order (fixed order => bitwise reproducible).
@@ -1947,10 +2156,31 @@ static int launch_wgrad1(const void* src, int src_kind, const int64_t* idx, cons
       const size_t one_pass = (size_t)ntiles * nwaves * 1024;
       if (nwaves == 8 && one_pass <= 80 * 1024 && lds < one_pass) lds = one_pass;
     }
+    // round 6: the bf16-matrix-core form (wgrad1_u8b_kernel) wherever a lane's 8 consecutive pixels wrap at most once
+    // (option wgrad1_u8: auto / b16; f32 keeps the f32-input MFMA)
+    const bool b16 = curla_opt(kOptWgrad1U8) != 1 && nwaves == 8 && a.Wo >= 8 && 3 * C <= 32;  // (C = 12: nine tiles per
+    // channel half do not fit four waves per SIMD)
+    if (b16) {
+      const int ntd = (3 * C + 15) / 16;
+      const size_t one_pass = (size_t)(2 * 3 * ntd) * nwaves * 1024;  // all of a wave's tiles in ONE pass of the final sum
+      if (one_pass <= 80 * 1024 && lds < one_pass) lds = one_pass;
+    }
     a.lds_bytes = (unsigned)lds;
     const int nitems = B * a.nbands;
     const int per_cu = nwaves == 4 ? 4 : 2;
     grid = nitems < per_cu * curla_cu_count() ? nitems : per_cu * curla_cu_count();
+#define WGRAD1_U8B_LAUNCH(CC)                                                                                      \
+  {                                                                                                                \
+    rc = set_lds(wgrad1_u8b_kernel<CC, 8>, lds);                                                                   \
+    if (rc == CURLA_OK) hipLaunchKernelGGL((wgrad1_u8b_kernel<CC, 8>), dim3(grid), dim3(512), lds, st, a);         \
+  }
+    if (b16) {
+      if (C == 9) WGRAD1_U8B_LAUNCH(9) else if (C == 6) WGRAD1_U8B_LAUNCH(6) else WGRAD1_U8B_LAUNCH(3)
+      if (rc != CURLA_OK) return rc;
+      *nslabs = grid;
+      return curla_launch_status();
+    }
+#undef WGRAD1_U8B_LAUNCH
 #define WGRAD1_U8_LAUNCH(CC)                                                                                       \
   {                                                                                                                \
     if (nwaves == 4) {                                                                                             \

@@ -19,6 +19,9 @@ enum CurlaOpt {
                     // bf16 matrix cores for every interior, aligned tile)
   kOptS1Wgrad,      // stride-1 weight gradient: 0 auto (= xy), 1 x (Winograd F(3,2) along x, conv_rw_wgrad.h), 2 xy (both directions,
                     // conv_rw_wgrad2.h)
+  kOptWgrad1U8,     // first-layer weight gradient from the uint8 ring: 0 auto (= b16 where output rows hold >= 8 pixels), 1 f32 (the
+                    // f32-input MFMA, wgrad1_u8_kernel), 2 b16 (bf16 matrix cores: a uint8 pixel is exact in one bf16, the gradient
+                    // is split into three; wgrad1_u8b_kernel)
   kOptCount
 };
 

@@ -28,6 +28,7 @@ const OptDef kDefs[kOptCount] = {
     {"linear_bwd", {"pair", "split", nullptr}, {nullptr, nullptr, nullptr}},
     {"gemm_mfma", {"auto", "f32", "b3", nullptr}, {nullptr, nullptr, "bf16x3", nullptr}},
     {"s1_wgrad", {"auto", "x", "xy", nullptr}, {nullptr, "1d", "2d", nullptr}},
+    {"wgrad1_u8", {"auto", "f32", "b16", nullptr}, {nullptr, nullptr, "bf16", nullptr}},
 };
 
 std::atomic<int> g_value[kOptCount];

@@ -206,9 +206,12 @@ def test_crop_and_conv1_u8(ops, u8_impl, C, Hs, Ws, Hc, Wc, B):
     bl = b.clone().requires_grad_(True)
     F.conv2d(x / 255.0, wl, bl, stride=2).backward(g)
     ws = torch.empty(ops.wgrad_workspace_floats(C), device="cuda")
-    for name, o, impl in [("u8", obs, "rw"), ("f32", ops.ObsRef.from_tensor(out_f), "rw")] + \
-                         [(f"f32 NHWC [{i}]", obs_nhwc, i) for i in f32_impls]:
-        with _lib.option("conv1_f32", impl):
+    # (uint8 source: on the f32-input MFMA and on the bf16 matrix cores -- option wgrad1_u8; `auto` = b16 where it applies)
+    for name, o, impl, wg in [("u8 [wgrad1_u8=f32]", obs, "rw", "f32"), ("u8 [wgrad1_u8=b16]", obs, "rw", "b16"),
+                              ("f32", ops.ObsRef.from_tensor(out_f), "rw", "auto")] + \
+                             [(f"f32 NHWC [{i}]", obs_nhwc, i, "auto") for i in f32_impls]:
+        with _lib.option("conv1_f32", impl), _lib.option("wgrad1_u8", wg):
+            _poison_lds(ops)
             dw = torch.full((32, C, 3, 3), float("nan"), device="cuda")
             db = torch.full((32,), float("nan"), device="cuda")
             ops.conv1_wgrad(o, nhwc(g), dw, db, ws)

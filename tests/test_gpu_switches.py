@@ -182,6 +182,8 @@ SWITCHES = [
     ("s1_fwd=f23 (wide rows)", {"s1_fwd": "f23"}, {}, "wide", (), ()),
     ("s1_fwd=b3 (forward and data gradient)", {"s1_fwd": "b3"}, {}, "random_crop", (), ()),
     ("s1_fwd=b3 (wide rows)", {"s1_fwd": "b3"}, {}, "wide", (), ()),
+    ("wgrad1_u8=f32", {"wgrad1_u8": "f32"}, {}, "random_crop", (), ()),
+    ("wgrad1_u8=b16", {"wgrad1_u8": "b16"}, {}, "random_crop", (), ()),
     ("s1_wgrad=x", {"s1_wgrad": "x"}, {}, "random_crop", (), ()),
     ("s1_wgrad=x (wide rows)", {"s1_wgrad": "x"}, {}, "wide", (), ()),
     ("bwd_split=0", {"bwd_split": "0"}, {}, "random_crop", (), ()),
@@ -225,7 +227,7 @@ def test_whole_update_parity_under_switch(tag, options, env, aug_name, must_call
         assert calls[name] == 0, (tag, name, dict(calls))
 
 
-F32_FORMS = {"s1_fwd": "f23", "gemm_mfma": "f32", "conv1_u8": "rw"}  # every product on the exact f32-input MFMA
+F32_FORMS = {"s1_fwd": "f23", "gemm_mfma": "f32", "conv1_u8": "rw", "wgrad1_u8": "f32"}  # every product on the exact f32-input MFMA
 
 
 @pytest.mark.parametrize("forms", ["f32 forms (tight)", "default forms"])
