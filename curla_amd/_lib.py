@@ -35,7 +35,7 @@ SIGNATURES = {
     "curla_conv1_wgrad_slabs": [vp, c_int, vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, vp,
                                 vp],
     "curla_conv3x3_s1_bwd_slabs": [vp, vp, vp, vp, vp, c_int, c_int, c_int, c_int, vp, vp],
-    "curla_wgrad_reduce_multi": [c_int, vp, vp, vp, vp, vp, vp],
+    "curla_wgrad_reduce_multi": [c_int, vp, vp, vp, vp, vp, vp, vp],
     "curla_conv_wgrad_workspace_floats": [c_int],
     "curla_gemm": [vp, c_int, c_int, c_ll, vp, c_int, c_int, c_ll, vp, c_int, c_ll, c_int, c_int, c_int, c_int, c_int,
                    c_ll, c_float, vp, c_ll, c_int, vp, c_int, c_ll, vp],

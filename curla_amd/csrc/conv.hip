@@ -1477,12 +1477,12 @@ __global__ __launch_bounds__(64 * NW, NW / 2) void wgrad1_u8b_kernel(Wgrad1Args 
 // second pass: dW = sum over workgroup slabs.  32 elements x 32 slab-groups per
 // block; each group adds its slabs in slab order, the 32 group sums are added in
 // group order (fixed order => bitwise reproducible).
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* partial, int nslabs, int nw, float* dw,
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* partial, int nslabs, int nw, int nb, float* dw,
                                                             float* db) {
   __shared__ float sm[32][33];
   const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + c;
-  const int n = nw + 32;
+  const int n = nw + nb;  // (nb bias sums behind the nw weight sums of a slab: 32, or the filter count of the generic path)
   float s = 0.f;
   if (i < n) {
     int k = part;
@@ -1516,7 +1516,7 @@ struct ReduceJobs {
   const float* partial[kMaxReduceJobs];
   float* dw[kMaxReduceJobs];
   float* db[kMaxReduceJobs];
-  int nslabs[kMaxReduceJobs], nw[kMaxReduceJobs], first_block[kMaxReduceJobs + 1];
+  int nslabs[kMaxReduceJobs], nw[kMaxReduceJobs], nb[kMaxReduceJobs], first_block[kMaxReduceJobs + 1];
   int njobs;
 };
 
@@ -1528,7 +1528,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_multi_kernel(ReduceJobs J) 
   const int nslabs = J.nslabs[j], nw = J.nw[j];
   const int c = threadIdx.x & 31, part = threadIdx.x >> 5;
   const int i = ((int)blockIdx.x - J.first_block[j]) * 32 + c;
-  const int n = nw + 32;
+  const int n = nw + J.nb[j];
   float s = 0.f;
   if (i < n) {
     int k = part;
@@ -1737,10 +1737,66 @@ int curla_debug_rwb_stamps(unsigned long long* out8, int reset) {
 }
 #endif
 
+}  // extern "C"  (re-opened below: the generic-width helpers are C++)
+#include "conv_generic.h"
+
+namespace {
+// ---- filter counts other than 32: the plain kernels of conv_generic.h behind the same entry points -------------------
+int gen_fwd_s1(const float* in, const float* w, const float* bias, float* out, int B, int Hi, int Wi, int C, hipStream_t st) {
+  if (!gen::channels_ok(C)) return CURLA_ERR_UNSUPPORTED;
+  const int Ho = Hi - 2, Wo = Wi - 2;
+  gen::Src none{};
+  hipLaunchKernelGGL(gen::conv_fwd_kernel<false>, dim3(gen::grid_for((size_t)B * Ho * Wo * C)), dim3(256), 0, st, none, in, w,
+                     bias, out, B, Hi, Wi, C, Ho, Wo, C);
+  return curla_launch_status();
+}
+
+gen::Src gen_src(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1, int C, int Hs, int Ws,
+                 int Hc, int Wc, float scale) {
+  return gen::Src{src, src_kind, idx, h1, w1, C, Hs, Ws, Hc, Wc, scale};
+}
+
+int gen_fwd1(const gen::Src& s, const float* w, const float* bias, float* out, int B, int channels, hipStream_t st) {
+  if (!gen::channels_ok(channels)) return CURLA_ERR_UNSUPPORTED;
+  const int Ho = (s.Hc - 3) / 2 + 1, Wo = (s.Wc - 3) / 2 + 1;
+  hipLaunchKernelGGL(gen::conv_fwd_kernel<true>, dim3(gen::grid_for((size_t)B * Ho * Wo * channels)), dim3(256), 0, st, s,
+                     static_cast<const float*>(nullptr), w, bias, out, B, s.Hc, s.Wc, s.C, Ho, Wo, channels);
+  return curla_launch_status();
+}
+
+int gen_dgrad(const float* g, const float* w, const float* act_below, float* gin, int B, int Ho, int Wo, int C, hipStream_t st) {
+  if (!gen::channels_ok(C)) return CURLA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(gen::conv_dgrad_kernel, dim3(gen::grid_for((size_t)B * (Ho + 2) * (Wo + 2) * C)), dim3(256), 0, st, g, w,
+                     act_below, gin, B, Ho, Wo, C);
+  return curla_launch_status();
+}
+
+// (one slab: [channels * cin * 9 | channels])
+int gen_wgrad_s1(const float* in, const float* g, float* slab, int B, int Hi, int Wi, int C, hipStream_t st, int* nslabs) {
+  if (!gen::channels_ok(C)) return CURLA_ERR_UNSUPPORTED;
+  gen::Src none{};
+  hipLaunchKernelGGL(gen::conv_wgrad_kernel<false>, dim3(C * C + C), dim3(256), 0, st, none, in, g, slab, B, Hi, Wi, C, Hi - 2,
+                     Wi - 2, C);
+  *nslabs = 1;
+  return curla_launch_status();
+}
+
+int gen_wgrad1(const gen::Src& s, const float* g, float* slab, int B, int channels, hipStream_t st, int* nslabs) {
+  if (!gen::channels_ok(channels)) return CURLA_ERR_UNSUPPORTED;
+  const int Ho = (s.Hc - 3) / 2 + 1, Wo = (s.Wc - 3) / 2 + 1;
+  hipLaunchKernelGGL(gen::conv_wgrad_kernel<true>, dim3(channels * s.C + channels), dim3(256), 0, st, s,
+                     static_cast<const float*>(nullptr), g, slab, B, s.Hc, s.Wc, s.C, Ho, Wo, channels);
+  *nslabs = 1;
+  return curla_launch_status();
+}
+}  // namespace
+
+extern "C" {
+
 int curla_conv3x3_s1_fwd(const float* in, const float* w, const float* bias, float* out, int B, int Hi, int Wi,
                          int channels, void* stream) {
   CURLA_REQUIRE(in && w && bias && out && B > 0 && Hi >= 3 && Wi >= 3);
-  if (channels != 32) return CURLA_ERR_UNSUPPORTED;
+  if (channels != 32) return gen_fwd_s1(in, w, bias, out, B, Hi, Wi, channels, static_cast<hipStream_t>(stream));
   CURLA_REQUIRE(aligned16(in) && aligned16(out) && aligned16(bias) && aligned16(w));
   return launch_conv_s1(MODE_FWD, in, w, bias, out, B, Hi, Wi, static_cast<hipStream_t>(stream));
 }
@@ -1749,7 +1805,10 @@ int curla_conv3x3_s1_fwd2(const float* in, const float* w, const float* bias, fl
                           const float* w2, const float* bias2, float* out2, int B2, int Hi, int Wi, int channels,
                           void* stream) {
   CURLA_REQUIRE(in && w && bias && out && B > 0 && in2 && w2 && bias2 && out2 && B2 > 0 && Hi >= 3 && Wi >= 3);
-  if (channels != 32) return CURLA_ERR_UNSUPPORTED;
+  if (channels != 32) {  // (generic width: the two problems one after the other)
+    const int rc = gen_fwd_s1(in, w, bias, out, B, Hi, Wi, channels, static_cast<hipStream_t>(stream));
+    return rc != CURLA_OK ? rc : gen_fwd_s1(in2, w2, bias2, out2, B2, Hi, Wi, channels, static_cast<hipStream_t>(stream));
+  }
   CURLA_REQUIRE(aligned16(in) && aligned16(out) && aligned16(bias) && aligned16(w));
   CURLA_REQUIRE(aligned16(in2) && aligned16(out2) && aligned16(bias2) && aligned16(w2));
   return launch_conv_s1(MODE_FWD, in, w, bias, out, B, Hi, Wi, static_cast<hipStream_t>(stream), in2, w2, bias2, out2, B2);
@@ -1780,7 +1839,7 @@ int curla_conv3x3_s1_stack_granule(void) { return curla_cu_count(); }
 int curla_conv3x3_s1_dgrad(const float* g, const float* w, const float* act_below, float* gin, int B, int Ho, int Wo,
                            int channels, void* stream) {
   CURLA_REQUIRE(g && w && act_below && gin && B > 0 && Ho >= 1 && Wo >= 1);
-  if (channels != 32) return CURLA_ERR_UNSUPPORTED;
+  if (channels != 32) return gen_dgrad(g, w, act_below, gin, B, Ho, Wo, channels, static_cast<hipStream_t>(stream));
   CURLA_REQUIRE(aligned16(g) && aligned16(gin) && aligned16(act_below) && aligned16(w));
   return launch_conv_s1(MODE_DGRAD, g, w, act_below, gin, B, Ho, Wo, static_cast<hipStream_t>(stream));
 }
@@ -1842,9 +1901,17 @@ static int conv1_fwd_impl(const void* src, int src_kind, const int64_t* idx, con
                           const float* w, const float* bias, float* out, int B, int C, int Hs, int Ws, int Hc, int Wc,
                           int channels, float scale, void* stream, const Conv1Second* second) {
   CURLA_REQUIRE(w && bias && out);
-  if (channels != 32) return CURLA_ERR_UNSUPPORTED;
   int rc = conv1_common_check(src, src_kind, B, C, Hs, Ws, Hc, Wc, h1, w1);
   if (rc != CURLA_OK) return rc;
+  if (channels != 32) {  // generic width (conv_generic.h): the second minibatch, if any, as a launch of its own
+    if (second && src_kind != 1) return CURLA_ERR_UNSUPPORTED;
+    hipStream_t gst = static_cast<hipStream_t>(stream);
+    rc = gen_fwd1(gen_src(src, src_kind, idx, h1, w1, C, Hs, Ws, Hc, Wc, scale), w, bias, out, B, channels, gst);
+    if (rc == CURLA_OK && second)
+      rc = gen_fwd1(gen_src(src, src_kind, second->idx, second->h1, second->w1, C, Hs, Ws, Hc, Wc, scale), second->w,
+                    second->bias, second->out, second->B, channels, gst);
+    return rc;
+  }
   Conv1Args a;
   a.src = src, a.idx = idx, a.h1 = h1, a.w1 = w1, a.w = w, a.bias = bias, a.out = out;
   a.B = B, a.C = C, a.Hs = Hs, a.Ws = Ws, a.Hc = Hc, a.Wc = Wc;
@@ -1986,7 +2053,8 @@ static rw::WgradArgs wgrad_args(const float* in, const float* g, float* workspac
 static int launch_wgrad_s1(const float* in, const float* g, float* workspace, int B, int Hi, int Wi, int channels,
                            hipStream_t st, int* nslabs) {
   CURLA_REQUIRE(in && g && workspace && B > 0 && Hi >= 3 && Wi >= 3);
-  if (channels != 32 || !rw_supported(Hi, Wi)) return CURLA_ERR_UNSUPPORTED;
+  if (channels != 32) return gen_wgrad_s1(in, g, workspace, B, Hi, Wi, channels, st, nslabs);
+  if (!rw_supported(Hi, Wi)) return CURLA_ERR_UNSUPPORTED;
   CURLA_REQUIRE(aligned16(in) && aligned16(g));
   const rw::WgradArgs ra = wgrad_args(in, g, workspace, B, Hi, Wi, Hi - 2, Wi - 2);
   const int cap = 2 * curla_cu_count();
@@ -2006,7 +2074,8 @@ int curla_conv3x3_s1_wgrad(const float* in, const float* g, float* dw, float* db
   int grid = 0;
   int rc = launch_wgrad_s1(in, g, workspace, B, Hi, Wi, channels, st, &grid);
   if (rc != CURLA_OK) return rc;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((kPartialS1 + 31) / 32), dim3(1024), 0, st, workspace, grid, 32 * 288,
+  const int nw = channels * channels * 9;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nw + channels + 31) / 32), dim3(1024), 0, st, workspace, grid, nw, channels,
                      dw, db);
   return curla_launch_status();
 }
@@ -2020,7 +2089,11 @@ int curla_conv3x3_s1_wgrad_slabs(const float* in, const float* g, float* workspa
 int curla_conv3x3_s1_bwd_slabs(const float* in, const float* g, const float* w, float* gin, float* workspace, int B, int Hi,
                                int Wi, int channels, int* nslabs, void* stream) {
   CURLA_REQUIRE(in && g && w && gin && workspace && nslabs && B > 0 && Hi >= 3 && Wi >= 3);
-  if (channels != 32) return CURLA_ERR_UNSUPPORTED;
+  if (channels != 32) {  // generic width: the two gradients as two launches
+    hipStream_t gst = static_cast<hipStream_t>(stream);
+    const int rc = gen_wgrad_s1(in, g, workspace, B, Hi, Wi, channels, gst, nslabs);
+    return rc != CURLA_OK ? rc : gen_dgrad(g, w, in, gin, B, Hi - 2, Wi - 2, channels, gst);
+  }
   CURLA_REQUIRE(aligned16(in) && aligned16(g) && aligned16(w) && aligned16(gin));
   const int Ho = Hi - 2, Wo = Wi - 2;
   if (!rw_supported(Hi, Wi)) return CURLA_ERR_UNSUPPORTED;
@@ -2072,16 +2145,18 @@ int curla_conv3x3_s1_bwd_slabs(const float* in, const float* g, const float* w, 
   return curla_launch_status();
 }
 
-int curla_wgrad_reduce_multi(int njobs, const float* const* slabs, const int* nslabs, const int* nw, float* const* dw,
-                             float* const* db, void* stream) {
+int curla_wgrad_reduce_multi(int njobs, const float* const* slabs, const int* nslabs, const int* nw, const int* nb,
+                             float* const* dw, float* const* db, void* stream) {
   CURLA_REQUIRE(njobs > 0 && njobs <= kMaxReduceJobs && slabs && nslabs && nw && dw && db);
   ReduceJobs J;
   int blocks = 0;
   for (int j = 0; j < njobs; ++j) {
     CURLA_REQUIRE(slabs[j] && dw[j] && db[j] && nslabs[j] > 0 && nw[j] > 0);
     J.partial[j] = slabs[j], J.dw[j] = dw[j], J.db[j] = db[j], J.nslabs[j] = nslabs[j], J.nw[j] = nw[j];
+    J.nb[j] = nb ? nb[j] : 32;
+    CURLA_REQUIRE(J.nb[j] > 0);
     J.first_block[j] = blocks;
-    blocks += (nw[j] + 32 + 31) / 32;
+    blocks += (nw[j] + J.nb[j] + 31) / 32;
   }
   J.first_block[njobs] = blocks;
   J.njobs = njobs;
@@ -2099,9 +2174,11 @@ static int launch_wgrad1(const void* src, int src_kind, const int64_t* idx, cons
                          const float* g, float* workspace, int B, int C, int Hs, int Ws, int Hc, int Wc, int channels,
                          float scale, void* stream, int* nslabs) {
   CURLA_REQUIRE(g && workspace);
-  if (channels != 32) return CURLA_ERR_UNSUPPORTED;
   int rc = conv1_common_check(src, src_kind, B, C, Hs, Ws, Hc, Wc, h1, w1);
   if (rc != CURLA_OK) return rc;
+  if (channels != 32)
+    return gen_wgrad1(gen_src(src, src_kind, idx, h1, w1, C, Hs, Ws, Hc, Wc, scale), g, workspace, B, channels,
+                      static_cast<hipStream_t>(stream), nslabs);
   CURLA_REQUIRE(aligned16(g));
   Wgrad1Args a;
   a.src = src, a.idx = idx, a.h1 = h1, a.w1 = w1, a.g = g, a.partial = workspace;
@@ -2215,9 +2292,9 @@ int curla_conv1_wgrad(const void* src, int src_kind, const int64_t* idx, const i
   int grid = 0;
   int rc = launch_wgrad1(src, src_kind, idx, h1, w1, g, workspace, B, C, Hs, Ws, Hc, Wc, channels, scale, stream, &grid);
   if (rc != CURLA_OK) return rc;
-  const int nw = 32 * C * 9;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nw + 32 + 31) / 32), dim3(1024), 0, static_cast<hipStream_t>(stream),
-                     workspace, grid, nw, dw, db);
+  const int nw = channels * C * 9;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((nw + channels + 31) / 32), dim3(1024), 0, static_cast<hipStream_t>(stream),
+                     workspace, grid, nw, channels, dw, db);
   return curla_launch_status();
 }
 

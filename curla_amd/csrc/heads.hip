@@ -29,7 +29,8 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm) {
 }
 
 // ---- fc split-K reduce + bias + LayerNorm (one wave per row; a lane holds features lane, lane+64, ...:
-// NF = ceil(F / 64) <= 4, i.e. F <= 256) ----
+// NF = ceil(F / 64) rounded up to 1, 2, 3, 4, 8 or 16, i.e. F <= 1024: the reference's --encoder_feature_dim is free,
+// train.py:80; 50 is what every configuration uses) ----
 // (blockIdx.y = job: up to kMaxLnJobs encoders' features in one launch -- the actor's, the target critic's and the
 // critic's at the top of update_critic, curl_sac.py:350-358)
 constexpr int kMaxLnJobs = 4;
@@ -1343,7 +1344,7 @@ int curla_fc_ln_fwd_multi(int njobs, const CurlaFcLnJob* jobs, int nsplit, long 
     CURLA_REQUIRE(!j.xa || A > 0);
     js.j[i] = j;
   }
-  if (F > 256) return CURLA_ERR_UNSUPPORTED;
+  if (F > 1024) return CURLA_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
 #define CURLA_FC_LN(NF)                                                                                          \
   hipLaunchKernelGGL(fc_ln_fwd_kernel<NF>, dim3((B + 3) / 4, njobs), dim3(256), 0, st, js, nsplit, split_stride, ldp, \
@@ -1352,7 +1353,9 @@ int curla_fc_ln_fwd_multi(int njobs, const CurlaFcLnJob* jobs, int nsplit, long 
     case 1: CURLA_FC_LN(1); break;
     case 2: CURLA_FC_LN(2); break;
     case 3: CURLA_FC_LN(3); break;
-    default: CURLA_FC_LN(4); break;
+    case 4: CURLA_FC_LN(4); break;
+    case 5: case 6: case 7: case 8: CURLA_FC_LN(8); break;
+    default: CURLA_FC_LN(16); break;
   }
 #undef CURLA_FC_LN
   return curla_launch_status();
@@ -1372,7 +1375,7 @@ int curla_ln_bwd_twin(const float* dy, const float* dy2, int ld_dy, const float*
                       const float* gamma, int B, int F, float* dx, float* dgamma, float* dbeta, float* dbias_in,
                       void* stream) {
   CURLA_REQUIRE(dy && xhat && rstd && gamma && dx && B > 0 && F > 0 && ld_dy >= F);
-  if (F > 256) return CURLA_ERR_UNSUPPORTED;
+  if (F > 1024) return CURLA_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   CURLA_REQUIRE(!dbias_in || (dgamma && dbeta));
   float* const no_partial = nullptr;
@@ -1383,7 +1386,9 @@ int curla_ln_bwd_twin(const float* dy, const float* dy2, int ld_dy, const float*
     case 1: CURLA_LN_BWD(1, no_partial); break;
     case 2: CURLA_LN_BWD(2, no_partial); break;
     case 3: CURLA_LN_BWD(3, no_partial); break;
-    default: CURLA_LN_BWD(4, no_partial); break;
+    case 4: CURLA_LN_BWD(4, no_partial); break;
+    case 5: case 6: case 7: case 8: CURLA_LN_BWD(8, no_partial); break;
+    default: CURLA_LN_BWD(16, no_partial); break;
   }
   if (dgamma && dbeta)
     hipLaunchKernelGGL(ln_param_grad_kernel, dim3((F + 15) / 16), dim3(1024), 0, st, dy, dy2, ld_dy, xhat, dx, B, F,
@@ -1394,13 +1399,15 @@ int curla_ln_bwd_twin(const float* dy, const float* dy2, int ld_dy, const float*
 int curla_ln_bwd_partial(const float* dy, const float* dy2, int ld_dy, const float* xhat, const float* rstd,
                          const float* gamma, int B, int F, float* dx, float* partial, int* nparts, void* stream) {
   CURLA_REQUIRE(dy && xhat && rstd && gamma && dx && partial && nparts && B > 0 && F > 0 && ld_dy >= F);
-  if (F > 256) return CURLA_ERR_UNSUPPORTED;
+  if (F > 1024) return CURLA_ERR_UNSUPPORTED;
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch ((F + 63) / 64) {
     case 1: CURLA_LN_BWD(1, partial); break;
     case 2: CURLA_LN_BWD(2, partial); break;
     case 3: CURLA_LN_BWD(3, partial); break;
-    default: CURLA_LN_BWD(4, partial); break;
+    case 4: CURLA_LN_BWD(4, partial); break;
+    case 5: case 6: case 7: case 8: CURLA_LN_BWD(8, partial); break;
+    default: CURLA_LN_BWD(16, partial); break;
   }
 #undef CURLA_LN_BWD
   *nparts = (B + 3) / 4;

@@ -292,13 +292,14 @@ class _Workspace:
         self.gviews = [[g[:int(np.prod(s))].view(s) for s in shapes] for g in self.gbuf]
         # one slab workspace per conv layer: the layers' weight-gradient reductions run as ONE launch at the end of a
         # backward pass (ops.wgrad_reduce_multi)
-        self.wg_ws = [f(ops.wgrad_workspace_floats(enc.obs_shape[0] if i == 0 else 32)) for i in range(L)]
+        self.wg_ws = [f(ops.wgrad_workspace_floats(enc.obs_shape[0] if i == 0 else enc.num_filters)) for i in range(L)]
         # features
         self.z_a, self.z_t, self.z_c, self.z_pos = f(B, F), f(B, F), f(B, F), f(B, F)
         self.xhat_c, self.rstd_c, self.xhat_a, self.rstd_a = f(B, F), f(B), f(B, F), f(B)
         self.dz, self.dfc = f(B, F), f(B, F)
         self.ln_partial = f(ops.ln_partial_floats(B, F))  # LayerNorm parameter-gradient partial sums (ops.ln_bwd defer=)
-        self.w_partial = f(max(1, B // 16) * F * F)       # CURL.W gradient partial sums (ops.curl_head)
+        # CURL.W gradient partial sums (ops.curl_head: feature widths it is built for only)
+        self.w_partial = f(max(1, B // 16) * F * F) if ops.curl_head_supported(B, F) else None
         self.fc_out = f(B, F)  # pre-LayerNorm features, only written on histogram-logging steps
         # actor trunk
         self.a_h1, self.a_h2, self.a_out = f(B, H), f(B, H), f(B, 2 * A)

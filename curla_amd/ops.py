@@ -108,7 +108,7 @@ def conv_s1_fwd_stack(x, ws, bs, outs, x2=None, ws2=None, bs2=None, outs2=None):
     n = len(ws)
     B2 = 0 if x2 is None else x2.shape[0]
     G = stack_granule()
-    if n > 6 or B % G or B2 % G:
+    if n > 6 or B % G or B2 % G or C != 32:  # (other filter counts: the generic per-layer kernels, csrc/conv_generic.h)
         return False
     P = ctypes.c_void_p * n
     arr = lambda ts: P(*[ptr(t) for t in ts])  # noqa: E731
@@ -207,10 +207,11 @@ def wgrad_reduce_multi(jobs):
     slabs = P(*[ptr(j[0]) for j in jobs])
     ns = I(*[int(j[1]) for j in jobs])
     nw = I(*[int(j[2].numel()) for j in jobs])
+    nb = I(*[int(j[3].numel()) for j in jobs])  # (bias sums behind the weight sums of a slab: the layer's filter count)
     dw = P(*[ptr(j[2]) for j in jobs])
     db = P(*[ptr(j[3]) for j in jobs])
     call("curla_wgrad_reduce_multi", n, ctypes.addressof(slabs), ctypes.addressof(ns), ctypes.addressof(nw),
-         ctypes.addressof(dw), ctypes.addressof(db), stream())
+         ctypes.addressof(nb), ctypes.addressof(dw), ctypes.addressof(db), stream())
 
 
 def wgrad_workspace_floats(cin):

@@ -58,6 +58,9 @@ int curla_abi_version(void);
  *                                      auto = b3 on 128 x 64 tiles where those give every CU a workgroup, f32 elsewhere
  *   s1_wgrad    auto | x | xy          stride-1 weight gradient: Winograd F(3,2) along x, or (auto) in both directions (2 x 2 gradient
  *                                      blocks: a third fewer f32 matrix instructions)
+ *   wgrad1_u8   auto | f32 | b16       first-layer weight gradient from the uint8 ring: on the f32-input MFMA, or (auto, where
+ *                                      3 C <= 32 and output rows hold >= 8 pixels) on the bf16 matrix cores -- a uint8 pixel is
+ *                                      exact in one bf16, the gradient is split into three: nothing is dropped
  * curla_set_option returns CURLA_ERR_ARG for an unknown name or value; curla_get_option NULL for an unknown name. */
 int curla_set_option(const char* name, const char* value);
 const char* curla_get_option(const char* name);
@@ -121,7 +124,12 @@ int curla_conv1_wgrad(const void* src, int src_kind, const int64_t* idx, const i
  * them, each 32*cin*9 + 32 floats) and nothing is reduced yet.  A backward pass runs one of these per conv layer, each
  * into its own workspace, and ONE curla_wgrad_reduce_multi at the end sums all layers' slabs (fixed order) into their
  * dW / db -- the per-layer reductions of curla_conv3x3_s1_wgrad / curla_conv1_wgrad would each be a launch of their
- * own.  njobs <= 8; nw[j] = 32*cin*9 of job j. */
+ * own.  njobs <= 8; nw[j] = channels*cin*9 of job j, nb[j] = its bias count = channels (NULL: 32 each).
+ * FILTER COUNTS OTHER THAN 32 (the reference is generic in num_filters, encoder.py:54-63 / train.py:84): every conv
+ * entry point above and below takes `channels` in 4 .. 256 (a multiple of 4); 32 runs the gfx950 row-walk kernels,
+ * anything else plain direct convolutions on the vector ALU (csrc/conv_generic.h) -- the same results to fp32 rounding,
+ * one to two orders of magnitude slower; their weight-gradient slabs are ONE slab of channels*cin*9 + channels floats.
+ * curla_conv3x3_s1_fwd_stack stays 32-only (CURLA_ERR_UNSUPPORTED: one curla_conv3x3_s1_fwd / _fwd2 per layer). */
 int curla_conv3x3_s1_wgrad_slabs(const float* in, const float* g, float* workspace, int B, int Hi, int Wi, int channels,
                                  int* nslabs, void* stream);
 int curla_conv1_wgrad_slabs(const void* src, int src_kind, const int64_t* idx, const int32_t* h1, const int32_t* w1,
@@ -131,8 +139,8 @@ int curla_conv1_wgrad_slabs(const void* src, int src_kind, const int64_t* idx, c
  * the layer's input `in`) of one stride-1 layer in ONE launch: both only read the output gradient g. */
 int curla_conv3x3_s1_bwd_slabs(const float* in, const float* g, const float* w, float* gin, float* workspace, int B, int Hi,
                                int Wi, int channels, int* nslabs, void* stream);
-int curla_wgrad_reduce_multi(int njobs, const float* const* slabs, const int* nslabs, const int* nw, float* const* dw,
-                             float* const* db, void* stream);
+int curla_wgrad_reduce_multi(int njobs, const float* const* slabs, const int* nslabs, const int* nw, const int* nb,
+                             float* const* dw, float* const* db, void* stream);
 /* floats of `workspace` the two wgrad entry points need (per-workgroup partial slabs) */
 size_t curla_conv_wgrad_workspace_floats(int cin);
 

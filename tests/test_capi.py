@@ -70,9 +70,10 @@ def test_options_api_refuses_unknown_names_and_values():
     default after loading (no CURLA_<NAME> variable is set in the test environment), unknown names and values are
     refused, ``_lib.option`` scopes a value to a block."""
     from curla_amd import _lib
-    assert set(_lib.OPTIONS) == {"conv1_u8", "conv1_f32", "s1_fwd", "bwd_split", "gemm_tile", "linear_bwd", "gemm_mfma", "s1_wgrad"}
+    assert set(_lib.OPTIONS) == {"conv1_u8", "conv1_f32", "s1_fwd", "bwd_split", "gemm_tile", "linear_bwd", "gemm_mfma", "s1_wgrad",
+                                 "wgrad1_u8"}
     defaults = {"conv1_u8": "auto", "conv1_f32": "rw", "s1_fwd": "auto", "bwd_split": "auto", "gemm_tile": "auto",
-                "linear_bwd": "pair", "gemm_mfma": "auto", "s1_wgrad": "auto"}
+                "linear_bwd": "pair", "gemm_mfma": "auto", "s1_wgrad": "auto", "wgrad1_u8": "auto"}
     for k in _lib.OPTIONS:
         if "CURLA_" + k.upper() not in os.environ:
             assert _lib.get_option(k) == defaults[k]

@@ -592,15 +592,22 @@ def test_update_entry_point_runs_from_ring():
     assert _lib._lib is not None  # the native library is what ran
 
 
-@pytest.mark.parametrize("name,obs_shape,layers,pixel_sac,B,A,hidden,feat", [
-    ("c3_pixel_sac_84", (9, 84, 84), 4, True, 6, 2, 64, 50),        # BASELINE configs[2]: identity aug, no CURL head
-    ("c5_geometry_168x12_L6", (12, 168, 168), 6, False, 3, 2, 64, 50),  # BASELINE configs[4] geometry (augmentation-free)
-    ("rect_76x135", (9, 76, 135), 4, False, 4, 2, 64, 50),          # the reference's own thesis shape (encoder.py:42-43)
-    ("odd_sizes", (3, 31, 45), 3, False, 5, 3, 96, 37),             # nothing a multiple of a tile: |A|=3, hidden 96, feature 37
-    ("wide_feature", (9, 40, 40), 2, False, 4, 2, 64, 130),         # encoder_feature_dim > 64 (LayerNorm over 3 values per lane)
-    ("one_layer_stack2", (6, 33, 29), 1, False, 4, 2, 64, 50),      # a single (stride-2) conv layer, frame_stack 2
+@pytest.mark.parametrize("name,obs_shape,layers,pixel_sac,B,A,hidden,feat,filters", [
+    ("c3_pixel_sac_84", (9, 84, 84), 4, True, 6, 2, 64, 50, 32),        # BASELINE configs[2]: identity aug, no CURL head
+    ("c5_geometry_168x12_L6", (12, 168, 168), 6, False, 3, 2, 64, 50, 32),  # BASELINE configs[4] geometry (augmentation-free)
+    ("rect_76x135", (9, 76, 135), 4, False, 4, 2, 64, 50, 32),          # the reference's own thesis shape (encoder.py:42-43)
+    ("odd_sizes", (3, 31, 45), 3, False, 5, 3, 96, 37, 32),             # nothing a multiple of a tile: |A|=3, hidden 96, feature 37
+    ("wide_feature", (9, 40, 40), 2, False, 4, 2, 64, 130, 32),         # encoder_feature_dim > 64 (LayerNorm over 3 values per lane)
+    ("one_layer_stack2", (6, 33, 29), 1, False, 4, 2, 64, 50, 32),      # a single (stride-2) conv layer, frame_stack 2
+    # round 6: the reference's --num_filters / --encoder_feature_dim beyond the defaults (encoder.py:54-67, train.py:80,84):
+    # other filter counts run the generic direct convolutions of csrc/conv_generic.h behind the same entry points, wider
+    # features the LayerNorm kernels with 8 / 16 values per lane
+    ("filters_16", (9, 40, 44), 4, False, 4, 2, 64, 50, 16),
+    ("filters_64", (9, 36, 36), 3, False, 3, 2, 64, 50, 64),
+    ("feature_1024", (9, 40, 40), 2, False, 4, 2, 64, 1024, 32),
+    ("feature_300_filters_16_stack2", (6, 33, 29), 2, False, 4, 2, 64, 300, 16),
 ])
-def test_other_config_geometries_vs_oracle(name, obs_shape, layers, pixel_sac, B, A, hidden, feat):
+def test_other_config_geometries_vs_oracle(name, obs_shape, layers, pixel_sac, B, A, hidden, feat, filters):
     """One even-step update() on the other BASELINE geometries against the oracle
     agent (same weights, minibatch, noise): per-phase losses and the gradients
     that reach Adam."""
@@ -610,7 +617,7 @@ def test_other_config_geometries_vs_oracle(name, obs_shape, layers, pixel_sac, B
     np.random.seed(11)
     hw = obs_shape[1:]
     aug = curla_amd.IdentityAugmentation(hw)
-    hp = {**HP, "num_layers": layers, "encoder_feature_dim": feat}
+    hp = {**HP, "num_layers": layers, "encoder_feature_dim": feat, "num_filters": filters}
     agent = curla_amd.CurlSacAgent(obs_shape, (A,), torch.device("cuda"), aug, hidden_dim=hidden, pixel_sac=pixel_sac, **hp)
     oracle = O.OracleAgent(obs_shape, (A,), hidden_dim=hidden, pixel_sac=pixel_sac,
                            **{k: v for k, v in hp.items() if k != "log_interval"})

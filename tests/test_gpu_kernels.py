@@ -680,10 +680,10 @@ def test_concat_split_softupdate_mean(ops):
 
 def test_bad_arguments_fail_loudly(ops):
     from curla_amd._lib import CurlaHipError
-    x = torch.zeros(2, 9, 9, 16, device="cuda")  # 16 channels: not built
+    x = torch.zeros(2, 9, 9, 6, device="cuda")  # 6 channels: not a multiple of 4 (round 6: 16 / 64 / ... run the generic path)
     with pytest.raises(CurlaHipError):
-        ops.conv_s1_fwd(x, torch.zeros(16, 16, 3, 3, device="cuda"), torch.zeros(16, device="cuda"),
-                        torch.zeros(2, 7, 7, 16, device="cuda"))
+        ops.conv_s1_fwd(x, torch.zeros(6, 6, 3, 3, device="cuda"), torch.zeros(6, device="cuda"),
+                        torch.zeros(2, 7, 7, 6, device="cuda"))
     with pytest.raises(CurlaHipError):
         ops.ObsRef.from_tensor(torch.zeros(1, 9, 20, 20))  # CPU tensor
 
@@ -1362,3 +1362,76 @@ def test_f64_rider_kernels_match_the_host_arithmetic_bit_for_bit():
             if world == 2:
                 a, b = np.float64(vals[pick[0]]), np.float64(vals[pick[1]])
                 assert float(v) == (a + b) / np.float64(2)
+
+
+@pytest.mark.parametrize("nf", [16, 64, 8])
+def test_generic_filter_counts_against_pytorch(ops, nf):
+    """num_filters other than 32 (encoder.py:54-63, train.py:84) run plain direct convolutions behind the same C entry
+    points (csrc/conv_generic.h): the first layer from the uint8 ring (gather + crop) and from float NCHW / NHWC tensors,
+    a stride-1 layer, both data and weight gradients, the one-launch backward and the multi-layer slab reduction."""
+    from oracle import curla_oracle as O
+    C, Hs, Ws, Hc, Wc, B, N = 9, 30, 34, 25, 29, 5, 7
+    frames, ring = _ring(N, C, Hs, Ws, seed=nf)
+    rs = np.random.RandomState(3)
+    idx = rs.randint(0, N, B)
+    h1, w1 = rs.randint(0, Hs - Hc + 1, B).astype(np.int32), rs.randint(0, Ws - Wc + 1, B).astype(np.int32)
+    crop = torch.from_numpy(O.random_crop(frames[idx], h1, w1, (Hc, Wc)).astype(np.float32))
+    w0, b0 = rnd(nf, C, 3, 3, seed=11, scale=0.2), rnd(nf, seed=12, scale=0.1)
+    w1_, b1_ = rnd(nf, nf, 3, 3, seed=13, scale=0.1), rnd(nf, seed=14, scale=0.1)
+    w0r, b0r, w1r, b1r = (t.clone().requires_grad_(True) for t in (w0, b0, w1_, b1_))
+    a1 = torch.relu(F.conv2d(crop / 255.0, w0r, b0r, stride=2))
+    a2 = torch.relu(F.conv2d(a1, w1r, b1r))
+    g2 = rnd(*a2.shape, seed=15) * (a2 > 0)
+    a2.backward(g2)
+    Ho, Wo = a1.shape[2:]
+    # forward: the three first-layer sources, then the stride-1 layer
+    obs_u8 = ops.ObsRef.from_ring(ring, dev(idx.astype(np.int64)), dev(h1), dev(w1), B, (Hc, Wc))
+    srcs = [("u8 ring", obs_u8), ("f32 NCHW", ops.ObsRef.from_tensor(dev(crop))),
+            ("f32 NHWC", ops.ObsRef.from_nhwc(nhwc(crop)))]
+    d_w0, d_b0, d_w1, d_b1 = dev(w0), dev(b0), dev(w1_), dev(b1_)
+    for name, o in srcs:
+        out1 = torch.full((B, Ho, Wo, nf), float("nan"), device="cuda")
+        ops.conv1_fwd(o, d_w0, d_b0, out1)
+        check(f"generic conv1_fwd [{name}] nf{nf}", nchw(out1), a1.detach())
+    out2 = torch.full((B, Ho - 2, Wo - 2, nf), float("nan"), device="cuda")
+    ops.conv_s1_fwd(out1, d_w1, d_b1, out2)
+    check(f"generic conv_s1_fwd nf{nf}", nchw(out2), a2.detach())
+    if nf == 16:  # two problems per call: conv1_fwd2 / conv_s1_fwd2 run them one after the other
+        o1b, o2b = torch.full_like(out1, float("nan")), torch.full_like(out2, float("nan"))
+        o1c = torch.full_like(out1, float("nan"))
+        ops.conv1_fwd2(obs_u8, d_w0, d_b0, o1b, obs_u8, d_w0, d_b0, o1c)
+        assert torch.equal(o1b, out1) and torch.equal(o1c, out1)
+        o2c = torch.full_like(out2, float("nan"))
+        ops.conv_s1_fwd2(out1, d_w1, d_b1, o2b, out1, d_w1, d_b1, o2c)
+        assert torch.equal(o2b, out2) and torch.equal(o2c, out2)
+        assert not ops.conv_s1_fwd_stack(out1, [d_w1], [d_b1], [o2b])  # (the stack launch is the 32-filter kernels')
+    # backward of the stride-1 layer in one call (weight-gradient slab + data gradient), then the first layer's
+    # weight gradient from each source, all slabs summed by ONE reduction launch
+    g2d = nhwc(g2)
+    g1 = torch.full((B, Ho, Wo, nf), float("nan"), device="cuda")
+    ws1 = torch.empty(ops.wgrad_workspace_floats(nf), device="cuda")
+    n1 = ops.conv_s1_bwd_slabs(out1, g2d, d_w1, g1, ws1)
+    a1d = a1.detach().clone().requires_grad_(True)
+    torch.relu(F.conv2d(a1d, w1_, b1_)).backward(g2)
+    check(f"generic dgrad nf{nf}", nchw(g1), a1d.grad * (a1.detach() > 0))
+    gd = torch.full_like(g1, float("nan"))
+    ops.conv_s1_dgrad(g2d, d_w1, out1, gd)
+    assert torch.equal(gd, g1)
+    for name, o in srcs:
+        ws0 = torch.empty(ops.wgrad_workspace_floats(C), device="cuda")
+        n0 = ops.conv1_wgrad_slabs(o, g1, ws0, nf)
+        dw0, db0 = torch.full((nf, C, 3, 3), float("nan"), device="cuda"), torch.full((nf,), float("nan"), device="cuda")
+        dw1, db1 = torch.full((nf, nf, 3, 3), float("nan"), device="cuda"), torch.full((nf,), float("nan"), device="cuda")
+        ops.wgrad_reduce_multi([(ws1, n1, dw1, db1), (ws0, n0, dw0, db0)])
+        check(f"generic wgrad layer 2 dW nf{nf}", dw1.cpu(), w1r.grad)
+        check(f"generic wgrad layer 2 db nf{nf}", db1.cpu(), b1r.grad)
+        check(f"generic wgrad layer 1 dW [{name}] nf{nf}", dw0.cpu(), w0r.grad)
+        check(f"generic wgrad layer 1 db [{name}] nf{nf}", db0.cpu(), b0r.grad)
+    # the direct (slab + reduce in one call) entry points
+    dwa, dba = torch.full((nf, nf, 3, 3), float("nan"), device="cuda"), torch.full((nf,), float("nan"), device="cuda")
+    ops.conv_s1_wgrad(out1, g2d, dwa, dba, ws1)
+    check(f"generic conv_s1_wgrad dW nf{nf}", dwa.cpu(), w1r.grad)
+    dwb, dbb = torch.full((nf, C, 3, 3), float("nan"), device="cuda"), torch.full((nf,), float("nan"), device="cuda")
+    ops.conv1_wgrad(obs_u8, g1, dwb, dbb, ws0)
+    check(f"generic conv1_wgrad dW nf{nf}", dwb.cpu(), w0r.grad)
+    check(f"generic conv1_wgrad db nf{nf}", dbb.cpu(), b0r.grad)
