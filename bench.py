@@ -105,6 +105,57 @@ def flops_per_update(cfg, step):
     return cfg["batch"] * (5 * fc + 2 * (2 * fc - f1))
 
 
+def matrix_pipe_seconds_per_update(cfg, step, opts):
+    """Seconds per update the matrix pipes would need AT THEIR DENSE PEAKS for the conv work as the kernels issue it
+    (advisor, round 5: the fp32-roofline fractions above are not bounded by 1 once the stride-1 convs run on the bf16
+    matrix cores).  bf16 pipe (2.5 PFLOP/s): stride-1 forward and data gradient = direct FLOPs / 1.5 (Winograd F(2,3)
+    along x) x 6 products (bf16x3); the uint8 first layer and its weight gradient = direct FLOPs x 3 products (a pixel is
+    exact in one part).  f32-input pipe (157.3 TFLOP/s): the stride-1 weight gradient = direct / 2.25 (F(3,2) in both
+    directions; / 1.5 along x only), anything the options put back on that pipe, and the float first layer of the
+    colour-jittered configuration.  Strip padding and the k-padding of the first layer (27 -> 32) are not counted."""
+    hw = cfg["crop"] or cfg["obs"][1:]
+    f = conv_layer_flops(hw, cfg["layers"], cfg["obs"][0])
+    f1, fs = f[0], sum(f[1:])
+    n_f, n_b = ((4 if step % 2 == 0 else 3), 1) if cfg["pixel_sac"] else (5, 2)
+    bf16 = f32 = 0.0
+    s1 = opts.get("s1_fwd", "auto")
+    if s1 in ("auto", "b3"):
+        bf16 += (n_f + n_b) * fs / 1.5 * 6
+    else:
+        f32 += (n_f + n_b) * fs / (2.0 if s1 == "f43" else 1.5)
+    f32 += n_b * fs / (1.5 if opts.get("s1_wgrad", "auto") == "x" else 2.25)
+    u8 = cfg["aug"] != "color_jiggle"
+    if u8 and opts.get("conv1_u8", "auto") in ("auto", "rwb") and 3 * cfg["obs"][0] <= 32:
+        bf16 += n_f * f1 * 3
+    else:
+        f32 += n_f * f1
+    if u8 and opts.get("wgrad1_u8", "auto") in ("auto", "b16") and 3 * cfg["obs"][0] <= 32:
+        bf16 += n_b * f1 * 3
+    else:
+        f32 += n_b * f1
+    return cfg["batch"] * (bf16 / (PEAK_BF16_TFLOPS * 1e12) + f32 / (PEAK_F32_TFLOPS * 1e12))
+
+
+def committed_clock(kernel):
+    """The in-kernel clock and matrix-pipe utilisation of the dominant kernel INSIDE update() at configs[1], measured
+    offline by tools/clock_reconcile.sh (diagnostic build with two stamps per workgroup; the PMC counters of the same
+    launches are in the .txt beside it) -- quoted while the summary's source hash is the built library's."""
+    from curla_amd import build
+    try:
+        with open(os.path.join(ROOT, "profiles", "r06_clock_reconcile.json")) as f:
+            d = json.load(f)
+    except Exception:
+        return None
+    if d.get("_source_hash") != build.source_hash() or d.get("kernel") != kernel or "update" not in d:
+        return None
+    u = d["update"]
+    return {"in_kernel_clock_GHz": u["in_kernel_clock_GHz"], "matrix_pipe_busy_at_that_clock": u["matrix_pipe_util_at_in_kernel_clock"],
+            "how": "s_memtime / s_memrealtime stamps of every workgroup's first and last instruction, conv_rwb_fwd_kernel's "
+                   "launches inside update() at configs[1]; matrix instructions x 16 cycles / (1024 SIMDs x elapsed shader "
+                   "cycles); profiles/r06_clock_reconcile.txt has the PMC counters of the same launches "
+                   "(SQ_BUSY_CU_CYCLES / 256 and SQ_WAVE_CYCLES x 4 / 2048 agree with the stamps to 1-3 %)"}
+
+
 class NullLogger:
     def log(self, *a, **k):
         pass
@@ -173,7 +224,7 @@ def committed_counters(cfg_name, kernel):
     cur = build.source_hash()
     traffic = busy = None
     note = "no committed PMC summary for this configuration"
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         for fn, key in ((f"{rnd}_pmc_traffic_{cfg_name}.json", "traffic"), (f"{rnd}_pmc_sq_{cfg_name}.json", "sq")):
             try:
                 with open(os.path.join(ROOT, "profiles", fn)) as f:
@@ -507,6 +558,9 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
             "f43": ("conv_rw43_fwd_kernel", "F(4,3)", 2.0, "f32 MFMA 16x16x4", PEAK_F32_TFLOPS, 1)}[s1]
         issued = achieved / wino_factor * terms  # what the matrix pipe executes, in its own FLOPs
         traffic, mfma_busy, pmc_note = (None, None, "dry run") if job.dry else committed_counters(name, kname)
+        opts = {} if job.dry else {k: _clib.get_option(k) for k in ("s1_fwd", "s1_wgrad", "conv1_u8", "wgrad1_u8")}
+        pipe_s = sum(matrix_pipe_seconds_per_update(cfg, first_step + i, opts) for i in range(steps)) / steps
+        clock = None if (job.dry or name != "c2") else committed_clock(kname)
         n_launch = max(1, len(ev_pairs))
         avg_ms = kms / n_launch
         out = {
@@ -531,6 +585,15 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
             "transitions_per_s": updates_per_s * B,
             "conv_algorithmic_gflop_per_update": per_update / 1e9,
             "conv_roofline_frac_whole_update": per_update * (steps / dt) / (PEAK_F32_TFLOPS * 1e12),
+            "conv_roofline_note": "SURVEY.md 8d accounting (the north star's 'fraction of the conv roofline'): direct-conv "
+                                  "FLOPs of the update / time against the 157.3 TFLOP/s fp32 peak.  Read it as the SPEED-UP "
+                                  "over what the fp32 pipe could do at best, not as a fraction bounded by 1: the kernels skip "
+                                  "work (Winograd) and run most of it on the bf16 matrix cores.  matrix_pipe_time_frac_whole_"
+                                  "update is the bounded figure",
+            "matrix_pipe_time_frac_whole_update": pipe_s / (dt / steps),
+            "matrix_pipe_time_note": "time the two matrix pipes would need at their dense peaks (bf16 2.5 PFLOP/s, f32-input "
+                                     "157.3 TFLOP/s) for the conv work as the kernels issue it (Winograd factors and bf16x3 "
+                                     "products counted, padding not) / measured time per update",
             "roofline": {"bound": "mfma",
                          "kernel": (f"{kname} (row-walk Winograd {wino} along x: all 3x3 s1 32->32 + bias + ReLU layers of "
                                     f"two minibatches per launch, {mfma})")
@@ -548,6 +611,9 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
                                            + (f" x {terms} (six bf16 x bf16 products per fp32 product: x = xh + xm + xl exactly, the "
                                               "three products below 2^-24 dropped), against the dense bf16 MFMA peak" if terms > 1 else "")),
                          "direct_equiv_achieved": achieved, "direct_equiv_frac": achieved / PEAK_F32_TFLOPS,
+                         "direct_equiv_note": "direct-conv TFLOP/s of the launch and their ratio to the fp32 peak: a speed-up "
+                                              "over that pipe's best case, not a utilisation (see frac)",
+                         "in_kernel_clock": clock,
                          "traffic_unit": "HBM bytes per launch; " + pmc_note,
                          "algorithmic_bytes_per_launch": kbytes / n_launch,
                          "launches": len(ev_pairs), "avg_launch_ms": avg_ms,

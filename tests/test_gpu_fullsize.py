@@ -36,7 +36,8 @@ the device had one such unit and the reference none.  What IS a property of the 
       err(fp32 oracle, fp64 along the fp32 oracle's branches) <= 1e-4, its disagreements with float64 all within
       1e-5 of zero -- so its un-aligned error e_ref (1.6e-4 .. 8e-4 on the conv gradients) is branch decisions too;
   (D) un-aligned, where the statistics carry it (the maximum over all tensors of a configuration):
-      max e_hip <= max(1e-4, 4 max e_ref).
+      max e_hip <= max(1e-4, 4 max e_ref); and per tensor a hard cap, e_hip <= 5e-3 (round 6: what ONE near-zero ReLU can
+      do to a tensor is ~1e-3 of it; a dropped term or tap is far above the cap).
 Both un-aligned columns (e_hip, e_ref) and both aligned ones are written per tensor to gpurun_out/fullsize_arbiter.txt
 (committed as profiles/r04_fullsize_parity.txt).  The device's branches are also counted against the fp32 oracle's,
 conv layers and MLP hidden units alike (at most 64 per conv layer, 32 per MLP layer, all within 1e-5 of zero).
@@ -62,6 +63,7 @@ pytestmark = pytest.mark.gpu
 REPORT = []   # (name, number): values against the fp32 oracle, branch counts, timings
 ARBITER = []  # (name, e_hip, e_ref, a_hip, a_ref): errors against the float64 evaluation (a_*: along own branches)
 NEAR_ZERO = 1e-5
+UNALIGNED_CAP = 5e-3  # per-tensor bound on a gradient's un-aligned error against float64 (grad_arbiter)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -106,6 +108,13 @@ def grad_arbiter(name, got, ref32, g64_own, g64_along_hip, g64_along_ref, worst)
     ARBITER.append((name, e_hip, e_ref, a_hip, a_ref))
     worst[0], worst[1] = max(worst[0], e_hip), max(worst[1], e_ref)
     bad = []
+    # Per tensor, un-aligned: a hard cap.  The ratio form e_hip <= max(1e-4, 4 e_ref) is asserted per CONFIGURATION (end
+    # of _run) and not per tensor because a single near-zero ReLU on one side and none on the other makes a tensor's
+    # ratio anything (1900 seen on an MLP bias with e_hip = 1.6e-4: see there); what one such event CAN do to a tensor is
+    # bounded, though -- ~1e-3 of it at these sizes (observed maximum over rounds 4-6: 1.6e-3) -- so every tensor is held
+    # to 5e-3 un-aligned: a kernel that drops a term, a tap or a sample fails here whatever the branches do.
+    if not (np.isfinite(e_hip) and e_hip <= UNALIGNED_CAP):
+        bad.append((name + " [device vs fp64, un-aligned, per-tensor cap]", e_hip, UNALIGNED_CAP))
     if not (np.isfinite(a_hip) and a_hip <= RTOL):
         bad.append((name + " [device vs fp64 along the device's branches]", a_hip, RTOL))
     if not (np.isfinite(a_ref) and a_ref <= RTOL):

@@ -8,6 +8,8 @@ import json
 import sys
 
 O, out_path = sys.argv[1], sys.argv[2]
+src_hash = sys.argv[3] if len(sys.argv) > 3 else None
+summary = {"_source_hash": src_hash, "kernel": "conv_rwb_fwd_kernel"}
 lines = []
 say = lines.append
 
@@ -40,6 +42,10 @@ for mode in ("stack", "update"):
         continue
     say("")
     say(f"== {plain['what']}")
+    summary[mode] = {"what": plain["what"], "in_kernel_clock_GHz": plain["in_kernel_clock_GHz"]["median"],
+                     "kernel_us": plain["kernel_us_in_kernel"]["max"],
+                     "matrix_pipe_util_at_in_kernel_clock": plain["matrix_pipe_util_at_in_kernel_clock"],
+                     "issued_TFLOPs": plain["issued_TFLOPs"], "mfma_per_launch": plain["mfma_per_launch_from_shapes"]}
     for tag, fn in (("un-profiled", f"clock_{mode}_plain.json"), ("under rocprofv3 --pmc, pass 1", f"clock_{mode}_pmc1.json"),
                     ("under rocprofv3 --pmc, pass 2", f"clock_{mode}_pmc2.json")):
         try:
@@ -68,7 +74,9 @@ for mode in ("stack", "update"):
             say(f"      {k:28s} {m[k]:16.0f}")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in m:
         busy, cu = m["SQ_VALU_MFMA_BUSY_CYCLES"], m.get("SQ_BUSY_CU_CYCLES", 0.0)
-        say(f"      SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)            = {busy / (4 * cu) if cu else 0:.3f}   (bench.py's mfma_busy_frac_pmc until round 5)")
+        say(f"      SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES)            = {busy / (4 * cu) if cu else 0:.3f}   (bench.py's mfma_busy_frac_pmc)")
+        summary[mode]["pmc"] = {k: m[k] for k in m}
+        summary[mode]["pmc_in_kernel_clock_GHz"] = r1["in_kernel_clock_GHz"]["median"]
         say(f"      SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x in-kernel cycles)    = {busy / (1024 * cyc):.3f}   (same launches, stamps)")
         say(f"      SQ_BUSY_CU_CYCLES / 256 CUs                                   = {cu / 256:.0f} against {cyc:.0f} in-kernel shader cycles: ratio {cu / 256 / cyc:.3f}")
         if "SQ_WAVE_CYCLES" in m:
@@ -78,3 +86,5 @@ for mode in ("stack", "update"):
     if "SQ_INSTS_MFMA" in m:
         say(f"      SQ_INSTS_MFMA against the count from the shapes               = {m['SQ_INSTS_MFMA'] / r1['mfma_per_launch_from_shapes']:.4f}")
 open(out_path, "w").write("\n".join(lines) + "\n")
+with open(out_path.rsplit(".", 1)[0] + ".json", "w") as f:
+    json.dump(summary, f, indent=1)
