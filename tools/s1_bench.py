@@ -16,12 +16,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--c5", action="store_true")
     ap.add_argument("--impls", default="f23,f43")
+    ap.add_argument("--shapes", default="", help="B1+B2,B1+B2,... instead of the update's two launches (scaling with the batch)")
     args = ap.parse_args()
     from curla_amd import _lib, ops
     dev = "cuda"
     g = torch.Generator(device=dev).manual_seed(1)
     H, L = (83, 5) if args.c5 else (37, 3)
     shapes = [(2048, 1024), (1024, 1024)] if args.c5 else [(1024, 512), (512, 512)]
+    if args.shapes:
+        shapes = [tuple(int(v) for v in sh.split("+")) for sh in args.shapes.split(",")]
     r = lambda *s: torch.randn(*s, device=dev, generator=g)  # noqa: E731
     w1 = [r(32, 32, 3, 3) * 0.1 for _ in range(L)]
     w2 = [r(32, 32, 3, 3) * 0.1 for _ in range(L)]
