@@ -621,6 +621,12 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
                                            "timed region (the timed updates are graph replays)" if graphed else
                                            "HIP events around the kernel's launches inside the timed region"),
                          "hbm_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
+                         # the kernel's other roof: its ALGORITHMIC bytes (every activation read and written once) / its
+                         # launch time against the 8 TB/s HBM peak.  Round 6 found the time per sample the same at 1.7 and
+                         # 2.33 GHz: this, not the matrix pipe, is what bounds it (torch's streaming copy / add kernels
+                         # reach 4.8 / 6.0 TB/s on this chip: tools/hbm_mixed.py)
+                         "hbm_algorithmic_GBps": (kbytes / n_launch) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else None,
+                         "hbm_algorithmic_frac": (kbytes / n_launch) / (avg_ms * 1e-3) / 8e12 if avg_ms > 0 else None,
                          "hbm_peak_GBps": 8000.0,
                          "mfma_busy_frac_pmc": mfma_busy},
         }
