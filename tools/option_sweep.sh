@@ -18,6 +18,7 @@ for v in 6464 6432 3232 12864; do run "gemm_tile=$v" CURLA_GEMM_TILE=$v; done
 run "gemm_mfma=b3" CURLA_GEMM_MFMA=b3
 run "gemm_mfma=f32" CURLA_GEMM_MFMA=f32
 run "s1_wgrad=x" CURLA_S1_WGRAD=x
+run "wgrad1_u8=f32" CURLA_WGRAD1_U8=f32
 run "linear_bwd=split" CURLA_LINEAR_BWD=split
 run "CURLA_FC_FWD=gemm" CURLA_FC_FWD=gemm
 run "CURLA_CURL_HEAD=unfused" CURLA_CURL_HEAD=unfused
