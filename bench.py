@@ -247,6 +247,53 @@ def committed_counters(cfg_name, kernel):
     return traffic, busy, note
 
 
+def live_counters(cfg_name, kernel, timeout_s=150):
+    """HBM traffic and matrix-pipe busy fraction of ``kernel`` measured NOW, by this run: three short child runs of this
+    script under ``rocprofv3 --pmc`` (separate passes for FETCH_SIZE, WRITE_SIZE and the two SQ counters, as
+    MI355X_MICROARCH.md prescribes; FETCH_SIZE doubled as gfx950 needs: tools/pmc_summarize.py), each a fresh process --
+    the children are started, never exec'd into, and this process holds no HIP state they need.  Returns (traffic bytes
+    per launch, busy fraction, note) or None when rocprofv3 is missing, a pass fails or the budget runs out: the
+    caller then quotes the committed summaries (committed_counters)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None
+    t_end = time.time() + timeout_s
+    out = tempfile.mkdtemp(prefix="curla_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    vals = {}
+    try:
+        for tag, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
+                              ("sq", ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES"])):
+            left = t_end - time.time()
+            if left < 20:
+                return None
+            cmd = [rp, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", os.path.join(out, tag), "--",
+                                               sys.executable, os.path.abspath(__file__), "--config", cfg_name, "--steps", "6",
+                                               "--warmup", "2", "--no-cpu-baseline", "--clock-warmup-s", "0", "--capacity",
+                                               "20000", "--no-live-pmc"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=left)
+            if r.returncode != 0:
+                return None
+            for f in glob.glob(os.path.join(out, tag, "*", "*counter_collection.csv")):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if kernel in row["Kernel_Name"]:
+                            vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+        mean = lambda k: sum(vals[k]) / len(vals[k])  # noqa: E731
+        traffic = 2.0 * mean("FETCH_SIZE") * 1024.0 + mean("WRITE_SIZE") * 1024.0
+        busy = mean("SQ_VALU_MFMA_BUSY_CYCLES") / (4.0 * mean("SQ_BUSY_CU_CYCLES"))
+        return traffic, busy, (f"measured by this run: rocprofv3 --pmc child runs of this script (6 updates each; FETCH_SIZE x 2 "
+                               f"+ WRITE_SIZE, KiB; means over {len(vals['FETCH_SIZE'])} launches)")
+    except Exception:  # noqa: BLE001  (a missing counter, a timeout, a profiler that is not allowed here ...)
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def respawn_under_torchrun(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a child job (before anything here has
     touched the GPU) and leave with its exit code."""
@@ -558,6 +605,14 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
             "f43": ("conv_rw43_fwd_kernel", "F(4,3)", 2.0, "f32 MFMA 16x16x4", PEAK_F32_TFLOPS, 1)}[s1]
         issued = achieved / wino_factor * terms  # what the matrix pipe executes, in its own FLOPs
         traffic, mfma_busy, pmc_note = (None, None, "dry run") if job.dry else committed_counters(name, kname)
+        pmc_live = False
+        if (not job.dry and not args.no_live_pmc and world == 1 and name == (args.config or "c2") and with_cpu_baseline):
+            # (the headline configuration of a plain one-GPU run: counters measured live, by child runs under rocprofv3)
+            torch.cuda.empty_cache()
+            live = live_counters(name, kname)
+            if live is not None:
+                traffic, mfma_busy, pmc_note = live
+                pmc_live = True
         opts = {} if job.dry else {k: _clib.get_option(k) for k in ("s1_fwd", "s1_wgrad", "conv1_u8", "wgrad1_u8")}
         pipe_s = sum(matrix_pipe_seconds_per_update(cfg, first_step + i, opts) for i in range(steps)) / steps
         clock = None if (job.dry or name != "c2") else committed_clock(kname)
@@ -614,7 +669,7 @@ def measure(job, name, steps, warmup, with_cpu_baseline, pg=None, n=None, overla
                          "direct_equiv_note": "direct-conv TFLOP/s of the launch and their ratio to the fp32 peak: a speed-up "
                                               "over that pipe's best case, not a utilisation (see frac)",
                          "in_kernel_clock": clock,
-                         "traffic_unit": "HBM bytes per launch; " + pmc_note,
+                         "traffic_unit": "HBM bytes per launch; " + pmc_note, "pmc_measured_live": pmc_live,
                          "algorithmic_bytes_per_launch": kbytes / n_launch,
                          "launches": len(ev_pairs), "avg_launch_ms": avg_ms,
                          "launch_timing": ("HIP events around the kernel's launches in 8 eager updates right after the "
@@ -679,6 +734,9 @@ def main():
                     help="measure c3 and c5 after c2 at N > 1 as well (default: only at N = 1 -- a multi-GPU run that "
                          "fails in a secondary configuration would take the headline line down with it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not measure roofline.traffic / mfma_busy_frac_pmc live (child runs under rocprofv3 --pmc, ~1 "
+                         "minute): quote the committed summaries of profiles/ instead")
     ap.add_argument("--capacity", type=int, default=CAPACITY)
     ap.add_argument("--prefill", choices=("device", "host"), default="device")
     ap.add_argument("--clock-warmup-s", type=float, default=0.6,
